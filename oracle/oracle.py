@@ -1,0 +1,298 @@
+"""CPU oracle -- TEST INFRASTRUCTURE ONLY.
+
+Python face of ``oracle/depthstereo_oracle.c`` (ctypes) plus numpy restatements of the pieces whose
+arithmetic lives in OpenCV in the reference.  Function names and signatures mirror the reference
+(``/root/reference`` = thygate/stable-diffusion-webui-depthmap-script v0.4.8):
+
+* ``create_stereoimages`` / ``apply_stereo_divergence`` / ``overlap_red_cyan``
+  -- src/stereoimage_generation.py:13-74, :77-92, :286-307
+* ``create_normalmap``   -- src/normalmap_generation.py:5-56
+* ``convert_to_i16``     -- src/core.py:44-50
+* ``depth_normalize01``  -- src/core.py:189-206 (no-clip branch)
+
+Pinned: the stereo functions against the reference's own Python code executed in the build
+container (``tests/golden/*.npz`` made by ``tests/golden/make_golden.py``) and SURVEY.md Appendix A.
+The normal map's default path (Sobel 3x3, no blur) and every integer-kernel Sobel are exactly
+representable in float64, so the restatement is authoritative; the Gaussian blur paths depend on
+OpenCV's summation order and are **parity unpinned** (cv2 is not installed here).
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import this.
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+def build(force=False):
+    """Compile liboracle.so with gcc (see oracle/Makefile)."""
+    so = os.path.join(_HERE, "liboracle.so")
+    src = os.path.join(_HERE, "depthstereo_oracle.c")
+    if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-s", "-B"])
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        so = os.path.join(_HERE, "liboracle.so")
+        if not os.path.exists(so):
+            build()
+        L = ctypes.CDLL(so)
+        u8p, u16p = ctypes.POINTER(ctypes.c_uint8), ctypes.POINTER(ctypes.c_uint16)
+        f64p, f32p = ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_float)
+        ci, cd, i64 = ctypes.c_int, ctypes.c_double, ctypes.c_int64
+        L.orc_normalize_depth_u16.argtypes = [u16p, i64, f64p]
+        L.orc_normalize_depth_f64.argtypes = [f64p, i64, f64p]
+        L.orc_normalize_depth_f32.argtypes = [f32p, i64, f64p]
+        L.orc_stereo_naive.argtypes = [u8p, ci, ci, ci, f64p, cd, cd, cd, ci, u8p]
+        L.orc_stereo_naive.restype = ci
+        L.orc_stereo_polylines.argtypes = [u8p, ci, ci, ci, f64p, cd, cd, cd, ci, u8p]
+        L.orc_stereo_polylines.restype = ci
+        L.orc_overlap_red_cyan.argtypes = [u8p, u8p, ci, ci, ci, u8p]
+        L.orc_normalmap_sobel3.argtypes = [u16p, ci, ci, ci, u8p]
+        L.orc_normalmap_gradient.argtypes = [u16p, ci, ci, ci, u8p]
+        L.orc_convert_to_i16_f64.argtypes = [f64p, i64, u16p]
+        L.orc_convert_to_i16_f32.argtypes = [f32p, i64, u16p]
+        L.orc_depth_normalize01_f32.argtypes = [f32p, i64, ci, f32p]
+        L.orc_num_threads.restype = ci
+        _LIB = L
+    return _LIB
+
+
+def _p(a, t):
+    return a.ctypes.data_as(ctypes.POINTER(t))
+
+
+FILLS_NAIVE = {"none": 0, "naive": 1, "naive_interpolating": 2}
+FILLS_POLY = {"polylines_soft": 0, "polylines_sharp": 1}
+
+
+def normalize_depth(depth):
+    """stereoimage_generation.py:79-81 -> float64 HxW."""
+    depth = np.asarray(depth)
+    out = np.empty(depth.shape, np.float64)
+    L = lib()
+    if depth.dtype == np.uint16:
+        d = np.ascontiguousarray(depth)
+        L.orc_normalize_depth_u16(_p(d, ctypes.c_uint16), d.size, _p(out, ctypes.c_double))
+    elif depth.dtype == np.float32:
+        d = np.ascontiguousarray(depth)
+        L.orc_normalize_depth_f32(_p(d, ctypes.c_float), d.size, _p(out, ctypes.c_double))
+    elif depth.dtype == np.float64:
+        d = np.ascontiguousarray(depth)
+        L.orc_normalize_depth_f64(_p(d, ctypes.c_double), d.size, _p(out, ctypes.c_double))
+    else:  # other integer dtypes: numpy semantics directly
+        with np.errstate(all="ignore"):
+            out = ((depth - depth.min()) / (depth.max() - depth.min())).astype(np.float64)
+    return out
+
+
+def apply_stereo_divergence(original_image, depth, divergence, separation, stereo_offset_exponent, fill_technique):
+    """stereoimage_generation.py:77-92."""
+    original_image = np.ascontiguousarray(original_image)
+    assert original_image.shape[:2] == depth.shape, 'Depthmap and the image must have the same size'
+    h, w, c = original_image.shape
+    norm = normalize_depth(depth)
+    divergence_px = (divergence / 100.0) * w
+    separation_px = (separation / 100.0) * w
+    out = np.empty_like(original_image)
+    L = lib()
+    if fill_technique in FILLS_NAIVE:
+        rc = L.orc_stereo_naive(_p(original_image, ctypes.c_uint8), h, w, c, _p(norm, ctypes.c_double),
+                                divergence_px, separation_px, float(stereo_offset_exponent),
+                                FILLS_NAIVE[fill_technique], _p(out, ctypes.c_uint8))
+        assert rc == 0
+        return out
+    if fill_technique in FILLS_POLY:
+        rc = L.orc_stereo_polylines(_p(original_image, ctypes.c_uint8), h, w, c, _p(norm, ctypes.c_double),
+                                    divergence_px, separation_px, float(stereo_offset_exponent),
+                                    FILLS_POLY[fill_technique], _p(out, ctypes.c_uint8))
+        assert rc == 0
+        return out
+    return None  # reference: unknown fill silently yields None (:85-92)
+
+
+def overlap_red_cyan(im1, im2):
+    im1, im2 = np.ascontiguousarray(im1), np.ascontiguousarray(im2)
+    h, w, c = im2.shape
+    out = np.zeros((h, w, 3), np.uint8)
+    lib().orc_overlap_red_cyan(_p(im1, ctypes.c_uint8), _p(im2, ctypes.c_uint8), h, w, c, _p(out, ctypes.c_uint8))
+    return out
+
+
+def create_stereoimages_arrays(original_image, depthmap, divergence, separation=0.0, modes=None,
+                               stereo_balance=0.0, stereo_offset_exponent=1.0, fill_technique='polylines_sharp'):
+    """stereoimage_generation.py:13-74, returning ndarrays instead of PIL images."""
+    if modes is None:
+        modes = ['left-right']
+    if not isinstance(modes, list):
+        modes = [modes]
+    if len(modes) == 0:
+        return []
+    original_image = np.asarray(original_image)
+    balance = (stereo_balance + 1) / 2
+    left_eye = original_image if balance < 0.001 else \
+        apply_stereo_divergence(original_image, depthmap, +1 * divergence * balance, -1 * separation,
+                                stereo_offset_exponent, fill_technique)
+    right_eye = original_image if balance > 0.999 else \
+        apply_stereo_divergence(original_image, depthmap, -1 * divergence * (1 - balance), separation,
+                                stereo_offset_exponent, fill_technique)
+    results = []
+    for mode in modes:
+        if mode == 'left-right':
+            results.append(np.hstack([left_eye, right_eye]))
+        elif mode == 'right-left':
+            results.append(np.hstack([right_eye, left_eye]))
+        elif mode == 'top-bottom':
+            results.append(np.vstack([left_eye, right_eye]))
+        elif mode == 'bottom-top':
+            results.append(np.vstack([right_eye, left_eye]))
+        elif mode == 'red-cyan-anaglyph':
+            results.append(overlap_red_cyan(left_eye, right_eye))
+        elif mode == 'left-only':
+            results.append(left_eye)
+        elif mode == 'only-right':
+            results.append(right_eye)
+        elif mode == 'cyan-red-reverseanaglyph':
+            results.append(overlap_red_cyan(right_eye, left_eye))
+        else:
+            raise Exception('Unknown mode')
+    return results
+
+
+def create_stereoimages(*args, **kwargs):
+    from PIL import Image
+    return [Image.fromarray(r) for r in create_stereoimages_arrays(*args, **kwargs)]
+
+
+# ------------------------------------------------------------------------------------------------
+# normal map
+def _reflect101_idx(n, r):
+    idx = np.arange(-r, n + r)
+    if n == 1:
+        return np.zeros_like(idx)
+    period = 2 * (n - 1)
+    idx = np.abs(idx) % period
+    return np.where(idx >= n, period - idx, idx)
+
+
+def sobel_kernels(ksize, order):
+    """OpenCV getDerivKernels/getSobelKernels for one axis (order 0 = smoothing, 1 = derivative)."""
+    if ksize == 1:
+        return np.array([[0., 1., 0.], [-1., 0., 1.]][order]) if order else np.array([1.0])
+    if ksize == 3:
+        return np.array([[1., 2., 1.], [-1., 0., 1.]][order])
+    ker = np.zeros(ksize + 1)
+    ker[0] = 1
+    for _ in range(ksize - order - 1):
+        old = ker[0]
+        for j in range(1, ksize + 1):
+            new = ker[j] + ker[j - 1]
+            ker[j - 1] = old
+            old = new
+    for _ in range(order):
+        old = -ker[0]
+        for j in range(1, ksize + 1):
+            new = ker[j - 1] - ker[j]
+            ker[j - 1] = old
+            old = new
+    return ker[:ksize].copy()
+
+
+def _sep_filter(a, kx, ky):
+    """Separable correlation with BORDER_REFLECT_101: rows (kx) first, then columns (ky); taps summed in order."""
+    h, w = a.shape[:2]
+    rx, ry = len(kx) // 2, len(ky) // 2
+    ix, iy = _reflect101_idx(w, rx), _reflect101_idx(h, ry)
+    t = np.zeros_like(a)
+    for k, cf in enumerate(kx):
+        t = t + cf * a[:, ix[k:k + w]]
+    o = np.zeros_like(a)
+    for k, cf in enumerate(ky):
+        o = o + cf * t[iy[k:k + h]]
+    return o
+
+
+def gaussian_kernel(ksize, sigma):
+    """cv2.getGaussianKernel(ksize, sigma>0, CV_64F)."""
+    x = np.arange(ksize, dtype=np.float64) - (ksize - 1) * 0.5
+    cf = np.exp((-0.5 / (sigma * sigma)) * x * x)
+    return cf * (1.0 / cf.sum())
+
+
+def create_normalmap_array(depthmap, pre_blur=None, sobel_gradient=3, post_blur=None, invert=False):
+    depthmap = np.asarray(depthmap)
+    if (pre_blur is None or pre_blur <= 0) and (post_blur is None or post_blur <= 0) and depthmap.dtype == np.uint16:
+        h, w = depthmap.shape
+        d = np.ascontiguousarray(depthmap)
+        out = np.empty((h, w, 3), np.uint8)
+        if sobel_gradient == 3:
+            lib().orc_normalmap_sobel3(_p(d, ctypes.c_uint16), h, w, int(bool(invert)), _p(out, ctypes.c_uint8))
+            return out
+        if sobel_gradient is None or sobel_gradient <= 0:
+            lib().orc_normalmap_gradient(_p(d, ctypes.c_uint16), h, w, int(bool(invert)), _p(out, ctypes.c_uint8))
+            return out
+    normalmap = depthmap if invert else depthmap * (-1.0)
+    normalmap = normalmap / 256.0
+    if pre_blur is not None and pre_blur > 0:
+        g = gaussian_kernel(pre_blur, float(pre_blur))
+        normalmap = _sep_filter(np.float64(normalmap), g, g)
+    if sobel_gradient is not None and sobel_gradient > 0:
+        kd, ks = sobel_kernels(sobel_gradient, 1), sobel_kernels(sobel_gradient, 0)
+        zx = _sep_filter(np.float64(normalmap), kd, ks)
+        zy = _sep_filter(np.float64(normalmap), ks, kd)
+    else:
+        zy, zx = np.gradient(normalmap)
+    normal = np.dstack((zx, -zy, np.ones_like(normalmap)))
+    n = np.sqrt(normal[:, :, 0] ** 2 + normal[:, :, 1] ** 2 + normal[:, :, 2] ** 2)
+    normal[:, :, 0] /= n
+    normal[:, :, 1] /= n
+    normal[:, :, 2] /= n
+    if post_blur is not None and post_blur > 0:
+        g = gaussian_kernel(post_blur, float(post_blur))
+        normal = np.dstack([_sep_filter(np.ascontiguousarray(normal[:, :, k]), g, g) for k in range(3)])
+        n = np.sqrt(normal[:, :, 0] ** 2 + normal[:, :, 1] ** 2 + normal[:, :, 2] ** 2)
+        normal[:, :, 0] /= n
+        normal[:, :, 1] /= n
+        normal[:, :, 2] /= n
+    normal += 1
+    normal /= 2
+    normal = np.clip(normal * 256, 0, 256 - 0.1)
+    return normal.astype(np.uint8)
+
+
+def create_normalmap(depthmap, pre_blur=None, sobel_gradient=3, post_blur=None, invert=False):
+    from PIL import Image
+    return Image.fromarray(create_normalmap_array(depthmap, pre_blur, sobel_gradient, post_blur, invert))
+
+
+# ------------------------------------------------------------------------------------------------
+def convert_to_i16(arr):
+    """core.py:44-50."""
+    arr = np.asarray(arr)
+    out = np.empty(arr.shape, np.uint16)
+    if arr.dtype == np.float32:
+        a = np.ascontiguousarray(arr)
+        lib().orc_convert_to_i16_f32(_p(a, ctypes.c_float), a.size, _p(out, ctypes.c_uint16))
+    else:
+        a = np.ascontiguousarray(arr, dtype=np.float64)
+        lib().orc_convert_to_i16_f64(_p(a, ctypes.c_double), a.size, _p(out, ctypes.c_uint16))
+    return out
+
+
+def depth_normalize01(raw_prediction, invert=False):
+    """core.py:189-206 without clipping, float32 predictions."""
+    a = np.ascontiguousarray(raw_prediction, dtype=np.float32)
+    out = np.empty(a.shape, np.float32)
+    lib().orc_depth_normalize01_f32(_p(a, ctypes.c_float), a.size, int(bool(invert)), _p(out, ctypes.c_float))
+    return out
+
+
+def num_threads():
+    return int(lib().orc_num_threads())
