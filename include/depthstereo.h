@@ -1,0 +1,148 @@
+/*
+ * depthstereo.h -- C ABI of libdepthstereo_hip.so: the MI355X (gfx950) replacement for the per-pixel
+ * hot path of thygate/stable-diffusion-webui-depthmap-script v0.4.8.
+ *
+ * The reference has no FFI layer: the path is plain Python/numba.  Each entry point
+ * below names the reference code it replaces (file:line under the reference tree); INTEGRATION.md
+ * shows the ctypes stub a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - every function returns 0 on success, a negative DS_E* code on failure; nothing throws across
+ *     the ABI; ds_last_error() returns a thread-local message for the last failure.
+ *   - all image/depth/output pointers are DEVICE pointers (HBM) owned by the caller; the callee
+ *     never frees or retains them.  Buffers are batched: n images of h x w pixels, c channels,
+ *     pixel-interleaved (HWC), densely packed unless a stride argument says otherwise.
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream).  Calls are
+ *     asynchronous with respect to the host unless stated otherwise.
+ *   - a ds_ctx owns scratch memory (row flags, work lists, min/max slots, LUTs).  One ctx per
+ *     host thread/stream; calls on the same ctx must be issued on one stream at a time.
+ *   - results are bit-identical to the reference (uint8/uint16 outputs); float64 arithmetic is
+ *     done in IEEE-754 binary64 without FMA contraction, in the reference's operation order.
+ */
+#ifndef DEPTHSTEREO_H
+#define DEPTHSTEREO_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DS_VERSION 100
+
+/* error codes */
+#define DS_OK            0
+#define DS_EINVAL       -1   /* bad argument (null pointer, bad shape, unknown enum) */
+#define DS_EUNSUPPORTED -2   /* legal in the reference but outside what the kernels cover */
+#define DS_EHIP         -3   /* a HIP runtime call failed (message has the hipError string) */
+#define DS_ENOMEM       -4
+
+/* depth element types accepted by the stereo entry points */
+#define DS_DEPTH_U16 0       /* what core_generation_funnel passes (core.py:211,253) */
+#define DS_DEPTH_F32 1
+#define DS_DEPTH_F64 2
+
+/* fill techniques, src/stereoimage_generation.py:85-92 */
+#define DS_FILL_NONE                0
+#define DS_FILL_NAIVE               1
+#define DS_FILL_NAIVE_INTERPOLATING 2
+#define DS_FILL_POLYLINES_SOFT      3
+#define DS_FILL_POLYLINES_SHARP     4
+
+typedef struct ds_ctx ds_ctx;
+
+/* library / context ----------------------------------------------------------------------------- */
+int ds_version(void);
+const char *ds_last_error(void);
+/* device = HIP device ordinal the context allocates its scratch on */
+int ds_ctx_create(ds_ctx **out, int device);
+int ds_ctx_destroy(ds_ctx *ctx);
+
+/* One eye of a stereo pair: where it is written and how far pixels move. */
+typedef struct ds_eye {
+    double divergence_px;    /* (divergence/100)*w, signed; stereoimage_generation.py:82 */
+    double separation_px;    /* (separation/100)*w, signed; stereoimage_generation.py:83 */
+    uint8_t *out;            /* device pointer of pixel (image 0, row 0, col 0) of this eye */
+    int64_t out_row_stride;  /* bytes between rows     (w*c for a lone eye, 2*w*c inside a side-by-side) */
+    int64_t out_img_stride;  /* bytes between images */
+} ds_eye;
+
+/*
+ * ds_stereo_warp -- replaces apply_stereo_divergence (src/stereoimage_generation.py:77-92) and the
+ * numba kernels it dispatches to: apply_stereo_divergence_naive (:95-159) and
+ * apply_stereo_divergence_polylines (:162-283).  One call renders n_eyes (1 or 2) views of each of
+ * the n images; min/max normalisation of the depth (:79-81) is done per image on the device.
+ *   image   n*h*w*c uint8, c in 1..4
+ *   depth   n*h*w elements of depth_dtype
+ *   exponent  stereo_offset_exponent.  1.0 is computed directly; any other value needs a host-built
+ *           table (pow must match the host libm): pass pow_lut = device pointer to n*65536 doubles,
+ *           pow_lut[i*65536+v] = ((v-min_i)/(max_i-min_i))**exponent, depth_dtype must be U16.
+ *           pow_lut == NULL with exponent != 1.0 -> DS_EUNSUPPORTED.
+ * Undefined corners of the reference are defined in DESIGN.md ("Defined corners").
+ */
+int ds_stereo_warp(ds_ctx *ctx, const uint8_t *image, const void *depth, int depth_dtype,
+                   int n, int h, int w, int c, double exponent, const double *pow_lut,
+                   int fill, const ds_eye *eyes, int n_eyes, void *stream);
+
+/* Per-image depth min/max as doubles {min,max} (device, n*2 doubles) -- the reduction of
+ * stereoimage_generation.py:79-80 exposed so the host can build pow_lut.  Asynchronous. */
+int ds_depth_minmax(ds_ctx *ctx, const void *depth, int depth_dtype, int n, int h, int w,
+                    double *minmax_out, void *stream);
+
+/* Kernel timing for roofline accounting.  When enabled, ds_stereo_warp brackets its dominant kernel (the naive or
+ * polylines render kernel) and the exact-fallback kernel with HIP events recorded ON THE CALLER'S STREAM;
+ * ds_profile_last_ms synchronises those events and returns the two durations of the most recent call. */
+int ds_profile_enable(ds_ctx *ctx, int enable);
+int ds_profile_last_ms(ds_ctx *ctx, float *render_ms, float *exact_ms);
+
+/* Number of image rows the last ds_stereo_warp on this ctx re-rendered with the exact sequential
+ * sweep (polylines only; see DESIGN.md "exact fallback").  Synchronises the stream. */
+int ds_stereo_last_exact_rows(ds_ctx *ctx, int64_t *rows_out, void *stream);
+
+/*
+ * ds_copy_view -- the "eye is the untouched original" branch of create_stereoimages
+ * (stereoimage_generation.py:46,49) plus the np.hstack/np.vstack copies (:56-62): strided copy of
+ * n images h x (w*c bytes) into a packed output.
+ */
+int ds_copy_view(ds_ctx *ctx, const uint8_t *src, int64_t src_row_stride, int64_t src_img_stride,
+                 uint8_t *dst, int64_t dst_row_stride, int64_t dst_img_stride,
+                 int n, int h, int64_t row_bytes, void *stream);
+
+/*
+ * ds_overlap_red_cyan -- replaces overlap_red_cyan (src/stereoimage_generation.py:286-307):
+ * out[...,0] = im1[...,0]; out[...,1:3] = im2[...,1:3]; out is n*h*w*3 dense.
+ * im1/im2 are addressed with (row, image) byte strides so they can live inside a side-by-side.
+ */
+int ds_overlap_red_cyan(ds_ctx *ctx, const uint8_t *im1, int64_t im1_row_stride, int64_t im1_img_stride,
+                        const uint8_t *im2, int64_t im2_row_stride, int64_t im2_img_stride,
+                        int n, int h, int w, int c, uint8_t *out, void *stream);
+
+/*
+ * ds_normalmap -- replaces create_normalmap (src/normalmap_generation.py:5-56) for uint16 depth.
+ *   pre_blur / post_blur: Gaussian kernel size (odd, >0) or 0 to disable (:23-24, :42-48)
+ *   sobel_ksize: 3 (default) / 1 / 5 / 7 ... odd, or 0 for np.gradient (:27-31)
+ *   out: n*h*w*3 uint8
+ */
+int ds_normalmap(ds_ctx *ctx, const uint16_t *depth, int n, int h, int w, int pre_blur,
+                 int sobel_ksize, int post_blur, int invert, uint8_t *out, void *stream);
+
+/*
+ * ds_depth_to_u16 -- replaces the depth post-processing of core_generation_funnel
+ * (src/core.py:189-206, no-clip branch) followed by convert_to_i16 (src/core.py:44-50) for a batch
+ * of float32 predictions: per image min/max, optional negate (models whose raw output is
+ * near-is-dark), normalise to [0,1] in float32, then clip(x*65536+1e-4, 0, 65535.9) -> uint16.
+ * A flat prediction (max-min <= float64 eps) gives zeros (:204-206).
+ *   pred n*h*w float32; out n*h*w uint16; norm_out (optional, may be NULL) n*h*w float32 = the
+ *   normalised map before quantisation.
+ */
+int ds_depth_to_u16(ds_ctx *ctx, const float *pred, int n, int h, int w, int invert,
+                    uint16_t *out, float *norm_out, void *stream);
+
+/* convert_to_i16 alone (src/core.py:44-50): float32 or float64 input already in [0,1]. */
+int ds_convert_to_i16(ds_ctx *ctx, const void *arr, int is_f64, int64_t count, uint16_t *out, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DEPTHSTEREO_H */

@@ -221,9 +221,16 @@ def _sep_filter(a, kx, ky):
 
 def gaussian_kernel(ksize, sigma):
     """cv2.getGaussianKernel(ksize, sigma>0, CV_64F)."""
-    x = np.arange(ksize, dtype=np.float64) - (ksize - 1) * 0.5
-    cf = np.exp((-0.5 / (sigma * sigma)) * x * x)
-    return cf * (1.0 / cf.sum())
+    import math
+    scale2x = -0.5 / (sigma * sigma)
+    cf, total = [], 0.0
+    for i in range(ksize):                       # OpenCV sums the taps sequentially in double
+        x = i - (ksize - 1) * 0.5
+        t = math.exp(scale2x * x * x)
+        cf.append(t)
+        total += t
+    inv = 1.0 / total
+    return np.array([t * inv for t in cf], dtype=np.float64)
 
 
 def create_normalmap_array(depthmap, pre_blur=None, sobel_gradient=3, post_blur=None, invert=False):

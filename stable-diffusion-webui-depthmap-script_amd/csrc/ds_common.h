@@ -1,0 +1,96 @@
+// Internal helpers shared by the HIP translation units of libdepthstereo_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/depthstereo.h"
+
+#define DS_API extern "C" __attribute__((visibility("default")))
+
+// ---- error plumbing -------------------------------------------------------------------------
+void ds_set_error(const char *fmt, ...);
+
+#define DS_HIP_CHECK(expr)                                                              \
+    do {                                                                                \
+        hipError_t _e = (expr);                                                         \
+        if (_e != hipSuccess) {                                                         \
+            ds_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+            return DS_EHIP;                                                             \
+        }                                                                               \
+    } while (0)
+
+#define DS_REQUIRE(cond, code, ...)      \
+    do {                                 \
+        if (!(cond)) {                   \
+            ds_set_error(__VA_ARGS__);   \
+            return (code);               \
+        }                                \
+    } while (0)
+
+// ---- context ----------------------------------------------------------------------------------
+struct ds_ctx {
+    int device;
+    // growable scratch blocks (device memory)
+    void *minmax;      size_t minmax_bytes;      // n * 2 doubles
+    void *partials;    size_t partials_bytes;    // block partials of the min/max reduction
+    void *row_flags;   size_t row_flags_bytes;   // one int per (image, eye, row) + counters
+    void *row_list;    size_t row_list_bytes;    // compacted list of flagged rows
+    void *exact_ws;    size_t exact_ws_bytes;    // scratch of the exact sequential sweep
+    void *tmp_a;       size_t tmp_a_bytes;       // generic temporaries (normal-map blur planes ...)
+    void *tmp_b;       size_t tmp_b_bytes;
+    int64_t last_exact_rows_valid;
+    // optional kernel timing (ds_profile_enable)
+    int profile;
+    hipEvent_t ev[4];          // render start/stop, exact start/stop
+    int ev_created, ev_recorded;
+};
+
+int ds_ctx_reserve(ds_ctx *ctx, void **slot, size_t *cur, size_t need);
+
+// ---- device helpers -----------------------------------------------------------------------------
+// float64 -> uint8 exactly as numpy/numba do on x86-64: truncate toward zero, keep the low byte.
+__device__ __forceinline__ uint8_t ds_f64_to_u8(double v)
+{
+    if (!(v == v)) return 0;
+    if (v >= 9.2e18 || v <= -9.2e18) return 0;
+    return (uint8_t)(long long)v;
+}
+
+__device__ __forceinline__ double ds_wave_min(double v)
+{
+    for (int o = 32; o > 0; o >>= 1) { double t = __shfl_xor(v, o, 64); v = t < v ? t : v; }
+    return v;
+}
+__device__ __forceinline__ double ds_wave_max(double v)
+{
+    for (int o = 32; o > 0; o >>= 1) { double t = __shfl_xor(v, o, 64); v = t > v ? t : v; }
+    return v;
+}
+
+// Depth normalisation of stereoimage_generation.py:79-81 for one element.
+//   U16: (depth - min) stays uint16, '/' promotes both operands to float64
+//   F32: subtraction and division in float32, the kernel then reads the value as float64
+//   F64: float64 throughout
+template <int DT> struct ds_depth_traits;
+template <> struct ds_depth_traits<DS_DEPTH_U16> {
+    typedef uint16_t T;
+    __device__ static __forceinline__ double norm(T v, double mn, double mx) {
+        return (double)(uint16_t)(v - (uint16_t)mn) / (double)(uint16_t)((uint16_t)mx - (uint16_t)mn);
+    }
+};
+template <> struct ds_depth_traits<DS_DEPTH_F32> {
+    typedef float T;
+    __device__ static __forceinline__ double norm(T v, double mn, double mx) {
+        float den = (float)mx - (float)mn;
+        float q = (v - (float)mn) / den;
+        return (double)q;
+    }
+};
+template <> struct ds_depth_traits<DS_DEPTH_F64> {
+    typedef double T;
+    __device__ static __forceinline__ double norm(T v, double mn, double mx) {
+        return (v - mn) / (mx - mn);
+    }
+};

@@ -1,0 +1,269 @@
+// ds_normalmap: create_normalmap (reference: src/normalmap_generation.py:5-56) on gfx950.
+//
+// Fused path (no blur): one lane per output pixel reads its 3x3 (Sobel) or 4-neighbour (np.gradient)
+// uint16 neighbourhood, does the float64 arithmetic of :20-54 and writes 3 bytes.  With inputs that
+// are multiples of 2^-8 every sum is exact, so only sqrt and the three divisions round -- and those are
+// correctly rounded IEEE operations on the device, hence bit-exact results.
+//
+// General path (Gaussian pre/post blur, other Sobel sizes): separable float64 passes over planes in
+// the context's scratch, rows first then columns, taps accumulated in order (BORDER_REFLECT_101).
+#include <math.h>
+
+#include "ds_common.h"
+
+__device__ __forceinline__ int nm_reflect101(int i, int n)
+{
+    if (n == 1) return 0;
+    while (i < 0 || i >= n) { if (i < 0) i = -i; else i = 2 * (n - 1) - i; }
+    return i;
+}
+
+// normal = (zx, -zy, 1)/|.| ; (+1)/2*256 clipped to [0, 255.9] ; truncate   (:34-39, :51-54)
+__device__ __forceinline__ void nm_store(double zx, double zy, uint8_t *o)
+{
+    const double nx = zx, ny = -zy, nz = 1.0;
+    const double n = sqrt(nx * nx + ny * ny + nz * nz);
+    const double v[3] = { nx / n, ny / n, nz / n };
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        double t = v[k] + 1.0;
+        t = t / 2.0;
+        t = t * 256.0;
+        t = t < 0.0 ? 0.0 : t;
+        t = t > 256.0 - 0.1 ? 256.0 - 0.1 : t;
+        o[k] = ds_f64_to_u8(t);
+    }
+}
+
+#define NM_BX 64
+#define NM_BY 4
+
+template <int SOBEL3>
+__global__ __launch_bounds__(NM_BX * NM_BY) void k_normalmap_fused(const uint16_t *__restrict__ depth, int h, int w, int invert,
+                                                                   uint8_t *__restrict__ out)
+{
+    const int img = blockIdx.z;
+    const int x = blockIdx.x * NM_BX + threadIdx.x;
+    const int y = blockIdx.y * NM_BY + threadIdx.y;
+    if (x >= w || y >= h) return;
+    const uint16_t *d = depth + (size_t)img * h * w;
+    const double sgn = invert ? 1.0 : -1.0;
+#define NMV(yy, xx) (((double)d[(size_t)(yy) * w + (xx)] * sgn) / 256.0)        /* :20-21 */
+    double zx, zy;
+    if (SOBEL3) {
+        const int xm = nm_reflect101(x - 1, w), xp = nm_reflect101(x + 1, w);
+        const int ym = nm_reflect101(y - 1, h), yp = nm_reflect101(y + 1, h);
+        const double p00 = NMV(ym, xm), p01 = NMV(ym, x), p02 = NMV(ym, xp);
+        const double p10 = NMV(y, xm), p12 = NMV(y, xp);
+        const double p20 = NMV(yp, xm), p21 = NMV(yp, x), p22 = NMV(yp, xp);
+        zx = (p02 - p00) + 2.0 * (p12 - p10) + (p22 - p20);                     /* cv2.Sobel dx, ksize 3 */
+        zy = (p20 - p00) + 2.0 * (p21 - p01) + (p22 - p02);                     /* cv2.Sobel dy, ksize 3 */
+    } else {                                                                    /* np.gradient, :31 */
+        if (w == 1) zx = 0.0;
+        else if (x == 0) zx = NMV(y, 1) - NMV(y, 0);
+        else if (x == w - 1) zx = NMV(y, w - 1) - NMV(y, w - 2);
+        else zx = (NMV(y, x + 1) - NMV(y, x - 1)) / 2.0;
+        if (h == 1) zy = 0.0;
+        else if (y == 0) zy = NMV(1, x) - NMV(0, x);
+        else if (y == h - 1) zy = NMV(h - 1, x) - NMV(h - 2, x);
+        else zy = (NMV(y + 1, x) - NMV(y - 1, x)) / 2.0;
+    }
+#undef NMV
+    nm_store(zx, zy, out + ((size_t)img * h * w + (size_t)y * w + x) * 3);
+}
+
+// ---- general path ---------------------------------------------------------------------------------
+#define NM_MAXK 63
+struct NmKernel { double cf[NM_MAXK]; int n; };
+
+__global__ __launch_bounds__(256) void k_nm_load(const uint16_t *__restrict__ depth, int64_t count, int invert, double *__restrict__ plane)
+{
+    const double sgn = invert ? 1.0 : -1.0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (int64_t)gridDim.x * 256)
+        plane[i] = ((double)depth[i] * sgn) / 256.0;
+}
+
+// one separable pass along x (AXIS 0) or y (AXIS 1): out = sum_k cf[k] * in[reflect101(pos + k - r)]
+template <int AXIS>
+__global__ __launch_bounds__(256) void k_nm_sep(const double *__restrict__ in, double *__restrict__ out, int h, int w, NmKernel K)
+{
+    const int img = blockIdx.z;
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= w || y >= h) return;
+    const double *p = in + (size_t)img * h * w;
+    const int r = K.n / 2;
+    double acc = 0.0;
+    for (int k = 0; k < K.n; k++) {
+        double v;
+        if (AXIS == 0) v = p[(size_t)y * w + nm_reflect101(x + k - r, w)];
+        else v = p[(size_t)nm_reflect101(y + k - r, h) * w + x];
+        acc = acc + K.cf[k] * v;
+    }
+    out[(size_t)img * h * w + (size_t)y * w + x] = acc;
+}
+
+__global__ __launch_bounds__(256) void k_nm_gradient(const double *__restrict__ in, double *__restrict__ zx, double *__restrict__ zy, int h, int w)
+{
+    const int img = blockIdx.z;
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= w || y >= h) return;
+    const double *p = in + (size_t)img * h * w;
+#define PV(yy, xx) p[(size_t)(yy) * w + (xx)]
+    double gx, gy;
+    if (w == 1) gx = 0.0;
+    else if (x == 0) gx = PV(y, 1) - PV(y, 0);
+    else if (x == w - 1) gx = PV(y, w - 1) - PV(y, w - 2);
+    else gx = (PV(y, x + 1) - PV(y, x - 1)) / 2.0;
+    if (h == 1) gy = 0.0;
+    else if (y == 0) gy = PV(1, x) - PV(0, x);
+    else if (y == h - 1) gy = PV(h - 1, x) - PV(h - 2, x);
+    else gy = (PV(y + 1, x) - PV(y - 1, x)) / 2.0;
+#undef PV
+    const size_t o = (size_t)img * h * w + (size_t)y * w + x;
+    zx[o] = gx; zy[o] = gy;
+}
+
+// planes n0 = zx, n1 = zy (in) -> unit normal components in n0,n1,n2  (:34-39)
+__global__ __launch_bounds__(256) void k_nm_normalize_first(double *__restrict__ n0, double *__restrict__ n1, double *__restrict__ n2, int64_t count)
+{
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (int64_t)gridDim.x * 256) {
+        const double a = n0[i], b = -n1[i], c = 1.0;
+        const double n = sqrt(a * a + b * b + c * c);
+        n0[i] = a / n; n1[i] = b / n; n2[i] = c / n;
+    }
+}
+
+// optional renormalise (:45-48) then quantise (:51-54)
+__global__ __launch_bounds__(256) void k_nm_finish(const double *__restrict__ n0, const double *__restrict__ n1, const double *__restrict__ n2,
+                                                   int64_t count, int renorm, uint8_t *__restrict__ out)
+{
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (int64_t)gridDim.x * 256) {
+        double v[3] = { n0[i], n1[i], n2[i] };
+        if (renorm) {
+            const double n = sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+            v[0] = v[0] / n; v[1] = v[1] / n; v[2] = v[2] / n;
+        }
+        for (int k = 0; k < 3; k++) {
+            double t = v[k] + 1.0;
+            t = t / 2.0;
+            t = t * 256.0;
+            t = t < 0.0 ? 0.0 : t;
+            t = t > 256.0 - 0.1 ? 256.0 - 0.1 : t;
+            out[i * 3 + k] = ds_f64_to_u8(t);
+        }
+    }
+}
+
+// cv2.getGaussianKernel(ksize, sigma > 0, CV_64F): exp(-x^2/(2 sigma^2)) normalised, sequential sum
+static void nm_gaussian(int ksize, double sigma, NmKernel *K)
+{
+    K->n = ksize;
+    const double scale2x = -0.5 / (sigma * sigma);
+    double sum = 0.0;
+    for (int i = 0; i < ksize; i++) {
+        const double x = (double)i - (double)(ksize - 1) * 0.5;
+        K->cf[i] = exp(scale2x * x * x);
+        sum += K->cf[i];
+    }
+    const double inv = 1.0 / sum;
+    for (int i = 0; i < ksize; i++) K->cf[i] = K->cf[i] * inv;
+}
+
+// cv2.getDerivKernels / getSobelKernels for one axis (order 0 = smoothing, 1 = derivative)
+static int nm_sobel(int ksize, int order, NmKernel *K)
+{
+    if (ksize == 1) {
+        if (order == 0) { K->n = 1; K->cf[0] = 1.0; }
+        else { K->n = 3; K->cf[0] = -1.0; K->cf[1] = 0.0; K->cf[2] = 1.0; }
+        return 0;
+    }
+    if (ksize == 3) {
+        K->n = 3;
+        if (order == 0) { K->cf[0] = 1.0; K->cf[1] = 2.0; K->cf[2] = 1.0; }
+        else { K->cf[0] = -1.0; K->cf[1] = 0.0; K->cf[2] = 1.0; }
+        return 0;
+    }
+    if (ksize + 1 > NM_MAXK) return -1;
+    double ker[NM_MAXK + 1];
+    for (int i = 0; i <= ksize; i++) ker[i] = 0.0;
+    ker[0] = 1.0;
+    for (int i = 0; i < ksize - order - 1; i++) {
+        double oldv = ker[0];
+        for (int j = 1; j <= ksize; j++) { const double nv = ker[j] + ker[j - 1]; ker[j - 1] = oldv; oldv = nv; }
+    }
+    for (int i = 0; i < order; i++) {
+        double oldv = -ker[0];
+        for (int j = 1; j <= ksize; j++) { const double nv = ker[j - 1] - ker[j]; ker[j - 1] = oldv; oldv = nv; }
+    }
+    K->n = ksize;
+    for (int i = 0; i < ksize; i++) K->cf[i] = ker[i];
+    return 0;
+}
+
+DS_API int ds_normalmap(ds_ctx *ctx, const uint16_t *depth, int n, int h, int w, int pre_blur,
+                        int sobel_ksize, int post_blur, int invert, uint8_t *out, void *stream)
+{
+    DS_REQUIRE(ctx && depth && out, DS_EINVAL, "ds_normalmap: null argument");
+    DS_REQUIRE(n > 0 && h > 0 && w > 0, DS_EINVAL, "ds_normalmap: bad shape n=%d h=%d w=%d", n, h, w);
+    DS_REQUIRE(n <= 65535, DS_EUNSUPPORTED, "ds_normalmap: n must be <= 65535");
+    if (pre_blur < 0) pre_blur = 0;
+    if (post_blur < 0) post_blur = 0;
+    if (sobel_ksize < 0) sobel_ksize = 0;
+    DS_REQUIRE((pre_blur == 0 || (pre_blur & 1)) && (post_blur == 0 || (post_blur & 1)), DS_EINVAL,
+               "ds_normalmap: Gaussian kernel sizes must be odd (cv2.GaussianBlur asserts)");
+    DS_REQUIRE(sobel_ksize == 0 || (sobel_ksize & 1), DS_EINVAL, "ds_normalmap: Sobel kernel size must be odd");
+    DS_REQUIRE(pre_blur <= NM_MAXK && post_blur <= NM_MAXK && sobel_ksize < NM_MAXK, DS_EUNSUPPORTED,
+               "ds_normalmap: kernel sizes above %d are not supported", NM_MAXK);
+    if (sobel_ksize == 0) DS_REQUIRE(h >= 2 && w >= 2, DS_EINVAL, "ds_normalmap: np.gradient needs at least 2 samples per axis");
+    DS_HIP_CHECK(hipSetDevice(ctx->device));
+    hipStream_t st = (hipStream_t)stream;
+
+    if (pre_blur == 0 && post_blur == 0 && (sobel_ksize == 3 || sobel_ksize == 0)) {
+        dim3 grid((w + NM_BX - 1) / NM_BX, (h + NM_BY - 1) / NM_BY, n), block(NM_BX, NM_BY);
+        DS_REQUIRE(grid.y <= 65535, DS_EUNSUPPORTED, "ds_normalmap: image too tall");
+        if (sobel_ksize == 3) hipLaunchKernelGGL(k_normalmap_fused<1>, grid, block, 0, st, depth, h, w, invert ? 1 : 0, out);
+        else hipLaunchKernelGGL(k_normalmap_fused<0>, grid, block, 0, st, depth, h, w, invert ? 1 : 0, out);
+        DS_HIP_CHECK(hipGetLastError());
+        return DS_OK;
+    }
+
+    // general path: 5 float64 planes in scratch
+    const int64_t count = (int64_t)n * h * w;
+    int rc = ds_ctx_reserve(ctx, &ctx->tmp_a, &ctx->tmp_a_bytes, (size_t)count * sizeof(double) * 5);
+    if (rc) return rc;
+    double *A = (double *)ctx->tmp_a, *B = A + count, *C = B + count, *D = C + count, *E = D + count;
+    int nb = (int)((count + 1023) / 1024); if (nb > 4096) nb = 4096;
+    dim3 g2((w + 63) / 64, (h + 3) / 4, n);
+    DS_REQUIRE(g2.y <= 65535, DS_EUNSUPPORTED, "ds_normalmap: image too tall");
+    hipLaunchKernelGGL(k_nm_load, dim3(nb), dim3(256), 0, st, depth, count, invert ? 1 : 0, A);
+    NmKernel G, KD, KS;
+    if (pre_blur > 0) {                                            // :23-24
+        nm_gaussian(pre_blur, (double)pre_blur, &G);
+        hipLaunchKernelGGL(k_nm_sep<0>, g2, dim3(256), 0, st, A, B, h, w, G);
+        hipLaunchKernelGGL(k_nm_sep<1>, g2, dim3(256), 0, st, B, A, h, w, G);
+    }
+    // gradients: zx -> C, zy -> D
+    if (sobel_ksize > 0) {                                         // :27-29
+        DS_REQUIRE(nm_sobel(sobel_ksize, 1, &KD) == 0 && nm_sobel(sobel_ksize, 0, &KS) == 0, DS_EUNSUPPORTED, "ds_normalmap: Sobel size");
+        hipLaunchKernelGGL(k_nm_sep<0>, g2, dim3(256), 0, st, A, B, h, w, KD);
+        hipLaunchKernelGGL(k_nm_sep<1>, g2, dim3(256), 0, st, B, C, h, w, KS);
+        hipLaunchKernelGGL(k_nm_sep<0>, g2, dim3(256), 0, st, A, B, h, w, KS);
+        hipLaunchKernelGGL(k_nm_sep<1>, g2, dim3(256), 0, st, B, D, h, w, KD);
+    } else {
+        hipLaunchKernelGGL(k_nm_gradient, g2, dim3(256), 0, st, A, C, D, h, w);
+    }
+    hipLaunchKernelGGL(k_nm_normalize_first, dim3(nb), dim3(256), 0, st, C, D, E, count);
+    if (post_blur > 0) {                                           // :42-48
+        nm_gaussian(post_blur, (double)post_blur, &G);
+        double *planes[3] = { C, D, E };
+        for (int k = 0; k < 3; k++) {
+            hipLaunchKernelGGL(k_nm_sep<0>, g2, dim3(256), 0, st, planes[k], B, h, w, G);
+            hipLaunchKernelGGL(k_nm_sep<1>, g2, dim3(256), 0, st, B, planes[k], h, w, G);
+        }
+    }
+    hipLaunchKernelGGL(k_nm_finish, dim3(nb), dim3(256), 0, st, C, D, E, count, post_blur > 0 ? 1 : 0, out);
+    DS_HIP_CHECK(hipGetLastError());
+    return DS_OK;
+}

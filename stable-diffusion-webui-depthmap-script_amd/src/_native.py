@@ -1,0 +1,225 @@
+"""ctypes binding of libdepthstereo_hip.so (C ABI: include/depthstereo.h) for torch tensors in HBM.
+
+PyTorch is plumbing here: it owns device memory and streams; every per-pixel operation is a
+hand-written HIP kernel reached through the C ABI.  There is NO CPU fallback: if the shared library is
+missing, or no MI355X is visible, the calls raise.
+"""
+import ctypes
+import math
+import os
+import threading
+
+import numpy as np
+
+_PKG_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB_PATH = os.path.join(_PKG_ROOT, "libdepthstereo_hip.so")
+
+DS_DEPTH_U16, DS_DEPTH_F32, DS_DEPTH_F64 = 0, 1, 2
+FILL_IDS = {"none": 0, "naive": 1, "naive_interpolating": 2, "polylines_soft": 3, "polylines_sharp": 4}
+
+EXPORTS = [
+    "ds_version", "ds_last_error", "ds_ctx_create", "ds_ctx_destroy", "ds_stereo_warp", "ds_depth_minmax",
+    "ds_stereo_last_exact_rows", "ds_copy_view", "ds_overlap_red_cyan", "ds_normalmap", "ds_depth_to_u16",
+    "ds_convert_to_i16", "ds_profile_enable", "ds_profile_last_ms",
+]
+
+
+class DepthStereoError(RuntimeError):
+    pass
+
+
+class ds_eye(ctypes.Structure):
+    _fields_ = [("divergence_px", ctypes.c_double), ("separation_px", ctypes.c_double),
+                ("out", ctypes.c_void_p), ("out_row_stride", ctypes.c_int64), ("out_img_stride", ctypes.c_int64)]
+
+
+_lib = None
+_lib_lock = threading.Lock()
+
+
+def lib():
+    """Load the shared library (once).  Raises if it has not been built: there is no fallback."""
+    global _lib
+    with _lib_lock:
+        if _lib is None:
+            if not os.path.exists(LIB_PATH):
+                raise DepthStereoError(
+                    f"{LIB_PATH} is missing: build it with `python __graft_entry__.py build` "
+                    "(hipcc --offload-arch=gfx950).  There is no CPU fallback.")
+            L = ctypes.CDLL(LIB_PATH)
+            vp, ci, cd, i64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_double, ctypes.c_int64
+            L.ds_version.restype = ci
+            L.ds_last_error.restype = ctypes.c_char_p
+            L.ds_ctx_create.argtypes = [ctypes.POINTER(vp), ci]
+            L.ds_ctx_destroy.argtypes = [vp]
+            L.ds_stereo_warp.argtypes = [vp, vp, vp, ci, ci, ci, ci, ci, cd, vp, ci, ctypes.POINTER(ds_eye), ci, vp]
+            L.ds_depth_minmax.argtypes = [vp, vp, ci, ci, ci, ci, vp, vp]
+            L.ds_stereo_last_exact_rows.argtypes = [vp, ctypes.POINTER(i64), vp]
+            L.ds_copy_view.argtypes = [vp, vp, i64, i64, vp, i64, i64, ci, ci, i64, vp]
+            L.ds_overlap_red_cyan.argtypes = [vp, vp, i64, i64, vp, i64, i64, ci, ci, ci, ci, vp, vp]
+            L.ds_normalmap.argtypes = [vp, vp, ci, ci, ci, ci, ci, ci, ci, vp, vp]
+            L.ds_depth_to_u16.argtypes = [vp, vp, ci, ci, ci, ci, vp, vp, vp]
+            L.ds_convert_to_i16.argtypes = [vp, vp, ci, i64, vp, vp]
+            L.ds_profile_enable.argtypes = [vp, ci]
+            L.ds_profile_last_ms.argtypes = [vp, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float)]
+            for name in EXPORTS:          # fail at load time, not at first use, if a symbol is missing
+                getattr(L, name)
+            _lib = L
+    return _lib
+
+
+def _check(rc):
+    if rc != 0:
+        raise DepthStereoError(f"libdepthstereo_hip error {rc}: {lib().ds_last_error().decode(errors='replace')}")
+
+
+_ctxs = {}
+
+
+def ctx_for(device_index):
+    """One ds_ctx per (thread, device)."""
+    key = (threading.get_ident(), int(device_index))
+    c = _ctxs.get(key)
+    if c is None:
+        h = ctypes.c_void_p()
+        _check(lib().ds_ctx_create(ctypes.byref(h), int(device_index)))
+        _ctxs[key] = c = h
+    return c
+
+
+def _torch():
+    import torch
+    return torch
+
+
+def require_gpu():
+    torch = _torch()
+    if not torch.cuda.is_available():
+        raise DepthStereoError("no MI355X visible to torch (torch.cuda.is_available() is False); "
+                               "this package has no CPU path")
+    return torch
+
+
+def _stream(t):
+    torch = _torch()
+    return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+
+def _dev_index(t):
+    torch = _torch()
+    return t.device.index if t.device.index is not None else torch.cuda.current_device()
+
+
+def _depth_dtype_id(t):
+    torch = _torch()
+    if t.dtype in (torch.uint16, torch.int16):
+        return DS_DEPTH_U16
+    if t.dtype == torch.float32:
+        return DS_DEPTH_F32
+    if t.dtype == torch.float64:
+        return DS_DEPTH_F64
+    raise DepthStereoError(f"unsupported device depth dtype {t.dtype}")
+
+
+# ------------------------------------------------------------------------------------------------
+def depth_minmax(depth):
+    """Per-image {min,max} (float64, on device) of a [N,H,W] depth tensor."""
+    torch = require_gpu()
+    n, h, w = depth.shape
+    out = torch.empty((n, 2), dtype=torch.float64, device=depth.device)
+    _check(lib().ds_depth_minmax(ctx_for(_dev_index(depth)), depth.data_ptr(), _depth_dtype_id(depth), n, h, w,
+                                 out.data_ptr(), _stream(depth)))
+    return out
+
+
+def build_pow_lut(depth_u16, exponent):
+    """norm**exponent for every uint16 code of every image, computed on the HOST with libm pow
+    (what `normalized_depth[row][col] ** stereo_offset_exponent` does, stereoimage_generation.py:108,182)."""
+    torch = require_gpu()
+    mm = depth_minmax(depth_u16).cpu().numpy()
+    n = mm.shape[0]
+    lut = np.zeros((n, 65536), np.float64)
+    codes = np.arange(65536, dtype=np.float64)
+    for i in range(n):
+        mn, mx = mm[i]
+        if not mx > mn:
+            lut[i, :] = np.nan
+            continue
+        norm = (codes - mn) / (mx - mn)
+        lo, hi = int(mn), int(mx)
+        vals = [math.pow(x, exponent) for x in norm[lo:hi + 1].tolist()]
+        lut[i, lo:hi + 1] = vals
+    return torch.from_numpy(lut).to(depth_u16.device)
+
+
+def stereo_warp(image, depth, eyes, fill, exponent=1.0, pow_lut=None):
+    """image [N,H,W,C] uint8, depth [N,H,W]; eyes = list of (divergence_px, separation_px, out_tensor_view_ptr,
+    row_stride_bytes, img_stride_bytes)."""
+    require_gpu()
+    assert image.is_contiguous() and depth.is_contiguous()
+    n, h, w, c = image.shape
+    arr = (ds_eye * len(eyes))()
+    for i, (dv, sp, ptr, rs, is_) in enumerate(eyes):
+        arr[i].divergence_px = float(dv)
+        arr[i].separation_px = float(sp)
+        arr[i].out = ptr
+        arr[i].out_row_stride = int(rs)
+        arr[i].out_img_stride = int(is_)
+    _check(lib().ds_stereo_warp(ctx_for(_dev_index(image)), image.data_ptr(), depth.data_ptr(), _depth_dtype_id(depth),
+                                n, h, w, c, float(exponent), pow_lut.data_ptr() if pow_lut is not None else None,
+                                FILL_IDS[fill], arr, len(eyes), _stream(image)))
+
+
+def last_exact_rows(image):
+    v = ctypes.c_int64(0)
+    _check(lib().ds_stereo_last_exact_rows(ctx_for(_dev_index(image)), ctypes.byref(v), _stream(image)))
+    return int(v.value)
+
+
+def profile_enable(device_index, enable=True):
+    _check(lib().ds_profile_enable(ctx_for(device_index), 1 if enable else 0))
+
+
+def profile_last_ms(device_index):
+    """(render_kernel_ms, exact_fallback_ms) of the most recent ds_stereo_warp on this thread's ctx."""
+    a, b = ctypes.c_float(0), ctypes.c_float(0)
+    _check(lib().ds_profile_last_ms(ctx_for(device_index), ctypes.byref(a), ctypes.byref(b)))
+    return float(a.value), float(b.value)
+
+
+def copy_view(src_ptr, src_rs, src_is, dst_ptr, dst_rs, dst_is, n, h, row_bytes, like):
+    _check(lib().ds_copy_view(ctx_for(_dev_index(like)), src_ptr, src_rs, src_is, dst_ptr, dst_rs, dst_is, n, h, row_bytes,
+                              _stream(like)))
+
+
+def overlap_red_cyan(im1_ptr, r1, i1, im2_ptr, r2, i2, n, h, w, c, out):
+    _check(lib().ds_overlap_red_cyan(ctx_for(_dev_index(out)), im1_ptr, r1, i1, im2_ptr, r2, i2, n, h, w, c, out.data_ptr(),
+                                     _stream(out)))
+
+
+def normalmap(depth_u16, pre_blur, sobel_ksize, post_blur, invert):
+    torch = require_gpu()
+    n, h, w = depth_u16.shape
+    out = torch.empty((n, h, w, 3), dtype=torch.uint8, device=depth_u16.device)
+    _check(lib().ds_normalmap(ctx_for(_dev_index(depth_u16)), depth_u16.data_ptr(), n, h, w, int(pre_blur), int(sobel_ksize),
+                              int(post_blur), 1 if invert else 0, out.data_ptr(), _stream(depth_u16)))
+    return out
+
+
+def depth_to_u16(pred_f32, invert=False, want_norm=False):
+    torch = require_gpu()
+    n, h, w = pred_f32.shape
+    out = torch.empty((n, h, w), dtype=torch.uint16, device=pred_f32.device)
+    norm = torch.empty((n, h, w), dtype=torch.float32, device=pred_f32.device) if want_norm else None
+    _check(lib().ds_depth_to_u16(ctx_for(_dev_index(pred_f32)), pred_f32.data_ptr(), n, h, w, 1 if invert else 0,
+                                 out.data_ptr(), norm.data_ptr() if want_norm else None, _stream(pred_f32)))
+    return (out, norm) if want_norm else out
+
+
+def convert_to_i16(arr):
+    torch = require_gpu()
+    assert arr.dtype in (torch.float32, torch.float64) and arr.is_contiguous()
+    out = torch.empty(arr.shape, dtype=torch.uint16, device=arr.device)
+    _check(lib().ds_convert_to_i16(ctx_for(_dev_index(arr)), arr.data_ptr(), 1 if arr.dtype == torch.float64 else 0,
+                                   arr.numel(), out.data_ptr(), _stream(arr)))
+    return out

@@ -1,0 +1,33 @@
+"""Drop-in for the reference's ``src/normalmap_generation.py`` (create_normalmap, :5-56) on HIP kernels."""
+import numpy as np
+from PIL import Image
+
+from . import _native
+
+
+def _ksize(v):
+    return int(v) if v is not None and v > 0 else 0
+
+
+def create_normalmap(depthmap, pre_blur=None, sobel_gradient=3, post_blur=None, invert=False):
+    """Generates normalmaps (reference: src/normalmap_generation.py:5-56).
+    :param depthmap: HxW depthmap (uint16 from the funnel)
+    :param pre_blur: Gaussian blur before the gradient, None/<=0 to disable, otherwise kernel size
+    :param sobel_gradient: Sobel kernel size, None/<=0 for np.gradient
+    :param post_blur: Gaussian blur after the gradient, None/<=0 to disable, otherwise kernel size
+    :param invert: depthmap will be inverted before calculating normalmap
+    """
+    torch = _native.require_gpu()
+    depth = np.asarray(depthmap)
+    if depth.dtype != np.uint16:
+        raise _native.DepthStereoError('create_normalmap: only uint16 depthmaps (what core_generation_funnel passes, '
+                                       'core.py:211,262) are supported, got %s' % depth.dtype)
+    dev = torch.device('cuda', torch.cuda.current_device())
+    d = torch.from_numpy(np.array(depth, order='C')).to(dev).unsqueeze(0)
+    out = create_normalmap_batch(d, pre_blur, sobel_gradient, post_blur, invert)
+    return Image.fromarray(out[0].cpu().numpy())
+
+
+def create_normalmap_batch(depth_u16, pre_blur=None, sobel_gradient=3, post_blur=None, invert=False):
+    """Device-resident batch: uint16 cuda tensor [N,H,W] -> uint8 cuda tensor [N,H,W,3]."""
+    return _native.normalmap(depth_u16.contiguous(), _ksize(pre_blur), _ksize(sobel_gradient), _ksize(post_blur), bool(invert))

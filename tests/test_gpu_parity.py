@@ -1,0 +1,285 @@
+"""GPU parity: the HIP path (through the C ABI / the drop-in Python API) against
+  * the golden vectors produced by the reference's own code (tests/golden/), and
+  * the CPU oracle on seeded sweeps,
+bit-exact (uint8/uint16 outputs).  Nothing here reads /root/reference.
+"""
+import warnings
+
+import numpy as np
+import pytest
+
+import util
+
+pytestmark = pytest.mark.gpu
+
+FILLS = ['none', 'naive', 'naive_interpolating', 'polylines_soft', 'polylines_sharp']
+
+
+@pytest.fixture(scope="module")
+def sg(gpu):
+    import src.stereoimage_generation as sg
+    return sg
+
+
+@pytest.fixture(scope="module")
+def native(gpu):
+    import src._native as nat
+    nat.lib()
+    return nat
+
+
+def test_library_loaded_is_in_tree(native):
+    import os
+    assert os.path.exists(native.LIB_PATH) and native.lib().ds_version() == 100
+
+
+def test_golden_reference_vectors(sg):
+    """Every case the reference itself produced (82 cases: all fills, all modes, RGBA, odd sizes, quantised depth with
+    coincident breakpoints, constant depth, float64 depth, balance extremes, off-frame separation)."""
+    z, index = util.load_stereo_golden()
+    for case in index:
+        img, dep = util.golden_inputs(case)
+        with warnings.catch_warnings():
+            warnings.simplefilter('ignore')
+            res = sg.create_stereoimages(img, dep, case['div'], case['sep'], case['modes'], case['bal'], case['exp'], case['fill'])
+        key = case['name'].replace('/', '__')
+        for m, r in zip(case['modes'], res):
+            g = z[f'{key}__{m}']
+            o = np.asarray(r)
+            assert g.shape == o.shape, (case['name'], m)
+            assert np.array_equal(g, o), (case['name'], m, int((g != o).sum()))
+
+
+def _rand_case(rng, H, W, c=3, kind='noise'):
+    img = rng.integers(0, 256, (H, W, c), dtype=np.uint8)
+    if kind == 'noise':
+        dep = rng.integers(0, 65536, (H, W), dtype=np.uint16)
+    elif kind == 'smooth':
+        dep = (util.smooth_depth(H, W, int(rng.integers(1 << 30))) * 20000 + 20000).clip(0, 65535).astype(np.uint16)
+    elif kind == 'quant':
+        dep = (rng.integers(0, 5, (H, W)) * 16383).astype(np.uint16)
+    else:
+        raise ValueError(kind)
+    if rng.random() < 0.5:
+        img[:, rng.integers(0, W, 3)] = 0
+    return img, dep
+
+
+@pytest.mark.parametrize("fill", FILLS)
+def test_sweep_vs_oracle(sg, oracle, fill):
+    rng = np.random.default_rng(1234)
+    shapes = [(5, 17), (9, 64), (7, 65), (12, 129), (6, 255), (4, 300), (3, 513), (2, 1024), (16, 96)]
+    for i, (H, W) in enumerate(shapes):
+        for kind in ('noise', 'smooth', 'quant'):
+            c = 4 if (i % 4 == 3 and fill != 'naive_interpolating') else 3
+            img, dep = _rand_case(rng, H, W, c, kind)
+            div = float(rng.choice([0.3, 2.5, 5.0, -4.0, 9.0]))
+            sep = float(rng.choice([0.0, 0.0, 1.0, -2.5]))
+            bal = float(rng.choice([0.0, 0.0, 0.4, -0.7]))
+            ex = float(rng.choice([1.0, 1.0, 1.0, 2.0, 0.5]))
+            modes = ['left-right', 'red-cyan-anaglyph'] if c == 3 else ['left-right']
+            want = oracle.create_stereoimages_arrays(img, dep, div, sep, modes, bal, ex, fill)
+            got = sg.create_stereoimages(img, dep, div, sep, modes, bal, ex, fill)
+            for m, w_, g_ in zip(modes, want, got):
+                g_ = np.asarray(g_)
+                assert np.array_equal(w_, g_), (fill, H, W, kind, div, sep, bal, ex, m, int((w_ != g_).sum()))
+
+
+def test_large_divergence_windows(sg, oracle):
+    """Window sizes that need the 2- and 4-word masks of the polylines kernel (|divergence_px| up to ~100)."""
+    rng = np.random.default_rng(77)
+    for W, div in ((640, 12.0), (900, 20.0), (1200, 16.0)):
+        img, dep = _rand_case(rng, 6, W, 3, 'smooth')
+        for fill in ('polylines_sharp', 'polylines_soft', 'naive'):
+            want = oracle.create_stereoimages_arrays(img, dep, div, 0.0, ['left-right'], 0.0, 1.0, fill)[0]
+            got = np.asarray(sg.create_stereoimages(img, dep, div, 0.0, ['left-right'], 0.0, 1.0, fill)[0])
+            assert np.array_equal(want, got), (W, div, fill, int((want != got).sum()))
+
+
+def test_exact_fallback_is_exercised(sg, native, oracle, gpu):
+    """Quantised depth with power-of-two divergence_px makes coincident breakpoints and exact closeness ties:
+    rows must go through the sequential fallback (and still match); smooth depth should not need it."""
+    torch = gpu
+    rng = np.random.default_rng(5)
+    H, W = 32, 256
+    img = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
+    dep_q = (rng.integers(0, 4, (H, W)) * 21845).astype(np.uint16)
+    it = torch.from_numpy(img).cuda().unsqueeze(0)
+    res = sg.create_stereoimages_batch(it, torch.from_numpy(dep_q).cuda().unsqueeze(0), 12.5, 0.0, ['left-right'], 0.0, 1.0,
+                                       'polylines_soft')
+    rows_q = native.last_exact_rows(it)
+    want = oracle.create_stereoimages_arrays(img, dep_q, 12.5, 0.0, ['left-right'], 0.0, 1.0, 'polylines_soft')[0]
+    assert np.array_equal(want, res[0][0].cpu().numpy())
+    assert rows_q > 0
+    dep_s = (util.smooth_depth(H, W, 3) * 20000 + 20000).clip(0, 65535).astype(np.uint16)
+    res = sg.create_stereoimages_batch(it, torch.from_numpy(dep_s).cuda().unsqueeze(0), 5.0, 0.0, ['left-right'], 0.0, 1.0,
+                                       'polylines_sharp')
+    rows_s = native.last_exact_rows(it)
+    want = oracle.create_stereoimages_arrays(img, dep_s, 5.0, 0.0, ['left-right'], 0.0, 1.0, 'polylines_sharp')[0]
+    assert np.array_equal(want, res[0][0].cpu().numpy())
+    assert rows_s <= 2 * H // 8, rows_s
+
+
+def test_float_depth_inputs(sg, oracle):
+    rng = np.random.default_rng(9)
+    img = rng.integers(0, 256, (10, 90, 3), dtype=np.uint8)
+    d32 = util.smooth_depth(10, 90, 4)
+    d64 = d32.astype(np.float64) + rng.random((10, 90)) * 1e-6
+    for dep in (d32, d64, (d64 * 200).astype(np.uint8), (d64 * 1000).astype(np.int32)):
+        for fill in ('naive', 'polylines_sharp'):
+            want = oracle.create_stereoimages_arrays(img, dep, 6.0, 0.0, ['left-right'], 0.0, 1.0, fill)[0]
+            got = np.asarray(sg.create_stereoimages(img, dep, 6.0, 0.0, ['left-right'], 0.0, 1.0, fill)[0])
+            assert np.array_equal(want, got), (dep.dtype, fill, int((want != got).sum()))
+
+
+def test_api_edge_behaviour(sg):
+    img = np.zeros((4, 8, 3), np.uint8)
+    dep = np.arange(32, dtype=np.uint16).reshape(4, 8)
+    assert sg.create_stereoimages(img, dep, 2.5, modes=[]) == []
+    with pytest.raises(Exception, match='Unknown mode'):
+        sg.create_stereoimages(img, dep, 2.5, modes=['sideways'])
+    with pytest.raises(AssertionError):
+        sg.create_stereoimages(img, dep[:, :4], 2.5)
+    out = sg.create_stereoimages(img, dep, 2.5, modes='left-only')       # non-list mode is wrapped
+    assert len(out) == 1 and out[0].size == (8, 4)
+    assert len(sg.create_stereoimages(img, dep, 2.5)) == 1               # default ['left-right']
+    assert sg.apply_stereo_divergence(img, dep, 2.5, 0.0, 1.0, 'bogus') is None
+
+
+def test_batch_equals_single(sg, gpu):
+    """A batch normalises every image by its own min/max: N-batch == N single calls (byte identical)."""
+    torch = gpu
+    img, dep = util.survey_inputs(40, 200, 3, n=3)
+    dep = dep.copy()
+    dep[1] //= 2
+    dep[2, :, :100] = 7
+    it, dt = torch.from_numpy(img).cuda(), torch.from_numpy(dep).cuda()
+    for fill in ('polylines_sharp', 'naive_interpolating'):
+        b = sg.create_stereoimages_batch(it, dt, 3.0, 0.5, ['top-bottom', 'red-cyan-anaglyph', 'right-left'], 0.2, 1.0, fill)
+        for i in range(3):
+            s = sg.create_stereoimages_batch(it[i:i + 1], dt[i:i + 1], 3.0, 0.5, ['top-bottom', 'red-cyan-anaglyph', 'right-left'],
+                                             0.2, 1.0, fill)
+            for bb, ss in zip(b, s):
+                assert torch.equal(bb[i], ss[0])
+
+
+def test_normalmap_vs_oracle(gpu, oracle):
+    import src.normalmap_generation as nm
+    rng = np.random.default_rng(11)
+    deps = [rng.integers(0, 65536, (33, 70), dtype=np.uint16),
+            (util.smooth_depth(50, 41, 2) * 20000 + 20000).clip(0, 65535).astype(np.uint16),
+            util.survey_inputs(48, 64, 1)[1][0]]
+    for dep in deps:
+        for inv in (False, True):
+            for args in ((None, 3, None), (None, None, None), (None, 5, None), (None, 1, None), (None, 7, None)):
+                want = oracle.create_normalmap_array(dep, args[0], args[1], args[2], inv)
+                got = np.asarray(nm.create_normalmap(dep, args[0], args[1], args[2], inv))
+                assert np.array_equal(want, got), (dep.shape, inv, args, int((want != got).sum()))
+
+
+def test_normalmap_blur_paths_vs_oracle(gpu, oracle):
+    """Gaussian pre/post blur: parity with the oracle's restatement (OpenCV's own summation order is unpinned)."""
+    import src.normalmap_generation as nm
+    dep = (util.smooth_depth(40, 52, 8) * 20000 + 20000).clip(0, 65535).astype(np.uint16)
+    for args in ((3, 3, None), (None, 3, 3), (5, 3, 5), (3, None, 3)):
+        want = oracle.create_normalmap_array(dep, *args, False)
+        got = np.asarray(nm.create_normalmap(dep, *args, False))
+        assert np.array_equal(want, got), (args, int((want != got).sum()))
+
+
+def test_depth_to_u16_vs_oracle(native, oracle, gpu):
+    torch = gpu
+    preds = np.stack([util.smooth_depth(64, 80, s) * (s + 1) - s for s in range(4)])
+    preds[3] = 2.5      # flat prediction -> zeros
+    t = torch.from_numpy(preds).cuda()
+    for inv in (False, True):
+        out, norm = native.depth_to_u16(t, inv, want_norm=True)
+        for i in range(4):
+            n_ref = oracle.depth_normalize01(preds[i], inv)
+            assert np.array_equal(norm[i].cpu().numpy(), n_ref)
+            assert np.array_equal(out[i].cpu().numpy(), oracle.convert_to_i16(n_ref))
+
+
+def test_convert_to_i16_vs_oracle(gpu, oracle):
+    import src.core as core
+    rng = np.random.default_rng(2)
+    a = np.concatenate([rng.random(5000), [0.0, 1.0, 0.99999999, 1e-12, -0.3, 1.7]])
+    assert np.array_equal(core.convert_to_i16(a), oracle.convert_to_i16(a))
+    a32 = a.astype(np.float32)
+    assert np.array_equal(core.convert_to_i16(a32), oracle.convert_to_i16(a32))
+
+
+def test_funnel_golden(gpu):
+    """core_generation_funnel (custom-depth branch) against what the reference's own funnel yielded."""
+    from PIL import Image
+    import src.core as core
+    z, index = util.load_funnel_golden()
+    img = z['image']
+    for case in index:
+        d = z[f"{case['name']}__depth_in"]
+        if case['name'].startswith('pil'):
+            d = Image.fromarray(d)
+        got = list(core.core_generation_funnel(None, [Image.fromarray(img)], [d], None, case['opts']))
+        assert [[int(i), k] for i, k, _ in got] == case['kinds']
+        for j, (idx, kind, res) in enumerate(got):
+            want = z[f"{case['name']}__{j}__{kind}"]
+            have = np.asarray(res)
+            assert want.shape == have.shape and want.dtype == have.dtype, (case['name'], kind)
+            assert np.array_equal(want, have), (case['name'], kind)
+    assert core.run_depthmap is core.core_generation_funnel
+    assert list(core.core_generation_funnel(None, [], None, None, {})) == []
+
+
+def test_funnel_model_branch_with_registered_predictor(gpu, oracle):
+    from PIL import Image
+    import src.core as core
+    torch = gpu
+    rng = np.random.default_rng(4)
+    img = rng.integers(0, 256, (48, 72, 3), dtype=np.uint8)
+    pred = util.smooth_depth(48, 72, 6)
+    core.model_holder.register_predictor(4, lambda pil, nw, nh, dev: torch.from_numpy(pred).to(dev))
+    core.model_holder.register_predictor(0, lambda pil, nw, nh, dev: torch.from_numpy(pred).to(dev))
+    for mt, inv in ((4, False), (0, True)):
+        got = list(core.core_generation_funnel(None, [Image.fromarray(img)], None, None,
+                                               {'model_type': mt, 'gen_stereo': True, 'gen_normalmap': True,
+                                                'stereo_modes': ['left-right']}))
+        assert [k for _, k, _ in got] == ['depth', 'left-right', 'normalmap']
+        d16 = oracle.convert_to_i16(oracle.depth_normalize01(pred, inv))
+        assert np.array_equal(np.asarray(got[0][2]), d16)
+        sbs = oracle.create_stereoimages_arrays(img, d16, 2.5, 0.0, ['left-right'], 0.0, 1.0, 'polylines_sharp')[0]
+        assert np.array_equal(np.asarray(got[1][2]), sbs)
+        assert np.array_equal(np.asarray(got[2][2]), oracle.create_normalmap_array(d16))
+    with pytest.raises(NotImplementedError):
+        list(core.core_generation_funnel(None, [Image.fromarray(img)], None, None, {'model_type': 1}))
+    with pytest.raises(NotImplementedError):
+        list(core.core_generation_funnel(None, [Image.fromarray(img)], [pred], None, {'gen_rembg': True}))
+
+
+def test_full_size_properties(sg, native, oracle, gpu):
+    """BASELINE size (1024x1024): size-independent properties on the whole batch, plus the oracle on a subset of rows
+    (row 500 is made to hold the image's min and max so the subset normalises like the full image)."""
+    torch = gpu
+    img, dep = util.survey_inputs(1024, 1024, 0, n=2)
+    dep = dep.copy()
+    dep[:, 500, 0] = 0
+    dep[:, 500, 1] = 65535
+    it, dt = torch.from_numpy(img).cuda(), torch.from_numpy(dep).cuda()
+    sbs, ana = sg.create_stereoimages_batch(it, dt, 2.5, 0.0, ['left-right', 'red-cyan-anaglyph'], 0.0, 1.0, 'polylines_sharp')
+    assert tuple(sbs.shape) == (2, 1024, 2048, 3) and tuple(ana.shape) == (2, 1024, 1024, 3)
+    s = sbs.cpu().numpy()
+    a = ana.cpu().numpy()
+    # anaglyph = red of the left half + green/blue of the right half
+    assert np.array_equal(a[..., 0], s[:, :, :1024, 0]) and np.array_equal(a[..., 1:], s[:, :, 1024:, 1:])
+    # zero divergence: both eyes are the picture itself (every pixel is covered by its own segments, total weight < 1)
+    z = sg.create_stereoimages_batch(it, dt, 0.0, 0.0, ['left-right'], 0.0, 1.0, 'polylines_sharp')[0].cpu().numpy()
+    assert np.array_equal(z[:, :, :1024], img) and np.array_equal(z[:, :, 1024:], img)
+    rows = [0, 255, 256, 500, 511, 777, 1023]
+    for fill in ('polylines_sharp', 'polylines_soft', 'naive', 'naive_interpolating', 'none'):
+        got = sg.create_stereoimages_batch(it, dt, 2.5, 0.0, ['left-right'], 0.0, 1.0, fill)[0].cpu().numpy()
+        for i in range(2):
+            want = oracle.create_stereoimages_arrays(img[i, rows], dep[i, rows], 2.5, 0.0, ['left-right'], 0.0, 1.0, fill)[0]
+            assert np.array_equal(want, got[i, rows]), (fill, i, int((want != got[i, rows]).sum()))
+    # normal map at full size against the oracle (cheap on the CPU)
+    import src.normalmap_generation as nm
+    nmap = nm.create_normalmap_batch(dt).cpu().numpy()
+    assert np.array_equal(nmap[0], oracle.create_normalmap_array(dep[0]))

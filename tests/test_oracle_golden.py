@@ -1,0 +1,94 @@
+"""CPU: the C oracle reproduces every reference-generated golden vector bit for bit.
+
+The fixtures under tests/golden/ were produced by running the reference's own Python code
+(tests/golden/make_golden.py); SURVEY.md Appendix A hashes are asserted when they are generated and again here.
+"""
+import hashlib
+import warnings
+
+import numpy as np
+import pytest
+
+import util
+
+h16 = lambda a: hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()[:16]
+
+
+def test_appendix_a_input_hashes():
+    img, dep = util.survey_inputs(48, 64, 1)
+    assert h16(img[0]) == 'c2f6d254fbd9afe6' and h16(dep[0]) == 'dcbaca95416947e6'
+    img, dep = util.survey_inputs(96, 128, 2)
+    assert h16(img[0]) == '962470ffe997cea7' and h16(dep[0]) == 'f7f1494b03dcb398'
+
+
+def test_oracle_matches_reference_golden(oracle):
+    z, index = util.load_stereo_golden()
+    assert len(index) >= 80
+    for case in index:
+        img, dep = util.golden_inputs(case)
+        with warnings.catch_warnings():
+            warnings.simplefilter('ignore')
+            res = oracle.create_stereoimages_arrays(img, dep, case['div'], case['sep'], case['modes'], case['bal'],
+                                                    case['exp'], case['fill'])
+        key = case['name'].replace('/', '__')
+        for m, o in zip(case['modes'], res):
+            g = z[f'{key}__{m}']
+            assert g.shape == o.shape, (case['name'], m)
+            assert np.array_equal(g, o), (case['name'], m, int((g != o).sum()))
+
+
+def test_oracle_appendix_a_hashes(oracle):
+    import make_golden as mg
+    for (prefix, fill), (sbs, ana) in mg.SURVEY_A.items():
+        case = next(c for c in mg.stereo_case_list() if c['name'] == f'{prefix}/{fill}')
+        img, dep = mg.gen_inputs(case)
+        r = oracle.create_stereoimages_arrays(img, dep, case['div'], case['sep'], case['modes'], case['bal'], case['exp'], fill)
+        assert (h16(r[0]), h16(r[1])) == (sbs, ana), (prefix, fill)
+
+
+def test_oracle_normalmap_known_answers(oracle):
+    # SURVEY.md Appendix A (restatement-derived): default path on the Appendix A depth arrays
+    _, dep = util.survey_inputs(48, 64, 1)
+    nm = oracle.create_normalmap_array(dep[0])
+    assert h16(nm) == 'bc1264e3fb8eb3d2' and int(nm.sum()) == 1027584 and tuple(nm[0, 0]) == (128, 128, 255)
+    _, dep = util.survey_inputs(96, 128, 2)
+    nm = oracle.create_normalmap_array(dep[0])
+    assert h16(nm) == 'c3a9ce0f64a2f5e3' and int(nm.sum()) == 4218191
+
+
+def test_oracle_normalmap_c_equals_numpy(oracle):
+    # the fused C paths (Sobel 3, np.gradient) against the generic numpy restatement
+    rng = np.random.default_rng(5)
+    dep = rng.integers(0, 65536, (37, 53), dtype=np.uint16)
+    for inv in (False, True):
+        a = oracle.create_normalmap_array(dep, None, 3, None, inv)
+        zx = oracle._sep_filter(np.float64(dep if inv else dep * -1.0) / 256.0, oracle.sobel_kernels(3, 1), oracle.sobel_kernels(3, 0))
+        assert a.shape == (37, 53, 3) and zx.shape == (37, 53)
+        # numpy path via a fake float depth to force the generic branch
+        normalmap = (dep if inv else dep * (-1.0)) / 256.0
+        zy_, zx_ = np.gradient(normalmap)
+        g = oracle.create_normalmap_array(dep, None, None, None, inv)
+        n = np.sqrt(zx_ ** 2 + zy_ ** 2 + 1.0)
+        ref = np.clip(((np.dstack((zx_ / n, -zy_ / n, 1.0 / n)) + 1) / 2) * 256, 0, 255.9).astype(np.uint8)
+        assert np.array_equal(g, ref)
+
+
+def test_oracle_convert_to_i16(oracle):
+    rng = np.random.default_rng(3)
+    a = np.concatenate([rng.random(1000), [0.0, 1.0, 0.999999, 1e-9, -0.5, 1.5]])
+    ref = np.clip(a * 65536 + 0.0001, 0, 65536 - 0.1).astype("uint16")
+    assert np.array_equal(oracle.convert_to_i16(a), ref)
+    a32 = a.astype(np.float32)
+    ref32 = np.clip(a32 * 65536 + 0.0001, 0, 65536 - 0.1).astype("uint16")
+    assert np.array_equal(oracle.convert_to_i16(a32), ref32)
+
+
+def test_oracle_depth_normalize(oracle):
+    p = util.smooth_depth(40, 60, 1)
+    for inv in (False, True):
+        out = np.copy(p)
+        if inv:
+            out *= -1
+        ref = (out - out.min()) / (out.max() - out.min())
+        assert np.array_equal(oracle.depth_normalize01(p, inv), ref)
+    assert not oracle.depth_normalize01(np.full((4, 4), 3.0, np.float32)).any()
