@@ -270,9 +270,13 @@ def test_full_size_properties(sg, native, oracle, gpu):
     a = ana.cpu().numpy()
     # anaglyph = red of the left half + green/blue of the right half
     assert np.array_equal(a[..., 0], s[:, :, :1024, 0]) and np.array_equal(a[..., 1:], s[:, :, 1024:, 1:])
-    # zero divergence: both eyes are the picture itself (every pixel is covered by its own segments, total weight < 1)
-    z = sg.create_stereoimages_batch(it, dt, 0.0, 0.0, ['left-right'], 0.0, 1.0, 'polylines_sharp')[0].cpu().numpy()
-    assert np.array_equal(z[:, :, :1024], img) and np.array_equal(z[:, :, 1024:], img)
+    # zero divergence: the scatter kernels move nothing, both eyes are the picture itself
+    for fill in ('none', 'naive', 'naive_interpolating'):
+        z = sg.create_stereoimages_batch(it, dt, 0.0, 0.0, ['left-right'], 0.0, 1.0, fill)[0].cpu().numpy()
+        assert np.array_equal(z[:, :, :1024], img) and np.array_equal(z[:, :, 1024:], img)
+    # balance -1 / +1: one eye is the untouched original, the other carries the whole divergence
+    zl = sg.create_stereoimages_batch(it, dt, 2.5, 0.0, ['left-right'], -1.0, 1.0, 'polylines_sharp')[0].cpu().numpy()
+    assert np.array_equal(zl[:, :, :1024], img) and not np.array_equal(zl[:, :, 1024:], img)
     rows = [0, 255, 256, 500, 511, 777, 1023]
     for fill in ('polylines_sharp', 'polylines_soft', 'naive', 'naive_interpolating', 'none'):
         got = sg.create_stereoimages_batch(it, dt, 2.5, 0.0, ['left-right'], 0.0, 1.0, fill)[0].cpu().numpy()
