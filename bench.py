@@ -37,6 +37,9 @@ HBM_PEAK_GBPS = 8000.0            # MI355X HBM3E spec peak (guides/MI355X_MICROA
 ALGO_BYTES_PER_UNIT = 11 * H * W  # read RGB 3HW + depth u16 2HW, write two eyes 6HW
 
 
+DEPTH_KIND = "steps"
+
+
 def synth_batch(batch, seed):
     """Synthetic inputs of SURVEY.md 8(d): seeded RGB noise; depth prediction = smooth field with ramps, periodic steps
     and large occluders (float32, arbitrary scale, like a MiDaS output)."""
@@ -47,10 +50,11 @@ def synth_batch(batch, seed):
     for i in range(batch):
         ph = rng.uniform(0, 6.28, 4).astype(np.float32)
         f = 0.5 * xx / W + 0.25 * np.sin(xx / 97.0 + ph[0]) * np.cos(yy / 61.0 + ph[1]) + 0.05 * np.sin(xx / 9.0 + ph[2])
-        f += 0.1 * (((xx // 64 + yy // 64) % 2) == 0)
-        x0, y0 = int(rng.integers(0, W // 2)), int(rng.integers(0, H // 2))
-        f[y0:y0 + H // 4, x0:x0 + W // 3] += 0.8
-        f[(3 * H) // 4:, : W // 5] -= 0.4
+        if DEPTH_KIND != "smooth":
+            f += 0.1 * (((xx // 64 + yy // 64) % 2) == 0)
+            x0, y0 = int(rng.integers(0, W // 2)), int(rng.integers(0, H // 2))
+            f[y0:y0 + H // 4, x0:x0 + W // 3] += 0.8
+            f[(3 * H) // 4:, : W // 5] -= 0.4
         pred[i] = f * 37.0 + 5.0
     return img, pred
 
@@ -79,9 +83,13 @@ def main():
     ap.add_argument("--batch", type=int, default=32, help="units per GPU per step")
     ap.add_argument("--fill", default="polylines_sharp")
     ap.add_argument("--gather", action="store_true", help="gather the collated outputs to rank 0 (N > 1)")
+    ap.add_argument("--depth", default="steps", choices=["steps", "smooth"],
+                    help="synthetic prediction: smooth field + periodic steps + occluders (default), or smooth only")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=4)
     args = ap.parse_args()
+    global DEPTH_KIND
+    DEPTH_KIND = args.depth
 
     import torch
     import torch.distributed as dist
@@ -149,7 +157,7 @@ def main():
         r, e = nat.profile_last_ms(local_rank)
         render_ms.append(r)
         exact_ms.append(e)
-    exact_rows = nat.last_exact_rows(img)
+    exact_rows, queue_chunks = nat.last_stats(img)
     torch.cuda.synchronize()
 
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
@@ -184,7 +192,7 @@ def main():
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
                          "algorithmic_bytes_per_launch": args.batch * ALGO_BYTES_PER_UNIT,
                          "avg_kernel_ms": float(np.mean(render_ms)), "exact_fallback_ms": float(np.mean(exact_ms)),
-                         "exact_fallback_rows": exact_rows},
+                         "exact_fallback_rows": exact_rows, "general_pixel_chunks": queue_chunks},
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args.cpu_sample, seed=1000)

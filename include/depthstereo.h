@@ -99,6 +99,9 @@ int ds_profile_last_ms(ds_ctx *ctx, float *render_ms, float *exact_ms);
 /* Number of image rows the last ds_stereo_warp on this ctx re-rendered with the exact sequential
  * sweep (polylines only; see DESIGN.md "exact fallback").  Synchronises the stream. */
 int ds_stereo_last_exact_rows(ds_ctx *ctx, int64_t *rows_out, void *stream);
+/* Same, plus the number of queue chunks (128 pixels each, partly filled) the polylines kernel handed to its
+ * general-pixel kernel: stats_out[0] = exact rows, stats_out[1] = queue chunks.  Synchronises the stream. */
+int ds_stereo_last_stats(ds_ctx *ctx, int64_t *stats_out, void *stream);
 
 /*
  * ds_copy_view -- the "eye is the untouched original" branch of create_stereoimages

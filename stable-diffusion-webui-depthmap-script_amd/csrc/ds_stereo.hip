@@ -232,3 +232,16 @@ DS_API int ds_stereo_last_exact_rows(ds_ctx *ctx, int64_t *rows_out, void *strea
     *rows_out = v;
     return DS_OK;
 }
+
+DS_API int ds_stereo_last_stats(ds_ctx *ctx, int64_t *stats_out, void *stream)
+{
+    DS_REQUIRE(ctx && stats_out, DS_EINVAL, "ds_stereo_last_stats: null argument");
+    stats_out[0] = stats_out[1] = 0;
+    if (ctx->last_exact_rows_valid <= 0 || !ctx->row_flags) return DS_OK;
+    DS_HIP_CHECK(hipSetDevice(ctx->device));
+    int v[2] = { 0, 0 };
+    DS_HIP_CHECK(hipMemcpyAsync(v, (int *)ctx->row_flags + ctx->last_exact_rows_valid, 2 * sizeof(int), hipMemcpyDeviceToHost, (hipStream_t)stream));
+    DS_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
+    stats_out[0] = v[0]; stats_out[1] = v[1];
+    return DS_OK;
+}

@@ -20,7 +20,7 @@ FILL_IDS = {"none": 0, "naive": 1, "naive_interpolating": 2, "polylines_soft": 3
 EXPORTS = [
     "ds_version", "ds_last_error", "ds_ctx_create", "ds_ctx_destroy", "ds_stereo_warp", "ds_depth_minmax",
     "ds_stereo_last_exact_rows", "ds_copy_view", "ds_overlap_red_cyan", "ds_normalmap", "ds_depth_to_u16",
-    "ds_convert_to_i16", "ds_profile_enable", "ds_profile_last_ms",
+    "ds_convert_to_i16", "ds_profile_enable", "ds_profile_last_ms", "ds_stereo_last_stats",
 ]
 
 
@@ -60,6 +60,7 @@ def lib():
             L.ds_normalmap.argtypes = [vp, vp, ci, ci, ci, ci, ci, ci, ci, vp, vp]
             L.ds_depth_to_u16.argtypes = [vp, vp, ci, ci, ci, ci, vp, vp, vp]
             L.ds_convert_to_i16.argtypes = [vp, vp, ci, i64, vp, vp]
+            L.ds_stereo_last_stats.argtypes = [vp, ctypes.POINTER(i64), vp]
             L.ds_profile_enable.argtypes = [vp, ci]
             L.ds_profile_last_ms.argtypes = [vp, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float)]
             for name in EXPORTS:          # fail at load time, not at first use, if a symbol is missing
@@ -174,6 +175,13 @@ def last_exact_rows(image):
     v = ctypes.c_int64(0)
     _check(lib().ds_stereo_last_exact_rows(ctx_for(_dev_index(image)), ctypes.byref(v), _stream(image)))
     return int(v.value)
+
+
+def last_stats(image):
+    """(rows re-rendered by the exact sweep, queue chunks of general pixels) of the last polylines call."""
+    v = (ctypes.c_int64 * 2)()
+    _check(lib().ds_stereo_last_stats(ctx_for(_dev_index(image)), v, _stream(image)))
+    return int(v[0]), int(v[1])
 
 
 def profile_enable(device_index, enable=True):
