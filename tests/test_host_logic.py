@@ -1,0 +1,141 @@
+"""CPU: host-side logic of the drop-in (no GPU compute): option bundle, constants, the C ABI's exported symbols,
+loud failure without a GPU, shard arithmetic."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+import conftest
+
+
+def test_cabi_exports_every_declared_symbol():
+    """include/depthstereo.h is the contract: every function it declares must be exported by the built library."""
+    hdr = open(os.path.join(conftest.ROOT, "include", "depthstereo.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = sorted(set(re.findall(r"\b(ds_[a-z0-9_]+)\s*\(", hdr)))
+    assert len(declared) >= 12 and "ds_stereo_warp" in declared and "ds_normalmap" in declared
+    import src._native as nat
+    assert os.path.exists(nat.LIB_PATH), "libdepthstereo_hip.so must be built in-tree (python __graft_entry__.py build)"
+    L = ctypes.CDLL(nat.LIB_PATH)
+    for name in declared:
+        assert hasattr(L, name), f"{name} is declared in depthstereo.h but not exported"
+    assert sorted(nat.EXPORTS) == declared, "src/_native.py binds a different set of symbols than the header declares"
+    L.ds_version.restype = ctypes.c_int
+    assert L.ds_version() == 100
+    L.ds_last_error.restype = ctypes.c_char_p
+    assert isinstance(L.ds_last_error(), bytes)
+
+
+def test_cabi_argument_validation_without_gpu():
+    """Entry points reject bad arguments with an error code and a message instead of crashing (no GPU needed)."""
+    import src._native as nat
+    L = nat.lib()
+    assert L.ds_ctx_create(None, 0) != 0
+    assert b"NULL" in L.ds_last_error() or b"null" in L.ds_last_error().lower()
+    assert L.ds_ctx_destroy(None) == 0
+    assert L.ds_stereo_warp(None, None, None, 0, 1, 1, 1, 3, 1.0, None, 4, None, 2, None) != 0
+    assert L.ds_normalmap(None, None, 1, 1, 1, 0, 3, 0, 0, None, None) != 0
+    assert L.ds_depth_to_u16(None, None, 1, 1, 1, 0, None, None, None) != 0
+
+
+def test_product_path_fails_loudly_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is visible")
+    import src._native as nat
+    import src.stereoimage_generation as sg
+    import src.normalmap_generation as nm
+    img = np.zeros((4, 8, 3), np.uint8)
+    dep = np.arange(32, dtype=np.uint16).reshape(4, 8)
+    with pytest.raises(nat.DepthStereoError, match="no MI355X"):
+        sg.create_stereoimages(img, dep, 2.5)
+    with pytest.raises(nat.DepthStereoError, match="no MI355X"):
+        nm.create_normalmap(dep)
+    # cheap argument handling happens before the device is needed, like in the reference
+    assert sg.create_stereoimages(img, dep, 2.5, modes=[]) == []
+
+
+def test_product_code_never_imports_the_oracle():
+    """The oracle is test infrastructure: nothing under the package may import or call it."""
+    pkg = conftest.PKG
+    for root, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h")):
+                txt = open(os.path.join(root, f), errors="ignore").read()
+                assert "oracle" not in txt.lower() or f == "depthmap_generation.py" and False, (root, f)
+
+
+def test_generation_options_contract():
+    """Names, order and defaults of the funnel options (the reference's GenerationOptions, common_constants.py:4-66)."""
+    from src.common_constants import GenerationOptions as go
+    names = [o.name for o in go]
+    assert names[:7] == ['COMPUTE_DEVICE', 'MODEL_TYPE', 'BOOST', 'NET_SIZE_MATCH', 'NET_WIDTH', 'NET_HEIGHT', 'TILING_MODE']
+    assert len(names) == 41 and [o.value for o in go] == list(range(1, 42))
+    assert go.STEREO_MODES.df == ["left-right", "red-cyan-anaglyph"]
+    assert go.STEREO_DIVERGENCE.df == 2.5 and go.STEREO_FILL_ALGO.df == "polylines_sharp" and go.STEREO_BALANCE.df == 0.0
+    assert go.NORMALMAP_SOBEL.df is True and go.NORMALMAP_SOBEL_KERNEL.df == 3 and go.DO_OUTPUT_DEPTH.df is True
+    assert go.NET_WIDTH.df == 448 and go.CLIPDEPTH_NEAR.df == 1.0 and go.REMBG_MODEL.df == "u2net"
+
+
+def test_funnel_inp_bundle():
+    from src.common_constants import GenerationOptions as go
+    from src.core import CoreGenerationFunnelInp
+    inp = CoreGenerationFunnelInp({'GEN_STEREO': True, go.STEREO_DIVERGENCE: 4.0, 'no_such_option': 1})
+    assert inp[go.GEN_STEREO] is True and inp['gen_stereo'] is True and inp.gen_stereo is True
+    assert inp[go.STEREO_DIVERGENCE] == 4.0
+    assert inp[go.STEREO_MODES] == ["left-right", "red-cyan-anaglyph"]         # default filled in
+    assert 'no_such_option' not in inp.values                                    # unknown keys dropped silently
+    assert CoreGenerationFunnelInp(inp).values == inp.values                      # idempotent
+
+
+def test_convert_i16_to_rgb_host_helper():
+    from src.core import convert_i16_to_rgb
+    img = np.array([[0, 255, 256, 65535]], dtype=np.uint16)
+    like = np.zeros((1, 4, 3), np.uint8)
+    out = convert_i16_to_rgb(img, like)
+    assert out.dtype == np.uint8 and out[0, :, 0].tolist() == [0, 0, 1, 255] and np.array_equal(out[..., 0], out[..., 2])
+
+
+def test_custom_depth_ingest_matches_reference_rules():
+    """core.py:145-174: bit depth is guessed from the maximum; RGB depth uses channel 0 / 256."""
+    from PIL import Image
+    from src.core import _custom_depth_to_float
+    image = Image.new('RGB', (6, 4))
+    d8 = Image.fromarray(np.full((4, 6), 200, np.uint8))
+    assert np.allclose(_custom_depth_to_float(d8, image), 200 / 256.0)
+    d16 = Image.fromarray(np.full((4, 6), 40000, np.uint16))
+    assert np.allclose(_custom_depth_to_float(d16, image), 40000 / 65536.0)
+    drgb = Image.fromarray(np.full((4, 6, 3), 64, np.uint8))
+    assert np.allclose(_custom_depth_to_float(drgb, image), 0.25)
+    arr = np.random.default_rng(0).random((4, 6))
+    assert np.array_equal(_custom_depth_to_float(arr, image), arr)
+    with pytest.raises(AssertionError):
+        _custom_depth_to_float(np.zeros((3, 6)), image)
+    small = Image.fromarray(np.full((2, 3), 100, np.uint8))
+    assert _custom_depth_to_float(small, image).shape == (4, 6)                  # resized to the image (LANCZOS)
+
+
+def test_model_holder_refuses_missing_models():
+    from src.depthmap_generation import ModelHolder
+    mh = ModelHolder()
+    assert mh.get_default_net_size(1) == [512, 512] and mh.get_default_net_size(14) == [518, 518]
+    with pytest.raises(NotImplementedError):
+        mh.ensure_models(1, 'cpu', False)
+    with pytest.raises(NotImplementedError):
+        mh.ensure_models(0, 'cpu', True)
+    mh.update_settings(boost_rmax=1600, no_half=True)
+    assert mh.boost_rmax == 1600 and mh.no_half is True
+
+
+def test_shard_bounds():
+    from src.multigpu import shard_bounds
+    assert shard_bounds(32, 8) == [(i * 4, i * 4 + 4) for i in range(8)]
+    assert shard_bounds(10, 4) == [(0, 3), (3, 6), (6, 9), (9, 10)]
+    assert shard_bounds(2, 4) == [(0, 1), (1, 2), (2, 2), (2, 2)]
+    assert shard_bounds(0, 3) == [(0, 0)] * 3
+    for n in range(0, 40):
+        for w in range(1, 9):
+            b = shard_bounds(n, w)
+            assert b[0][0] == 0 and b[-1][1] == n and all(b[i][1] == b[i + 1][0] for i in range(w - 1))
