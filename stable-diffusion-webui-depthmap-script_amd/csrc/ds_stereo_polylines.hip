@@ -5,63 +5,79 @@
 // every output pixel walks the sub-intervals between consecutive sorted points, keeping an "active
 // set" of segments and taking the colour of the closest one.
 //
-// Here every OUTPUT PIXEL is evaluated independently (one lane per pixel).  Points are kept in
-// ORIGINAL order in one array pt[k]; segment g runs from pt[g-1] to pt[g].
+// Here every OUTPUT PIXEL is evaluated independently (one lane per pixel).  Points stay in ORIGINAL
+// order in one LDS array pt[q]; segment q runs from pt[q-1] to pt[q].
 //
-//   * SIMPLE pixels.  Crossings of a vertical line x = c by the polyline (a continuous path from the
+//   * SIMPLE pixels.  Crossings of a vertical line x = t by the polyline (a continuous path from the
 //     -w sentinel to the 2w sentinel) alternate forward, backward, forward, ...  If no backward (or
-//     zero-length) segment overlaps the strip [col, col+1] the path is monotone inside the strip:
-//     the segments overlapping it are a contiguous run g0..g1 of forward segments, the sub-intervals
-//     of the pixel are exactly their pieces [max(x0,col), min(x1,col+1)] in that order, and each
+//     zero-length) segment overlaps the closed strip [col, col+1] the path is monotone inside it: the
+//     segments overlapping the strip are a contiguous run of forward segments, the sub-intervals of
+//     the pixel are exactly their pieces [max(x0,col), min(x1,col+1)] in that order, and each
 //     sub-interval has exactly one active segment, which the reference takes without looking at its
-//     closeness (csg_end == 1, :259).  The lane just walks g0..g1: no sort, no search.
-//     Which pixels are simple is established by binning (LDS atomics: min g, max g, forward/backward
-//     counts per pixel) and is self-checking: simple <=> no backward overlap and #forward == g1-g0+1.
-//   * GENERAL pixels (folds: occlusion boundaries, noisy depth) enumerate their breakpoints
-//     (points with floor(x) == col among pt[g0-1..g1]) and test every forward segment in g0..g1
-//     with the reference's rule: active <=> x0 < c and not (x1 < c), which is the reference's active
-//     set as long as the centres c are non-decreasing along the row, i.e. every sub-interval has
-//     positive length.  The winner rule (strict '>' on interpolated closeness, 0 < ip < 1) is order
-//     independent unless two valid candidates tie exactly or none is valid.
+//     closeness (csg_end == 1, :259).  The run starts at the one forward segment that ENTERS the pixel
+//     (floor(x0) < col <= floor(x1)); entering segments write their index into a per-pixel table while
+//     the points are computed (one LDS max per pixel entered), backward segments write a BAD mark into
+//     the same table, so "simple" costs the pixel one LDS read: no sort, no search, no binning pass.
+//   * GENERAL pixels (BAD: folds at occlusion boundaries, noisy depth; or more than 6 pieces) collect
+//     the forward segments that overlap the strip and the points inside it from a conservative source
+//     window (the wave tests 64 candidates at a time and hands the pixel's lane two bit masks), visit the
+//     points in sorted order, and apply the reference's rule per sub-interval: active <=> x0 < c and
+//     not (x1 < c), which is the reference's active set as long as the centres c are non-decreasing
+//     along the row, i.e. every sub-interval has positive length.  The winner rule (strict '>' on
+//     interpolated closeness, 0 < ip < 1) is order independent unless two valid candidates tie exactly
+//     or none is valid.
 // A pixel that hits a history-dependent situation (non-positive significance, empty active set,
-// exact tie, no valid candidate among >= 2) raises a flag for its ROW, and flagged rows are
-// re-rendered by k_polylines_exact: a statement-by-statement sequential transliteration of the
-// reference (one lane per row).  The result is therefore bit-identical to the reference for every
+// exact tie, no valid candidate among >= 2, list overflow, NaN) raises a flag for its ROW, and flagged
+// rows are re-rendered by k_polylines_exact: a statement-by-statement sequential transliteration of
+// the reference (one lane per row).  The result is therefore bit-identical to the reference for every
 // input; the fallback only costs time.  All arithmetic is IEEE binary64, compiled with
 // -ffp-contract=off, in the reference's operation order.
 //
-// Mapping to the machine: one WAVE (64-thread workgroup) renders 64 consecutive pixels of one row for
-// BOTH eyes; LDS scratch is private to the wave and there is no cross-wave barrier.  Workgroups are
-// persistent and walk (image, row, tile) work items with a grid stride.  Per work item the wave stages
-// what the eyes share (normalised depth: one float64 division per source column; the pixel bytes) with
-// coalesced loads -- |shift| <= |divergence_px| bounds the source window to tile + ~|divergence_px| + 7
-// columns -- then per eye computes the point coordinates, bins, renders out of LDS and writes the
-// tile's bytes with dword stores.
+// Mapping to the machine.  A 256-thread workgroup is persistent and walks (image, row, supertile) work
+// items; a supertile is S output pixels (S = the whole row when it fits) rendered for BOTH eyes from one
+// staging of what the eyes share:
+//   P01  each thread takes 4 consecutive source columns of the window: one 8-byte depth load + one
+//        12-byte pixel load, float64 normalisation (one division per column), both eyes' points written
+//        to LDS as aligned 16-byte pairs, entry table updated.                          -- barrier --
+//   P2   one lane per output pixel and eye: entry table -> 7 point coordinates + 4 packed RGBX words
+//        from LDS -> up to 6 predicated pieces -> bytes into an LDS output row.  General pixels go to an
+//        LDS queue.                                                                      -- barrier --
+//   P3   queued pixels, densely packed one per lane, evaluated from the same LDS staging. -- barrier --
+//        (skipped, with its barrier, when the queue is empty)
+//   S0   (start of the next work item) the finished output rows leave LDS as 16-byte stores.
+// HBM sees each input byte once per supertile (+ the window halo) and each output byte once.
 #include <stdlib.h>
 
 #include "ds_common.h"
 
-#define PL_TILE 64
+#define PL_THREADS 256
 #define PL_EPS 1e-7
-#define PL_QCHUNK 128      // queue chunk: entry 0 is the header {count}, entries 1..count are pixels
+#define PL_BAD 0x40000000u
+#define PL_KMAX 4            // general pixels: candidate segments are examined 64 at a time, up to PL_KMAX words
+#define PL_PT_PAD 10         // pt[] entries past the last real point (tail sentinel + fast-path over-read)
 
 struct PolyParams {
     const uint8_t *img;
     const void *depth;
     const double *minmax;      // n * {min,max}
     const double *lut;         // optional n*65536 table of norm**exponent (uint16 depth only)
-    int n, h, w, c;
+    int depth_dtype;
+    int n, h, w;
     int n_eyes;
+    int S;                     // supertile: output pixels per work item (multiple of 64)
+    int nwmax;                 // capacity of the source window in columns (multiple of 4)
+    int al4;                   // rows start 4-element aligned: vector loads allowed
+    int nseg;                  // candidate segments per general pixel (max over the eyes)
+    int K;                     // 64-segment words covering the per-pixel candidate window (> PL_KMAX: general pixels go to the exact sweep)
     double div_px[2], sep_px[2];
     uint8_t *out[2];
     int64_t ors[2], ois[2];
     int offL[2], offU[2];      // per-pixel source-column window [col+offL, col+offU]
     int *row_flags;            // one int per (image, eye, row)
     int *row_list;             // flagged rows, compacted
-    int *counters;             // [0] = number of flagged rows, [1] = number of queued (general) pixels
-    int4 *queue;               // general pixels in chunks of PL_QCHUNK: {rowid, col, g0, g1}, g absolute (col*NP + side)
-    int queue_chunks;          // capacity in chunks
+    int *counters;             // [0] = number of flagged rows, [1] = number of general pixels (statistics)
     int dbg;                   // DS_PL_DEBUG ablation knob (0 = off); results are WRONG when set
+    unsigned long long *prof;  // optional (DS_PL_PROF=1): 8 cycle accumulators, wave 0 of every workgroup
 };
 
 // coord_d of stereoimage_generation.py:182 for one depth element (used by the exact kernel)
@@ -76,256 +92,6 @@ __device__ __forceinline__ double pl_coord_d(const PolyParams &P, int img, const
     return nd * div_px;
 }
 
-// ---- wave-private LDS view ------------------------------------------------------------------------
-// Window columns are indexed i = j - ju0.  Points: k = i*NP + side (NP = 2 sharp: xl, xr; 1 soft), plus the
-// sentinels k = -1 (x = -w) when the window starts at column 0 and k = kend (x = 2w) when it ends at w-1.
-template <int SHARP> struct PlView {
-    static constexpr int NP = SHARP ? 2 : 1;
-    const double *ptp;         // ptp[k], k >= -1
-    const double *ad;          // |coord_d| per window column
-    const uint8_t *src;        // c bytes per window column
-    int ju0, c, ncol;          // ncol = number of window columns staged (union window of the two eyes)
-    int kfirst, klast;         // real points of this eye: kfirst..klast
-    int ghead, gtail;          // sentinel segment ids (or -1000000 when absent)
-
-    __device__ __forceinline__ double pt(int k) const { return ptp[k]; }
-    __device__ __forceinline__ int col_of(int k) const { const int kk = min(max(k, kfirst), klast); return SHARP ? (kk >> 1) : kk; }
-    __device__ __forceinline__ double dd(int k) const { return (k < kfirst || k > klast) ? 0.0 : ad[SHARP ? (k >> 1) : k]; }
-    __device__ __forceinline__ double pix(int colw, int ch) const { return (double)src[(size_t)colw * c + ch]; }
-};
-
-// The same interface over GLOBAL memory for one (image, eye, row): point k is an absolute index
-// (k = col*NP + side, -1 and NP*w are the sentinels); coordinates are recomputed on the fly.
-template <int DT, int SHARP> struct PlRowView {
-    static constexpr int NP = SHARP ? 2 : 1;
-    const typename ds_depth_traits<DT>::T *depth_row;
-    const uint8_t *src_row;
-    const double *lut;         // already offset to the image, or null
-    double mn, mx, div_px, sep_px;
-    int w, c;
-    int kfirst, klast;         // 0 .. NP*w-1
-    int ghead, gtail;          // 0 and NP*w
-
-    __device__ __forceinline__ double coord_d(int col) const {
-        const typename ds_depth_traits<DT>::T v = depth_row[col];
-        double nd;
-        if (DT == DS_DEPTH_U16 && lut != nullptr) nd = lut[(unsigned)v];
-        else nd = ds_depth_traits<DT>::norm(v, mn, mx);
-        return nd * div_px;                                                          // :182
-    }
-    __device__ __forceinline__ double pt(int k) const {
-        if (k < 0) return -1.0 * (double)w;                                          // :179
-        if (k > klast) return 2.0 * (double)w;                                       // :191
-        const int col = SHARP ? (k >> 1) : k;
-        const double coord_x = (double)col + 0.5 + coord_d(col) + sep_px;            // :183
-        if (!SHARP) return coord_x;
-        return (k & 1) ? coord_x + 0.45 : coord_x - 0.45;                            // :188-189
-    }
-    __device__ __forceinline__ int col_of(int k) const { const int kk = min(max(k, kfirst), klast); return SHARP ? (kk >> 1) : kk; }
-    __device__ __forceinline__ double dd(int k) const { return (k < kfirst || k > klast) ? 0.0 : fabs(coord_d(SHARP ? (k >> 1) : k)); }
-    __device__ __forceinline__ double pix(int col, int ch) const { return (double)src_row[(size_t)col * c + ch]; }
-};
-
-// colour of one sub-interval once its segment is known (stereoimage_generation.py:270-279)
-template <class View>
-__device__ __forceinline__ void pl_add_flat(const View &V, int colw, double significance, double *color)
-{
-#pragma unroll
-    for (int k = 0; k < 4; k++)
-        if (k < V.c) color[k] += V.pix(colw, k) * significance;                      // :273
-}
-
-template <class View>
-__device__ __forceinline__ void pl_add_lerp(const View &V, int cl, int cr, double x0, double x1, double coord_center,
-                                            double significance, double *color)
-{
-    const double ip_k = (coord_center - x0) / (x1 - x0);                             // :276
-#pragma unroll
-    for (int k = 0; k < 4; k++)
-        if (k < V.c) {
-            const double u = V.pix(cl, k) * (1.0 - ip_k);
-            const double v = V.pix(cr, k) * ip_k;
-            color[k] += (u + v) * significance;                                      // :277-279
-        }
-}
-
-// SIMPLE pixel: one piece of segment g inside pixel [fq, fq1]
-template <bool FLAT, class View>
-__device__ __forceinline__ void pl_piece(const View &V, int g, double fq, double fq1, double *color, int &flag)
-{
-    const double x0 = V.pt(g - 1), x1 = V.pt(g);
-    const double a = x0 > fq ? x0 : fq;                                              // max(col, pt[pt_i][0])      :235
-    const double b = x1 < fq1 ? x1 : fq1;                                            // min(col + 1, pt[pt_i+1][0]) :236
-    const double coord_from = a + PL_EPS;
-    const double coord_to = b - PL_EPS;
-    const double significance = coord_to - coord_from;                               // :237
-    const double coord_center = coord_from + 0.5 * significance;                     // :239
-    if (!(significance > 0.0)) flag = 1;
-    if (FLAT) pl_add_flat(V, V.col_of(g), significance, color);
-    else pl_add_lerp(V, V.col_of(g - 1), V.col_of(g), x0, x1, coord_center, significance, color);
-}
-
-// GENERAL pixel: one sub-interval [a, b]; candidates are the forward segments among g0..g1 (:235-279)
-template <class View>
-__device__ __forceinline__ void pl_subinterval(const View &V, int g0, int g1, double a, double b, double *color, int &flag)
-{
-    const double coord_from = a + PL_EPS;                                            // :235
-    const double coord_to = b - PL_EPS;                                              // :236
-    const double significance = coord_to - coord_from;                               // :237
-    const double coord_center = coord_from + 0.5 * significance;                     // :239
-    if (!(significance > 0.0)) flag = 1;     // centres may stop being monotone: history dependent
-
-    // active set = { g : x0 < c and not (x1 < c) }  (:242-253)
-    int count = 0, win = -1;
-    for (int g = g0; g <= g1; g++) {
-        const double x0 = V.pt(g - 1), x1 = V.pt(g);
-        if (x0 < coord_center && !(x1 < coord_center)) { if (count == 0) win = g; count++; }
-    }
-    if (count == 0) { flag = 1; return; }    // reference reads a stale csg[0]
-    if (count != 1) {                                                                // :259
-        double best = -PL_EPS;                                                       // :261
-        bool have = false;
-        win = -1;
-        for (int g = g0; g <= g1; g++) {
-            const double x0 = V.pt(g - 1), x1 = V.pt(g);
-            if (x0 < coord_center && !(x1 < coord_center)) {
-                const double ip_k = (coord_center - x0) / (x1 - x0);                 // :263
-                const double closeness = (1.0 - ip_k) * V.dd(g - 1) + ip_k * V.dd(g);   // :265
-                const bool valid = 0.0 < ip_k && ip_k < 1.0;
-                if (valid && have && closeness == best) flag = 1;                    // exact tie: csg order decides
-                if (best < closeness && valid) { best = closeness; win = g; have = true; }   // :266
-            }
-        }
-        if (!have) { flag = 1; return; }     // reference falls back to csg[0]
-    }
-    const int cl = V.col_of(win - 1), cr = V.col_of(win);
-    if (cl == cr) pl_add_flat(V, cl, significance, color);                           // :272
-    else pl_add_lerp(V, cl, cr, V.pt(win - 1), V.pt(win), coord_center, significance, color);
-}
-
-template <class View>
-__device__ __forceinline__ void pl_render_general(const View &V, int g0, int g1, double fq, double fq1, double *color, int &flag)
-{
-    // breakpoints: points k in g0-1..g1 with floor(x) == col, visited in (x, k) order
-    double a = fq, last_x = 0.0;
-    int last_k = -1000000;
-    bool first = true;
-    for (;;) {
-        double b = fq1;
-        int bk = -1000000;
-        for (int k = max(g0 - 1, V.kfirst); k <= min(g1, V.klast); k++) {
-            const double x = V.pt(k);
-            if (!(x < fq) && x < fq1) {
-                const bool after = first || x > last_x || (x == last_x && k > last_k);
-                if (after && (bk == -1000000 || x < b)) { b = x; bk = k; }
-            }
-        }
-        const bool more = bk != -1000000;
-        if (!more) b = fq1;
-        pl_subinterval(V, g0, g1, a, b, color, flag);
-        if (!more) break;
-        a = b; last_x = b; last_k = bk; first = false;
-    }
-}
-
-// SIMPLE pixel, SHARP, at most 3 column pairs (6 segments): everything the lane needs is loaded up front
-// (7 point coordinates, 4 columns of pixel bytes) so the LDS latency is paid once, then the pieces are evaluated
-// with predication instead of loops.  Slot layout: pair j (j = 0,1,2) = { even g = ge0 + 2j : incoming (lerp),
-// odd g + 1 : body (flat) }.
-struct PlPx { double v[4]; };
-
-template <int SHARP>
-__device__ __forceinline__ void pl_render_simple_sharp(const PlView<SHARP> &V, int g0, int g1, double fq, double fq1, bool third,
-                                                       double *color, int &flag)
-{
-    const int ge0 = g0 & ~1;
-    const int ib = ge0 >> 1;                         // window column of pair 0
-    const int c = V.c;
-    const int ncm1 = V.ncol - 1;
-    // points ge0-1 .. ge0+5, indices clamped into the staged range (clamped values are never used)
-    const int klo = V.ghead == 0 ? -1 : V.kfirst, khi = V.gtail >= 0 ? V.gtail : V.klast;
-    double p[7];
-#pragma unroll
-    for (int t = 0; t < 7; t++) {
-        if (t < 5 || third) p[t] = V.ptp[min(max(ge0 - 1 + t, klo), khi)];
-        else p[t] = 0.0;
-    }
-    // pixel bytes of columns ib-1 .. ib+2
-    PlPx px[4];
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-        if (j < 3 || third) {
-            const uint8_t *q = V.src + (size_t)min(max(ib - 1 + j, 0), ncm1) * c;
-#pragma unroll
-            for (int k = 0; k < 4; k++) px[j].v[k] = (k < c) ? (double)q[k] : 0.0;
-        } else {
-#pragma unroll
-            for (int k = 0; k < 4; k++) px[j].v[k] = 0.0;
-        }
-    }
-#pragma unroll
-    for (int j = 0; j < 3; j++) {
-        if (j == 2 && !third) break;
-        const int ge = ge0 + 2 * j;
-        // ---- even slot: incoming segment (pt[ge-1] -> pt[ge]), colours of columns ib+j-1 and ib+j
-        if (ge >= g0 && ge <= g1) {
-            const double x0 = p[2 * j], x1 = p[2 * j + 1];
-            const double a = x0 > fq ? x0 : fq;                                              // :235
-            const double b = x1 < fq1 ? x1 : fq1;                                            // :236
-            const double coord_from = a + PL_EPS;
-            const double coord_to = b - PL_EPS;
-            const double significance = coord_to - coord_from;                               // :237
-            const double coord_center = coord_from + 0.5 * significance;                     // :239
-            if (!(significance > 0.0)) flag = 1;
-            if (ge == V.ghead || ge == V.gtail) {
-                // sentinel segment: both colour indices are the edge column (:179,:191) -> flat
-                const int cc = V.col_of(ge);
-                const uint8_t *q = V.src + (size_t)cc * c;
-#pragma unroll
-                for (int k = 0; k < 4; k++)
-                    if (k < c) color[k] += (double)q[k] * significance;                      // :273
-            } else {
-                const double ip_k = (coord_center - x0) / (x1 - x0);                         // :276
-                const double om = 1.0 - ip_k;
-#pragma unroll
-                for (int k = 0; k < 4; k++)
-                    if (k < c) {
-                        const double u = px[j].v[k] * om;
-                        const double v = px[j + 1].v[k] * ip_k;
-                        color[k] += (u + v) * significance;                                  // :277-279
-                    }
-            }
-        }
-        // ---- odd slot: body segment (pt[ge] -> pt[ge+1]), colour of column ib+j
-        const int go = ge + 1;
-        if (go >= g0 && go <= g1) {
-            const double x0 = p[2 * j + 1], x1 = p[2 * j + 2];
-            const double a = x0 > fq ? x0 : fq;
-            const double b = x1 < fq1 ? x1 : fq1;
-            const double coord_from = a + PL_EPS;
-            const double coord_to = b - PL_EPS;
-            const double significance = coord_to - coord_from;
-            if (!(significance > 0.0)) flag = 1;
-#pragma unroll
-            for (int k = 0; k < 4; k++)
-                if (k < c) color[k] += px[j + 1].v[k] * significance;                        // :273
-        }
-    }
-}
-
-__device__ __forceinline__ void pl_store_tile(const uint8_t *s_out, uint8_t *dst, int nbytes, int tid)
-{
-    if ((((uintptr_t)dst) & 3) == 0) {
-        const int nw4 = nbytes >> 2;
-        const uint32_t *s4 = reinterpret_cast<const uint32_t *>(s_out);
-        uint32_t *d4 = reinterpret_cast<uint32_t *>(dst);
-        for (int i = tid; i < nw4; i += PL_TILE) d4[i] = s4[i];
-        for (int i = (nw4 << 2) + tid; i < nbytes; i += PL_TILE) dst[i] = s_out[i];
-    } else {
-        for (int i = tid; i < nbytes; i += PL_TILE) dst[i] = s_out[i];
-    }
-}
-
 __device__ __forceinline__ void pl_flag_row(const PolyParams &P, int img, int eye, int row)
 {
     const int rowid = (img * P.n_eyes + eye) * P.h + row;
@@ -335,225 +101,801 @@ __device__ __forceinline__ void pl_flag_row(const PolyParams &P, int img, int ey
     }
 }
 
-static size_t pl_lds_bytes(int ncu_max, int c)
+// float64 -> uint8 for a colour accumulator that is known to be finite and small
+__device__ __forceinline__ uint32_t pl_u8(double v) { return (uint32_t)(int)v & 0xffu; }
+
+// ---- P01 helpers ------------------------------------------------------------------------------------
+// Normalised depth (:79-81) of 4 consecutive columns j..j+3 (the first nv are real) and of column j-1.
+//
+// uint16: numerator a = v - min and denominator b = max - min are integers <= 65535.  With y = 1/b (one correctly
+// rounded division per thread and work item), q0 = a*y, r = fma(-b, q0, a), q = fma(r, y, q0) IS the correctly
+// rounded a/b for every such pair -- checked exhaustively (all 2^32 pairs) by oracle/check_u16_division.c -- so the
+// per-column float64 division costs 3 instructions instead of the ~11 of the generic expansion.
+__device__ __forceinline__ void pl_load_nd(const PolyParams &P, const void *depth_row, int j, int nv, bool hasprev,
+                                           double mn, double mx, const double *lut, double *nd, double &ndp)
 {
-    // nd, ad (ncu_max doubles each), pt (2*ncu_max+2 doubles), gmin/gmax/cnt (PL_TILE ints each), out (PL_TILE*4), src
-    return (size_t)(4 * ncu_max + 2) * sizeof(double) + 3 * PL_TILE * sizeof(int) + PL_TILE * 4 + (size_t)ncu_max * c + 16;
+    if (P.depth_dtype == DS_DEPTH_U16) {
+        const uint16_t *d = (const uint16_t *)depth_row;
+        uint32_t v[4] = { 0, 0, 0, 0 };
+        if (nv == 4 && P.al4) {
+            const uint2 raw = *reinterpret_cast<const uint2 *>(d + j);
+            v[0] = raw.x & 0xffffu; v[1] = raw.x >> 16; v[2] = raw.y & 0xffffu; v[3] = raw.y >> 16;
+        } else {
+#pragma unroll
+            for (int m = 0; m < 4; m++) if (m < nv) v[m] = d[j + m];
+        }
+        const uint32_t vp = hasprev ? d[j - 1] : 0u;
+        if (lut != nullptr) {                                                       // norm ** exponent, host-built
+#pragma unroll
+            for (int m = 0; m < 4; m++) nd[m] = lut[v[m]];
+            ndp = lut[vp];
+        } else {
+            const uint32_t mn16 = (uint32_t)mn & 0xffffu;
+            const double b = (double)(((uint32_t)mx - mn16) & 0xffffu);
+            const double y = 1.0 / b;
+#pragma unroll
+            for (int m = 0; m < 4; m++) {
+                const double a = (double)((v[m] - mn16) & 0xffffu);                 // uint16 subtraction (:81)
+                const double q0 = a * y;
+                nd[m] = fma(fma(-b, q0, a), y, q0);
+            }
+            const double a = (double)((vp - mn16) & 0xffffu);
+            const double q0 = a * y;
+            ndp = fma(fma(-b, q0, a), y, q0);
+        }
+    } else if (P.depth_dtype == DS_DEPTH_F32) {
+        const float *d = (const float *)depth_row;
+        float v[4] = { 0.f, 0.f, 0.f, 0.f };
+        if (nv == 4 && P.al4) {
+            const float4 raw = *reinterpret_cast<const float4 *>(d + j);
+            v[0] = raw.x; v[1] = raw.y; v[2] = raw.z; v[3] = raw.w;
+        } else {
+#pragma unroll
+            for (int m = 0; m < 4; m++) if (m < nv) v[m] = d[j + m];
+        }
+        const float vp = hasprev ? d[j - 1] : 0.f;
+        const float mnf = (float)mn, den = (float)mx - (float)mn;
+#pragma unroll
+        for (int m = 0; m < 4; m++) nd[m] = (double)((v[m] - mnf) / den);
+        ndp = (double)((vp - mnf) / den);
+    } else {
+        const double *d = (const double *)depth_row;
+        double v[4] = { 0., 0., 0., 0. };
+        if (nv == 4 && P.al4) {
+            const double2 a = *reinterpret_cast<const double2 *>(d + j), b = *reinterpret_cast<const double2 *>(d + j + 2);
+            v[0] = a.x; v[1] = a.y; v[2] = b.x; v[3] = b.y;
+        } else {
+#pragma unroll
+            for (int m = 0; m < 4; m++) if (m < nv) v[m] = d[j + m];
+        }
+        const double vp = hasprev ? d[j - 1] : 0.;
+        const double den = mx - mn;
+#pragma unroll
+        for (int m = 0; m < 4; m++) nd[m] = (v[m] - mn) / den;
+        ndp = (vp - mn) / den;
+    }
 }
 
-template <int DT, int SHARP>
-__global__ __launch_bounds__(PL_TILE) void k_polylines(PolyParams P)
+// Pixel bytes of 4 consecutive columns -> one RGBX word per column (channel k in byte k).
+template <int C>
+__device__ __forceinline__ void pl_load_rgbx(const uint8_t *src, int nv, bool al4, uint32_t *rgbx)
+{
+    uint32_t raw[C];
+    if (nv == 4 && al4) {
+        const uint32_t *s32 = reinterpret_cast<const uint32_t *>(src);
+#pragma unroll
+        for (int k = 0; k < C; k++) raw[k] = s32[k];
+    } else {
+#pragma unroll
+        for (int k = 0; k < C; k++) {
+            uint32_t v = 0;
+#pragma unroll
+            for (int b = 0; b < 4; b++) if ((k * 4 + b) < nv * C) v |= (uint32_t)src[k * 4 + b] << (8 * b);
+            raw[k] = v;
+        }
+    }
+#pragma unroll
+    for (int m = 0; m < 4; m++) {
+        uint32_t v = 0;
+#pragma unroll
+        for (int k = 0; k < C; k++) {
+            const int b = m * C + k;
+            v |= ((raw[b >> 2] >> (8 * (b & 3))) & 0xffu) << (8 * k);
+        }
+        rgbx[m] = v;
+    }
+}
+
+// Entry table.  A forward segment q = (x0 -> x1) ENTERS pixels floor(x0)+1 .. floor(x1); a backward or zero-length
+// one marks every pixel it touches as BAD.  g0 = table of the current eye, indexed by pixel - c0; f0/f1 = floors.
+// Common case first (a forward segment that enters exactly one pixel, or none); everything else is the slow path.
+__device__ __forceinline__ void pl_scatter_slow(uint32_t *g0, double x0, double x1, int f0, int f1, uint32_t q, int c0, int tn)
+{
+    if (x0 < x1) {
+        const int lo = max(f0 + 1, c0) - c0;
+        const int hi = min(f1, c0 + tn - 1) - c0;
+        for (int p = lo; p <= hi; p++) atomicMax(&g0[p], q);
+    } else {
+        const int lo = max(min(f0, f1), c0) - c0;
+        const int hi = min(max(f0, f1), c0 + tn - 1) - c0;
+        for (int p = lo; p <= hi; p++) atomicMax(&g0[p], PL_BAD);
+    }
+}
+// returns true when the segment needs the slow path (the caller collects those and runs them in one shared loop)
+__device__ __forceinline__ bool pl_scatter(uint32_t *g0, double x0, double x1, int f0, int f1, uint32_t q, int c0, int tn)
+{
+    const bool fwd = x0 < x1;
+    const int d = f1 - f0;
+    if (fwd && d == 1) {
+        const unsigned p = (unsigned)(f1 - c0);
+        if (p < (unsigned)tn) atomicMax(&g0[p], q);
+    }
+    return !(fwd && (unsigned)d <= 1u);
+}
+__device__ __forceinline__ int pl_floor_i(double x)
+{
+    // v_floor_f64 + v_cvt_i32_f64 (saturating).  Rows with |x| >= 4e9 or NaN are re-rendered by the exact sweep, and
+    // every loop over pixels is clipped to the tile, so an out-of-range value cannot do harm here.
+    return (int)floor(x);
+}
+
+// ---- P2/P3 helpers -----------------------------------------------------------------------------------
+template <int C>
+__device__ __forceinline__ void pl_unpack(uint32_t v, double *px)
+{
+#pragma unroll
+    for (int k = 0; k < C; k++) px[k] = (double)((v >> (8 * k)) & 0xffu);
+}
+
+template <int C>
+__device__ __forceinline__ void pl_add_flat(const double *px, double significance, double *color)
+{
+#pragma unroll
+    for (int k = 0; k < C; k++) color[k] += px[k] * significance;                    // :273
+}
+
+template <int C>
+__device__ __forceinline__ void pl_add_lerp(const double *pl, const double *pr, double x0, double x1, double coord_center,
+                                            double significance, double *color)
+{
+    const double ip_k = (coord_center - x0) / (x1 - x0);                             // :276
+    const double om = 1.0 - ip_k;
+#pragma unroll
+    for (int k = 0; k < C; k++) {
+        const double u = pl[k] * om;
+        const double v = pr[k] * ip_k;
+        color[k] += (u + v) * significance;                                          // :277-279
+    }
+}
+
+// The reference's sub-interval geometry (:235-239).  0.5*significance is exact, so the fused form of
+// coord_from + 0.5*significance rounds exactly like the reference's two operations.
+struct PlSub { double significance, coord_center; };
+__device__ __forceinline__ PlSub pl_sub(double a, double b)
+{
+    const double coord_from = a + PL_EPS;                                            // :235
+    const double coord_to = b - PL_EPS;                                              // :236
+    PlSub s;
+    s.significance = coord_to - coord_from;                                          // :237
+    s.coord_center = fma(0.5, s.significance, coord_from);                           // :239
+    return s;
+}
+
+// what P2/P3 need to know about the staged window
+struct PlWin {
+    const double *pt;          // this eye's points, pt[0] .. pt[NP*ncols + 1]
+    const double *nd;          // normalised depth per window column
+    const uint32_t *rgbx;      // rgbx[i] = window column i, rgbx[-1] exists
+    int ncols;
+    bool head, tail;
+    double div_px;
+};
+
+// colour index (window column) of point q: the sentinels carry the edge columns (:179,:191)
+template <int NP>
+__device__ __forceinline__ int pl_col_of(const PlWin &V, int q)
+{
+    if (q == 0) return V.head ? 0 : -1;
+    if (q == NP * V.ncols + 1) return V.ncols - 1;
+    return (q - 1) >> (NP - 1);
+}
+// closeness |coord_d| of point q (:184,:188-189); 0 for the sentinels
+template <int NP>
+__device__ __forceinline__ double pl_dd_of(const PlWin &V, int q)
+{
+    if ((q == 0 && V.head) || q == NP * V.ncols + 1) return 0.0;
+    return fabs(V.nd[q == 0 ? -1 : ((q - 1) >> (NP - 1))] * V.div_px);
+}
+
+// colour of segment q over one sub-interval (:270-279)
+template <int C, int NP>
+__device__ __forceinline__ void pl_add_segment(const PlWin &V, int q, double x0, double x1, const PlSub &s, double *color)
+{
+    const int cl = pl_col_of<NP>(V, q - 1), cr = pl_col_of<NP>(V, q);               // :270-271
+    double pl[C], pr[C];
+    pl_unpack<C>(V.rgbx[cr], pr);
+    if (cl == cr) pl_add_flat<C>(pr, s.significance, color);                         // :272
+    else { pl_unpack<C>(V.rgbx[cl], pl); pl_add_lerp<C>(pl, pr, x0, x1, s.coord_center, s.significance, color); }
+}
+
+// One piece of segment q inside pixel [fq, fq1], given that it is the only active segment
+template <int C, int NP>
+__device__ __forceinline__ void pl_piece(const PlWin &V, int q, double x0, double x1, double fq, double fq1, double *color, int &flag)
+{
+    const PlSub s = pl_sub(fmax(x0, fq), fmin(x1, fq1));                             // max(col, pt[pt_i][0]), min(col+1, pt[pt_i+1][0])
+    if (!(s.significance > 0.0)) flag = 1;
+    pl_add_segment<C, NP>(V, q, x0, x1, s, color);
+}
+
+// GENERAL pixel.  fm/bm: bit t of word k <=> segment / point q = qlo + 64k + t is a forward segment overlapping the
+// closed strip [fq, fq1] / a point inside [fq, fq1).  Sub-intervals are visited in (x, original index) order of the
+// points -- the order of the reference's stable insertion sort (:214-219).
+template <int C, int NP>
+__device__ __forceinline__ void pl_general_pixel_lds(const PlWin &V, int qlo, int K, const unsigned long long *fm, unsigned long long *bm,
+                                                  double fq, double fq1, double *color, int &flag)
+{
+    double a = fq;
+    for (;;) {
+        // next point: smallest (x, q) among the remaining ones
+        double b = fq1;
+        int bk = -1, bt = 0;
+#pragma unroll
+        for (int k = 0; k < PL_KMAX; k++) {
+            if (k < K) {
+                unsigned long long m = bm[k];
+                while (m != 0ull) {
+                    const int t = __ffsll((long long)m) - 1;
+                    m &= m - 1ull;
+                    const double x = V.pt[qlo + 64 * k + t];
+                    if (bk < 0 || x < b) { b = x; bk = k; bt = t; }
+                }
+            }
+        }
+        const bool more = bk >= 0;
+        if (more) {
+#pragma unroll
+            for (int k = 0; k < PL_KMAX; k++) if (k == bk) bm[k] &= ~(1ull << bt);
+        } else {
+            b = fq1;
+        }
+        const PlSub s = pl_sub(a, b);
+        a = b;
+        if (!(s.significance > 0.0)) flag = 1;     // centres may stop being monotone: history dependent
+        // active set = { q : x0 < c and not (x1 < c) }  (:242-253); winner by interpolated closeness (:259-268)
+        int count = 0, first = -1, win = -1;
+        double best = -PL_EPS;                                                       // :261
+        bool have = false;
+#pragma unroll
+        for (int k = 0; k < PL_KMAX; k++) {
+            if (k < K) {
+                unsigned long long m = fm[k];
+                while (m != 0ull) {
+                    const int t = __ffsll((long long)m) - 1;
+                    m &= m - 1ull;
+                    const int q = qlo + 64 * k + t;
+                    const double x0 = V.pt[q - 1], x1 = V.pt[q];
+                    if (x0 < s.coord_center && !(x1 < s.coord_center)) {
+                        if (count == 0) first = q;
+                        count++;
+                        const double d0 = pl_dd_of<NP>(V, q - 1), d1 = pl_dd_of<NP>(V, q);
+                        const double ip_k = (s.coord_center - x0) / (x1 - x0);       // :263
+                        const double closeness = (1.0 - ip_k) * d0 + ip_k * d1;      // :265
+                        const bool valid = 0.0 < ip_k && ip_k < 1.0;
+                        if (valid && have && closeness == best) flag = 1;            // exact tie: csg order decides
+                        if (best < closeness && valid) { best = closeness; win = q; have = true; }   // :266
+                    }
+                }
+            }
+        }
+        if (count == 1) win = first;                                                 // :259
+        if (count == 0 || (count > 1 && !have)) flag = 1;   // reference reads a stale / falls back to csg[0]
+        else pl_add_segment<C, NP>(V, win, V.pt[win - 1], V.pt[win], s, color);
+        if (!more) break;
+    }
+}
+
+
+// SIMPLE sharp pixel, straight line: the run starts at segment g0 and is assumed to have at most 6 pieces inside the
+// pairs { gap, body } of window columns ib, ib+1 (straight line) and ib+2 (wave-uniform branch).  Every slot is computed and selected
+// (no branches: the divisions of the two gaps and of the other eye's pixel overlap).  Returns false when the pixel needs
+// the walker instead (a fifth piece, or a sentinel segment in the run); color is then meaningless.
+template <int C>
+__device__ __forceinline__ bool pl_simple4(const double *pt, const uint32_t *rgbx, uint32_t g0, bool ok, bool head, int qT,
+                                           double fq, double fq1, double *color, int &flag)
+{
+    const int ib = ok ? (int)((g0 - 1) >> 1) : 0;
+    const double *pp = pt + 2 * ib;
+    const double2 p01 = *reinterpret_cast<const double2 *>(pp);
+    const double2 p23 = *reinterpret_cast<const double2 *>(pp + 2);
+    const double x4 = pp[4];
+    double px0[C], px1[C], px2[C];
+    pl_unpack<C>(rgbx[ib - 1], px0);
+    pl_unpack<C>(rgbx[ib], px1);
+    pl_unpack<C>(rgbx[ib + 1], px2);
+    const double x0 = p01.x, x1 = p01.y, x2 = p23.x, x3 = p23.y;
+    const bool a0 = ok && (g0 & 1u) != 0;                  // gap of column ib
+    const bool a1 = ok && (!(g0 & 1u) || x1 < fq1);        // body of column ib
+    const bool a2 = a1 && x2 < fq1;                        // gap of column ib+1
+    const bool a3 = a2 && x3 < fq1;                        // body of column ib+1
+    const bool a4 = a3 && x4 < fq1;                        // gap of column ib+2 (rare: compressed stretches)
+    const int q0 = 2 * ib + 1;
+    bool sentinel = (a0 && ((q0 == 1 && head) || q0 == qT)) || (a2 && q0 + 2 == qT) || (a4 && q0 + 4 == qT);
+    // geometry of the four pieces (:235-239)
+    const PlSub s0 = pl_sub(fmax(x0, fq), fmin(x1, fq1));
+    const PlSub s2 = pl_sub(fmax(x2, fq), fmin(x3, fq1));
+    const double sg1 = (fmin(x2, fq1) - PL_EPS) - (fmax(x1, fq) + PL_EPS);
+    const double sg3 = (fmin(x4, fq1) - PL_EPS) - (fmax(x3, fq) + PL_EPS);
+    const double ip0 = (s0.coord_center - x0) / (x1 - x0), om0 = 1.0 - ip0;          // :276
+    const double ip2 = (s2.coord_center - x2) / (x3 - x2), om2 = 1.0 - ip2;
+    if ((a0 && !(s0.significance > 0.0)) || (a1 && !(sg1 > 0.0)) || (a2 && !(s2.significance > 0.0)) || (a3 && !(sg3 > 0.0))) flag = 1;
+#pragma unroll
+    for (int k = 0; k < C; k++) {
+        const double t0 = (px0[k] * om0 + px1[k] * ip0) * s0.significance;           // :277-279
+        const double t1 = px1[k] * sg1;                                              // :273
+        const double t2 = (px1[k] * om2 + px2[k] * ip2) * s2.significance;
+        const double t3 = px2[k] * sg3;
+        double c = color[k];
+        c = a0 ? c + t0 : c;
+        c = a1 ? c + t1 : c;
+        c = a2 ? c + t2 : c;
+        c = a3 ? c + t3 : c;
+        color[k] = c;
+    }
+    bool more = false;
+    if (__any(a4)) {                                       // wave-uniform: the pair of column ib+2
+        const double x5 = pp[5], x6 = pp[6];
+        double px3[C];
+        pl_unpack<C>(rgbx[ib + 2], px3);
+        const bool a5 = a4 && x5 < fq1;
+        more = a5 && x6 < fq1;
+        const PlSub s4 = pl_sub(fmax(x4, fq), fmin(x5, fq1));
+        const double sg5 = (fmin(x6, fq1) - PL_EPS) - (fmax(x5, fq) + PL_EPS);
+        const double ip4 = (s4.coord_center - x4) / (x5 - x4), om4 = 1.0 - ip4;
+        if ((a4 && !(s4.significance > 0.0)) || (a5 && !(sg5 > 0.0))) flag = 1;
+#pragma unroll
+        for (int k = 0; k < C; k++) {
+            const double t4 = (px2[k] * om4 + px3[k] * ip4) * s4.significance;
+            const double t5 = px3[k] * sg5;
+            double c = color[k];
+            c = a4 ? c + t4 : c;
+            c = a5 ? c + t5 : c;
+            color[k] = c;
+        }
+    }
+    return !(more || sentinel);
+}
+
+// SIMPLE pixel, any number of pieces: walk the run from the entering segment g0 (:234-280 with a single active segment)
+template <int C, int NP>
+__device__ __forceinline__ void pl_walk(const PlWin &V, uint32_t g0, double fq, double fq1, double *color, int &flag)
+{
+    int q = (int)g0;
+    const int qT = NP * V.ncols + 1;
+    double x0 = V.pt[q - 1];
+#pragma unroll
+    for (int k = 0; k < C; k++) color[k] = 0.5;                                      // :229
+    for (;;) {
+        const double x1 = V.pt[q];
+        pl_piece<C, NP>(V, q, x0, x1, fq, fq1, color, flag);
+        if (!(x1 < fq1)) break;
+        if (q >= qT) { flag = 1; break; }
+        x0 = x1; q++;
+    }
+}
+
+// LDS carve-up, shared by the kernel and the host-side size computation
+struct PlLds {
+    int npt, off_nd, off_rgbx, off_g0, off_out, outstride, off_queue, off_misc, total;
+};
+__host__ __device__ inline PlLds pl_lds_layout(int S, int nwmax, int c, int np)
+{
+    PlLds L;
+    L.npt = np * nwmax + PL_PT_PAD;                       // doubles per eye (even)
+    L.off_nd = 2 * L.npt * 8;                              // nd[-4 .. nwmax): 4 doubles of lead-in (nd[-1] is used)
+    L.off_rgbx = L.off_nd + (nwmax + 4) * 8;               // rgbx[-4 .. nwmax + 4)
+    L.off_g0 = L.off_rgbx + (nwmax + 8) * 4;
+    L.off_out = L.off_g0 + 2 * S * 4;
+    L.outstride = (S * c + 15) & ~15;
+    L.off_queue = L.off_out + 2 * L.outstride;
+    L.off_misc = L.off_queue + 2 * S * 2;
+    L.total = L.off_misc + 8 * 4;
+    return L;
+}
+
+template <int C, int SHARP, int NE>
+__global__ __launch_bounds__(PL_THREADS, 4) void k_polylines(PolyParams P)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int NP = SHARP ? 2 : 1;
     const int tid = threadIdx.x;
-    const int w = P.w, c = P.c;
-    const int tiles_x = (w + PL_TILE - 1) / PL_TILE;
-    const long long nwork = (long long)P.n * P.h * tiles_x;
+    const int w = P.w, S = P.S;
+    const PlLds L = pl_lds_layout(S, P.nwmax, C, NP);
+    double *s_pt = reinterpret_cast<double *>(smem);                         // [eye][npt]
+    double *s_nd = reinterpret_cast<double *>(smem + L.off_nd) + 4;
+    uint32_t *s_rgbx = reinterpret_cast<uint32_t *>(smem + L.off_rgbx) + 4;
+    uint32_t *s_g0 = reinterpret_cast<uint32_t *>(smem + L.off_g0);          // [eye][S]
+    uint8_t *s_out = smem + L.off_out;                                       // [eye][outstride]
+    uint16_t *s_queue = reinterpret_cast<uint16_t *>(smem + L.off_queue);    // (eye << 15) | pixel
+    int *s_misc = reinterpret_cast<int *>(smem + L.off_misc);                // [0],[1]: queue counts (alternating), [2],[3]: row flag per eye
 
+    const int tiles = (w + S - 1) / S;
+    const int nwork = P.n * P.h * tiles;                    // < 2^31, checked by the host
     int uL = P.offL[0], uU = P.offU[0];                    // union of the two eyes' window offsets
-    if (P.n_eyes > 1) { uL = min(uL, P.offL[1]); uU = max(uU, P.offU[1]); }
-    const int ncu_max = PL_TILE + (uU - uL + 1) + 2;
-    double *s_nd = reinterpret_cast<double *>(smem);
-    double *s_ad = s_nd + ncu_max;
-    double *s_ptb = s_ad + ncu_max;                         // pt[k] = s_ptb[k + 1]
-    int *s_gmin = reinterpret_cast<int *>(s_ptb + 2 * ncu_max + 2);
-    int *s_gmax = s_gmin + PL_TILE;
-    int *s_cnt = s_gmax + PL_TILE;                          // low 16 bits: forward segments, high 16: backward/zero-length
-    uint8_t *s_out = reinterpret_cast<uint8_t *>(s_cnt + PL_TILE);
-    uint8_t *s_src = s_out + PL_TILE * 4;
-    double *s_pt = s_ptb + 1;
+    if (NE > 1) { uL = min(uL, P.offL[1]); uU = max(uU, P.offU[1]); }
 
-    typedef typename ds_depth_traits<DT>::T DTy;
-    // this wave's open queue chunk (one global atomic per PL_QCHUNK-1 queued pixels instead of one per pixel)
-    int chunk = -1, chunk_used = 0;
-    for (long long work = blockIdx.x; work < nwork; work += gridDim.x) {
-        const int tx = (int)(work % tiles_x);
-        const long long rr = work / tiles_x;
-        const int row = (int)(rr % P.h), img = (int)(rr / P.h);
-        const int c0 = tx * PL_TILE;
-        const int c1 = min(c0 + PL_TILE, w);               // exclusive
-        const int tn = c1 - c0;
+    for (int i = tid; i < 2 * S; i += PL_THREADS) s_g0[i] = 0;
+    if (tid < 8) s_misc[tid] = 0;
+    __syncthreads();
+
+    int prev = -1, prev_img = 0, prev_row = 0, prev_c0 = 0;
+    int iter = 0;
+    unsigned long long tacc[12] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 }, tl = P.prof ? __builtin_readcyclecounter() : 0ull;
+#define PL_TICK(i) do { if (P.prof) { const unsigned long long t_ = __builtin_readcyclecounter(); tacc[i] += t_ - tl; tl = t_; } } while (0)
+    for (int work = blockIdx.x;; work += gridDim.x) {
+        // ---- S0: the previous work item's rows leave LDS ------------------------------------------------
+        if (prev >= 0) {
+            const int row = prev_row, img = prev_img;
+            const int c0 = prev_c0, tn = min(S, w - c0);
+            const int nbytes = tn * C;
+#pragma unroll
+            for (int e = 0; e < NE; e++) {
+                uint8_t *dst = P.out[e] + (int64_t)img * P.ois[e] + (int64_t)row * P.ors[e] + (size_t)c0 * C;
+                const uint8_t *src = s_out + e * L.outstride;
+                if ((((uintptr_t)dst) & 15) == 0) {
+                    const int n16 = nbytes >> 4;
+                    for (int i = tid; i < n16; i += PL_THREADS)
+                        reinterpret_cast<uint4 *>(dst)[i] = reinterpret_cast<const uint4 *>(src)[i];
+                    for (int i = (n16 << 4) + tid; i < nbytes; i += PL_THREADS) dst[i] = src[i];
+                } else if ((((uintptr_t)dst) & 3) == 0) {
+                    const int n4 = nbytes >> 2;
+                    for (int i = tid; i < n4; i += PL_THREADS)
+                        reinterpret_cast<uint32_t *>(dst)[i] = reinterpret_cast<const uint32_t *>(src)[i];
+                    for (int i = (n4 << 2) + tid; i < nbytes; i += PL_THREADS) dst[i] = src[i];
+                } else {
+                    for (int i = tid; i < nbytes; i += PL_THREADS) dst[i] = src[i];
+                }
+            }
+            if (tid == 0)
+                for (int e = 0; e < NE; e++)
+                    if (s_misc[2 + e]) { pl_flag_row(P, img, e, row); s_misc[2 + e] = 0; }
+            prev = -1;
+        }
+        PL_TICK(0);
+        if (work >= nwork) break;
+
+        const unsigned uw = (unsigned)work, rr = uw / (unsigned)tiles;
+        const int ts = (int)(uw - rr * (unsigned)tiles);
+        const int img = (int)(rr / (unsigned)P.h), row = (int)(rr - (unsigned)img * (unsigned)P.h);
+        const int c0 = ts * S, c1 = min(c0 + S, w), tn = c1 - c0;
         const double mn = P.minmax[img * 2], mx = P.minmax[img * 2 + 1];
-        const uint8_t *src_row = P.img + ((size_t)img * P.h + row) * (size_t)w * c;
-        const DTy *depth_row = (const DTy *)P.depth + ((size_t)img * P.h + row) * (size_t)w;
+        const uint8_t *src_row = P.img + ((size_t)img * P.h + row) * (size_t)w * C;
+        const size_t esz = P.depth_dtype == DS_DEPTH_U16 ? 2 : (P.depth_dtype == DS_DEPTH_F32 ? 4 : 8);
+        const void *depth_row = (const char *)P.depth + ((size_t)img * P.h + row) * (size_t)w * esz;
 
         // 0/0: constant depth gives NaN for every point (stereoimage_generation.py:81); the sweep then
         // only ever sees the segment from the -w sentinel, whose colour index is 0 on both ends.
         if (!(mx > mn)) {
-            const int col = c0 + tid;
-            if (col < w) {
+            for (int p = tid; p < tn; p += PL_THREADS) {
+                const int col = c0 + p;
                 const double coord_from = (double)col + PL_EPS;
                 const double coord_to = (double)(col + 1) - PL_EPS;
                 const double significance = coord_to - coord_from;
-                for (int eye = 0; eye < P.n_eyes; eye++) {
-                    uint8_t *out_row = P.out[eye] + (int64_t)img * P.ois[eye] + (int64_t)row * P.ors[eye];
-                    for (int k = 0; k < c; k++) {
+                for (int e = 0; e < NE; e++) {
+                    uint8_t *out_row = P.out[e] + (int64_t)img * P.ois[e] + (int64_t)row * P.ors[e];
+                    for (int k = 0; k < C; k++) {
                         double color = 0.5;
                         color += (double)src_row[k] * significance;
-                        out_row[(size_t)col * c + k] = ds_f64_to_u8(color);
+                        out_row[(size_t)col * C + k] = ds_f64_to_u8(color);
                     }
                 }
             }
             continue;
         }
 
-        // ---- stage what both eyes share --------------------------------------------------------------
-        const int ju0 = max(0, min(c0 + uL - 1, w - 2));
-        const int ju1 = max(ju0, max(0, min(c1 - 1 + uU, w - 1)));
-        const int ncu = ju1 - ju0 + 1;
-        __syncthreads();                                    // previous work item is done with the LDS
-        for (int i = tid; i < ncu; i += PL_TILE) {
-            const DTy v = depth_row[ju0 + i];
-            double nd;
-            if (DT == DS_DEPTH_U16 && P.lut != nullptr) nd = P.lut[(size_t)img * 65536 + (unsigned)v];   // norm ** exponent
-            else nd = ds_depth_traits<DT>::norm(v, mn, mx);                                            // pow(x, 1.0) == x
-            s_nd[i] = nd;
-        }
-        for (int i = tid; i < ncu * c; i += PL_TILE) s_src[i] = src_row[(size_t)ju0 * c + i];
-
-        for (int eye = 0; eye < P.n_eyes; eye++) {
-            const double div_px = P.div_px[eye], sep_px = P.sep_px[eye];
-            const int offL = P.offL[eye], offU = P.offU[eye];
-            // this eye's source window (inclusive), always at least one real column
-            const int jt0 = max(0, min(c0 + offL - 1, w - 2));
-            const int jt1 = max(jt0, max(0, min(c1 - 1 + offU, w - 1)));
-            const int i0 = jt0 - ju0, i1 = jt1 - ju0;
-            const bool head = jt0 == 0, tail = jt1 == w - 1;
-
-            __syncthreads();                                // nd ready / previous eye done with pt, bins, out
-            s_gmin[tid] = 0x7fffffff; s_gmax[tid] = -0x7fffffff; s_cnt[tid] = 0;
-            for (int i = i0 + tid; i <= i1; i += PL_TILE) {
-                const double coord_d = s_nd[i] * div_px;                                       // :182
-                const double coord_x = (double)(ju0 + i) + 0.5 + coord_d + sep_px;             // :183
-                if (SHARP) { s_pt[2 * i] = coord_x - 0.45; s_pt[2 * i + 1] = coord_x + 0.45; }   // :188-189
-                else s_pt[i] = coord_x;                                                        // :185
-                s_ad[i] = fabs(coord_d);
+        // ---- P01: stage the source window, both eyes' points, entry tables --------------------------------
+        const int j0 = max(0, c0 + uL - 1) & ~3;
+        const int j1 = max(j0, min(w - 1, c1 - 1 + uU));
+        const int ncols = j1 - j0 + 1;
+        const bool head = j0 == 0, tail = j1 == w - 1;
+        const double *lut = (P.lut != nullptr && P.depth_dtype == DS_DEPTH_U16) ? P.lut + (size_t)img * 65536 : nullptr;
+        const int qi = iter & 1;
+        int bad = 0;                                        // non-finite / absurd coordinates seen by this thread
+        for (int i4 = tid * 4; i4 < ncols; i4 += 4 * PL_THREADS) {
+            const int j = j0 + i4;
+            const int nv = min(4, ncols - i4);
+            double nd[4], ndp;
+            pl_load_nd(P, depth_row, j, nv, j > 0, mn, mx, lut, nd, ndp);
+            uint32_t rgbx[4];
+            pl_load_rgbx<C>(src_row + (size_t)j * C, nv, P.al4 != 0, rgbx);
+            if (nv == 4) {
+                *reinterpret_cast<double2 *>(&s_nd[i4]) = make_double2(nd[0], nd[1]);
+                *reinterpret_cast<double2 *>(&s_nd[i4 + 2]) = make_double2(nd[2], nd[3]);
+                *reinterpret_cast<uint4 *>(&s_rgbx[i4]) = make_uint4(rgbx[0], rgbx[1], rgbx[2], rgbx[3]);
+            } else {
+                for (int m = 0; m < nv; m++) { s_nd[i4 + m] = nd[m]; s_rgbx[i4 + m] = rgbx[m]; }
             }
-            if (tid == 0) {
-                if (head) s_pt[-1] = -1.0 * (double)w;                                         // :179
-                if (tail) s_pt[NP * (i1 + 1)] = 2.0 * (double)w;                               // :191
+            if (i4 == 0) {                                  // window column -1 (never selected when the halo is right)
+                s_nd[-1] = j > 0 ? ndp : 0.0;
+                uint32_t v = 0;
+                if (j > 0) for (int k = 0; k < C; k++) v |= (uint32_t)src_row[(size_t)(j - 1) * C + k] << (8 * k);
+                s_rgbx[-1] = v;
             }
-            __syncthreads();
-            if (P.dbg == 1) continue;
-
-            PlView<SHARP> V;
-            V.ptp = s_pt; V.ad = s_ad; V.src = s_src; V.ju0 = ju0; V.c = c; V.ncol = ncu;
-            V.kfirst = NP * i0; V.klast = NP * i1 + NP - 1;
-            V.ghead = head ? 0 : -1000000; V.gtail = tail ? NP * (i1 + 1) : -1000000;
-
-            // ---- bin segments by the output pixels they overlap ----------------------------------------
-            // segment g = (pt[g-1], pt[g]); real segments g = kfirst+1 .. klast, plus the sentinel segments
-            const int gfirst = head ? 0 : V.kfirst + 1, glast = tail ? V.klast + 1 : V.klast;
-            for (int g = gfirst + tid; g <= glast; g += PL_TILE) {
-                const double x0 = s_pt[g - 1], x1 = s_pt[g];
-                const bool fwd = x0 < x1;
-                const double lo = fwd ? x0 : x1, hi = fwd ? x1 : x0;
-                const double qa = fmax(floor(lo), (double)c0), qb = fmin(floor(hi), (double)(c1 - 1));
-                const int code = fwd ? 1 : (1 << 16);
-                for (double q = qa; q <= qb; q += 1.0) {
-                    const int p = (int)q - c0;
-                    atomicMin(&s_gmin[p], g);
-                    atomicMax(&s_gmax[p], g);
-                    atomicAdd(&s_cnt[p], code);
-                }
-            }
-            __syncthreads();
-            if (P.dbg == 2) continue;
-
-            // ---- render ------------------------------------------------------------------------------
-            // SIMPLE pixels are rendered here; pixels under a fold are queued for k_polylines_general, which
-            // writes their bytes itself (one lane per queued pixel, so folds do not stall this wave).
-            const int col = c0 + tid;
-            int flag = 0;
-            bool queued = false;
-            int4 qe = make_int4(0, 0, 0, 0);
-            if (col < w) {
-                const double fq = (double)col, fq1 = (double)(col + 1);
-                double color[4] = { 0.5, 0.5, 0.5, 0.5 };                                       // :229
-                const int g0 = s_gmin[tid], g1 = s_gmax[tid], cnt = s_cnt[tid];
-                const bool simple = (cnt >> 16) == 0 && (cnt & 0xffff) == g1 - g0 + 1 && g1 >= g0;
-                const bool fast = SHARP && simple && g1 - (g0 & ~1) < 6;
-                const bool third = __any(fast && g1 - (g0 & ~1) >= 4) != 0;   // wave-uniform: does any lane need pair 2
-                if (P.dbg == 3) { color[0] += s_pt[NP * i0 + (tid & 7)]; }
-                else if (fast) {
-                    pl_render_simple_sharp<SHARP>(V, g0, g1, fq, fq1, third, color, flag);
-                } else if (simple && !SHARP) {
-                    for (int g = g0; g <= g1; g++) {
-                        if (g == V.ghead || g == V.gtail) pl_piece<true>(V, g, fq, fq1, color, flag);
-                        else pl_piece<false>(V, g, fq, fq1, color, flag);
-                    }
-                } else if (g1 >= g0) {
-                    queued = true;
-                    qe = make_int4((img * P.n_eyes + eye) * P.h + row, col, NP * ju0 + g0, NP * ju0 + g1);
-                } else {
-                    flag = 1;        // nothing overlaps this pixel: the reference reads a stale csg[0]
-                }
+            double colx[4];                                 // (col + 0.5), shared by the eyes (:183)
 #pragma unroll
-                for (int k = 0; k < 4; k++)
-                    if (k < c) s_out[tid * c + k] = ds_f64_to_u8(color[k]);                      // :281
-            }
-            {   // append this tile's general pixels to the wave's queue chunk
-                const unsigned long long qmask = __ballot(queued);
-                if (qmask != 0ull) {
-                    const int nq = __popcll(qmask);
-                    if (chunk < 0 || chunk_used + nq > PL_QCHUNK - 1) {
-                        int fresh = 0;
-                        if (tid == 0) {
-                            if (chunk >= 0) P.queue[(size_t)chunk * PL_QCHUNK] = make_int4(chunk_used, 0, 0, 0);
-                            fresh = atomicAdd(&P.counters[1], 1);
+            for (int m = 0; m < 4; m++) colx[m] = (double)(j + m) + 0.5;
+#pragma unroll
+            for (int e = 0; e < NE; e++) {
+                const double div_px = P.div_px[e], sep_px = P.sep_px[e];
+                double *pt = s_pt + e * L.npt;
+                uint32_t *g0 = s_g0 + e * S;
+                uint32_t slow = 0;                          // bit t: segment NP*i4 + 1 + t of this thread needs the slow path
+                double xprev;
+                if (j == 0) xprev = -1.0 * (double)w;                                           // :179
+                else {
+                    const double coord_d = ndp * div_px;
+                    const double coord_x = (double)(j - 1) + 0.5 + coord_d + sep_px;
+                    xprev = SHARP ? coord_x + 0.45 : coord_x;
+                }
+                int fprev = pl_floor_i(xprev);
+                if (!SHARP) pt[i4] = xprev;              // also stored (same bits) by the previous thread: see the slow loop
+#pragma unroll
+                for (int m = 0; m < 4; m++) {
+                    if (m < nv) {
+                        const double coord_d = nd[m] * div_px;                                  // :182
+                        const double coord_x = colx[m] + coord_d + sep_px;                      // :183
+                        if (!(fabs(coord_x) < 4.0e9)) bad = 1;
+                        if (SHARP) {
+                            const double xl = coord_x - 0.45, xr = coord_x + 0.45;              // :188-189
+                            const int fl = pl_floor_i(xl), fr = pl_floor_i(xr);
+                            const int q = 2 * (i4 + m) + 1;
+                            *reinterpret_cast<double2 *>(&pt[q - 1]) = make_double2(xprev, xl);
+                            if (pl_scatter(g0, xprev, xl, fprev, fl, (uint32_t)q, c0, tn)) slow |= 1u << (2 * m);
+                            if (pl_scatter(g0, xl, xr, fl, fr, (uint32_t)(q + 1), c0, tn)) slow |= 2u << (2 * m);
+                            xprev = xr; fprev = fr;
+                        } else {
+                            const int fx = pl_floor_i(coord_x);
+                            const int q = i4 + m + 1;
+                            pt[q] = coord_x;                                                    // :185
+                            if (pl_scatter(g0, xprev, coord_x, fprev, fx, (uint32_t)q, c0, tn)) slow |= 1u << m;
+                            xprev = coord_x; fprev = fx;
                         }
-                        chunk = __shfl(fresh, 0, 64);
-                        chunk_used = 0;
                     }
-                    if (queued) {
-                        const int rank = __popcll(qmask & ((1ull << tid) - 1ull));
-                        P.queue[(size_t)chunk * PL_QCHUNK + 1 + chunk_used + rank] = qe;
+                }
+                if (SHARP) pt[2 * (i4 + nv)] = xprev;       // also stored (same bits) by the next thread: see the slow loop
+                if (i4 + nv == ncols) {                     // owner of the last column: tail sentinel, padding
+                    const int qT = NP * ncols + 1;
+                    for (int k = 0; k < PL_PT_PAD - 1; k++) pt[qT + k] = 2.0 * (double)w;        // :191 (or harmless padding)
+                    if (tail) slow |= 1u << (NP * nv);      // the tail sentinel segment qT follows this thread's last point
+                }
+                // long gaps, backward segments, the tail sentinel: rare, one shared loop (the points are re-read from LDS;
+                // a thread reads back only what it stored itself)
+                while (__any(slow != 0u)) {
+                    if (slow != 0u) {
+                        const int t = __ffs((int)slow) - 1;
+                        slow &= slow - 1u;
+                        const int q = NP * i4 + 1 + t;
+                        const double x0 = pt[q - 1], x1 = pt[q];
+                        pl_scatter_slow(g0, x0, x1, (int)floor(x0), (int)floor(x1), (uint32_t)q, c0, tn);
                     }
-                    chunk_used += nq;
                 }
             }
-            const int any = __syncthreads_or(flag);
-            uint8_t *out_row = P.out[eye] + (int64_t)img * P.ois[eye] + (int64_t)row * P.ors[eye];
-            // queued pixels get placeholder bytes here; k_polylines_general (next on the stream) overwrites them
-            pl_store_tile(s_out, out_row + (size_t)c0 * c, tn * c, tid);
-            if (any && tid == 0) pl_flag_row(P, img, eye, row);
         }
-    }
-    if (chunk >= 0 && tid == 0) P.queue[(size_t)chunk * PL_QCHUNK] = make_int4(chunk_used, 0, 0, 0);
-}
+        PL_TICK(1);
+        __syncthreads();                                                                        // ---- A ----
+        PL_TICK(2);
+        if (tid == 0) s_misc[qi ^ 1] = 0;
+        if (bad) { atomicOr(&s_misc[2], 1); atomicOr(&s_misc[3], 1); }
 
-// ---- general pixels: one LANE per queued pixel, coordinates recomputed on the fly from global memory -----
-template <int DT, int SHARP>
-__global__ __launch_bounds__(64) void k_polylines_general(PolyParams P)
-{
-    constexpr int NP = SHARP ? 2 : 1;
-    const int nchunks = P.counters[1];
-    const int w = P.w, c = P.c;
-    for (int ch = blockIdx.x; ch < nchunks; ch += gridDim.x)
-    for (int it = 1 + threadIdx.x, cnt = P.queue[(size_t)ch * PL_QCHUNK].x; it <= cnt; it += 64) {
-        const int4 e = P.queue[(size_t)ch * PL_QCHUNK + it];
-        const int rowid = e.x, col = e.y, g0 = e.z, g1 = e.w;
-        const int row = rowid % P.h;
-        const int ie = rowid / P.h;
-        const int eye = ie % P.n_eyes, img = ie / P.n_eyes;
-        PlRowView<DT, SHARP> V;
-        V.depth_row = (const typename ds_depth_traits<DT>::T *)P.depth + ((size_t)img * P.h + row) * (size_t)w;
-        V.src_row = P.img + ((size_t)img * P.h + row) * (size_t)w * c;
-        V.lut = P.lut ? P.lut + (size_t)img * 65536 : nullptr;
-        V.mn = P.minmax[img * 2]; V.mx = P.minmax[img * 2 + 1];
-        V.div_px = P.div_px[eye]; V.sep_px = P.sep_px[eye];
-        V.w = w; V.c = c; V.kfirst = 0; V.klast = NP * w - 1; V.ghead = 0; V.gtail = NP * w;
-        double color[4] = { 0.5, 0.5, 0.5, 0.5 };
-        int flag = 0;
-        pl_render_general(V, g0, g1, (double)col, (double)(col + 1), color, flag);
-        uint8_t *dst = P.out[eye] + (int64_t)img * P.ois[eye] + (int64_t)row * P.ors[eye] + (size_t)col * c;
-        for (int k = 0; k < 4; k++)
-            if (k < c) dst[k] = ds_f64_to_u8(color[k]);
-        if (flag) pl_flag_row(P, img, eye, row);
-    }
-}
+        // ---- P2: one lane per output pixel, both eyes in one straight line -----------------------------------
+        if (P.dbg != 1)
+        for (int p0 = 0; p0 < tn; p0 += PL_THREADS) {
+            const int p = p0 + tid;
+            const bool inb = p < tn;
+            const double fq = (double)(c0 + p), fq1 = (double)(c0 + p + 1);
+            const int qT = NP * ncols + 1;
+            double color[NE][C];
+            uint32_t g0[NE];
+            int flag[NE];
+            bool walk[NE], queued[NE];
+#pragma unroll
+            for (int e = 0; e < NE; e++) {
+                g0[e] = 0;
+                if (inb) { g0[e] = s_g0[e * S + p]; s_g0[e * S + p] = 0; }
+                flag[e] = (inb && g0[e] == 0) ? 1 : 0;     // nothing enters this pixel: only possible with non-finite coordinates
+                queued[e] = inb && g0[e] >= PL_BAD;
+                const bool ok = inb && g0[e] != 0 && g0[e] < PL_BAD;
+#pragma unroll
+                for (int k = 0; k < C; k++) color[e][k] = 0.5;                                   // :229
+                if (SHARP) walk[e] = ok && !pl_simple4<C>(s_pt + e * L.npt, s_rgbx, g0[e], ok, head, qT, fq, fq1, color[e], flag[e]);
+                else walk[e] = ok;
+            }
+            // runs with a fifth piece or a sentinel segment (image borders), and every polylines_soft pixel: the walker
+#pragma unroll
+            for (int e = 0; e < NE; e++) {
+                if (__any(walk[e])) {
+                    if (walk[e]) {
+                        PlWin V;
+                        V.pt = s_pt + e * L.npt; V.nd = s_nd; V.rgbx = s_rgbx; V.ncols = ncols; V.head = head; V.tail = tail; V.div_px = P.div_px[e];
+                        flag[e] = 0;
+                        pl_walk<C, NP>(V, g0[e], fq, fq1, color[e], flag[e]);
+                    }
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < NE; e++) {
+                if (inb) {
+                    uint8_t *o = s_out + e * L.outstride + p * C;
+#pragma unroll
+                    for (int k = 0; k < C; k++) o[k] = (uint8_t)pl_u8(color[e][k]);              // :281
+                }
+                if (flag[e]) atomicOr(&s_misc[2 + e], 1);
+                const unsigned long long qmask = __ballot(queued[e]);
+                if (qmask != 0ull) {
+                    const int lane = tid & 63;
+                    int base = 0;
+                    if (lane == 0) base = atomicAdd(&s_misc[qi], __popcll(qmask));
+                    base = __shfl(base, 0, 64);
+                    if (queued[e]) s_queue[base + __popcll(qmask & ((1ull << lane) - 1ull))] = (uint16_t)((e << 15) | p);
+                }
+            }
+        }
+        PL_TICK(3);
+        __syncthreads();                                                                        // ---- B ----
+        PL_TICK(4);
 
+        // ---- P3: queued pixels from the same staging, EIGHT LANES PER PIXEL ---------------------------------
+        // The 8 lanes of a group first test the pixel's candidate window together (8 segments per step) and share two
+        // bit masks (forward segments overlapping the strip, points inside the pixel); lane u then takes the u-th point,
+        // the group ranks its points (the reference's stable sort, :214-219), and lane t evaluates sub-interval t.  The
+        // terms are finally added in order (float64 addition is not associative) by every lane of the group.
+        const int nq = P.dbg == 2 ? 0 : s_misc[qi];
+        if (nq > 0) {
+            if (tid == 0) atomicAdd(&P.counters[1], nq);
+            const int wave = tid >> 6, lane = tid & 63, grp = lane >> 3, u = lane & 7;
+            for (int r = wave; r * 8 < nq; r += PL_THREADS / 64) {
+                const int idx = r * 8 + grp;
+                const bool have = idx < nq;
+                const uint32_t ent = have ? s_queue[idx] : 0u;
+                const int e = ent >> 15, p = ent & 0x7fff;
+                const int col = c0 + p;
+                // candidate window of the pixel: segments qlo .. qhi
+                const int iL = min(max(col + P.offL[e] - 1 - j0, 0), ncols - 1);
+                const int iU = min(max(col + P.offU[e] - j0, 0), ncols - 1);
+                const int qlo = NP * iL + 1;
+                const int qhi = !have ? 0 : ((iU == ncols - 1 && tail) ? NP * ncols + 1 : NP * (iU + 1));
+                PlWin V;
+                V.pt = s_pt + e * L.npt; V.nd = s_nd; V.rgbx = s_rgbx; V.ncols = ncols; V.head = head; V.tail = tail; V.div_px = P.div_px[e];
+                const double fq = (double)col, fq1 = (double)(col + 1);
+                unsigned long long fm[PL_KMAX], bm[PL_KMAX];
+#pragma unroll
+                for (int k = 0; k < PL_KMAX; k++) { fm[k] = 0ull; bm[k] = 0ull; }
+                const bool wide = P.K > PL_KMAX;                     // window too wide for the masks: exact sweep
+                if (!wide) {
+#pragma unroll
+                    for (int k = 0; k < PL_KMAX; k++) {
+                        if (k < P.K) {
+                            for (int st = 0; st < 8 && 64 * k + 8 * st < P.nseg; st++) {
+                                const int q = qlo + 64 * k + 8 * st + u;
+                                const bool valid = q <= qhi;
+                                const double x0 = V.pt[valid ? q - 1 : 0], x1 = V.pt[valid ? q : 0];
+                                const unsigned long long mf = __ballot(valid && x0 < x1 && x0 < fq1 && !(x1 < fq));
+                                const unsigned long long mb = __ballot(valid && !(x1 < fq) && x1 < fq1);
+                                fm[k] |= ((mf >> (8 * grp)) & 0xffull) << (8 * st);
+                                bm[k] |= ((mb >> (8 * grp)) & 0xffull) << (8 * st);
+                            }
+                        }
+                    }
+                }
+                int nb = 0;
+#pragma unroll
+                for (int k = 0; k < PL_KMAX; k++) nb += __popcll(bm[k]);
+                const bool ovf = wide || nb > 7;                     // more than 8 sub-intervals: one lane walks them all
+                const bool par = have && !ovf;
+                // lane u's point, its rank among the group's points, the sorted sequence
+                const double BIG = 1.0e300;
+                double bx = BIG;
+                {
+                    int n = u, qb = -1;
+#pragma unroll
+                    for (int k = 0; k < PL_KMAX; k++) {
+                        const int c = __popcll(bm[k]);
+                        if (qb < 0 && n < c) {
+                            unsigned long long mm = bm[k];
+#pragma unroll
+                            for (int i = 0; i < 7; i++) if (i < n) mm &= mm - 1ull;
+                            qb = 64 * k + __ffsll((long long)mm) - 1;
+                        }
+                        n -= c;
+                    }
+                    if (par && qb >= 0) bx = V.pt[qlo + qb];
+                }
+                int rank = 0;
+#pragma unroll
+                for (int i = 1; i < 8; i++) {
+                    const int ou = (u + i) & 7;
+                    const double ox = __shfl(bx, (lane & ~7) | ou, 64);
+                    rank += (ox < bx || (ox == bx && ou < u)) ? 1 : 0;
+                }
+                double sx;
+                {
+                    const int tgt = ((lane & ~7) | rank) << 2;
+                    const int lo = __builtin_amdgcn_ds_permute(tgt, __double2loint(bx));
+                    const int hi = __builtin_amdgcn_ds_permute(tgt, __double2hiint(bx));
+                    sx = __hiloint2double(hi, lo);
+                }
+                const double sprev = __shfl(sx, (lane & ~7) | ((u + 7) & 7), 64);
+                const double a = u == 0 ? fq : sprev;
+                const double b = u < nb ? sx : fq1;
+                double term[C];
+#pragma unroll
+                for (int k = 0; k < C; k++) term[k] = 0.0;
+                int flag = 0;
+                if (par && u <= nb) {
+                    // sub-interval u of the pixel: active set, winner, colour term (:235-279)
+                    const PlSub sb = pl_sub(a, b);
+                    if (!(sb.significance > 0.0)) flag = 1;          // centres may stop being monotone: history dependent
+                    int count = 0, first = -1, win = -1;
+                    double best = -PL_EPS;                                                       // :261
+                    bool hv = false;
+#pragma nounroll
+                    for (;;) {
+                        int q = -1;                                  // next forward candidate: lowest set bit of the multi-word mask
+#pragma unroll
+                        for (int k = 0; k < PL_KMAX; k++) {
+                            if (q < 0 && fm[k] != 0ull) {
+                                q = qlo + 64 * k + __ffsll((long long)fm[k]) - 1;
+                                fm[k] &= fm[k] - 1ull;
+                            }
+                        }
+                        if (q < 0) break;
+                        const double x0 = V.pt[q - 1], x1 = V.pt[q];
+                        if (x0 < sb.coord_center && !(x1 < sb.coord_center)) {                  // :242-253
+                            if (count == 0) first = q;
+                            count++;
+                            const double d0 = pl_dd_of<NP>(V, q - 1), d1 = pl_dd_of<NP>(V, q);
+                            const double ip_k = (sb.coord_center - x0) / (x1 - x0);             // :263
+                            const double closeness = (1.0 - ip_k) * d0 + ip_k * d1;             // :265
+                            const bool valid = 0.0 < ip_k && ip_k < 1.0;
+                            if (valid && hv && closeness == best) flag = 1;                     // exact tie: csg order decides
+                            if (best < closeness && valid) { best = closeness; win = q; hv = true; }   // :266
+                        }
+                    }
+                    if (count == 1) win = first;                                                 // :259
+                    if (count == 0 || (count > 1 && !hv)) flag = 1;  // reference reads a stale / falls back to csg[0]
+                    else pl_add_segment<C, NP>(V, win, V.pt[win - 1], V.pt[win], sb, term);
+                }
+                double color[C];
+#pragma unroll
+                for (int k = 0; k < C; k++) color[k] = 0.5;                                      // :229
+                for (int t = 0; __any(par && t <= nb); t++) {
+#pragma unroll
+                    for (int k = 0; k < C; k++) color[k] += __shfl(term[k], (lane & ~7) | (t & 7), 64);   // lanes past nb hold 0.0
+                }
+                if (have && ovf && u == 0) {
+                    if (wide) flag = 1;
+                    else pl_general_pixel_lds<C, NP>(V, qlo, P.K, fm, bm, fq, fq1, color, flag);
+                }
+                if (have && u == 0) {
+                    uint8_t *o = s_out + e * L.outstride + p * C;
+#pragma unroll
+                    for (int k = 0; k < C; k++) o[k] = ds_f64_to_u8(color[k]);
+                }
+                if (flag) atomicOr(&s_misc[2 + e], 1);
+            }
+            PL_TICK(5);
+            __syncthreads();                                                                    // ---- C ----
+            PL_TICK(6);
+        }
+        prev = work; prev_img = img; prev_row = row; prev_c0 = c0;
+        iter++;
+    }
+    if (P.prof && tid == 0) {
+        for (int i = 0; i < 7; i++) atomicAdd(&P.prof[i], tacc[i]);
+        atomicAdd(&P.prof[7], 1ull);
+        for (int i = 7; i < 12; i++) atomicAdd(&P.prof[i + 1], tacc[i]);
+    }
+#undef PL_TICK
+}
 
 // ------------------------------------------------------------------------------------------------
 // Exact fallback: the reference's row sweep, statement by statement, one lane per flagged row.
@@ -561,14 +903,14 @@ __global__ __launch_bounds__(64) void k_polylines_general(PolyParams P)
 //   OX[np] OD[np]  points in original order        (x, |d|)
 //   SX[np] SK[np]  points in sorted order          (x, original index); segment k travels with point k
 //   CSG[np]        active set as original segment indices
-struct ExactScratch { double *ox, *od, *sx; int *sk, *csg; int nworkers; int np_max; };
+struct ExactScratch { double *ox, *od, *sx; int *sk, *csg; int nworkers; int np_max; int c; };
 
 template <int DT, int SHARP>
 __global__ __launch_bounds__(64) void k_polylines_exact(PolyParams P, ExactScratch S)
 {
     const int worker = blockIdx.x * 64 + threadIdx.x;
     const int count = P.counters[0];
-    const int w = P.w, c = P.c;
+    const int w = P.w, c = S.c;
     const int NW_ = S.nworkers;
 #define A_(arr, i) arr[(size_t)(i) * NW_ + worker]
     for (int it = worker; it < count; it += NW_) {
@@ -674,19 +1016,47 @@ __global__ __launch_bounds__(64) void k_polylines_exact(PolyParams P, ExactScrat
 }
 
 
-template <int DT>
-static int launch_dt(ds_ctx *ctx, const PolyParams &P, int sharp, dim3 grid, size_t lds, const ExactScratch &S, int exact_blocks, hipStream_t st)
+
+template <int C, int SHARP, int NE>
+static int pl_launch_main(const PolyParams &P, int ncu, long long nwork, size_t lds, hipStream_t st)
 {
-    if (ctx->profile) (void)hipEventRecord(ctx->ev[0], st);
-    if (sharp) hipLaunchKernelGGL((k_polylines<DT, 1>), grid, dim3(PL_TILE), lds, st, P);
-    else hipLaunchKernelGGL((k_polylines<DT, 0>), grid, dim3(PL_TILE), lds, st, P);
-    if (ctx->profile) { (void)hipEventRecord(ctx->ev[1], st); (void)hipEventRecord(ctx->ev[2], st); }
-    if (sharp) hipLaunchKernelGGL((k_polylines_general<DT, 1>), dim3(256 * 64), dim3(64), 0, st, P);
-    else hipLaunchKernelGGL((k_polylines_general<DT, 0>), dim3(256 * 64), dim3(64), 0, st, P);
+    auto kfn = k_polylines<C, SHARP, NE>;
+    DS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    int per_cu = 0;
+    DS_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kfn, PL_THREADS, lds));
+    DS_REQUIRE(per_cu > 0, DS_EUNSUPPORTED, "ds_stereo_warp: polylines kernel does not fit a compute unit (%zu bytes of LDS)", lds);
+    long long nblocks = (long long)per_cu * ncu;
+    { const char *e = getenv("DS_PL_BLOCKS"); if (e && atoi(e) > 0) nblocks = atoi(e); }
+    if (nblocks > nwork) nblocks = nwork;
+    if (getenv("DS_PL_VERBOSE")) fprintf(stderr, "k_polylines<%d,%d>: S=%d nwmax=%d K=%d lds=%zu per_cu=%d ncu=%d grid=%lld nwork=%lld\n", C, SHARP, P.S, P.nwmax, P.K, lds, per_cu, ncu, nblocks, nwork);
+    hipLaunchKernelGGL(kfn, dim3((unsigned)nblocks), dim3(PL_THREADS), lds, st, P);
+    return DS_OK;
+}
+
+template <int SHARP>
+static int pl_launch_c(const PolyParams &P, int c, int ncu, long long nwork, size_t lds, hipStream_t st)
+{
+    if (P.n_eyes == 2) {
+        switch (c) {
+        case 1: return pl_launch_main<1, SHARP, 2>(P, ncu, nwork, lds, st);
+        case 2: return pl_launch_main<2, SHARP, 2>(P, ncu, nwork, lds, st);
+        case 3: return pl_launch_main<3, SHARP, 2>(P, ncu, nwork, lds, st);
+        default: return pl_launch_main<4, SHARP, 2>(P, ncu, nwork, lds, st);
+        }
+    }
+    switch (c) {
+    case 1: return pl_launch_main<1, SHARP, 1>(P, ncu, nwork, lds, st);
+    case 2: return pl_launch_main<2, SHARP, 1>(P, ncu, nwork, lds, st);
+    case 3: return pl_launch_main<3, SHARP, 1>(P, ncu, nwork, lds, st);
+    default: return pl_launch_main<4, SHARP, 1>(P, ncu, nwork, lds, st);
+    }
+}
+
+template <int DT>
+static void pl_launch_exact(const PolyParams &P, int sharp, const ExactScratch &S, int exact_blocks, hipStream_t st)
+{
     if (sharp) hipLaunchKernelGGL((k_polylines_exact<DT, 1>), dim3(exact_blocks), dim3(64), 0, st, P, S);
     else hipLaunchKernelGGL((k_polylines_exact<DT, 0>), dim3(exact_blocks), dim3(64), 0, st, P, S);
-    if (ctx->profile) { (void)hipEventRecord(ctx->ev[3], st); ctx->ev_recorded = 1; }
-    return DS_OK;
 }
 
 // called from ds_stereo_warp (ds_stereo.hip)
@@ -696,9 +1066,11 @@ int ds_polylines_launch(ds_ctx *ctx, const uint8_t *image, const void *depth, in
 {
     PolyParams P;
     memset(&P, 0, sizeof(P));
-    P.img = image; P.depth = depth; P.minmax = minmax; P.lut = lut;
-    P.n = n; P.h = h; P.w = w; P.c = c; P.n_eyes = n_eyes;
+    P.img = image; P.depth = depth; P.depth_dtype = depth_dtype; P.minmax = minmax; P.lut = lut;
+    P.n = n; P.h = h; P.w = w; P.n_eyes = n_eyes;
     { const char *e = getenv("DS_PL_DEBUG"); P.dbg = e ? atoi(e) : 0; }
+    DS_REQUIRE(depth_dtype == DS_DEPTH_U16 || depth_dtype == DS_DEPTH_F32 || depth_dtype == DS_DEPTH_F64, DS_EINVAL,
+               "unknown depth dtype %d", depth_dtype);
     for (int e = 0; e < n_eyes; e++) {
         const double dv = eyes[e].divergence_px, sp = eyes[e].separation_px;
         DS_REQUIRE(dv == dv && sp == sp && fabs(dv) < 1e6 && fabs(sp) < 1e6, DS_EINVAL, "ds_stereo_warp: divergence/separation not finite");
@@ -714,14 +1086,39 @@ int ds_polylines_launch(ds_ctx *ctx, const uint8_t *image, const void *depth, in
     }
     int uL = P.offL[0], uU = P.offU[0];
     if (n_eyes > 1) { uL = P.offL[1] < uL ? P.offL[1] : uL; uU = P.offU[1] > uU ? P.offU[1] : uU; }
-    const int ncu_max = PL_TILE + (uU - uL + 1) + 2;
-    const size_t lds = pl_lds_bytes(ncu_max, c);
-    DS_REQUIRE(lds <= 64 * 1024, DS_EUNSUPPORTED,
-               "ds_stereo_warp: divergence/separation window of %d columns does not fit the LDS budget", uU - uL + 1);
+    P.K = 1; P.nseg = 1;
+    for (int e = 0; e < n_eyes; e++) {
+        const int nseg = (sharp ? 2 : 1) * (P.offU[e] - P.offL[e] + 3) + 2;
+        if (nseg > P.nseg) P.nseg = nseg;
+        if ((nseg + 63) / 64 > P.K) P.K = (nseg + 63) / 64;
+    }
+    P.al4 = ((w & 3) == 0 && (((uintptr_t)depth) & 15) == 0 && (((uintptr_t)image) & 3) == 0) ? 1 : 0;
+
+    // supertile: the largest S (multiple of 64, <= 32704 so a pixel fits the 15-bit queue entry) whose staging fits the LDS budget
+    const int np = sharp ? 2 : 1;
+    const int wr = (w + 63) / 64 * 64;
+    int S = 512;
+    { const char *e = getenv("DS_PL_S"); if (e && atoi(e) >= 64) S = atoi(e) / 64 * 64; }
+    if (S > wr) S = wr;
+    size_t lds_budget = 64 * 1024;
+    { const char *e = getenv("DS_PL_LDS"); if (e && atoi(e) >= 8192) lds_budget = (size_t)atoi(e); }
+    PlLds L;
+    for (;;) {
+        long long nw = (long long)S + (uU - uL + 1) + 8;
+        if (nw > (long long)w + 4) nw = (long long)w + 4;
+        nw = (nw + 3) / 4 * 4;
+        DS_REQUIRE(nw < (1 << 20), DS_EUNSUPPORTED, "ds_stereo_warp: source window too large");
+        P.S = S; P.nwmax = (int)nw;
+        L = pl_lds_layout(S, P.nwmax, c, np);
+        if ((size_t)L.total <= lds_budget || S == 64) break;
+        S = (S / 2 + 63) / 64 * 64;
+    }
+    DS_REQUIRE((size_t)L.total <= 160 * 1024 && np * (long long)P.nwmax + PL_PT_PAD < 65536, DS_EUNSUPPORTED,
+               "ds_stereo_warp: divergence/separation window of %d columns does not fit the LDS", uU - uL + 1);
 
     const int64_t nrows = (int64_t)n * n_eyes * h;
     DS_REQUIRE(nrows < (1ll << 30), DS_EUNSUPPORTED, "ds_stereo_warp: too many rows in one call");
-    int rc = ds_ctx_reserve(ctx, &ctx->row_flags, &ctx->row_flags_bytes, (size_t)(nrows + 16) * sizeof(int));
+    int rc = ds_ctx_reserve(ctx, &ctx->row_flags, &ctx->row_flags_bytes, (size_t)(nrows + 64) * sizeof(int));
     if (rc) return rc;
     rc = ds_ctx_reserve(ctx, &ctx->row_list, &ctx->row_list_bytes, (size_t)nrows * sizeof(int));
     if (rc) return rc;
@@ -732,43 +1129,54 @@ int ds_polylines_launch(ds_ctx *ctx, const uint8_t *image, const void *depth, in
     const size_t per_worker = (size_t)np_max * (3 * sizeof(double) + 2 * sizeof(int));
     rc = ds_ctx_reserve(ctx, &ctx->exact_ws, &ctx->exact_ws_bytes, per_worker * nworkers);
     if (rc) return rc;
-    ExactScratch S;
-    S.nworkers = nworkers; S.np_max = np_max;
-    S.ox = (double *)ctx->exact_ws;
-    S.od = S.ox + (size_t)np_max * nworkers;
-    S.sx = S.od + (size_t)np_max * nworkers;
-    S.sk = (int *)(S.sx + (size_t)np_max * nworkers);
-    S.csg = S.sk + (size_t)np_max * nworkers;
+    ExactScratch X;
+    X.nworkers = nworkers; X.np_max = np_max; X.c = c;
+    X.ox = (double *)ctx->exact_ws;
+    X.od = X.ox + (size_t)np_max * nworkers;
+    X.sx = X.od + (size_t)np_max * nworkers;
+    X.sk = (int *)(X.sx + (size_t)np_max * nworkers);
+    X.csg = X.sk + (size_t)np_max * nworkers;
 
     // row_flags[0..nrows) flags, then 16 ints of counters
     P.row_flags = (int *)ctx->row_flags;
     P.counters = P.row_flags + nrows;
     P.row_list = (int *)ctx->row_list;
-    DS_HIP_CHECK(hipMemsetAsync(ctx->row_flags, 0, (size_t)(nrows + 16) * sizeof(int), st));
+    static const bool s_prof = getenv("DS_PL_PROF") != nullptr;
+    P.prof = s_prof ? reinterpret_cast<unsigned long long *>(P.row_flags + ((nrows + 17) & ~(int64_t)1)) : nullptr;
+    DS_HIP_CHECK(hipMemsetAsync(ctx->row_flags, 0, (size_t)(nrows + 64) * sizeof(int), st));
 
-    // queue of general pixels: worst case every pixel of every eye
-    // persistent grid of single-wave workgroups
-    const int tiles_x = (w + PL_TILE - 1) / PL_TILE;
-    const long long nwork = (long long)n * h * tiles_x;
-    long long nblocks = 256 * 128;
-    { const char *e = getenv("DS_PL_BLOCKS"); if (e && atoi(e) > 0) nblocks = atoi(e); }
-    if (nblocks > nwork) nblocks = nwork;
-    // queue of general pixels: worst case every pixel of every eye, plus one partly filled chunk per wave and the
-    // slack of closing a chunk early (at most one tile's worth per chunk)
-    const long long qchunks = ((long long)nrows * w) / (PL_QCHUNK - 1 - PL_TILE) + nblocks + 2;
-    rc = ds_ctx_reserve(ctx, &ctx->tmp_b, &ctx->tmp_b_bytes, (size_t)qchunks * PL_QCHUNK * sizeof(int4));
-    if (rc) return rc;
-    P.queue = (int4 *)ctx->tmp_b;
-    P.queue_chunks = (int)qchunks;
-    dim3 grid((unsigned)nblocks, 1, 1);
-
-    switch (depth_dtype) {
-    case DS_DEPTH_U16: rc = launch_dt<DS_DEPTH_U16>(ctx, P, sharp, grid, lds, S, nworkers / 64, st); break;
-    case DS_DEPTH_F32: rc = launch_dt<DS_DEPTH_F32>(ctx, P, sharp, grid, lds, S, nworkers / 64, st); break;
-    case DS_DEPTH_F64: rc = launch_dt<DS_DEPTH_F64>(ctx, P, sharp, grid, lds, S, nworkers / 64, st); break;
-    default: ds_set_error("unknown depth dtype %d", depth_dtype); return DS_EINVAL;
+    static int s_ncu[64];
+    DS_REQUIRE(ctx->device >= 0 && ctx->device < 64, DS_EUNSUPPORTED, "device ordinal %d", ctx->device);
+    if (s_ncu[ctx->device] == 0) {
+        int v = 0;
+        DS_HIP_CHECK(hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, ctx->device));
+        s_ncu[ctx->device] = v > 0 ? v : 256;
     }
+    const int tiles = (w + S - 1) / S;
+    const long long nwork = (long long)n * h * tiles;
+    DS_REQUIRE(nwork < (1ll << 31) - (1 << 20), DS_EUNSUPPORTED, "ds_stereo_warp: too many row tiles in one call");
+
+    if (ctx->profile) (void)hipEventRecord(ctx->ev[0], st);
+    rc = sharp ? pl_launch_c<1>(P, c, s_ncu[ctx->device], nwork, (size_t)L.total, st)
+               : pl_launch_c<0>(P, c, s_ncu[ctx->device], nwork, (size_t)L.total, st);
+    if (rc) return rc;
+    if (ctx->profile) { (void)hipEventRecord(ctx->ev[1], st); (void)hipEventRecord(ctx->ev[2], st); }
+    switch (depth_dtype) {
+    case DS_DEPTH_U16: pl_launch_exact<DS_DEPTH_U16>(P, sharp, X, nworkers / 64, st); break;
+    case DS_DEPTH_F32: pl_launch_exact<DS_DEPTH_F32>(P, sharp, X, nworkers / 64, st); break;
+    default: pl_launch_exact<DS_DEPTH_F64>(P, sharp, X, nworkers / 64, st); break;
+    }
+    if (ctx->profile) { (void)hipEventRecord(ctx->ev[3], st); ctx->ev_recorded = 1; }
     DS_HIP_CHECK(hipGetLastError());
+    if (s_prof) {
+        unsigned long long hp[16];
+        DS_HIP_CHECK(hipMemcpyAsync(hp, P.prof, sizeof(hp), hipMemcpyDeviceToHost, st));
+        DS_HIP_CHECK(hipStreamSynchronize(st));
+        const double nb = hp[7] ? (double)hp[7] : 1.0;
+        fprintf(stderr, "pl prof (cycles per workgroup, wave 0): flush %.0f  P01 %.0f  barA %.0f  P2 %.0f  barB %.0f  P3 %.0f  barC %.0f  (%llu workgroups)\n",
+                hp[0] / nb, hp[1] / nb, hp[2] / nb, hp[3] / nb, hp[4] / nb, hp[5] / nb, hp[6] / nb, hp[7]);
+        fprintf(stderr, "pl prof P01 split: setup+loads %.0f  points+fast scatter %.0f  slow scatter(+rest) %.0f\n", hp[8] / nb, hp[9] / nb, hp[1] / nb);
+    }
     ctx->last_exact_rows_valid = nrows;
     return DS_OK;
 }
