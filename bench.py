@@ -59,20 +59,44 @@ def synth_batch(batch, seed):
     return img, pred
 
 
-def cpu_baseline(sample_units, seed):
+def cpu_baseline(distinct_units, seed, min_seconds=12.0):
     """The CPU oracle (C restatement of the reference's numba path, OpenMP over rows like numba's prange) on a bounded
-    sample of the same workload, timed on this host's cores."""
+    sample of the same workload, timed on this host's cores: `distinct_units` synthetic units are rendered round-robin
+    until at least `min_seconds` of wall time have been spent (one untimed pass first, like the numba JIT warm-up)."""
     from oracle import oracle as orc
     orc.build()
-    img, pred = synth_batch(sample_units, seed)
-    t0 = time.perf_counter()
-    for i in range(sample_units):
+    img, pred = synth_batch(distinct_units, seed)
+
+    def one(i):
         d16 = orc.convert_to_i16(orc.depth_normalize01(pred[i], False))
         orc.create_stereoimages_arrays(img[i], d16, 2.5, 0.0, ['left-right'], 0.0, 1.0, 'polylines_sharp')
-    dt = time.perf_counter() - t0
-    return {"value": sample_units / dt, "unit": "pairs/s", "cores": orc.num_threads(), "kind": "port",
-            "sample": f"{sample_units} units of 1024x1024 (depth->u16 + polylines_sharp left-right), gcc -O2 -fopenmp "
-                      f"restatement of the reference's numba kernels, {dt:.2f} s"}
+
+    one(0)
+    done = 0
+    t0 = time.perf_counter()
+    while True:
+        one(done % distinct_units)
+        done += 1
+        dt = time.perf_counter() - t0
+        if dt >= min_seconds and done >= distinct_units:
+            break
+    return {"value": done / dt, "unit": "pairs/s", "cores": orc.num_threads(), "kind": "port",
+            "sample": f"{done} units of 1024x1024 ({distinct_units} distinct; depth->u16 + polylines_sharp left-right), "
+                      f"gcc -O2 -fopenmp restatement of the reference's numba kernels, {dt:.2f} s"}
+
+
+def pmc_traffic(batch):
+    """HBM bytes per k_polylines launch from the committed rocprofv3 PMC summary (separate --pmc passes, FETCH_SIZE
+    doubled as MI355X_MICROARCH.md prescribes for gfx950): profiles/round1_pmc_summary.json.  None when the summary is
+    missing or was taken at another batch size -- bench.py cannot read PMC counters itself."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "round1_pmc_summary.json")) as f:
+            j = json.load(f)
+        if int(j.get("batch", -1)) != int(batch):
+            return None
+        return float(j["k_polylines"]["hbm_bytes_per_launch"])
+    except Exception:
+        return None
 
 
 def main():
@@ -86,7 +110,8 @@ def main():
     ap.add_argument("--depth", default="steps", choices=["steps", "smooth"],
                     help="synthetic prediction: smooth field + periodic steps + occluders (default), or smooth only")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample", type=int, default=4)
+    ap.add_argument("--cpu-sample", type=int, default=8, help="distinct units of the CPU baseline sample")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="minimum wall time of the CPU baseline leg")
     args = ap.parse_args()
     global DEPTH_KIND
     DEPTH_KIND = args.depth
@@ -189,13 +214,13 @@ def main():
                        "parallelism": f"units sharded over {world} GPU(s), no data-path collective"
                                       + (", RCCL gather to rank 0 overlapped" if gather_ok else "")},
             "roofline": {"bound": "hbm", "kernel": "k_polylines", "achieved": achieved, "peak": HBM_PEAK_GBPS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": pmc_traffic(args.batch),
                          "algorithmic_bytes_per_launch": args.batch * ALGO_BYTES_PER_UNIT,
                          "avg_kernel_ms": float(np.mean(render_ms)), "exact_fallback_ms": float(np.mean(exact_ms)),
-                         "exact_fallback_rows": exact_rows, "general_pixel_chunks": queue_chunks},
+                         "exact_fallback_rows": exact_rows, "general_pixels": queue_chunks},
         }
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(args.cpu_sample, seed=1000)
+            out["cpu_baseline"] = cpu_baseline(args.cpu_sample, seed=1000, min_seconds=args.cpu_seconds)
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

@@ -518,6 +518,17 @@ __global__ __launch_bounds__(PL_THREADS, 4) void k_polylines(PolyParams P)
     uint16_t *s_queue = reinterpret_cast<uint16_t *>(smem + L.off_queue);    // (eye << 15) | pixel
     int *s_misc = reinterpret_cast<int *>(smem + L.off_misc);                // [0],[1]: queue counts (alternating), [2],[3]: row flag per eye
 
+    // per-eye constants pinned in scalar registers: without this the compiler re-reads them from the kernel-argument
+    // segment inside the per-column code (s_load + s_waitcnt lgkmcnt(0) in the hot path)
+    double k_div[NE], k_sep[NE];
+#pragma unroll
+    for (int e = 0; e < NE; e++) {
+        int dl = __double2loint(P.div_px[e]), dh = __double2hiint(P.div_px[e]);
+        int sl = __double2loint(P.sep_px[e]), sh = __double2hiint(P.sep_px[e]);
+        asm volatile("" : "+s"(dl), "+s"(dh), "+s"(sl), "+s"(sh));
+        k_div[e] = __hiloint2double(dh, dl);
+        k_sep[e] = __hiloint2double(sh, sl);
+    }
     const int tiles = (w + S - 1) / S;
     const int nwork = P.n * P.h * tiles;                    // < 2^31, checked by the host
     int uL = P.offL[0], uU = P.offU[0];                    // union of the two eyes' window offsets
@@ -529,8 +540,14 @@ __global__ __launch_bounds__(PL_THREADS, 4) void k_polylines(PolyParams P)
 
     int prev = -1, prev_img = 0, prev_row = 0, prev_c0 = 0;
     int iter = 0;
+#ifdef DS_PL_PROFILE        // build with -DDS_PL_PROFILE to get per-phase cycle counts (DS_PL_PROF=1 at run time)
     unsigned long long tacc[12] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 }, tl = P.prof ? __builtin_readcyclecounter() : 0ull;
 #define PL_TICK(i) do { if (P.prof) { const unsigned long long t_ = __builtin_readcyclecounter(); tacc[i] += t_ - tl; tl = t_; } } while (0)
+#define PL_TICKW(w, i) do { if (P.prof) { asm volatile(w ::: "memory"); PL_TICK(i); } } while (0)
+#else
+#define PL_TICK(i) do { } while (0)
+#define PL_TICKW(w, i) do { } while (0)
+#endif
     for (int work = blockIdx.x;; work += gridDim.x) {
         // ---- S0: the previous work item's rows leave LDS ------------------------------------------------
         if (prev >= 0) {
@@ -539,6 +556,7 @@ __global__ __launch_bounds__(PL_THREADS, 4) void k_polylines(PolyParams P)
             const int nbytes = tn * C;
 #pragma unroll
             for (int e = 0; e < NE; e++) {
+                if (P.dbg == 3) break;
                 uint8_t *dst = P.out[e] + (int64_t)img * P.ois[e] + (int64_t)row * P.ors[e] + (size_t)c0 * C;
                 const uint8_t *src = s_out + e * L.outstride;
                 if ((((uintptr_t)dst) & 15) == 0) {
@@ -604,9 +622,11 @@ __global__ __launch_bounds__(PL_THREADS, 4) void k_polylines(PolyParams P)
             const int j = j0 + i4;
             const int nv = min(4, ncols - i4);
             double nd[4], ndp;
+            PL_TICK(7);
             pl_load_nd(P, depth_row, j, nv, j > 0, mn, mx, lut, nd, ndp);
             uint32_t rgbx[4];
             pl_load_rgbx<C>(src_row + (size_t)j * C, nv, P.al4 != 0, rgbx);
+            PL_TICKW("s_waitcnt vmcnt(0)", 8);
             if (nv == 4) {
                 *reinterpret_cast<double2 *>(&s_nd[i4]) = make_double2(nd[0], nd[1]);
                 *reinterpret_cast<double2 *>(&s_nd[i4 + 2]) = make_double2(nd[2], nd[3]);
@@ -620,12 +640,13 @@ __global__ __launch_bounds__(PL_THREADS, 4) void k_polylines(PolyParams P)
                 if (j > 0) for (int k = 0; k < C; k++) v |= (uint32_t)src_row[(size_t)(j - 1) * C + k] << (8 * k);
                 s_rgbx[-1] = v;
             }
+            PL_TICKW("s_waitcnt lgkmcnt(0)", 9);
             double colx[4];                                 // (col + 0.5), shared by the eyes (:183)
 #pragma unroll
             for (int m = 0; m < 4; m++) colx[m] = (double)(j + m) + 0.5;
 #pragma unroll
             for (int e = 0; e < NE; e++) {
-                const double div_px = P.div_px[e], sep_px = P.sep_px[e];
+                const double div_px = k_div[e], sep_px = k_sep[e];
                 double *pt = s_pt + e * L.npt;
                 uint32_t *g0 = s_g0 + e * S;
                 uint32_t slow = 0;                          // bit t: segment NP*i4 + 1 + t of this thread needs the slow path
@@ -667,6 +688,7 @@ __global__ __launch_bounds__(PL_THREADS, 4) void k_polylines(PolyParams P)
                     for (int k = 0; k < PL_PT_PAD - 1; k++) pt[qT + k] = 2.0 * (double)w;        // :191 (or harmless padding)
                     if (tail) slow |= 1u << (NP * nv);      // the tail sentinel segment qT follows this thread's last point
                 }
+                PL_TICKW("s_waitcnt lgkmcnt(0)", 10);
                 // long gaps, backward segments, the tail sentinel: rare, one shared loop (the points are re-read from LDS;
                 // a thread reads back only what it stored itself)
                 while (__any(slow != 0u)) {
@@ -715,7 +737,7 @@ __global__ __launch_bounds__(PL_THREADS, 4) void k_polylines(PolyParams P)
                 if (__any(walk[e])) {
                     if (walk[e]) {
                         PlWin V;
-                        V.pt = s_pt + e * L.npt; V.nd = s_nd; V.rgbx = s_rgbx; V.ncols = ncols; V.head = head; V.tail = tail; V.div_px = P.div_px[e];
+                        V.pt = s_pt + e * L.npt; V.nd = s_nd; V.rgbx = s_rgbx; V.ncols = ncols; V.head = head; V.tail = tail; V.div_px = k_div[e];
                         flag[e] = 0;
                         pl_walk<C, NP>(V, g0[e], fq, fq1, color[e], flag[e]);
                     }
@@ -764,7 +786,7 @@ __global__ __launch_bounds__(PL_THREADS, 4) void k_polylines(PolyParams P)
                 const int qlo = NP * iL + 1;
                 const int qhi = !have ? 0 : ((iU == ncols - 1 && tail) ? NP * ncols + 1 : NP * (iU + 1));
                 PlWin V;
-                V.pt = s_pt + e * L.npt; V.nd = s_nd; V.rgbx = s_rgbx; V.ncols = ncols; V.head = head; V.tail = tail; V.div_px = P.div_px[e];
+                V.pt = s_pt + e * L.npt; V.nd = s_nd; V.rgbx = s_rgbx; V.ncols = ncols; V.head = head; V.tail = tail; V.div_px = k_div[e];
                 const double fq = (double)col, fq1 = (double)(col + 1);
                 unsigned long long fm[PL_KMAX], bm[PL_KMAX];
 #pragma unroll
@@ -889,12 +911,15 @@ __global__ __launch_bounds__(PL_THREADS, 4) void k_polylines(PolyParams P)
         prev = work; prev_img = img; prev_row = row; prev_c0 = c0;
         iter++;
     }
+#ifdef DS_PL_PROFILE
     if (P.prof && tid == 0) {
         for (int i = 0; i < 7; i++) atomicAdd(&P.prof[i], tacc[i]);
         atomicAdd(&P.prof[7], 1ull);
         for (int i = 7; i < 12; i++) atomicAdd(&P.prof[i + 1], tacc[i]);
     }
+#endif
 #undef PL_TICK
+#undef PL_TICKW
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1175,7 +1200,7 @@ int ds_polylines_launch(ds_ctx *ctx, const uint8_t *image, const void *depth, in
         const double nb = hp[7] ? (double)hp[7] : 1.0;
         fprintf(stderr, "pl prof (cycles per workgroup, wave 0): flush %.0f  P01 %.0f  barA %.0f  P2 %.0f  barB %.0f  P3 %.0f  barC %.0f  (%llu workgroups)\n",
                 hp[0] / nb, hp[1] / nb, hp[2] / nb, hp[3] / nb, hp[4] / nb, hp[5] / nb, hp[6] / nb, hp[7]);
-        fprintf(stderr, "pl prof P01 split: setup+loads %.0f  points+fast scatter %.0f  slow scatter(+rest) %.0f\n", hp[8] / nb, hp[9] / nb, hp[1] / nb);
+        fprintf(stderr, "pl prof P01 split: setup %.0f  loads %.0f  normalise+store %.0f  points+scatter(2 eyes, +slow loop of eye 0) %.0f  rest %.0f\n", hp[8] / nb, hp[9] / nb, hp[10] / nb, hp[11] / nb, hp[1] / nb);
     }
     ctx->last_exact_rows_valid = nrows;
     return DS_OK;

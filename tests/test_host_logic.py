@@ -139,3 +139,13 @@ def test_shard_bounds():
         for w in range(1, 9):
             b = shard_bounds(n, w)
             assert b[0][0] == 0 and b[-1][1] == n and all(b[i][1] == b[i + 1][0] for i in range(w - 1))
+
+
+def test_u16_normalisation_identity_exhaustive(oracle):
+    """The device computes (depth-min)/(max-min) for uint16 depth with one reciprocal and two FMAs per element; the C
+    program enumerates all 2^32 operand pairs and compares with true float64 division (a few seconds on 8 cores)."""
+    import subprocess
+    here = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle")
+    subprocess.check_call(["make", "-C", here, "-s", "check_u16_division"])
+    out = subprocess.run([os.path.join(here, "check_u16_division")], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and out.stdout.startswith("bad=0 of 4294901760"), out.stdout
