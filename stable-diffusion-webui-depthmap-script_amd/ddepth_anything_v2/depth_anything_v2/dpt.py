@@ -1,0 +1,147 @@
+"""Depth-Anything-V2: DINOv2 encoder + DPT head, MI355X-first.
+
+Reference: ddepth_anything_v2/depth_anything_v2/dpt.py (DPTHead :37-150, DepthAnythingV2 :153-221),
+util/blocks.py (ResidualConvUnit :32-85, FeatureFusionBlock :88-148, _make_scratch :4-29),
+util/transform.py (Resize.get_size :58-107), and its caller src/depthmap_generation.py:548-559.
+Checkpoint key names are the reference's.  The decoder's convolutions run through MIOpen (channels_last on the GPU).
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .dinov2 import DINOv2
+
+
+class ResidualConvUnit(nn.Module):
+    def __init__(self, features):
+        super().__init__()
+        self.conv1 = nn.Conv2d(features, features, kernel_size=3, stride=1, padding=1, bias=True)
+        self.conv2 = nn.Conv2d(features, features, kernel_size=3, stride=1, padding=1, bias=True)
+
+    def forward(self, x):               # blocks.py:56-85 (bn=False, activation ReLU(False))
+        out = self.conv1(F.relu(x))
+        out = self.conv2(F.relu(out))
+        return out + x
+
+
+class FeatureFusionBlock(nn.Module):
+    def __init__(self, features):
+        super().__init__()
+        self.out_conv = nn.Conv2d(features, features, kernel_size=1, stride=1, padding=0, bias=True)
+        self.resConfUnit1 = ResidualConvUnit(features)
+        self.resConfUnit2 = ResidualConvUnit(features)
+
+    def forward(self, *xs, size=None):  # blocks.py:121-148 (align_corners=True)
+        output = xs[0]
+        if len(xs) == 2:
+            output = output + self.resConfUnit1(xs[1])
+        output = self.resConfUnit2(output)
+        if size is None:
+            output = F.interpolate(output, scale_factor=2, mode="bilinear", align_corners=True)
+        else:
+            output = F.interpolate(output, size=size, mode="bilinear", align_corners=True)
+        return self.out_conv(output)
+
+
+class DPTHead(nn.Module):
+    def __init__(self, in_channels, features=256, use_bn=False, out_channels=(256, 512, 1024, 1024), use_clstoken=False):
+        super().__init__()
+        if use_bn or use_clstoken:
+            raise NotImplementedError("use_bn / use_clstoken are never enabled by the reference's model table "
+                                      "(src/depthmap_generation.py:243-247)")
+        oc = list(out_channels)
+        self.projects = nn.ModuleList([nn.Conv2d(in_channels, c, kernel_size=1) for c in oc])
+        self.resize_layers = nn.ModuleList([
+            nn.ConvTranspose2d(oc[0], oc[0], kernel_size=4, stride=4, padding=0),
+            nn.ConvTranspose2d(oc[1], oc[1], kernel_size=2, stride=2, padding=0),
+            nn.Identity(),
+            nn.Conv2d(oc[3], oc[3], kernel_size=3, stride=2, padding=1)])
+        scratch = nn.Module()
+        for i in range(4):
+            setattr(scratch, f"layer{i + 1}_rn", nn.Conv2d(oc[i], features, kernel_size=3, stride=1, padding=1, bias=False))
+        for i in range(1, 5):
+            setattr(scratch, f"refinenet{i}", FeatureFusionBlock(features))
+        scratch.output_conv1 = nn.Conv2d(features, features // 2, kernel_size=3, stride=1, padding=1)
+        scratch.output_conv2 = nn.Sequential(
+            nn.Conv2d(features // 2, 32, kernel_size=3, stride=1, padding=1), nn.ReLU(True),
+            nn.Conv2d(32, 1, kernel_size=1, stride=1, padding=0), nn.ReLU(True), nn.Identity())
+        self.scratch = scratch
+
+    def forward(self, out_features, patch_h, patch_w):          # dpt.py:117-150
+        out = []
+        for i, x in enumerate(out_features):
+            x = x[0]
+            x = x.permute(0, 2, 1).reshape((x.shape[0], x.shape[-1], patch_h, patch_w))
+            x = self.resize_layers[i](self.projects[i](x))
+            out.append(x)
+        l1, l2, l3, l4 = out
+        s = self.scratch
+        l1, l2, l3, l4 = s.layer1_rn(l1), s.layer2_rn(l2), s.layer3_rn(l3), s.layer4_rn(l4)
+        path_4 = s.refinenet4(l4, size=l3.shape[2:])
+        path_3 = s.refinenet3(path_4, l3, size=l2.shape[2:])
+        path_2 = s.refinenet2(path_3, l2, size=l1.shape[2:])
+        path_1 = s.refinenet1(path_2, l1)
+        out = s.output_conv1(path_1)
+        out = F.interpolate(out, (int(patch_h * 14), int(patch_w * 14)), mode="bilinear", align_corners=True)
+        return s.output_conv2(out)
+
+
+_LAYER_IDX = {'vits': [2, 5, 8, 11], 'vitb': [2, 5, 8, 11], 'vitl': [4, 11, 17, 23]}
+
+
+def _constrain(x, multiple, min_val):
+    y = int(np.round(x / multiple) * multiple)
+    if y < min_val:
+        y = int(np.ceil(x / multiple) * multiple)
+    return y
+
+
+def lower_bound_size(width, height, target, multiple=14):
+    """Resize.get_size with keep_aspect_ratio, 'lower_bound', ensure_multiple_of=14 (transform.py:58-107)."""
+    scale_h, scale_w = target / height, target / width
+    if scale_w > scale_h:
+        scale_h = scale_w
+    else:
+        scale_w = scale_h
+    return _constrain(scale_w * width, multiple, target), _constrain(scale_h * height, multiple, target)
+
+
+class DepthAnythingV2(nn.Module):
+    def __init__(self, encoder='vitl', features=256, out_channels=(256, 512, 1024, 1024), use_bn=False, use_clstoken=False):
+        super().__init__()
+        self.intermediate_layer_idx = dict(_LAYER_IDX)
+        self.encoder = encoder
+        self.pretrained = DINOv2(model_name=encoder)
+        self.depth_head = DPTHead(self.pretrained.embed_dim, features, use_bn, out_channels=out_channels, use_clstoken=use_clstoken)
+
+    def forward(self, x):               # dpt.py:176-184
+        patch_h, patch_w = x.shape[-2] // 14, x.shape[-1] // 14
+        features = self.pretrained.get_intermediate_layers(x, self.intermediate_layer_idx[self.encoder], return_class_token=True)
+        depth = self.depth_head(features, patch_h, patch_w)
+        return F.relu(depth).squeeze(1)
+
+    # ---- device-resident pre/post: replaces image2tensor (dpt.py:196-221) + the bilinear upsample of
+    # estimatedepthanything_v2 (src/depthmap_generation.py:548-559) without leaving the GPU --------------------------
+    @torch.no_grad()
+    def image2tensor_device(self, images_u8, input_size=518):
+        """images_u8: uint8 [B, H, W, 3] on the model's device, channel order AS THE FUNNEL HANDS IT OVER (RGB).
+        The reference swaps channels three times on the way in (get_raw_prediction :381, estimatedepthanything_v2
+        :550, image2tensor :209), i.e. the network sees BGR order with RGB-ordered mean/std -- reproduced here.
+        Bicubic resize = cv2.INTER_CUBIC's kernel (a = -0.75, half-pixel centres, replicated border, no antialias);
+        cv2 itself is not available in this environment: parity of the resize is unpinned."""
+        b, h, w, _ = images_u8.shape
+        nw, nh = lower_bound_size(w, h, input_size)
+        x = images_u8.flip(-1).permute(0, 3, 1, 2).float() / 255.0
+        x = F.interpolate(x, size=(nh, nw), mode="bicubic", align_corners=False)
+        mean = torch.tensor([0.485, 0.456, 0.406], device=x.device).view(1, 3, 1, 1)
+        std = torch.tensor([0.229, 0.224, 0.225], device=x.device).view(1, 3, 1, 1)
+        return (x - mean) / std, (h, w)
+
+    @torch.no_grad()
+    def infer_batch(self, images_u8, input_size=518):
+        """uint8 [B,H,W,3] -> float32 [B,H,W] raw prediction (larger = nearer), on the device."""
+        x, (h, w) = self.image2tensor_device(images_u8, input_size)
+        dtype = self.pretrained.blocks[0].norm1.weight.dtype      # the reference casts to the model's dtype (:555)
+        depth = self.forward(x.to(dtype)).float()
+        return F.interpolate(depth[:, None], (h, w), mode="bilinear", align_corners=True)[:, 0]

@@ -1,0 +1,56 @@
+"""Generates tests/golden/model_cases.npz by running the REFERENCE's own torch modules (imported from /root/reference
+with stubs for the third-party modules that are absent here and unused by forward(): cv2, torchvision) on synthetic
+name-seeded weights (model_weights.py).  Run in the build container only; the tests read the committed .npz.
+
+    python tests/golden/make_golden_models.py
+"""
+import os
+import sys
+import types
+from unittest import mock
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.dont_write_bytecode = True
+sys.path.insert(0, HERE)
+import model_weights as mw  # noqa: E402
+
+REF = "/root/reference"
+
+
+def reference_dav2(encoder, features, out_channels):
+    for name in ("cv2", "torchvision", "torchvision.transforms"):
+        if name not in sys.modules:
+            sys.modules[name] = mock.MagicMock()
+    sys.path.insert(0, REF)
+    from ddepth_anything_v2.depth_anything_v2.dpt import DepthAnythingV2
+    sys.path.pop(0)
+    return DepthAnythingV2(encoder=encoder, features=features, out_channels=out_channels)
+
+
+def main():
+    out = {}
+    torch.manual_seed(0)
+    # Depth-Anything-V2 small (src/depthmap_generation.py:243): 10 x 13 patches -> 131 tokens (non-square pos-embed, padding)
+    m = reference_dav2('vits', 64, [48, 96, 192, 384]).eval()
+    m.load_state_dict(mw.fill_state_dict(m.state_dict()), strict=True)
+    x = mw.synthetic_image((2, 3, 140, 182), seed=11)
+    with torch.no_grad():
+        y = m(x)
+        taps = m.pretrained.get_intermediate_layers(x, [2, 5, 8, 11], return_class_token=True)
+    out["dav2_vits_140x182_out"] = y.numpy()
+    out["dav2_vits_140x182_tap3_tokens"] = taps[3][0].numpy()
+    out["dav2_vits_140x182_tap0_cls"] = taps[0][1].numpy()
+    # square input at the native 37x37 grid would skip the interpolation branch; 70x70 exercises the w == h, npatch != N case
+    x2 = mw.synthetic_image((1, 3, 70, 70), seed=12)
+    with torch.no_grad():
+        out["dav2_vits_70x70_out"] = m(x2).numpy()
+    np.savez_compressed(os.path.join(HERE, "model_cases.npz"), **out)
+    for k, v in out.items():
+        print(k, v.shape, float(np.abs(v).mean()))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,41 @@
+"""Deterministic synthetic weights for model-parity tests: every parameter is a function of its NAME and shape only,
+so the reference's module and ours (same checkpoint key names) get bit-identical weights without shipping a checkpoint.
+Pure torch; used by make_golden_models.py (which imports the reference) and by the tests (which do not)."""
+import math
+import zlib
+
+import torch
+
+
+def fill_state_dict(sd):
+    out = {}
+    for name in sorted(sd.keys()):
+        p = sd[name]
+        g = torch.Generator().manual_seed(zlib.crc32(name.encode()) & 0x7fffffff)
+        r = torch.randn(p.shape, generator=g, dtype=torch.float32)
+        leaf = name.split('.')[-1]
+        if not p.dtype.is_floating_point:
+            out[name] = p.clone()
+            continue
+        if leaf in ('gamma', 'gamma_1', 'gamma_2'):
+            v = 1.0 + 0.1 * r
+        elif leaf == 'weight' and p.dim() == 1:                 # LayerNorm / BatchNorm scale
+            v = 1.0 + 0.1 * r
+        elif leaf == 'weight':
+            fan_in = p[0].numel() if p.dim() > 1 else p.numel()
+            v = r / math.sqrt(max(fan_in, 1))
+        elif leaf == 'bias':
+            v = 0.1 * r
+        elif leaf in ('running_mean',):
+            v = 0.1 * r
+        elif leaf in ('running_var',):
+            v = 1.0 + 0.1 * r.abs()
+        else:                                                   # cls_token, pos_embed, mask_token, bias tables ...
+            v = 0.02 * r
+        out[name] = v.to(p.dtype)
+    return out
+
+
+def synthetic_image(shape, seed):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(shape, generator=g, dtype=torch.float32)

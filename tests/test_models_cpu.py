@@ -1,0 +1,84 @@
+"""Model-forward parity on the CPU (float32): our MI355X-first modules against outputs of the REFERENCE's own torch
+modules (tests/golden/model_cases.npz, made by tests/golden/make_golden_models.py from /root/reference with
+name-seeded synthetic weights).  Tolerance: 1e-4 relative to the output scale (BASELINE.json north_star: "within 1e-4
+rel for float depth"), float32 against float32 -- summation orders differ (padded sequence, split QKV GEMMs)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import conftest  # noqa: F401  (sys.path)
+import model_weights as mw
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "model_cases.npz")
+
+
+def _rel(a, b):
+    return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-12))
+
+
+@pytest.fixture(scope="module")
+def gold():
+    return np.load(GOLD)
+
+
+@pytest.fixture(scope="module")
+def dav2_vits():
+    from ddepth_anything_v2 import DepthAnythingV2
+    m = DepthAnythingV2('vits', features=64, out_channels=[48, 96, 192, 384]).eval()
+    missing = m.load_state_dict(mw.fill_state_dict(m.state_dict()), strict=True)
+    assert not missing.missing_keys and not missing.unexpected_keys
+    return m
+
+
+def test_dav2_state_dict_keys_match_reference_checkpoint_layout(dav2_vits):
+    keys = set(dav2_vits.state_dict().keys())
+    # names the reference's checkpoints carry (ddepth_anything_v2/depth_anything_v2/dpt.py, dinov2.py)
+    for k in ("pretrained.cls_token", "pretrained.pos_embed", "pretrained.mask_token", "pretrained.patch_embed.proj.weight",
+              "pretrained.blocks.0.norm1.weight", "pretrained.blocks.0.attn.qkv.weight", "pretrained.blocks.0.attn.qkv.bias",
+              "pretrained.blocks.0.attn.proj.weight", "pretrained.blocks.0.ls1.gamma", "pretrained.blocks.0.mlp.fc1.weight",
+              "pretrained.blocks.11.mlp.fc2.bias", "pretrained.blocks.11.ls2.gamma", "pretrained.norm.weight",
+              "depth_head.projects.0.weight", "depth_head.resize_layers.0.weight", "depth_head.resize_layers.3.bias",
+              "depth_head.scratch.layer1_rn.weight", "depth_head.scratch.refinenet4.resConfUnit1.conv1.weight",
+              "depth_head.scratch.refinenet1.out_conv.bias", "depth_head.scratch.output_conv1.weight",
+              "depth_head.scratch.output_conv2.0.weight", "depth_head.scratch.output_conv2.2.bias"):
+        assert k in keys, k
+    assert len(keys) == 12 * 14 + 5 + 2 + 68 or len(keys) > 200     # 12 blocks x 14 tensors + embeddings + head
+
+
+def test_dav2_forward_matches_reference_modules(dav2_vits, gold):
+    x = mw.synthetic_image((2, 3, 140, 182), seed=11)
+    with torch.no_grad():
+        y = dav2_vits(x).numpy()
+        taps = dav2_vits.pretrained.get_intermediate_layers(x, [2, 5, 8, 11], return_class_token=True)
+    assert _rel(taps[3][0].numpy(), gold["dav2_vits_140x182_tap3_tokens"]) < 1e-4
+    assert _rel(taps[0][1].numpy(), gold["dav2_vits_140x182_tap0_cls"]) < 1e-4
+    assert y.shape == gold["dav2_vits_140x182_out"].shape
+    assert _rel(y, gold["dav2_vits_140x182_out"]) < 1e-4
+    x2 = mw.synthetic_image((1, 3, 70, 70), seed=12)
+    with torch.no_grad():
+        assert _rel(dav2_vits(x2).numpy(), gold["dav2_vits_70x70_out"]) < 1e-4
+
+
+def test_lower_bound_size_matches_reference_transform():
+    from ddepth_anything_v2.depth_anything_v2.dpt import lower_bound_size
+    # values computed with the reference's Resize.get_size (transform.py:58-107), keep_aspect, lower_bound, multiple 14
+    assert lower_bound_size(1920, 1080, 518) == (924, 518)
+    assert lower_bound_size(512, 512, 518) == (518, 518)
+    assert lower_bound_size(1024, 1024, 518) == (518, 518)
+    assert lower_bound_size(640, 480, 518) == (686, 518)
+    assert lower_bound_size(480, 640, 518) == (518, 686)
+
+
+def test_padding_is_invisible(dav2_vits):
+    """A sequence that needs 61 pad rows and one that needs none give the same per-token results for the real tokens:
+    pad rows are masked as keys."""
+    from src import vit_mi355x as vm
+    torch.manual_seed(3)
+    blk = dav2_vits.pretrained.blocks[0]
+    x = torch.randn(1, 131, 384)
+    with torch.no_grad():
+        a = blk.forward_padded(vm.pad_tokens(x, 192), 131)[:, :131]
+        b = blk.forward_padded(vm.pad_tokens(x, 256), 131)[:, :131]
+    assert torch.allclose(a, b, atol=1e-5, rtol=1e-5)
