@@ -145,6 +145,24 @@ int ds_depth_to_u16(ds_ctx *ctx, const float *pred, int n, int h, int w, int inv
 /* convert_to_i16 alone (src/core.py:44-50): float32 or float64 input already in [0,1]. */
 int ds_convert_to_i16(ds_ctx *ctx, const void *arr, int is_f64, int64_t count, uint16_t *out, void *stream);
 
+/* element types of the tensor-core entry points */
+#define DS_DTYPE_F16  1
+#define DS_DTYPE_BF16 2
+
+/*
+ * ds_attention_fwd -- fused attention forward of one transformer block; replaces the q@k^T -> (+bias) -> softmax -> @v
+ * sequence of ddepth_anything_v2/depth_anything_v2/dinov2_layers/attention.py:49-62 (MemEffAttention falls back to it,
+ * :65-82) and of dmidas/backbones/beit.py:65-91 (attention_forward with relative position bias); head_dim = 64.
+ *   qk      [B, Np, 2, H, 64]  Q (index 0) and K (index 1), token major, as the projection GEMM writes them
+ *   vt      [B, H*64, Np]      V transposed (key index contiguous)
+ *   bias_t  [H, Np, Np] or NULL: additive logits bias stored KEY-major: bias_t[h][key][query]
+ *   out     [B, Np, H*64]
+ * Np is a multiple of 64 (the padded token count); keys >= n_valid are masked; query rows >= n_valid are computed
+ * like any other row (they stay finite) and are never read as keys.  scale multiplies q.k before the bias is added.
+ */
+int ds_attention_fwd(ds_ctx *ctx, const void *qk, const void *vt, const void *bias_t, void *out,
+                     int B, int Np, int H, int n_valid, float scale, int dtype, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,250 @@
+// ds_attention_fwd: fused (flash-style) attention forward for the ViT encoders of the depth models, on the gfx950
+// matrix cores.  Replaces, per transformer block, the reference's
+//     attn = (q * scale) @ k^T [+ relative_position_bias];  attn = softmax(attn);  x = attn @ v
+// (ddepth_anything_v2/depth_anything_v2/dinov2_layers/attention.py:49-62, dmidas/backbones/beit.py:65-91), which
+// materialises a B x H x N x N tensor in HBM, by one kernel that never leaves the chip between Q.K^T and P.V.
+//
+// Operands (head_dim is 64 for every encoder the reference ships):
+//   qk   [B, Np, 2, H, 64]  f16/bf16   Q and K exactly as the projection GEMM writes them (token major)
+//   vt   [B, H*64, Np]      f16/bf16   V TRANSPOSED (key index contiguous), produced in that layout by its own GEMM
+//   bias [H, Np(key), Np(query)] optional, same dtype: additive logits bias, stored key-major so that the 32 lanes of
+//        a query block read 64 contiguous bytes per key
+//   out  [B, Np, H*64]      f16/bf16
+// Np is a multiple of 64; keys >= n_valid are masked (pad rows of the padded token sequence).
+//
+// Mapping: workgroup = 4 waves = 128 query rows of one (batch, head); each wave owns 32 query rows.  Per 64-key tile:
+//   S^T = K . Q^T   "swapped" so that a lane holds logits of ONE query (column lane&31) for 32 of the 64 keys: the
+//                   row max / row sum of the online softmax are in-lane reductions plus one exchange with lane^32;
+//                   2 key blocks x 4 d-slices of v_mfma_f32_32x32x16 (A = K rows from LDS, B = Q rows in registers)
+//   O^T += V^T . P^T  A = V^T rows (two ds_read_b64 of 4 consecutive keys each), B = P^T built in registers straight
+//                   from the S^T accumulators: the accumulator's row order fixes which keys sit in which k-slot, and
+//                   the V^T reads use the same order, so no cross-lane traffic is needed between the two GEMMs.
+// K tiles sit in LDS XOR-swizzled by 16-byte chunk (conflict-free ds_read_b128 of 32 rows x 128 B); V^T rows are padded
+// to 136 B (conflict-free ds_read_b64).  The next tile is fetched into registers while the current one is computed.
+#include "ds_common.h"
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define AT_THREADS 256
+#define AT_QW 32                 // query rows per wave
+#define AT_QB (AT_QW * 4)        // query rows per workgroup
+#define AT_KB 64                 // keys per tile
+#define AT_D 64
+#define AT_VROW 136              // bytes per V^T row in LDS (128 + 8 pad)
+
+template <int BF16> struct at_traits;
+template <> struct at_traits<0> {
+    typedef _Float16 T; typedef f16x8 V8;
+    static __device__ __forceinline__ f32x16 mfma(V8 a, V8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
+    static __device__ __forceinline__ T from_f32(float x) { return (_Float16)x; }
+    static __device__ __forceinline__ float to_f32(T x) { return (float)x; }
+};
+template <> struct at_traits<1> {
+    typedef __bf16 T; typedef bf16x8 V8;
+    static __device__ __forceinline__ f32x16 mfma(V8 a, V8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+    static __device__ __forceinline__ T from_f32(float x) { return (__bf16)x; }
+    static __device__ __forceinline__ float to_f32(T x) { return (float)x; }
+};
+
+// row of the 32x32 accumulator held in register r of a lane with hi = lane >> 5 (cdna_hip_programming.md, 3. MFMA)
+__device__ __forceinline__ int at_crow(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }
+
+struct AttnParams {
+    const void *qk, *vt, *bias;
+    void *out;
+    int B, Np, H, n_valid;
+    float scale_log2e;           // softmax scale * log2(e): logits are kept in the exp2 domain
+    float log2e;
+};
+
+template <int BF16, int HAS_BIAS>
+__global__ __launch_bounds__(AT_THREADS) void k_attention_fwd(AttnParams P)
+{
+    typedef at_traits<BF16> TR;
+    typedef typename TR::T T;
+    typedef typename TR::V8 V8;
+    __shared__ __attribute__((aligned(16))) unsigned char s_k[AT_KB * 128];          // [key][64 d], chunk-swizzled
+    __shared__ __attribute__((aligned(16))) unsigned char s_v[AT_D * AT_VROW];       // [d][64 keys], padded rows
+
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, hi = lane >> 5, l31 = lane & 31;
+    const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * AT_QB + wave * AT_QW;
+    const int Np = P.Np, H = P.H;
+    const size_t tok_stride = (size_t)2 * H * AT_D;                                   // elements between tokens in qk
+    const T *qk = (const T *)P.qk + (size_t)b * Np * tok_stride;
+    const T *q_base = qk + (size_t)h * AT_D;                                          // s = 0
+    const T *k_base = qk + (size_t)(H + h) * AT_D;                                    // s = 1
+    const T *vt = (const T *)P.vt + ((size_t)b * H + h) * AT_D * (size_t)Np;
+    const bool wave_live = q0 < Np;                                                   // whole wave beyond the padded sequence?
+
+    // Q fragments: B operand of S^T = K.Q^T: lane holds Q[q0 + l31][16 s + 8 hi .. +7]
+    V8 qf[4];
+    {
+        const int qrow = min(q0 + l31, Np - 1);
+        const T *qp = q_base + (size_t)qrow * tok_stride + 8 * hi;
+#pragma unroll
+        for (int s = 0; s < 4; s++) qf[s] = *reinterpret_cast<const V8 *>(qp + 16 * s);
+    }
+
+    f32x16 o_acc[2];
+#pragma unroll
+    for (int d = 0; d < 2; d++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) o_acc[d][r] = 0.f;
+    float m_run = -__builtin_inff(), l_run = 0.f;
+
+    // staging assignment: K tile = 64 rows x 8 chunks of 16 B; V^T tile = 64 rows x 8 chunks: 512 chunks each, 2 per thread
+    const int st_row = tid >> 3, st_chunk = tid & 7;                                  // rows st_row and st_row + 32
+    uint4 kreg[2], vreg[2];
+    auto fetch = [&](int kt) {
+        const int key0 = kt * AT_KB;
+#pragma unroll
+        for (int p = 0; p < 2; p++) {
+            const int row = st_row + 32 * p;
+            kreg[p] = *reinterpret_cast<const uint4 *>(k_base + (size_t)(key0 + row) * tok_stride + 8 * st_chunk);
+            vreg[p] = *reinterpret_cast<const uint4 *>(vt + (size_t)row * Np + key0 + 8 * st_chunk);
+        }
+    };
+    auto stash = [&]() {
+#pragma unroll
+        for (int p = 0; p < 2; p++) {
+            const int row = st_row + 32 * p;
+            *reinterpret_cast<uint4 *>(s_k + row * 128 + ((st_chunk ^ (row & 7)) << 4)) = kreg[p];
+            uint2 *vd = reinterpret_cast<uint2 *>(s_v + row * AT_VROW + 16 * st_chunk);
+            vd[0] = make_uint2(vreg[p].x, vreg[p].y);
+            vd[1] = make_uint2(vreg[p].z, vreg[p].w);
+        }
+    };
+
+    const int ntiles = (P.n_valid + AT_KB - 1) / AT_KB;
+    fetch(0);
+    for (int kt = 0; kt < ntiles; kt++) {
+        __syncthreads();                                    // everyone is done reading the previous tile
+        stash();
+        __syncthreads();
+        if (kt + 1 < ntiles) fetch(kt + 1);                 // in flight while this tile is computed
+        if (!wave_live) continue;
+
+        // ---- S^T = K . Q^T for the 64 keys of the tile: 2 key blocks of 32 -----------------------------------
+        f32x16 s_acc[2];
+#pragma unroll
+        for (int kb = 0; kb < 2; kb++) {
+#pragma unroll
+            for (int r = 0; r < 16; r++) s_acc[kb][r] = 0.f;
+            const int row = kb * 32 + l31;
+#pragma unroll
+            for (int s = 0; s < 4; s++) {
+                const V8 kf = *reinterpret_cast<const V8 *>(s_k + row * 128 + (((2 * s + hi) ^ (row & 7)) << 4));
+                s_acc[kb] = TR::mfma(kf, qf[s], s_acc[kb]);
+            }
+        }
+        // ---- logits (exp2 domain), bias, key mask, running max -------------------------------------------------
+        const int key0 = kt * AT_KB;
+        float m_loc = -__builtin_inff();
+#pragma unroll
+        for (int kb = 0; kb < 2; kb++) {
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int key = key0 + kb * 32 + at_crow(r, hi);
+                float v = s_acc[kb][r] * P.scale_log2e;
+                if (HAS_BIAS) {
+                    const T *bp = (const T *)P.bias + ((size_t)h * Np + key) * (size_t)Np + min(q0 + l31, Np - 1);
+                    v += TR::to_f32(*bp) * P.log2e;
+                }
+                v = key < P.n_valid ? v : -__builtin_inff();
+                s_acc[kb][r] = v;
+                m_loc = fmaxf(m_loc, v);
+            }
+        }
+        m_loc = fmaxf(m_loc, __shfl_xor(m_loc, 32, 64));    // the other half of this query's keys
+        const float m_new = fmaxf(m_run, m_loc);
+        const float alpha = exp2f(m_run - m_new);           // first tile: exp2(-inf) = 0
+        m_run = m_new;
+        float l_loc = 0.f;
+        // ---- P = exp2(S - m); P^T fragments for the four 16-key slices: registers 8j..8j+7 of key block kb ------
+        V8 pf[2][2];
+#pragma unroll
+        for (int kb = 0; kb < 2; kb++) {
+#pragma unroll
+            for (int j = 0; j < 2; j++) {
+#pragma unroll
+                for (int t = 0; t < 8; t++) {
+                    const float p = exp2f(s_acc[kb][8 * j + t] - m_new);
+                    l_loc += p;
+                    pf[kb][j][t] = TR::from_f32(p);
+                }
+            }
+        }
+        l_run = l_run * alpha + l_loc;
+#pragma unroll
+        for (int d = 0; d < 2; d++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) o_acc[d][r] *= alpha;
+        // ---- O^T += V^T . P^T : A = V^T[d][key slots], slot t of half hi = key 16j + (t&3) + 8(t>>2) + 4hi -------
+#pragma unroll
+        for (int d = 0; d < 2; d++) {
+            const unsigned char *vrow = s_v + (d * 32 + l31) * AT_VROW;
+#pragma unroll
+            for (int kb = 0; kb < 2; kb++) {
+#pragma unroll
+                for (int j = 0; j < 2; j++) {
+                    const int kofs = kb * 32 + 16 * j + 4 * hi;
+                    const uint2 lo = *reinterpret_cast<const uint2 *>(vrow + 2 * kofs);
+                    const uint2 hi8 = *reinterpret_cast<const uint2 *>(vrow + 2 * (kofs + 8));
+                    union { uint4 u; V8 v; } cvt;
+                    cvt.u = make_uint4(lo.x, lo.y, hi8.x, hi8.y);
+                    o_acc[d] = TR::mfma(cvt.v, pf[kb][j], o_acc[d]);
+                }
+            }
+        }
+    }
+    if (!wave_live) return;
+
+    // ---- epilogue: O / l, lane holds O[q0 + l31][32 d + crow(r, hi)] -------------------------------------------------
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const float inv = 1.0f / l_tot;
+    const int qrow = q0 + l31;
+    if (qrow < Np) {
+        T *op = (T *)P.out + ((size_t)b * Np + qrow) * (size_t)(H * AT_D) + (size_t)h * AT_D;
+#pragma unroll
+        for (int d = 0; d < 2; d++) {
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+                T v4[4];
+#pragma unroll
+                for (int t = 0; t < 4; t++) v4[t] = TR::from_f32(o_acc[d][4 * g + t] * inv);
+                *reinterpret_cast<uint2 *>(op + d * 32 + 8 * g + 4 * hi) = *reinterpret_cast<const uint2 *>(v4);
+            }
+        }
+    }
+}
+
+DS_API int ds_attention_fwd(ds_ctx *ctx, const void *qk, const void *vt, const void *bias_t, void *out,
+                            int B, int Np, int H, int n_valid, float scale, int dtype, void *stream)
+{
+    DS_REQUIRE(ctx && qk && vt && out, DS_EINVAL, "ds_attention_fwd: null argument");
+    DS_REQUIRE(B > 0 && H > 0 && Np > 0 && (Np % 64) == 0, DS_EINVAL, "ds_attention_fwd: Np must be a positive multiple of 64 (got %d)", Np);
+    DS_REQUIRE(n_valid > 0 && n_valid <= Np, DS_EINVAL, "ds_attention_fwd: n_valid %d outside 1..%d", n_valid, Np);
+    DS_REQUIRE(dtype == DS_DTYPE_F16 || dtype == DS_DTYPE_BF16, DS_EINVAL, "ds_attention_fwd: dtype must be f16 or bf16");
+    DS_REQUIRE(H <= 65535 && B <= 65535, DS_EUNSUPPORTED, "ds_attention_fwd: batch/heads too large for the grid");
+    DS_REQUIRE(((uintptr_t)qk & 15) == 0 && ((uintptr_t)vt & 15) == 0 && ((uintptr_t)out & 7) == 0, DS_EINVAL,
+               "ds_attention_fwd: operands must be 16-byte aligned");
+    DS_HIP_CHECK(hipSetDevice(ctx->device));
+    AttnParams P;
+    P.qk = qk; P.vt = vt; P.bias = bias_t; P.out = out;
+    P.B = B; P.Np = Np; P.H = H; P.n_valid = n_valid;
+    P.log2e = 1.4426950408889634f;
+    P.scale_log2e = scale * P.log2e;
+    dim3 grid((Np + AT_QB - 1) / AT_QB, H, B);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == DS_DTYPE_F16) {
+        if (bias_t) hipLaunchKernelGGL((k_attention_fwd<0, 1>), grid, dim3(AT_THREADS), 0, st, P);
+        else hipLaunchKernelGGL((k_attention_fwd<0, 0>), grid, dim3(AT_THREADS), 0, st, P);
+    } else {
+        if (bias_t) hipLaunchKernelGGL((k_attention_fwd<1, 1>), grid, dim3(AT_THREADS), 0, st, P);
+        else hipLaunchKernelGGL((k_attention_fwd<1, 0>), grid, dim3(AT_THREADS), 0, st, P);
+    }
+    DS_HIP_CHECK(hipGetLastError());
+    return DS_OK;
+}

@@ -20,7 +20,7 @@ FILL_IDS = {"none": 0, "naive": 1, "naive_interpolating": 2, "polylines_soft": 3
 EXPORTS = [
     "ds_version", "ds_last_error", "ds_ctx_create", "ds_ctx_destroy", "ds_stereo_warp", "ds_depth_minmax",
     "ds_stereo_last_exact_rows", "ds_copy_view", "ds_overlap_red_cyan", "ds_normalmap", "ds_depth_to_u16",
-    "ds_convert_to_i16", "ds_profile_enable", "ds_profile_last_ms", "ds_stereo_last_stats",
+    "ds_convert_to_i16", "ds_profile_enable", "ds_profile_last_ms", "ds_stereo_last_stats", "ds_attention_fwd",
 ]
 
 
@@ -61,6 +61,7 @@ def lib():
             L.ds_depth_to_u16.argtypes = [vp, vp, ci, ci, ci, ci, vp, vp, vp]
             L.ds_convert_to_i16.argtypes = [vp, vp, ci, i64, vp, vp]
             L.ds_stereo_last_stats.argtypes = [vp, ctypes.POINTER(i64), vp]
+            L.ds_attention_fwd.argtypes = [vp, vp, vp, vp, vp, ci, ci, ci, ci, ctypes.c_float, ci, vp]
             L.ds_profile_enable.argtypes = [vp, ci]
             L.ds_profile_last_ms.argtypes = [vp, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float)]
             for name in EXPORTS:          # fail at load time, not at first use, if a symbol is missing
@@ -230,4 +231,27 @@ def convert_to_i16(arr):
     out = torch.empty(arr.shape, dtype=torch.uint16, device=arr.device)
     _check(lib().ds_convert_to_i16(ctx_for(_dev_index(arr)), arr.data_ptr(), 1 if arr.dtype == torch.float64 else 0,
                                    arr.numel(), out.data_ptr(), _stream(arr)))
+    return out
+
+
+def attention_fwd(qk, vt, n_valid, scale, bias=None, bias_t=None):
+    """Fused MFMA attention (include/depthstereo.h: ds_attention_fwd).  qk [B,Np,2,H,64], vt [B,H*64,Np], float16 or
+    bfloat16 CUDA tensors; bias [H,Np(query),Np(key)] or, to skip the transpose, bias_t [H,Np(key),Np(query)].
+    Returns [B,Np,H*64]."""
+    torch = require_gpu()
+    assert qk.is_cuda and vt.is_cuda and qk.dtype == vt.dtype and qk.dtype in (torch.float16, torch.bfloat16)
+    b, npad, two, h, d = qk.shape
+    assert two == 2 and d == 64 and npad % 64 == 0 and tuple(vt.shape) == (b, h * 64, npad), (qk.shape, vt.shape)
+    qk = qk.contiguous()
+    vt = vt.contiguous()
+    if bias is not None and bias_t is None:
+        bias_t = bias.transpose(1, 2)
+    if bias_t is not None:
+        bias_t = bias_t.to(qk.dtype).contiguous()
+        assert tuple(bias_t.shape) == (h, npad, npad)
+    out = torch.empty((b, npad, h * 64), dtype=qk.dtype, device=qk.device)
+    dt = 1 if qk.dtype == torch.float16 else 2
+    _check(lib().ds_attention_fwd(ctx_for(_dev_index(qk)), qk.data_ptr(), vt.data_ptr(),
+                                  bias_t.data_ptr() if bias_t is not None else None, out.data_ptr(),
+                                  b, npad, h, int(n_valid), float(scale), dt, _stream(qk)))
     return out
