@@ -109,7 +109,7 @@ __device__ __forceinline__ uint32_t pl_u8(double v) { return (uint32_t)(int)v & 
 //
 // uint16: numerator a = v - min and denominator b = max - min are integers <= 65535.  With y = 1/b (one correctly
 // rounded division per thread and work item), q0 = a*y, r = fma(-b, q0, a), q = fma(r, y, q0) IS the correctly
-// rounded a/b for every such pair -- checked exhaustively (all 2^32 pairs) by oracle/check_u16_division.c -- so the
+// rounded a/b for every such pair -- checked exhaustively (all 2^32 pairs) by the test suite (check_u16_division.c) -- so the
 // per-column float64 division costs 3 instructions instead of the ~11 of the generic expansion.
 __device__ __forceinline__ void pl_load_nd(const PolyParams &P, const void *depth_row, int j, int nv, bool hasprev,
                                            double mn, double mx, const double *lut, double *nd, double &ndp)

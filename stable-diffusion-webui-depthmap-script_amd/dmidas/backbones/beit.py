@@ -1,0 +1,242 @@
+"""BEiT backbone of MiDaS 3.1 DPT on the shared MI355X transformer machinery.
+
+Reference: dmidas/backbones/beit.py (patch_embed_forward :18-27, _get_rel_pos_bias :29-62, attention_forward :65-91,
+block_forward :94-107, beit_forward_features :110-129, _make_pretrained_beit* :159-198) and dmidas/backbones/utils.py
+(ProjectReadout :28-39, forward_adapted_unflatten :83-124, make_backbone_default :144-249).  The transformer body itself
+lives in the un-vendored dependency timm~=0.9.2 (requirements.txt:8; timm/models/beit.py: Attention, Block, Beit,
+gen_relative_position_index); it is restated here from its published source.  Parity: the reference's OWN dmidas code
+(all the forwards it monkey-patches into timm's classes, the read-out, the DPT decoder) was executed on a stand-in for
+timm's parameter containers (tests/golden/fake_timm_beit.py) and our outputs match it to 1e-4 (tests/test_models_cpu.py);
+what remains unpinned is timm's own part: the containers' shapes, Mlp/LayerNorm/patch-conv and
+gen_relative_position_index (timm is not installable in the build container).
+
+What is different from the reference on purpose:
+  * the relative-position bias of a block depends only on (table, window): it is interpolated + gathered ONCE per
+    resolution and cached key-major ([H, Np, Np], the layout ds_attention_fwd reads), instead of in every block of every
+    forward (beit.py:29-62 runs F.interpolate + a 1M-element gather 24 times per image);
+  * forward hooks and the module-global `activations` dict (utils.py:60-67,155-160) are replaced by returning the four
+    taps from the block loop.
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from src import vit_mi355x as vm
+
+
+def gen_relative_position_index(window_size):
+    """timm/models/beit.py gen_relative_position_index (0.9.x): pairwise relative positions inside the window plus three
+    extra entries for cls->token, token->cls and cls->cls."""
+    num_relative_distance = (2 * window_size[0] - 1) * (2 * window_size[1] - 1) + 3
+    window_area = window_size[0] * window_size[1]
+    coords = torch.stack(torch.meshgrid([torch.arange(window_size[0]), torch.arange(window_size[1])], indexing='ij'))
+    coords_flatten = torch.flatten(coords, 1)
+    relative_coords = coords_flatten[:, :, None] - coords_flatten[:, None, :]
+    relative_coords = relative_coords.permute(1, 2, 0).contiguous()
+    relative_coords[:, :, 0] += window_size[0] - 1
+    relative_coords[:, :, 1] += window_size[1] - 1
+    relative_coords[:, :, 0] *= 2 * window_size[1] - 1
+    relative_position_index = torch.zeros(size=(window_area + 1,) * 2, dtype=relative_coords.dtype)
+    relative_position_index[1:, 1:] = relative_coords.sum(-1)
+    relative_position_index[0, 0:] = num_relative_distance - 3
+    relative_position_index[0:, 0] = num_relative_distance - 2
+    relative_position_index[0, 0] = num_relative_distance - 1
+    return relative_position_index
+
+
+class _Attention(nn.Module):
+    """Parameter container with timm's names: qkv.weight (no bias), q_bias, v_bias, relative_position_bias_table,
+    proj; k_bias is a constant zero (a non-persistent buffer in timm)."""
+
+    def __init__(self, dim, num_heads, window_size):
+        super().__init__()
+        self.qkv = nn.Linear(dim, dim * 3, bias=False)
+        self.q_bias = nn.Parameter(torch.zeros(dim))
+        self.v_bias = nn.Parameter(torch.zeros(dim))
+        self.window_size = window_size
+        self.num_relative_distance = (2 * window_size[0] - 1) * (2 * window_size[1] - 1) + 3
+        self.relative_position_bias_table = nn.Parameter(torch.zeros(self.num_relative_distance, num_heads))
+        self.proj = nn.Linear(dim, dim)
+
+
+class Block(vm.EncoderBlock):
+    """x += gamma_1 * attn(norm1(x)); x += gamma_2 * mlp(norm2(x))  (beit.py:94-107)."""
+
+    def __init__(self, dim, num_heads, window_size, mlp_ratio=4.0, init_values=1e-5):
+        super().__init__(dim, num_heads, mlp_ratio)
+        self.norm1 = nn.LayerNorm(dim, eps=1e-6)
+        self.attn = _Attention(dim, num_heads, window_size)
+        self.norm2 = nn.LayerNorm(dim, eps=1e-6)
+        self.mlp = vm.Mlp(dim, int(dim * mlp_ratio))
+        self.gamma_1 = nn.Parameter(init_values * torch.ones(dim))
+        self.gamma_2 = nn.Parameter(init_values * torch.ones(dim))
+        self._bias_cache = {}
+
+    def ln1(self, x):
+        return self.norm1(x)
+
+    def ln2(self, x):
+        return self.norm2(x)
+
+    def qkv_weights(self):
+        c = self.dim
+        w = self.attn.qkv.weight
+        b_qk = torch.cat((self.attn.q_bias, torch.zeros_like(self.attn.q_bias)))        # k_bias == 0 (beit.py:71)
+        return w[:2 * c], b_qk, w[2 * c:], self.attn.v_bias
+
+    def proj(self, o):
+        return self.attn.proj(o)
+
+    def gammas(self):
+        return self.gamma_1, self.gamma_2
+
+    def rel_pos_bias(self, window_size):
+        """[H, N, N] (query, key) for N = Wh*Ww + 1: beit.py:29-62 (bilinear resize of the table to the new window, then
+        the index gather)."""
+        a = self.attn
+        old_h, old_w = 2 * a.window_size[0] - 1, 2 * a.window_size[1] - 1
+        new_h, new_w = 2 * window_size[0] - 1, 2 * window_size[1] - 1
+        table = a.relative_position_bias_table
+        old_sub = table[:a.num_relative_distance - 3].reshape(1, old_w, old_h, -1).permute(0, 3, 1, 2)
+        new_sub = F.interpolate(old_sub.float(), size=(int(new_h), int(new_w)), mode="bilinear").to(table.dtype)
+        new_sub = new_sub.permute(0, 2, 3, 1).reshape(new_h * new_w, -1)
+        new_table = torch.cat([new_sub, table[a.num_relative_distance - 3:]])
+        index = gen_relative_position_index(window_size).to(table.device)
+        n = window_size[0] * window_size[1] + 1
+        bias = new_table[index.view(-1)].view(n, n, -1)
+        return bias.permute(2, 0, 1).contiguous()
+
+    def attention_bias(self, n_pad, grid_hw, dtype, device):
+        """Key-major, padded: bias_t[h][key][query]; cached per (window, dtype) until the table changes."""
+        a = self.attn
+        key = (tuple(grid_hw), n_pad, dtype, device, a.relative_position_bias_table._version)
+        hit = self._bias_cache.get(key)
+        if hit is not None:
+            return hit
+        with torch.no_grad():
+            bias = self.rel_pos_bias(tuple(grid_hw))                                     # H, N, N (query, key)
+            n = bias.shape[-1]
+            bt = torch.zeros((bias.shape[0], n_pad, n_pad), dtype=dtype, device=device)
+            bt[:, :n, :n] = bias.transpose(1, 2).to(dtype)
+        self._bias_cache.clear()
+        self._bias_cache[key] = bt
+        return bt
+
+    def forward_padded(self, x, n_valid, grid_hw=None):
+        b, npad, c = x.shape
+        h = self.ln1(x)
+        w_qk, b_qk, w_v, b_v = self.qkv_weights()
+        qk = F.linear(h, w_qk, b_qk).view(b, npad, 2, self.num_heads, vm.HEAD_DIM)
+        vt = torch.matmul(w_v, h.transpose(1, 2)) + b_v.view(1, c, 1)
+        bias_t = self.attention_bias(npad, grid_hw, x.dtype, x.device)
+        if x.dtype == torch.float32:
+            o = vm.attention_reference(qk, vt, n_valid, self.scale, bias_t.transpose(1, 2))
+        else:
+            from src import _native
+            o = _native.attention_fwd(qk, vt, n_valid, self.scale, bias_t=bias_t)
+        x = x + self.gamma_1 * self.attn.proj(o)
+        return x + self.gamma_2 * self.mlp(self.ln2(x))
+
+
+class PatchEmbed(nn.Module):
+    def __init__(self, patch_size, embed_dim):
+        super().__init__()
+        self.proj = nn.Conv2d(3, embed_dim, kernel_size=patch_size, stride=patch_size)
+
+    def forward(self, x):               # beit.py:18-27: any input size
+        return self.proj(x).flatten(2).transpose(1, 2)
+
+
+class Beit(nn.Module):
+    """timm Beit with use_abs_pos_emb=False, use_rel_pos_bias=True, global_pool='avg' (the beit_*_patch16_* entry points
+    the reference instantiates, beit.py:160,177,188).  `fc_norm` and `head` exist only so that MiDaS checkpoints load
+    strictly; the DPT taps are raw block outputs."""
+
+    def __init__(self, img_size, embed_dim, depth, num_heads, init_values, num_classes=1000):
+        super().__init__()
+        self.patch_size = [16, 16]
+        self.embed_dim = embed_dim
+        window = (img_size // 16, img_size // 16)
+        self.patch_embed = PatchEmbed(16, embed_dim)
+        self.cls_token = nn.Parameter(torch.zeros(1, 1, embed_dim))
+        self.blocks = nn.ModuleList([Block(embed_dim, num_heads, window, 4.0, init_values) for _ in range(depth)])
+        self.fc_norm = nn.LayerNorm(embed_dim, eps=1e-6)
+        self.head = nn.Linear(embed_dim, num_classes)
+        nn.init.trunc_normal_(self.cls_token, std=0.02)
+        for m in self.modules():
+            if isinstance(m, nn.Linear):
+                nn.init.trunc_normal_(m.weight, std=0.02)
+                if m.bias is not None:
+                    nn.init.zeros_(m.bias)
+
+    def forward_taps(self, x, hooks):
+        """beit.py:110-129 + the forward hooks of utils.py:155-158: outputs of blocks `hooks`, unpadded [B, N, C]."""
+        grid = (x.shape[2] // 16, x.shape[3] // 16)
+        t = self.patch_embed(x)
+        t = torch.cat((self.cls_token.expand(t.shape[0], -1, -1).to(t.dtype), t), dim=1)
+        n_valid = t.shape[1]
+        t = vm.pad_tokens(t, vm.pad_len(n_valid))
+        taps = []
+        for i, blk in enumerate(self.blocks):
+            t = blk.forward_padded(t, n_valid, grid)
+            if i in hooks:
+                taps.append(t[:, :n_valid])
+        return taps, grid
+
+
+class ProjectReadout(nn.Module):       # utils.py:28-39
+    def __init__(self, in_features, start_index=1):
+        super().__init__()
+        self.start_index = start_index
+        self.project = nn.Sequential(nn.Linear(2 * in_features, in_features), nn.GELU())
+
+    def forward(self, x):
+        readout = x[:, 0].unsqueeze(1).expand_as(x[:, self.start_index:])
+        return self.project(torch.cat((x[:, self.start_index:], readout), -1))
+
+
+class _Skip(nn.Module):                 # placeholder for Transpose / Unflatten slots (no parameters) so indices match
+    def forward(self, x):
+        return x
+
+
+def _postprocess(vit_features, out_features, tail):
+    # indices 0..2 = readout, Transpose, Unflatten (utils.py:165-169); 3.. = the convolutions
+    return nn.Sequential(ProjectReadout(vit_features), _Skip(), _Skip(), nn.Conv2d(vit_features, out_features, 1), *tail)
+
+
+class BeitBackbone(nn.Module):
+    """`pretrained` of the reference: .model (Beit) + .act_postprocess1-4 (utils.py:144-249, readout 'project')."""
+
+    def __init__(self, model, features, vit_features, hooks):
+        super().__init__()
+        self.model = model
+        self.hooks = list(hooks)
+        f = features
+        self.act_postprocess1 = _postprocess(vit_features, f[0], [nn.ConvTranspose2d(f[0], f[0], 4, 4, 0)])
+        self.act_postprocess2 = _postprocess(vit_features, f[1], [nn.ConvTranspose2d(f[1], f[1], 2, 2, 0)])
+        self.act_postprocess3 = _postprocess(vit_features, f[2], [])
+        self.act_postprocess4 = _postprocess(vit_features, f[3], [nn.Conv2d(f[3], f[3], 3, 2, 1)])
+
+    def forward(self, x):
+        """forward_beit = forward_adapted_unflatten (utils.py:83-124): readout-project, tokens -> [B, C, h/16, w/16]
+        (run-time grid, not the constructor's), then the per-tap convolutions."""
+        taps, grid = self.model.forward_taps(x, self.hooks)
+        outs = []
+        for tap, post in zip(taps, (self.act_postprocess1, self.act_postprocess2, self.act_postprocess3, self.act_postprocess4)):
+            y = post[0](tap)                                   # ProjectReadout: [B, N-1, C]
+            y = y.transpose(1, 2).reshape(y.shape[0], y.shape[2], grid[0], grid[1])
+            for layer in list(post)[3:]:
+                y = layer(y)
+            outs.append(y)
+        return outs
+
+
+def make_beit(name, hooks):
+    cfg = {"beitl16_512": (512, 1024, 24, 16, [256, 512, 1024, 1024]),
+           "beitl16_384": (384, 1024, 24, 16, [256, 512, 1024, 1024]),
+           "beitb16_384": (384, 768, 12, 12, [96, 192, 384, 768])}[name]
+    img, dim, depth, heads, features = cfg
+    # timm: beit_large_* use init_values=1e-5, beit_base_* 0.1
+    model = Beit(img, dim, depth, heads, init_values=1e-5 if dim == 1024 else 0.1)
+    return BeitBackbone(model, features, dim, hooks), features

@@ -1,0 +1,160 @@
+"""MiDaS 3.1 DPT depth model (BEiT backbones), MI355X-first.
+
+Reference: dmidas/dpt_depth.py (DPT :31-139, DPTDepthModel :142-166), dmidas/blocks.py (_make_scratch, Interpolate,
+ResidualConvUnit_custom :322-377, FeatureFusionBlock_custom :382-441), and its caller estimatemidas
+(src/depthmap_generation.py:455-499) + Resize.get_size (dmidas/transforms.py:105-160).
+Checkpoint key names are the reference's (pretrained.model.*, pretrained.act_postprocessN.*, scratch.*).
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .backbones.beit import make_beit
+
+_HOOKS = {"beitl16_512": [5, 11, 17, 23], "beitl16_384": [5, 11, 17, 23], "beitb16_384": [2, 5, 8, 11]}
+
+
+class ResidualConvUnit_custom(nn.Module):
+    def __init__(self, features):
+        super().__init__()
+        self.conv1 = nn.Conv2d(features, features, kernel_size=3, stride=1, padding=1, bias=True)
+        self.conv2 = nn.Conv2d(features, features, kernel_size=3, stride=1, padding=1, bias=True)
+
+    def forward(self, x):               # blocks.py:352-377, activation ReLU(False), bn False
+        out = self.conv1(F.relu(x))
+        out = self.conv2(F.relu(out))
+        return out + x
+
+
+class FeatureFusionBlock_custom(nn.Module):
+    def __init__(self, features):
+        super().__init__()
+        self.out_conv = nn.Conv2d(features, features, kernel_size=1, stride=1, padding=0, bias=True)
+        self.resConfUnit1 = ResidualConvUnit_custom(features)
+        self.resConfUnit2 = ResidualConvUnit_custom(features)
+
+    def forward(self, *xs, size=None):  # blocks.py:412-441, align_corners=True
+        output = xs[0]
+        if len(xs) == 2:
+            output = output + self.resConfUnit1(xs[1])
+        output = self.resConfUnit2(output)
+        if size is None:
+            output = F.interpolate(output, scale_factor=2, mode="bilinear", align_corners=True)
+        else:
+            output = F.interpolate(output, size=size, mode="bilinear", align_corners=True)
+        return self.out_conv(output)
+
+
+class Interpolate(nn.Module):           # blocks.py:213-244 (no parameters; keeps the Sequential indices of the head)
+    def __init__(self, scale_factor, mode, align_corners=False):
+        super().__init__()
+        self.scale_factor, self.mode, self.align_corners = scale_factor, mode, align_corners
+
+    def forward(self, x):
+        return F.interpolate(x, scale_factor=self.scale_factor, mode=self.mode, align_corners=self.align_corners)
+
+
+class DPT(nn.Module):
+    def __init__(self, head, features=256, backbone="beitl16_512", readout="project", channels_last=False, use_bn=False, **kwargs):
+        super().__init__()
+        if backbone not in _HOOKS:
+            raise NotImplementedError(f"DPT backbone '{backbone}' is not built yet (BEiT family only: {sorted(_HOOKS)})")
+        if readout != "project" or use_bn:
+            raise NotImplementedError("only readout='project', use_bn=False (what src/depthmap_generation.py:129-176 uses)")
+        self.channels_last = channels_last
+        self.pretrained, in_shape = make_beit(backbone, _HOOKS[backbone])
+        scratch = nn.Module()
+        for i in range(4):
+            setattr(scratch, f"layer{i + 1}_rn", nn.Conv2d(in_shape[i], features, kernel_size=3, stride=1, padding=1, bias=False))
+        for i in range(1, 5):
+            setattr(scratch, f"refinenet{i}", FeatureFusionBlock_custom(features))
+        scratch.output_conv = head
+        self.scratch = scratch
+
+    def forward(self, x):               # dpt_depth.py:110-139
+        l1, l2, l3, l4 = self.pretrained(x)
+        s = self.scratch
+        l1, l2, l3, l4 = s.layer1_rn(l1), s.layer2_rn(l2), s.layer3_rn(l3), s.layer4_rn(l4)
+        path_4 = s.refinenet4(l4, size=l3.shape[2:])
+        path_3 = s.refinenet3(path_4, l3, size=l2.shape[2:])
+        path_2 = s.refinenet2(path_3, l2, size=l1.shape[2:])
+        path_1 = s.refinenet1(path_2, l1)
+        return s.output_conv(path_1)
+
+
+def _constrain(x, multiple, min_val=0, max_val=None):
+    y = int(np.round(x / multiple) * multiple)
+    if max_val is not None and y > max_val:
+        y = int(np.floor(x / multiple) * multiple)
+    if y < min_val:
+        y = int(np.ceil(x / multiple) * multiple)
+    return y
+
+
+def midas_net_size(width, height, net_w, net_h, resize_method="minimal", multiple=32):
+    """Resize.get_size with keep_aspect_ratio=True (dmidas/transforms.py:105-160)."""
+    scale_h, scale_w = net_h / height, net_w / width
+    if resize_method == "lower_bound":
+        scale_h = scale_w = max(scale_w, scale_h)
+    elif resize_method == "upper_bound":
+        scale_h = scale_w = min(scale_w, scale_h)
+    elif resize_method == "minimal":
+        if abs(1 - scale_w) < abs(1 - scale_h):
+            scale_h = scale_w
+        else:
+            scale_w = scale_h
+    else:
+        raise ValueError(f"resize_method {resize_method} not implemented")
+    if resize_method == "lower_bound":
+        return _constrain(scale_w * width, multiple, min_val=net_w), _constrain(scale_h * height, multiple, min_val=net_h)
+    if resize_method == "upper_bound":
+        return _constrain(scale_w * width, multiple, max_val=net_w), _constrain(scale_h * height, multiple, max_val=net_h)
+    return _constrain(scale_w * width, multiple), _constrain(scale_h * height, multiple)
+
+
+class DPTDepthModel(DPT):
+    def __init__(self, path=None, non_negative=True, **kwargs):
+        features = kwargs.get("features", 256)
+        head_features_1 = kwargs.pop("head_features_1", features)
+        head_features_2 = kwargs.pop("head_features_2", 32)
+        head = nn.Sequential(
+            nn.Conv2d(head_features_1, head_features_1 // 2, kernel_size=3, stride=1, padding=1),
+            Interpolate(scale_factor=2, mode="bilinear", align_corners=True),
+            nn.Conv2d(head_features_1 // 2, head_features_2, kernel_size=3, stride=1, padding=1),
+            nn.ReLU(True),
+            nn.Conv2d(head_features_2, 1, kernel_size=1, stride=1, padding=0),
+            nn.ReLU(True) if non_negative else nn.Identity(),
+            nn.Identity())
+        super().__init__(head, **kwargs)
+        if path is not None:
+            self.load(path)
+
+    def load(self, path):               # dmidas/base_model.py:5-16
+        parameters = torch.load(path, map_location=torch.device('cpu'))
+        if "optimizer" in parameters:
+            parameters = parameters["model"]
+        self.load_state_dict(parameters, strict=False)     # timm's non-persistent buffers may or may not be in the file
+
+    def forward(self, x):
+        return super().forward(x).squeeze(dim=1)
+
+    # ---- device-resident pre/post of estimatemidas (src/depthmap_generation.py:455-499) ------------------
+    @torch.no_grad()
+    def infer_batch(self, images_u8, net_size=512, resize_mode="minimal", mean=0.5, std=0.5):
+        """uint8 [B,H,W,3] (RGB as the funnel hands it over) -> float32 [B,H,W] raw prediction, on the device.
+        get_raw_prediction swaps R and B once (:381) and estimatemidas does not swap back, so the network sees BGR
+        order -- reproduced.  cv2.INTER_CUBIC resize -> torch bicubic (same kernel a=-0.75, half-pixel centres; cv2 is
+        not available here: unpinned); prediction upsampled with torch bicubic align_corners=False exactly as :484-489."""
+        b, h, w, _ = images_u8.shape
+        nw, nh = midas_net_size(w, h, net_size, net_size, resize_mode)
+        x = images_u8.flip(-1).permute(0, 3, 1, 2).float() / 255.0
+        x = F.interpolate(x, size=(nh, nw), mode="bicubic", align_corners=False)
+        x = (x - mean) / std
+        dtype = self.scratch.layer1_rn.weight.dtype
+        x = x.to(dtype)
+        if x.is_cuda:
+            x = x.contiguous(memory_format=torch.channels_last)
+        pred = self.forward(x)
+        pred = F.interpolate(pred.unsqueeze(1), size=(h, w), mode="bicubic", align_corners=False).squeeze(1)
+        return pred.float()

@@ -1,13 +1,19 @@
 """Model side of the funnel: ``ModelHolder`` (reference: src/depthmap_generation.py:40-403).
 
-Round-1 state: the holder keeps the reference's interface (``ensure_models``, ``get_raw_prediction``,
-``offload``/``reload``/``unload_models``, ``update_settings``, ``get_default_net_size``) so
-``core_generation_funnel`` is wired exactly like the reference, but the model families themselves
-(DPT/BEiT, ViT-hybrid, Depth-Anything-V2, LeReS+pix2pix Boost -- SURVEY.md 8a rows a10-a17) are not built
-yet.  A depth predictor can be plugged in with ``register_predictor`` (tests and the bench use a
-synthetic one); without it ``ensure_models`` raises -- it never silently falls back to anything.
+The holder keeps the reference's interface (``ensure_models``, ``get_raw_prediction``, ``offload``/``reload``/
+``unload_models``, ``update_settings``, ``get_default_net_size``) so ``core_generation_funnel`` is wired exactly like
+the reference.  Built model families:
+    ids 1, 2        MiDaS 3.1 DPT BEiT-L/16 512 / 384   (dmidas.dpt_depth.DPTDepthModel; reference :116-146)
+    ids 12, 13, 14  Depth-Anything-V2 small/base/large   (ddepth_anything_v2.DepthAnythingV2; reference :237-248)
+Checkpoints are looked up in ``model_dir`` under the reference's file names; the reference downloads them when missing
+(ensure_file_downloaded) -- this build has no network path and raises FileNotFoundError instead, unless
+``allow_random_init`` is set (bench / tests: random weights of the same architecture).
+Other ids (LeReS 0, dpt_large/hybrid 3-4, midas_v21 5-6, ZoeDepth 7-9, Marigold 10, Depth-Anything v1 11) and Boost are
+not built: ``ensure_models`` raises NotImplementedError unless a predictor was registered with ``register_predictor``.
+Nothing ever falls back silently.
 """
 import gc
+import os
 
 # Appendix B of SURVEY.md: ids whose raw output is near-is-dark (src/depthmap_generation.py:402)
 INVERTED_MODEL_IDS = (0, 7, 8, 9, 10)
@@ -17,6 +23,67 @@ DEFAULT_NET_SIZES = {          # src/depthmap_generation.py:323-339
     7: [512, 384], 8: [768, 384], 9: [512, 384], 10: [768, 768], 11: [518, 518], 12: [518, 518], 13: [518, 518],
     14: [518, 518],
 }
+
+
+def _build_dpt_beit(backbone, filename):
+    def make():
+        from dmidas.dpt_depth import DPTDepthModel
+        return DPTDepthModel(path=None, backbone=backbone, non_negative=True), filename
+    return make
+
+
+def _build_dav2(letter):
+    cfg = {'s': ('vits', 64, [48, 96, 192, 384]), 'b': ('vitb', 128, [96, 192, 384, 768]), 'l': ('vitl', 256, [256, 512, 1024, 1024])}[letter]
+
+    def make():
+        from ddepth_anything_v2 import DepthAnythingV2
+        return DepthAnythingV2(encoder=cfg[0], features=cfg[1], out_channels=cfg[2]), f"depth_anything_v2_vit{letter}.pth"
+    return make
+
+
+_BUILDERS = {1: _build_dpt_beit("beitl16_512", "dpt_beit_large_512.pt"), 2: _build_dpt_beit("beitl16_384", "dpt_beit_large_384.pt"),
+             12: _build_dav2('s'), 13: _build_dav2('b'), 14: _build_dav2('l')}
+
+
+class _NetPredictor:
+    """One loaded network + its device-resident pre/post-processing (estimatemidas :455-499 / estimatedepthanything_v2
+    :548-559).  Callable like a registered predictor: (pil_image, net_width, net_height, device) -> float32 tensor [H,W]."""
+
+    def __init__(self, model_type, device, model_dir, allow_random_init, no_half):
+        import torch
+        net, filename = _BUILDERS[model_type]()
+        path = os.path.join(model_dir, filename)
+        if os.path.exists(path):
+            sd = torch.load(path, map_location='cpu')
+            if "optimizer" in sd:
+                sd = sd["model"]
+            missing, unexpected = net.load_state_dict(sd, strict=False)
+            # timm's index buffers / k_bias may or may not be stored; anything else missing is an error
+            bad = [k for k in missing if not k.endswith(("relative_position_index", "k_bias"))]
+            if bad:
+                raise RuntimeError(f"{path}: checkpoint lacks {len(bad)} tensors, e.g. {bad[:3]}")
+        elif not allow_random_init:
+            raise FileNotFoundError(f"{path} not found (the reference would download it; this build has no network path). "
+                                    "Place the checkpoint there or set ModelHolder.allow_random_init for a dry run")
+        self.model_type = model_type
+        self.net = net.eval().to(device)
+        dev = torch.device(device)
+        if dev.type == 'cuda' and not no_half:              # reference :268-275
+            self.net = self.net.half()
+
+    @property
+    def is_dav2(self):
+        return self.model_type in (12, 13, 14)
+
+    def __call__(self, pil_image, net_width, net_height, device):
+        import numpy as np
+        import torch
+        img = torch.from_numpy(np.array(pil_image.convert("RGB"), dtype=np.uint8, order="C")).to(next(self.net.parameters()).device)
+        batch = img.unsqueeze(0)
+        if self.is_dav2:
+            return self.net.infer_batch(batch, int(net_width))[0]          # reference passes net_width as input_size (:553)
+        mode = "minimal"                                                    # resize_mode of ids 1, 2 (:127, :141)
+        return self.net.infer_batch(batch, net_size=int(net_width), resize_mode=mode)[0]
 
 
 class ModelHolder:
@@ -30,6 +97,9 @@ class ModelHolder:
         self.normalization = None
         self.tiling_mode = False
         self._predictors = {}
+        self.model_dir = "./models/midas"        # reference: src/depthmap_generation.py:95-99 (models/midas, models/leres, ...)
+        self.allow_random_init = False
+        self.no_half = False
 
     def update_settings(self, **kvargs):
         """reference :54-57 -- free-form settings (boost_rmax, precision, no_half, ...) become attributes."""
@@ -44,12 +114,15 @@ class ModelHolder:
         """reference :60-74."""
         if boost:
             raise NotImplementedError("Boost (res101 + pix2pix merge) is not built yet")
-        if model_type not in self._predictors:
+        if model_type in self._predictors:
+            self.depth_model = self._predictors[model_type]
+        elif model_type in _BUILDERS:
+            if self.depth_model is None or self.depth_model_type != model_type or not isinstance(self.depth_model, _NetPredictor):
+                self.depth_model = _NetPredictor(model_type, device, self.model_dir, self.allow_random_init, self.no_half)
+        else:
             raise NotImplementedError(
-                f"depth model {model_type!r} is not available in this build: the model families of SURVEY.md 8a "
-                "(a10-a17) come after the per-pixel path; register a predictor with ModelHolder.register_predictor "
-                "or pass precomputed depthmaps")
-        self.depth_model = self._predictors[model_type]
+                f"depth model {model_type!r} is not available in this build (built: ids {sorted(_BUILDERS)}); register a "
+                "predictor with ModelHolder.register_predictor or pass precomputed depthmaps")
         self.depth_model_type = model_type
         self.device = device
         self.tiling_mode = tiling_mode

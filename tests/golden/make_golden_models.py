@@ -30,6 +30,22 @@ def reference_dav2(encoder, features, out_channels):
     return DepthAnythingV2(encoder=encoder, features=features, out_channels=out_channels)
 
 
+def reference_dpt(backbone):
+    """The reference's own dmidas.dpt_depth.DPTDepthModel, running on a stand-in for timm's Beit containers
+    (fake_timm_beit.py): every forward on the path -- beit_forward_features, block_forward, attention_forward,
+    _get_rel_pos_bias, forward_adapted_unflatten, ProjectReadout, FeatureFusionBlock_custom, the head -- is the
+    reference's code."""
+    import fake_timm_beit
+    fake_timm_beit.install()
+    for name in ("cv2",):
+        if name not in sys.modules:
+            sys.modules[name] = mock.MagicMock()
+    sys.path.insert(0, REF)
+    from dmidas.dpt_depth import DPTDepthModel
+    sys.path.pop(0)
+    return DPTDepthModel(path=None, backbone=backbone, non_negative=True)
+
+
 def main():
     out = {}
     torch.manual_seed(0)
@@ -47,6 +63,17 @@ def main():
     x2 = mw.synthetic_image((1, 3, 70, 70), seed=12)
     with torch.no_grad():
         out["dav2_vits_70x70_out"] = m(x2).numpy()
+    # MiDaS 3.1 DPT BEiT-B/16 (reference backbone "beitb16_384"): 10 x 14 patches -> window (10, 14) != the table's
+    # native (24, 24): exercises the bilinear table resize + index gather; 141 tokens -> padded to 192
+    m = reference_dpt("beitb16_384").eval()
+    sd = mw.fill_state_dict_beit(m.state_dict())
+    m.load_state_dict(sd, strict=True)
+    x3 = mw.synthetic_image((2, 3, 160, 224), seed=13)
+    with torch.no_grad():
+        out["dpt_beitb_160x224_out"] = m(x3).numpy()
+        l1, l2, l3, l4 = m.forward_transformer(m.pretrained, x3)
+    out["dpt_beitb_160x224_layer4"] = l4.numpy()
+    out["dpt_beitb_160x224_layer1_sample"] = l1[:, ::16, ::4, ::4].numpy()
     np.savez_compressed(os.path.join(HERE, "model_cases.npz"), **out)
     for k, v in out.items():
         print(k, v.shape, float(np.abs(v).mean()))

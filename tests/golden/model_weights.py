@@ -39,3 +39,15 @@ def fill_state_dict(sd):
 def synthetic_image(shape, seed):
     g = torch.Generator().manual_seed(seed)
     return torch.randn(shape, generator=g, dtype=torch.float32)
+
+
+def fill_state_dict_beit(sd):
+    """fill_state_dict + BEiT-specific scales: gamma_1/gamma_2 near 1 would let a dozen random blocks blow the activations
+    up, and a bias table of std 0.02 would not shape the softmax visibly."""
+    out = fill_state_dict(sd)
+    for k in list(out.keys()):
+        if k.endswith("gamma_1") or k.endswith("gamma_2"):
+            out[k] = out[k] * 0.3
+        if k.endswith("relative_position_bias_table"):
+            out[k] = out[k] * 25.0
+    return out

@@ -90,3 +90,39 @@ def test_dav2_infer_batch_shapes(gpu):
     img = torch.randint(0, 256, (2, 96, 160, 3), dtype=torch.uint8, device='cuda')
     d = m.infer_batch(img, input_size=70)
     assert tuple(d.shape) == (2, 96, 160) and d.dtype == torch.float32 and torch.isfinite(d).all()
+
+
+def test_dpt_beit_half_forward_vs_reference_fp32(gpu):
+    """fp16 BEiT-DPT on the GPU (fused attention WITH the relative-position bias operand) against the float32 outputs of the
+    reference's own dmidas code (tests/golden/model_cases.npz)."""
+    from dmidas.dpt_depth import DPTDepthModel
+    gold = np.load(GOLD)
+    m = DPTDepthModel(path=None, backbone="beitb16_384", non_negative=True).eval()
+    m.load_state_dict(mw.fill_state_dict_beit(m.state_dict()), strict=True)
+    x = mw.synthetic_image((2, 3, 160, 224), seed=13).cuda()
+    ref = gold["dpt_beitb_160x224_out"]
+    with torch.no_grad():
+        y32 = m.cuda()(x).cpu().numpy()
+    assert np.abs(y32 - ref).max() / np.abs(ref).max() < 1e-4
+    with torch.no_grad():
+        y16 = m.half()(x.half().contiguous(memory_format=torch.channels_last)).float().cpu().numpy()
+    assert np.abs(y16 - ref).max() / np.abs(ref).max() < 2e-2
+
+
+def test_funnel_with_built_model_family(gpu):
+    """core_generation_funnel end to end with a built network (random init: no checkpoints offline): depth + stereo."""
+    from PIL import Image
+    import src.core as core
+    core.model_holder.allow_random_init = True
+    try:
+        img = Image.fromarray(np.random.default_rng(0).integers(0, 256, (96, 128, 3), dtype=np.uint8))
+        res = list(core.core_generation_funnel(None, [img], None, None,
+                                               {'model_type': 12, 'net_width': 70, 'net_height': 70, 'gen_stereo': True,
+                                                'stereo_modes': ['left-right']}))
+        kinds = [k for _, k, _ in res]
+        assert 'depth' in kinds and 'left-right' in kinds, kinds
+        sbs = [r for _, k, r in res if k == 'left-right'][0]
+        assert sbs.size == (256, 96)
+    finally:
+        core.model_holder.allow_random_init = False
+        core.unload_models()

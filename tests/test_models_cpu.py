@@ -82,3 +82,47 @@ def test_padding_is_invisible(dav2_vits):
         a = blk.forward_padded(vm.pad_tokens(x, 192), 131)[:, :131]
         b = blk.forward_padded(vm.pad_tokens(x, 256), 131)[:, :131]
     assert torch.allclose(a, b, atol=1e-5, rtol=1e-5)
+
+
+@pytest.fixture(scope="module")
+def dpt_beitb():
+    from dmidas.dpt_depth import DPTDepthModel
+    m = DPTDepthModel(path=None, backbone="beitb16_384", non_negative=True).eval()
+    m.load_state_dict(mw.fill_state_dict_beit(m.state_dict()), strict=True)
+    return m
+
+
+def test_dpt_beit_forward_matches_reference_code(dpt_beitb, gold):
+    """Against the reference's OWN dmidas code (dpt_depth.py, blocks.py, backbones/beit.py, backbones/utils.py) executed on
+    a stand-in for timm's Beit parameter containers (tests/golden/fake_timm_beit.py; timm itself is not installable here).
+    Window (10, 14) != the table's native (24, 24): the bilinear table resize and the index gather are exercised."""
+    x = mw.synthetic_image((2, 3, 160, 224), seed=13)
+    with torch.no_grad():
+        y = dpt_beitb(x).numpy()
+        l1, l2, l3, l4 = dpt_beitb.pretrained(x)
+    assert _rel(l4.numpy(), gold["dpt_beitb_160x224_layer4"]) < 1e-4
+    assert _rel(l1[:, ::16, ::4, ::4].numpy(), gold["dpt_beitb_160x224_layer1_sample"]) < 1e-4
+    assert _rel(y, gold["dpt_beitb_160x224_out"]) < 1e-4
+
+
+def test_dpt_beit_checkpoint_key_names(dpt_beitb):
+    keys = set(dpt_beitb.state_dict().keys())
+    for k in ("pretrained.model.cls_token", "pretrained.model.patch_embed.proj.weight", "pretrained.model.blocks.0.gamma_1",
+              "pretrained.model.blocks.0.attn.q_bias", "pretrained.model.blocks.0.attn.v_bias",
+              "pretrained.model.blocks.0.attn.relative_position_bias_table", "pretrained.model.blocks.0.attn.qkv.weight",
+              "pretrained.model.blocks.11.mlp.fc2.bias", "pretrained.model.fc_norm.weight", "pretrained.model.head.weight",
+              "pretrained.act_postprocess1.0.project.0.weight", "pretrained.act_postprocess1.3.weight",
+              "pretrained.act_postprocess1.4.weight", "pretrained.act_postprocess2.4.bias", "pretrained.act_postprocess4.4.weight",
+              "scratch.layer1_rn.weight", "scratch.refinenet4.resConfUnit1.conv1.weight", "scratch.refinenet1.out_conv.weight",
+              "scratch.output_conv.0.weight", "scratch.output_conv.2.weight", "scratch.output_conv.4.bias"):
+        assert k in keys, k
+    assert "pretrained.model.blocks.0.attn.qkv.bias" not in keys and "pretrained.model.pos_embed" not in keys
+
+
+def test_midas_net_size_matches_reference_transform():
+    from dmidas.dpt_depth import midas_net_size
+    # dmidas/transforms.py Resize.get_size, keep_aspect_ratio=True, ensure_multiple_of=32
+    assert midas_net_size(1024, 1024, 512, 512, "minimal") == (512, 512)
+    assert midas_net_size(1920, 1080, 512, 512, "minimal") == (896, 512)
+    assert midas_net_size(640, 480, 384, 384, "minimal") == (512, 384)
+    assert midas_net_size(640, 480, 384, 384, "upper_bound") == (384, 288)
