@@ -121,9 +121,11 @@ def test_model_holder_refuses_missing_models():
     from src.depthmap_generation import ModelHolder
     mh = ModelHolder()
     assert mh.get_default_net_size(1) == [512, 512] and mh.get_default_net_size(14) == [518, 518]
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(FileNotFoundError):          # built family, no checkpoint, no silent random init
         mh.ensure_models(1, 'cpu', False)
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(NotImplementedError):        # family that is not built
+        mh.ensure_models(3, 'cpu', False)
+    with pytest.raises(NotImplementedError):        # Boost
         mh.ensure_models(0, 'cpu', True)
     mh.update_settings(boost_rmax=1600, no_half=True)
     assert mh.boost_rmax == 1600 and mh.no_half is True
