@@ -140,7 +140,7 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=32, help="units per GPU per step")
-    ap.add_argument("--model", default="dav2_vitl", choices=["dav2_vitl", "dpt_beit_large_512", "none"])
+    ap.add_argument("--model", default="dpt_beit_large_512", choices=["dav2_vitl", "dpt_beit_large_512", "none"])
     ap.add_argument("--fill", default="polylines_sharp")
     ap.add_argument("--gather", action="store_true", help="gather the collated outputs to rank 0 (N > 1)")
     ap.add_argument("--depth", default="steps", choices=["steps", "smooth"],

@@ -163,6 +163,18 @@ int ds_convert_to_i16(ds_ctx *ctx, const void *arr, int is_f64, int64_t count, u
 int ds_attention_fwd(ds_ctx *ctx, const void *qk, const void *vt, const void *bias_t, void *out,
                      int B, int Np, int H, int n_valid, float scale, int dtype, void *stream);
 
+/*
+ * ds_residual_layernorm -- the element-wise part of a transformer block between two GEMMs, fused:
+ *     x_out = x + gamma * branch           (LayerScale + residual; dinov2_layers/block.py:100-107, beit.py:101-106)
+ *     h_out = LayerNorm(x_out) * ln_weight + ln_bias
+ * x, branch, x_out, h_out: [rows, channels]; gamma, ln_weight, ln_bias: [channels]; all of `dtype` (f16/bf16).
+ * branch == NULL: plain LayerNorm of x (x_out unused).  gamma == NULL: gamma = 1.  x_out may alias x.
+ * channels in {384, 768, 1024, 1536}.
+ */
+int ds_residual_layernorm(ds_ctx *ctx, const void *x, const void *branch, const void *gamma, const void *ln_weight,
+                          const void *ln_bias, void *x_out, void *h_out, int64_t rows, int channels, float eps, int dtype,
+                          void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -96,34 +96,29 @@ __global__ __launch_bounds__(AT_THREADS) void k_attention_fwd(AttnParams P)
 
     // staging assignment: K tile = 64 rows x 8 chunks of 16 B; V^T tile = 64 rows x 8 chunks: 512 chunks each, 2 per thread
     const int st_row = tid >> 3, st_chunk = tid & 7;                                  // rows st_row and st_row + 32
-    uint4 kreg[2], vreg[2];
-    auto fetch = [&](int kt) {
-        const int key0 = kt * AT_KB;
-#pragma unroll
-        for (int p = 0; p < 2; p++) {
-            const int row = st_row + 32 * p;
-            kreg[p] = *reinterpret_cast<const uint4 *>(k_base + (size_t)(key0 + row) * tok_stride + 8 * st_chunk);
-            vreg[p] = *reinterpret_cast<const uint4 *>(vt + (size_t)row * Np + key0 + 8 * st_chunk);
-        }
-    };
-    auto stash = [&]() {
-#pragma unroll
-        for (int p = 0; p < 2; p++) {
-            const int row = st_row + 32 * p;
-            *reinterpret_cast<uint4 *>(s_k + row * 128 + ((st_chunk ^ (row & 7)) << 4)) = kreg[p];
-            uint2 *vd = reinterpret_cast<uint2 *>(s_v + row * AT_VROW + 16 * st_chunk);
-            vd[0] = make_uint2(vreg[p].x, vreg[p].y);
-            vd[1] = make_uint2(vreg[p].z, vreg[p].w);
-        }
-    };
+    uint4 kreg0, kreg1, vreg0, vreg1;
+#define AT_FETCH(kt_) do {                                                                                             \
+        const int key0_ = (kt_) * AT_KB;                                                                                \
+        kreg0 = *reinterpret_cast<const uint4 *>(k_base + (size_t)(key0_ + st_row) * tok_stride + 8 * st_chunk);        \
+        kreg1 = *reinterpret_cast<const uint4 *>(k_base + (size_t)(key0_ + st_row + 32) * tok_stride + 8 * st_chunk);   \
+        vreg0 = *reinterpret_cast<const uint4 *>(vt + (size_t)st_row * Np + key0_ + 8 * st_chunk);                      \
+        vreg1 = *reinterpret_cast<const uint4 *>(vt + (size_t)(st_row + 32) * Np + key0_ + 8 * st_chunk);               \
+    } while (0)
+#define AT_STASH1(row_, kr_, vr_) do {                                                                                  \
+        *reinterpret_cast<uint4 *>(s_k + (row_) * 128 + ((st_chunk ^ ((row_) & 7)) << 4)) = kr_;                        \
+        uint2 *vd_ = reinterpret_cast<uint2 *>(s_v + (row_) * AT_VROW + 16 * st_chunk);                                 \
+        vd_[0] = make_uint2(vr_.x, vr_.y);                                                                              \
+        vd_[1] = make_uint2(vr_.z, vr_.w);                                                                              \
+    } while (0)
 
     const int ntiles = (P.n_valid + AT_KB - 1) / AT_KB;
-    fetch(0);
+    AT_FETCH(0);
     for (int kt = 0; kt < ntiles; kt++) {
         __syncthreads();                                    // everyone is done reading the previous tile
-        stash();
+        AT_STASH1(st_row, kreg0, vreg0);
+        AT_STASH1(st_row + 32, kreg1, vreg1);
         __syncthreads();
-        if (kt + 1 < ntiles) fetch(kt + 1);                 // in flight while this tile is computed
+        if (kt + 1 < ntiles) AT_FETCH(kt + 1);              // in flight while this tile is computed
         if (!wave_live) continue;
 
         // ---- S^T = K . Q^T for the 64 keys of the tile: 2 key blocks of 32 -----------------------------------
@@ -152,14 +147,23 @@ __global__ __launch_bounds__(AT_THREADS) void k_attention_fwd(AttnParams P)
                     const T *bp = (const T *)P.bias + ((size_t)h * Np + key) * (size_t)Np + min(q0 + l31, Np - 1);
                     v += TR::to_f32(*bp) * P.log2e;
                 }
-                v = key < P.n_valid ? v : -__builtin_inff();
                 s_acc[kb][r] = v;
-                m_loc = fmaxf(m_loc, v);
             }
         }
+        if (key0 + AT_KB > P.n_valid) {                     // wave-uniform: only the last tile can hold pad keys
+#pragma unroll
+            for (int kb = 0; kb < 2; kb++)
+#pragma unroll
+                for (int r = 0; r < 16; r++)
+                    if (key0 + kb * 32 + at_crow(r, hi) >= P.n_valid) s_acc[kb][r] = -__builtin_inff();
+        }
+#pragma unroll
+        for (int kb = 0; kb < 2; kb++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) m_loc = fmaxf(m_loc, s_acc[kb][r]);
         m_loc = fmaxf(m_loc, __shfl_xor(m_loc, 32, 64));    // the other half of this query's keys
         const float m_new = fmaxf(m_run, m_loc);
-        const float alpha = exp2f(m_run - m_new);           // first tile: exp2(-inf) = 0
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);   // v_exp_f32; first tile: exp2(-inf) = 0
         m_run = m_new;
         float l_loc = 0.f;
         // ---- P = exp2(S - m); P^T fragments for the four 16-key slices: registers 8j..8j+7 of key block kb ------
@@ -170,17 +174,19 @@ __global__ __launch_bounds__(AT_THREADS) void k_attention_fwd(AttnParams P)
             for (int j = 0; j < 2; j++) {
 #pragma unroll
                 for (int t = 0; t < 8; t++) {
-                    const float p = exp2f(s_acc[kb][8 * j + t] - m_new);
+                    const float p = __builtin_amdgcn_exp2f(s_acc[kb][8 * j + t] - m_new);
                     l_loc += p;
                     pf[kb][j][t] = TR::from_f32(p);
                 }
             }
         }
         l_run = l_run * alpha + l_loc;
+        if (!__all(alpha == 1.0f)) {                         // the running max moved for some query of this wave
 #pragma unroll
-        for (int d = 0; d < 2; d++)
+            for (int d = 0; d < 2; d++)
 #pragma unroll
-            for (int r = 0; r < 16; r++) o_acc[d][r] *= alpha;
+                for (int r = 0; r < 16; r++) o_acc[d][r] *= alpha;
+        }
         // ---- O^T += V^T . P^T : A = V^T[d][key slots], slot t of half hi = key 16j + (t&3) + 8(t>>2) + 4hi -------
 #pragma unroll
         for (int d = 0; d < 2; d++) {

@@ -39,19 +39,13 @@ class Block(vm.EncoderBlock):
         self.mlp = vm.Mlp(dim, int(dim * mlp_ratio))
         self.ls2 = _LayerScale(dim, init_values)
 
-    def ln1(self, x):
-        return self.norm1(x)
-
-    def ln2(self, x):
-        return self.norm2(x)
-
     def qkv_weights(self):
         c = self.dim
         w, b = self.attn.qkv.weight, self.attn.qkv.bias
         return w[:2 * c], b[:2 * c], w[2 * c:], b[2 * c:]
 
-    def proj(self, o):
-        return self.attn.proj(o)
+    def proj(self, o, b_v=None):
+        return F.linear(o, self.attn.proj.weight, vm.folded_proj_bias(self.attn.proj, b_v))
 
     def gammas(self):
         return self.ls1.gamma, self.ls2.gamma
@@ -133,13 +127,9 @@ class DinoVisionTransformer(nn.Module):
         tokens = self.prepare_tokens(x)
         n_valid = tokens.shape[1]
         tokens = vm.pad_tokens(tokens, vm.pad_len(n_valid))
-        take = set(range(len(self.blocks) - n, len(self.blocks))) if isinstance(n, int) else set(n)
-        outs = []
-        for i, blk in enumerate(self.blocks):
-            tokens = blk.forward_padded(tokens, n_valid)
-            if i in take:
-                outs.append(tokens[:, :n_valid])
-        assert len(outs) == len(take)
+        take = sorted(set(range(len(self.blocks) - n, len(self.blocks))) if isinstance(n, int) else set(n))
+        _, taps = vm.run_blocks(self.blocks, tokens, n_valid, None, set(take))
+        outs = [taps[i] for i in take]
         if norm:
             outs = [self.norm(o) for o in outs]
         cls = [o[:, 0] for o in outs]

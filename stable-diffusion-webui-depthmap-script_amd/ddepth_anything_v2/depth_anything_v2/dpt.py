@@ -37,11 +37,12 @@ class FeatureFusionBlock(nn.Module):
         if len(xs) == 2:
             output = output + self.resConfUnit1(xs[1])
         output = self.resConfUnit2(output)
+        # the reference interpolates, then applies the 1x1 out_conv; both are linear and the bilinear weights sum to one,
+        # so they commute (bias included): the conv runs on 4x fewer pixels and the upsample writes the final tensor
+        output = self.out_conv(output)
         if size is None:
-            output = F.interpolate(output, scale_factor=2, mode="bilinear", align_corners=True)
-        else:
-            output = F.interpolate(output, size=size, mode="bilinear", align_corners=True)
-        return self.out_conv(output)
+            return F.interpolate(output, scale_factor=2, mode="bilinear", align_corners=True)
+        return F.interpolate(output, size=size, mode="bilinear", align_corners=True)
 
 
 class DPTHead(nn.Module):
@@ -72,7 +73,8 @@ class DPTHead(nn.Module):
         out = []
         for i, x in enumerate(out_features):
             x = x[0]
-            x = x.permute(0, 2, 1).reshape((x.shape[0], x.shape[-1], patch_h, patch_w))
+            # [B, ph*pw, C] IS the NHWC image: a channels_last view, not a permuted copy (reference: permute + reshape)
+            x = x.reshape(x.shape[0], patch_h, patch_w, x.shape[-1]).permute(0, 3, 1, 2)
             x = self.resize_layers[i](self.projects[i](x))
             out.append(x)
         l1, l2, l3, l4 = out

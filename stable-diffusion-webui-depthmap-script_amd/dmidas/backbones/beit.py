@@ -72,20 +72,14 @@ class Block(vm.EncoderBlock):
         self.gamma_2 = nn.Parameter(init_values * torch.ones(dim))
         self._bias_cache = {}
 
-    def ln1(self, x):
-        return self.norm1(x)
-
-    def ln2(self, x):
-        return self.norm2(x)
-
     def qkv_weights(self):
         c = self.dim
         w = self.attn.qkv.weight
         b_qk = torch.cat((self.attn.q_bias, torch.zeros_like(self.attn.q_bias)))        # k_bias == 0 (beit.py:71)
         return w[:2 * c], b_qk, w[2 * c:], self.attn.v_bias
 
-    def proj(self, o):
-        return self.attn.proj(o)
+    def proj(self, o, b_v=None):
+        return F.linear(o, self.attn.proj.weight, vm.folded_proj_bias(self.attn.proj, b_v))
 
     def gammas(self):
         return self.gamma_1, self.gamma_2
@@ -106,7 +100,7 @@ class Block(vm.EncoderBlock):
         bias = new_table[index.view(-1)].view(n, n, -1)
         return bias.permute(2, 0, 1).contiguous()
 
-    def attention_bias(self, n_pad, grid_hw, dtype, device):
+    def attention_bias_t(self, n_pad, grid_hw, dtype, device):
         """Key-major, padded: bias_t[h][key][query]; cached per (window, dtype) until the table changes."""
         a = self.attn
         key = (tuple(grid_hw), n_pad, dtype, device, a.relative_position_bias_table._version)
@@ -121,21 +115,6 @@ class Block(vm.EncoderBlock):
         self._bias_cache.clear()
         self._bias_cache[key] = bt
         return bt
-
-    def forward_padded(self, x, n_valid, grid_hw=None):
-        b, npad, c = x.shape
-        h = self.ln1(x)
-        w_qk, b_qk, w_v, b_v = self.qkv_weights()
-        qk = F.linear(h, w_qk, b_qk).view(b, npad, 2, self.num_heads, vm.HEAD_DIM)
-        vt = torch.matmul(w_v, h.transpose(1, 2)) + b_v.view(1, c, 1)
-        bias_t = self.attention_bias(npad, grid_hw, x.dtype, x.device)
-        if x.dtype == torch.float32:
-            o = vm.attention_reference(qk, vt, n_valid, self.scale, bias_t.transpose(1, 2))
-        else:
-            from src import _native
-            o = _native.attention_fwd(qk, vt, n_valid, self.scale, bias_t=bias_t)
-        x = x + self.gamma_1 * self.attn.proj(o)
-        return x + self.gamma_2 * self.mlp(self.ln2(x))
 
 
 class PatchEmbed(nn.Module):
@@ -176,12 +155,8 @@ class Beit(nn.Module):
         t = torch.cat((self.cls_token.expand(t.shape[0], -1, -1).to(t.dtype), t), dim=1)
         n_valid = t.shape[1]
         t = vm.pad_tokens(t, vm.pad_len(n_valid))
-        taps = []
-        for i, blk in enumerate(self.blocks):
-            t = blk.forward_padded(t, n_valid, grid)
-            if i in hooks:
-                taps.append(t[:, :n_valid])
-        return taps, grid
+        _, taps = vm.run_blocks(self.blocks, t, n_valid, grid, set(hooks))
+        return [taps[i] for i in hooks], grid
 
 
 class ProjectReadout(nn.Module):       # utils.py:28-39
@@ -225,7 +200,7 @@ class BeitBackbone(nn.Module):
         outs = []
         for tap, post in zip(taps, (self.act_postprocess1, self.act_postprocess2, self.act_postprocess3, self.act_postprocess4)):
             y = post[0](tap)                                   # ProjectReadout: [B, N-1, C]
-            y = y.transpose(1, 2).reshape(y.shape[0], y.shape[2], grid[0], grid[1])
+            y = y.reshape(y.shape[0], grid[0], grid[1], y.shape[2]).permute(0, 3, 1, 2)     # NHWC view, no copy
             for layer in list(post)[3:]:
                 y = layer(y)
             outs.append(y)

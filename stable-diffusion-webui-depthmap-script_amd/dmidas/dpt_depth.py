@@ -39,11 +39,11 @@ class FeatureFusionBlock_custom(nn.Module):
         if len(xs) == 2:
             output = output + self.resConfUnit1(xs[1])
         output = self.resConfUnit2(output)
+        # 1x1 out_conv and bilinear interpolation commute (linear, weights sum to one): conv first, on 4x fewer pixels
+        output = self.out_conv(output)
         if size is None:
-            output = F.interpolate(output, scale_factor=2, mode="bilinear", align_corners=True)
-        else:
-            output = F.interpolate(output, size=size, mode="bilinear", align_corners=True)
-        return self.out_conv(output)
+            return F.interpolate(output, scale_factor=2, mode="bilinear", align_corners=True)
+        return F.interpolate(output, size=size, mode="bilinear", align_corners=True)
 
 
 class Interpolate(nn.Module):           # blocks.py:213-244 (no parameters; keeps the Sequential indices of the head)

@@ -20,7 +20,7 @@ FILL_IDS = {"none": 0, "naive": 1, "naive_interpolating": 2, "polylines_soft": 3
 EXPORTS = [
     "ds_version", "ds_last_error", "ds_ctx_create", "ds_ctx_destroy", "ds_stereo_warp", "ds_depth_minmax",
     "ds_stereo_last_exact_rows", "ds_copy_view", "ds_overlap_red_cyan", "ds_normalmap", "ds_depth_to_u16",
-    "ds_convert_to_i16", "ds_profile_enable", "ds_profile_last_ms", "ds_stereo_last_stats", "ds_attention_fwd",
+    "ds_convert_to_i16", "ds_profile_enable", "ds_profile_last_ms", "ds_stereo_last_stats", "ds_attention_fwd", "ds_residual_layernorm",
 ]
 
 
@@ -62,6 +62,7 @@ def lib():
             L.ds_convert_to_i16.argtypes = [vp, vp, ci, i64, vp, vp]
             L.ds_stereo_last_stats.argtypes = [vp, ctypes.POINTER(i64), vp]
             L.ds_attention_fwd.argtypes = [vp, vp, vp, vp, vp, ci, ci, ci, ci, ctypes.c_float, ci, vp]
+            L.ds_residual_layernorm.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, i64, ci, ctypes.c_float, ci, vp]
             L.ds_profile_enable.argtypes = [vp, ci]
             L.ds_profile_last_ms.argtypes = [vp, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float)]
             for name in EXPORTS:          # fail at load time, not at first use, if a symbol is missing
@@ -255,3 +256,28 @@ def attention_fwd(qk, vt, n_valid, scale, bias=None, bias_t=None):
                                   bias_t.data_ptr() if bias_t is not None else None, out.data_ptr(),
                                   b, npad, h, int(n_valid), float(scale), dt, _stream(qk)))
     return out
+
+
+def residual_layernorm(x, branch, gamma, ln_weight, ln_bias, eps=1e-6):
+    """x_out = x + gamma * branch; h = LayerNorm(x_out) (include/depthstereo.h: ds_residual_layernorm), one pass.
+    x, branch [..., C] float16/bfloat16 CUDA tensors (branch may be None: plain LayerNorm).  Returns (x_out, h)."""
+    torch = require_gpu()
+    assert x.is_cuda and x.dtype in (torch.float16, torch.bfloat16)
+    x = x.contiguous()
+    c = x.shape[-1]
+    rows = x.numel() // c
+    h = torch.empty_like(x)
+    dt = 1 if x.dtype == torch.float16 else 2
+    if branch is None:
+        x_out, bp = x, None
+    else:
+        branch = branch.contiguous()
+        assert branch.shape == x.shape and branch.dtype == x.dtype
+        x_out = torch.empty_like(x)
+        bp = branch.data_ptr()
+    g = None if gamma is None else gamma.to(x.dtype).contiguous()
+    w, b = ln_weight.to(x.dtype).contiguous(), ln_bias.to(x.dtype).contiguous()
+    _check(lib().ds_residual_layernorm(ctx_for(_dev_index(x)), x.data_ptr(), bp, None if g is None else g.data_ptr(),
+                                       w.data_ptr(), b.data_ptr(), None if branch is None else x_out.data_ptr(), h.data_ptr(),
+                                       rows, c, float(eps), dt, _stream(x)))
+    return x_out, h

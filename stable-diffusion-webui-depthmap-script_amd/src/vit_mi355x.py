@@ -62,45 +62,89 @@ def attention_reference(qk, vt, n_valid, scale, bias=None):
     return out.permute(0, 2, 1, 3).reshape(b, npad, h * d).to(qk.dtype)
 
 
-def fused_attention(qk, vt, n_valid, scale, bias=None):
+def v_transposed(w_v, h):
+    """V^T = W_v . h^T as ONE batched GEMM whose second operand is read transposed in place ([B, C, Np] out of
+    h [B, Np, C]); torch.matmul(w_v, h.transpose(1, 2)) would first materialise h^T."""
+    b = h.shape[0]
+    return torch.bmm(w_v.unsqueeze(0).expand(b, -1, -1), h.transpose(1, 2))
+
+
+def folded_proj_bias(proj, b_v):
+    """softmax rows sum to one, so attn @ (v + b_v) = attn @ v + b_v: the V bias commutes with the attention and folds
+    into the output projection's bias, b_p + W_p . b_v -- one [C] vector per block instead of a pass over V^T."""
+    if b_v is None:
+        return proj.bias
+    return proj.bias + F.linear(b_v.to(proj.weight.dtype), proj.weight)
+
+
+def fused_attention(qk, vt, n_valid, scale, bias_t=None):
+    """bias_t: key-major additive bias [H, Np(key), Np(query)] or None."""
     if qk.dtype == torch.float32:
-        return attention_reference(qk, vt, n_valid, scale, bias)
+        return attention_reference(qk, vt, n_valid, scale, None if bias_t is None else bias_t.transpose(1, 2))
     from . import _native
-    return _native.attention_fwd(qk, vt, n_valid, scale, bias)
+    return _native.attention_fwd(qk, vt, n_valid, scale, bias_t=bias_t)
 
 
 class EncoderBlock(nn.Module):
-    """Pre-norm transformer block with optional LayerScale.  Parameter NAMES follow the reference checkpoints of the
-    family that instantiates it (see ``names``): DINOv2 ``norm1/attn.qkv/attn.proj/ls1.gamma/norm2/mlp.fc1/mlp.fc2/
-    ls2.gamma`` (dinov2_layers/block.py:60-83); the BEiT subclass keeps timm's ``gamma_1/gamma_2`` and q/v biases."""
+    """Pre-norm transformer block with LayerScale.  Parameter NAMES follow the reference checkpoints of the family that
+    instantiates it: DINOv2 ``norm1/attn.qkv/attn.proj/ls1.gamma/norm2/mlp.fc1/mlp.fc2/ls2.gamma`` (dinov2_layers/
+    block.py:60-83); the BEiT subclass keeps timm's ``gamma_1/gamma_2``, ``q_bias/v_bias`` and the bias table.
+    Subclasses provide: norm1, norm2 (nn.LayerNorm), mlp, qkv_weights() -> (w_qk, b_qk, w_v, b_v),
+    proj(o, b_v), gammas() -> (g1, g2), and optionally attention_bias_t()."""
 
-    def __init__(self, dim, num_heads, mlp_ratio=4.0, qkv_bias=True, eps=1e-6):
+    def __init__(self, dim, num_heads, mlp_ratio=4.0):
         super().__init__()
         assert dim == num_heads * HEAD_DIM, "the attention kernel is built for head_dim 64"
         self.dim, self.num_heads = dim, num_heads
         self.scale = HEAD_DIM ** -0.5
-        self.eps = eps
 
-    # subclasses provide: ln1(x), qkv_weights() -> (w_qk, b_qk, w_v, b_v), proj(o), gamma1/gamma2 (or None), ln2, mlp
-    def attention_bias(self, n_pad, grid_hw, dtype, device):
+    def attention_bias_t(self, n_pad, grid_hw, dtype, device):
         return None
 
-    def forward_padded(self, x, n_valid, grid_hw=None):
-        b, npad, c = x.shape
-        h = self.ln1(x)
+    def attend(self, h, n_valid, grid_hw):
+        """LayerNorm-ed tokens -> projected attention output (before LayerScale / residual)."""
+        b, npad, c = h.shape
         w_qk, b_qk, w_v, b_v = self.qkv_weights()
         qk = F.linear(h, w_qk, b_qk).view(b, npad, 2, self.num_heads, HEAD_DIM)
-        vt = torch.matmul(w_v, h.transpose(1, 2))               # [B, C, Np]: V transposed, straight out of the GEMM
-        if b_v is not None:
-            vt = vt + b_v.view(1, c, 1)
-        bias = self.attention_bias(npad, grid_hw, x.dtype, x.device)
-        o = fused_attention(qk, vt, n_valid, self.scale, bias)
-        o = self.proj(o)
+        vt = v_transposed(w_v, h)                               # [B, C, Np]: V transposed, straight out of the GEMM
+        o = fused_attention(qk, vt, n_valid, self.scale, self.attention_bias_t(npad, grid_hw, h.dtype, h.device))
+        return self.proj(o, b_v)                                # V bias folded into the projection bias
+
+    def forward_padded(self, x, n_valid, grid_hw=None):
+        """Reference operation order with stock torch element-wise ops (float32 parity path)."""
         g1, g2 = self.gammas()
-        x = x + (o * g1 if g1 is not None else o)
-        m = self.mlp(self.ln2(x))
-        x = x + (m * g2 if g2 is not None else m)
-        return x
+        x = x + g1 * self.attend(self.norm1(x), n_valid, grid_hw)
+        return x + g2 * self.mlp(self.norm2(x))
+
+
+def run_blocks(blocks, x, n_valid, grid_hw, take):
+    """Run the encoder on the padded sequence x [B, Np, C]; returns (x, {index: tap}) with taps = unpadded block outputs.
+    float16/bfloat16 on a GPU: LayerScale + residual + the NEXT LayerNorm are one fused pass (ds_residual_layernorm), so a
+    block is 5 GEMMs + 1 attention + 1 GELU + 2 fused element-wise kernels.  Otherwise: the plain torch sequence."""
+    taps = {}
+    fast = x.is_cuda and x.dtype in (torch.float16, torch.bfloat16)
+    if not fast:
+        for i, blk in enumerate(blocks):
+            x = blk.forward_padded(x, n_valid, grid_hw)
+            if i in take:
+                taps[i] = x[:, :n_valid]
+        return x, taps
+    from . import _native
+    n = len(blocks)
+    _, h = _native.residual_layernorm(x, None, None, blocks[0].norm1.weight, blocks[0].norm1.bias, blocks[0].norm1.eps)
+    for i, blk in enumerate(blocks):
+        g1, g2 = blk.gammas()
+        p = blk.attend(h, n_valid, grid_hw)
+        x, h2 = _native.residual_layernorm(x, p, g1, blk.norm2.weight, blk.norm2.bias, blk.norm2.eps)
+        m = blk.mlp(h2)
+        if i + 1 < n:
+            nxt = blocks[i + 1].norm1
+            x, h = _native.residual_layernorm(x, m, g2, nxt.weight, nxt.bias, nxt.eps)
+        else:
+            x = x + g2 * m
+        if i in take:
+            taps[i] = x[:, :n_valid]
+    return x, taps
 
 
 class Mlp(nn.Module):

@@ -126,3 +126,24 @@ def test_funnel_with_built_model_family(gpu):
     finally:
         core.model_holder.allow_random_init = False
         core.unload_models()
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_residual_layernorm_kernel(gpu, dtype):
+    from src import _native
+    g = torch.Generator().manual_seed(5)
+    for rows, c in [(3, 384), (70, 768), (1408, 1024), (5, 1536)]:
+        x = torch.randn((rows, c), generator=g).to(dtype).cuda()
+        o = torch.randn((rows, c), generator=g).to(dtype).cuda()
+        gamma = (1 + 0.1 * torch.randn(c, generator=g)).to(dtype).cuda()
+        w = (1 + 0.1 * torch.randn(c, generator=g)).to(dtype).cuda()
+        b = (0.1 * torch.randn(c, generator=g)).to(dtype).cuda()
+        x_out, h = _native.residual_layernorm(x, o, gamma, w, b, 1e-6)
+        xr = (x.float() + gamma.float() * o.float()).to(dtype)
+        hr = torch.nn.functional.layer_norm(xr.float(), (c,), w.float(), b.float(), 1e-6)
+        tol = 4e-3 if dtype == torch.float16 else 3e-2
+        assert (x_out.float() - xr.float()).abs().max().item() <= (1e-3 if dtype == torch.float16 else 1.6e-2) * (1 + xr.float().abs().max().item())
+        assert (h.float() - hr).abs().max().item() < tol * (1 + hr.abs().max().item())
+        _, h0 = _native.residual_layernorm(x, None, None, w, b, 1e-6)
+        h0r = torch.nn.functional.layer_norm(x.float(), (c,), w.float(), b.float(), 1e-6)
+        assert (h0.float() - h0r).abs().max().item() < tol * (1 + h0r.abs().max().item())
