@@ -12,7 +12,8 @@ One *step* = one pass of the hot path over a batch of `--batch` units already re
 
 `--model` picks the depth network (random-init weights of the named architecture -- there are no checkpoints offline):
     dav2_vitl            Depth-Anything-V2 ViT-L/14, net 518 (reference model id 14; BASELINE config 5's network)
-    dpt_beit_large_512   MiDaS 3.1 DPT BEiT-L/16, net 512   (reference model id 1;  BASELINE config 3's network)
+    dpt_beit_large_512   MiDaS 3.1 DPT BEiT-L/16, net 512   (reference model id 1;  BASELINE config 3's network) [default]
+    dpt_hybrid_384       MiDaS 3.0 ViT-B/16 + ResNetV2-50, net 384 (reference model id 4; BASELINE config 2's network)
     none                 no network: the float32 prediction is a synthetic INPUT and only the per-pixel path is timed
                          (what round 1 measured first; kept to track the stereo kernels on their own)
 
@@ -63,7 +64,7 @@ def synth_batch(batch, seed):
 
 
 def model_input_size(model_name):
-    return {"dav2_vitl": 518, "dpt_beit_large_512": 512}.get(model_name, 0)
+    return {"dav2_vitl": 518, "dpt_beit_large_512": 512, "dpt_hybrid_384": 384}.get(model_name, 0)
 
 
 def build_model(name, seed=0):
@@ -78,6 +79,10 @@ def build_model(name, seed=0):
         from dmidas.dpt_depth import DPTDepthModel
         m = DPTDepthModel(path=None, backbone="beitl16_512", non_negative=True)
         info = {"name": "MiDaS 3.1 DPT BEiT-L/16 512", "net": 512, "tokens": 32 * 32 + 1, "dim": 1024, "depth": 24, "heads": 16}
+    elif name == "dpt_hybrid_384":
+        from dmidas.dpt_depth import DPTDepthModel
+        m = DPTDepthModel(path=None, backbone="vitb_rn50_384", non_negative=True)
+        info = {"name": "MiDaS 3.0 dpt_hybrid_384 (ViT-B/16 + ResNetV2-50)", "net": 384, "tokens": 24 * 24 + 1, "dim": 768, "depth": 12, "heads": 12}
     else:
         raise SystemExit(f"unknown --model {name}")
     return m.eval(), info
@@ -140,7 +145,7 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=32, help="units per GPU per step")
-    ap.add_argument("--model", default="dpt_beit_large_512", choices=["dav2_vitl", "dpt_beit_large_512", "none"])
+    ap.add_argument("--model", default="dpt_beit_large_512", choices=["dav2_vitl", "dpt_beit_large_512", "dpt_hybrid_384", "none"])
     ap.add_argument("--fill", default="polylines_sharp")
     ap.add_argument("--gather", action="store_true", help="gather the collated outputs to rank 0 (N > 1)")
     ap.add_argument("--depth", default="steps", choices=["steps", "smooth"],

@@ -6,7 +6,7 @@ block_forward :94-107, beit_forward_features :110-129, _make_pretrained_beit* :1
 lives in the un-vendored dependency timm~=0.9.2 (requirements.txt:8; timm/models/beit.py: Attention, Block, Beit,
 gen_relative_position_index); it is restated here from its published source.  Parity: the reference's OWN dmidas code
 (all the forwards it monkey-patches into timm's classes, the read-out, the DPT decoder) was executed on a stand-in for
-timm's parameter containers (tests/golden/fake_timm_beit.py) and our outputs match it to 1e-4 (tests/test_models_cpu.py);
+timm's parameter containers (tests/golden/fake_timm.py) and our outputs match it to 1e-4 (tests/test_models_cpu.py);
 what remains unpinned is timm's own part: the containers' shapes, Mlp/LayerNorm/patch-conv and
 gen_relative_position_index (timm is not installable in the build container).
 

@@ -1,4 +1,4 @@
-"""MiDaS 3.1 DPT depth model (BEiT backbones), MI355X-first.
+"""MiDaS 3.x DPT depth model (BEiT, ViT-L and ViT-B/ResNet-50 hybrid backbones), MI355X-first.
 
 Reference: dmidas/dpt_depth.py (DPT :31-139, DPTDepthModel :142-166), dmidas/blocks.py (_make_scratch, Interpolate,
 ResidualConvUnit_custom :322-377, FeatureFusionBlock_custom :382-441), and its caller estimatemidas
@@ -11,8 +11,10 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .backbones.beit import make_beit
+from .backbones.vit import make_vit
 
-_HOOKS = {"beitl16_512": [5, 11, 17, 23], "beitl16_384": [5, 11, 17, 23], "beitb16_384": [2, 5, 8, 11]}
+_HOOKS = {"beitl16_512": [5, 11, 17, 23], "beitl16_384": [5, 11, 17, 23], "beitb16_384": [2, 5, 8, 11],
+          "vitl16_384": [5, 11, 17, 23], "vitb_rn50_384": [0, 1, 8, 11]}
 
 
 class ResidualConvUnit_custom(nn.Module):
@@ -59,11 +61,12 @@ class DPT(nn.Module):
     def __init__(self, head, features=256, backbone="beitl16_512", readout="project", channels_last=False, use_bn=False, **kwargs):
         super().__init__()
         if backbone not in _HOOKS:
-            raise NotImplementedError(f"DPT backbone '{backbone}' is not built yet (BEiT family only: {sorted(_HOOKS)})")
+            raise NotImplementedError(f"DPT backbone '{backbone}' is not built (built: {sorted(_HOOKS)})")
         if readout != "project" or use_bn:
             raise NotImplementedError("only readout='project', use_bn=False (what src/depthmap_generation.py:129-176 uses)")
         self.channels_last = channels_last
-        self.pretrained, in_shape = make_beit(backbone, _HOOKS[backbone])
+        make = make_beit if backbone.startswith("beit") else make_vit
+        self.pretrained, in_shape = make(backbone, _HOOKS[backbone])
         scratch = nn.Module()
         for i in range(4):
             setattr(scratch, f"layer{i + 1}_rn", nn.Conv2d(in_shape[i], features, kernel_size=3, stride=1, padding=1, bias=False))

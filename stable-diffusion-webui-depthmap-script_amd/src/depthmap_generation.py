@@ -4,11 +4,12 @@ The holder keeps the reference's interface (``ensure_models``, ``get_raw_predict
 ``unload_models``, ``update_settings``, ``get_default_net_size``) so ``core_generation_funnel`` is wired exactly like
 the reference.  Built model families:
     ids 1, 2        MiDaS 3.1 DPT BEiT-L/16 512 / 384   (dmidas.dpt_depth.DPTDepthModel; reference :116-146)
+    ids 3, 4        MiDaS 3.0 dpt_large_384 (ViT-L/16) / dpt_hybrid_384 (ViT-B/16 + ResNetV2-50 stem)   (reference :147-170)
     ids 12, 13, 14  Depth-Anything-V2 small/base/large   (ddepth_anything_v2.DepthAnythingV2; reference :237-248)
 Checkpoints are looked up in ``model_dir`` under the reference's file names; the reference downloads them when missing
 (ensure_file_downloaded) -- this build has no network path and raises FileNotFoundError instead, unless
 ``allow_random_init`` is set (bench / tests: random weights of the same architecture).
-Other ids (LeReS 0, dpt_large/hybrid 3-4, midas_v21 5-6, ZoeDepth 7-9, Marigold 10, Depth-Anything v1 11) and Boost are
+Other ids (LeReS 0, midas_v21 5-6, ZoeDepth 7-9, Marigold 10, Depth-Anything v1 11) and Boost are
 not built: ``ensure_models`` raises NotImplementedError unless a predictor was registered with ``register_predictor``.
 Nothing ever falls back silently.
 """
@@ -42,6 +43,7 @@ def _build_dav2(letter):
 
 
 _BUILDERS = {1: _build_dpt_beit("beitl16_512", "dpt_beit_large_512.pt"), 2: _build_dpt_beit("beitl16_384", "dpt_beit_large_384.pt"),
+             3: _build_dpt_beit("vitl16_384", "dpt_large-midas-2f21e586.pt"), 4: _build_dpt_beit("vitb_rn50_384", "dpt_hybrid-midas-501f0c75.pt"),
              12: _build_dav2('s'), 13: _build_dav2('b'), 14: _build_dav2('l')}
 
 
@@ -82,7 +84,7 @@ class _NetPredictor:
         batch = img.unsqueeze(0)
         if self.is_dav2:
             return self.net.infer_batch(batch, int(net_width))[0]          # reference passes net_width as input_size (:553)
-        mode = "minimal"                                                    # resize_mode of ids 1, 2 (:127, :141)
+        mode = "minimal"                                                    # resize_mode of ids 1-4 (:127, :141, :155, :168)
         return self.net.infer_batch(batch, net_size=int(net_width), resize_mode=mode)[0]
 
 

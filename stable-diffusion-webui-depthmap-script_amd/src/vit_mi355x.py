@@ -113,8 +113,10 @@ class EncoderBlock(nn.Module):
     def forward_padded(self, x, n_valid, grid_hw=None):
         """Reference operation order with stock torch element-wise ops (float32 parity path)."""
         g1, g2 = self.gammas()
-        x = x + g1 * self.attend(self.norm1(x), n_valid, grid_hw)
-        return x + g2 * self.mlp(self.norm2(x))
+        a = self.attend(self.norm1(x), n_valid, grid_hw)
+        x = x + (a if g1 is None else g1 * a)
+        m = self.mlp(self.norm2(x))
+        return x + (m if g2 is None else g2 * m)
 
 
 def run_blocks(blocks, x, n_valid, grid_hw, take):
@@ -141,7 +143,7 @@ def run_blocks(blocks, x, n_valid, grid_hw, take):
             nxt = blocks[i + 1].norm1
             x, h = _native.residual_layernorm(x, m, g2, nxt.weight, nxt.bias, nxt.eps)
         else:
-            x = x + g2 * m
+            x = x + (m if g2 is None else g2 * m)
         if i in take:
             taps[i] = x[:, :n_valid]
     return x, taps

@@ -32,11 +32,11 @@ def reference_dav2(encoder, features, out_channels):
 
 def reference_dpt(backbone):
     """The reference's own dmidas.dpt_depth.DPTDepthModel, running on a stand-in for timm's Beit containers
-    (fake_timm_beit.py): every forward on the path -- beit_forward_features, block_forward, attention_forward,
+    (fake_timm.py): every forward on the path -- beit_forward_features, block_forward, attention_forward,
     _get_rel_pos_bias, forward_adapted_unflatten, ProjectReadout, FeatureFusionBlock_custom, the head -- is the
     reference's code."""
-    import fake_timm_beit
-    fake_timm_beit.install()
+    import fake_timm
+    fake_timm.install()
     for name in ("cv2",):
         if name not in sys.modules:
             sys.modules[name] = mock.MagicMock()
@@ -74,6 +74,16 @@ def main():
         l1, l2, l3, l4 = m.forward_transformer(m.pretrained, x3)
     out["dpt_beitb_160x224_layer4"] = l4.numpy()
     out["dpt_beitb_160x224_layer1_sample"] = l1[:, ::16, ::4, ::4].numpy()
+    # MiDaS 3.0 dpt_hybrid_384 (backbone "vitb_rn50_384": ViT-B/16 on a ResNetV2-50 stem; BASELINE config 2's network):
+    # 160 x 224 input -> 10 x 14 tokens, position embedding resized from 24 x 24
+    m = reference_dpt("vitb_rn50_384").eval()
+    m.load_state_dict(mw.fill_state_dict(m.state_dict()), strict=True)
+    x4 = mw.synthetic_image((2, 3, 160, 224), seed=14)
+    with torch.no_grad():
+        out["dpt_hybrid_160x224_out"] = m(x4).numpy()
+        l1, l2, l3, l4 = m.forward_transformer(m.pretrained, x4)
+    out["dpt_hybrid_160x224_layer2"] = l2[:, ::8].numpy()
+    out["dpt_hybrid_160x224_layer4"] = l4.numpy()
     np.savez_compressed(os.path.join(HERE, "model_cases.npz"), **out)
     for k, v in out.items():
         print(k, v.shape, float(np.abs(v).mean()))

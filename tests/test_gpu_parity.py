@@ -249,8 +249,8 @@ def test_funnel_model_branch_with_registered_predictor(gpu, oracle):
         sbs = oracle.create_stereoimages_arrays(img, d16, 2.5, 0.0, ['left-right'], 0.0, 1.0, 'polylines_sharp')[0]
         assert np.array_equal(np.asarray(got[1][2]), sbs)
         assert np.array_equal(np.asarray(got[2][2]), oracle.create_normalmap_array(d16))
-    with pytest.raises(NotImplementedError):        # dpt_large_384 (id 3): a family that is not built
-        list(core.core_generation_funnel(None, [Image.fromarray(img)], None, None, {'model_type': 3}))
+    with pytest.raises(NotImplementedError):        # midas_v21 (id 5): a family that is not built
+        list(core.core_generation_funnel(None, [Image.fromarray(img)], None, None, {'model_type': 5}))
     with pytest.raises(FileNotFoundError):          # dpt_beit_large_512 (id 1) is built, but there is no checkpoint offline
         list(core.core_generation_funnel(None, [Image.fromarray(img)], None, None, {'model_type': 1}))
     with pytest.raises(NotImplementedError):

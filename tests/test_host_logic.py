@@ -124,7 +124,7 @@ def test_model_holder_refuses_missing_models():
     with pytest.raises(FileNotFoundError):          # built family, no checkpoint, no silent random init
         mh.ensure_models(1, 'cpu', False)
     with pytest.raises(NotImplementedError):        # family that is not built
-        mh.ensure_models(3, 'cpu', False)
+        mh.ensure_models(5, 'cpu', False)
     with pytest.raises(NotImplementedError):        # Boost
         mh.ensure_models(0, 'cpu', True)
     mh.update_settings(boost_rmax=1600, no_half=True)

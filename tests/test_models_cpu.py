@@ -94,7 +94,7 @@ def dpt_beitb():
 
 def test_dpt_beit_forward_matches_reference_code(dpt_beitb, gold):
     """Against the reference's OWN dmidas code (dpt_depth.py, blocks.py, backbones/beit.py, backbones/utils.py) executed on
-    a stand-in for timm's Beit parameter containers (tests/golden/fake_timm_beit.py; timm itself is not installable here).
+    a stand-in for timm's Beit parameter containers (tests/golden/fake_timm.py; timm itself is not installable here).
     Window (10, 14) != the table's native (24, 24): the bilinear table resize and the index gather are exercised."""
     x = mw.synthetic_image((2, 3, 160, 224), seed=13)
     with torch.no_grad():
@@ -126,3 +126,29 @@ def test_midas_net_size_matches_reference_transform():
     assert midas_net_size(1920, 1080, 512, 512, "minimal") == (896, 512)
     assert midas_net_size(640, 480, 384, 384, "minimal") == (512, 384)
     assert midas_net_size(640, 480, 384, 384, "upper_bound") == (384, 288)
+
+
+def test_dpt_hybrid_forward_matches_reference_code(gold):
+    """dpt_hybrid_384 (ViT-B/16 on a ResNetV2-50 stem, BASELINE config 2's network): the reference's own dmidas code
+    (vit.py forward_flex / _resize_pos_embed / _make_vit_b_rn50_backbone, utils.py, blocks.py, dpt_depth.py) executed on a
+    stand-in for timm's VisionTransformer + ResNetV2 (tests/golden/fake_timm.py)."""
+    from dmidas.dpt_depth import DPTDepthModel
+    m = DPTDepthModel(path=None, backbone="vitb_rn50_384", non_negative=True).eval()
+    m.load_state_dict(mw.fill_state_dict(m.state_dict()), strict=True)
+    x = mw.synthetic_image((2, 3, 160, 224), seed=14)
+    with torch.no_grad():
+        y = m(x).numpy()
+        l1, l2, l3, l4 = m.pretrained(x)
+    assert _rel(l2[:, ::8].numpy(), gold["dpt_hybrid_160x224_layer2"]) < 1e-4
+    assert _rel(l4.numpy(), gold["dpt_hybrid_160x224_layer4"]) < 1e-4
+    assert _rel(y, gold["dpt_hybrid_160x224_out"]) < 1e-4
+    keys = set(m.state_dict().keys())
+    for k in ("pretrained.model.pos_embed", "pretrained.model.patch_embed.backbone.stem.conv.weight",
+              "pretrained.model.patch_embed.backbone.stem.norm.bias",
+              "pretrained.model.patch_embed.backbone.stages.2.blocks.8.conv3.weight",
+              "pretrained.model.patch_embed.backbone.stages.1.blocks.0.downsample.conv.weight",
+              "pretrained.model.patch_embed.proj.weight", "pretrained.model.blocks.11.attn.qkv.bias", "pretrained.model.norm.weight",
+              "pretrained.act_postprocess3.0.project.0.weight", "pretrained.act_postprocess3.3.weight",
+              "pretrained.act_postprocess4.4.weight", "scratch.layer1_rn.weight"):
+        assert k in keys, k
+    assert not any(k.startswith("pretrained.act_postprocess1") for k in keys)   # stem taps have no parameters (vit.py:148-150)
