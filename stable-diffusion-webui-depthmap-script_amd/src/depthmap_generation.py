@@ -3,13 +3,14 @@
 The holder keeps the reference's interface (``ensure_models``, ``get_raw_prediction``, ``offload``/``reload``/
 ``unload_models``, ``update_settings``, ``get_default_net_size``) so ``core_generation_funnel`` is wired exactly like
 the reference.  Built model families:
+    id  0           LeReS res101 (ResNeXt101-32x8d)      (lib.multi_depth_model_woauxi.RelDepthModel; reference :101-114)
     ids 1, 2        MiDaS 3.1 DPT BEiT-L/16 512 / 384   (dmidas.dpt_depth.DPTDepthModel; reference :116-146)
     ids 3, 4        MiDaS 3.0 dpt_large_384 (ViT-L/16) / dpt_hybrid_384 (ViT-B/16 + ResNetV2-50 stem)   (reference :147-170)
     ids 12, 13, 14  Depth-Anything-V2 small/base/large   (ddepth_anything_v2.DepthAnythingV2; reference :237-248)
 Checkpoints are looked up in ``model_dir`` under the reference's file names; the reference downloads them when missing
 (ensure_file_downloaded) -- this build has no network path and raises FileNotFoundError instead, unless
 ``allow_random_init`` is set (bench / tests: random weights of the same architecture).
-Other ids (LeReS 0, midas_v21 5-6, ZoeDepth 7-9, Marigold 10, Depth-Anything v1 11) and Boost are
+Other ids (midas_v21 5-6, ZoeDepth 7-9, Marigold 10, Depth-Anything v1 11) and Boost are
 not built: ``ensure_models`` raises NotImplementedError unless a predictor was registered with ``register_predictor``.
 Nothing ever falls back silently.
 """
@@ -42,7 +43,12 @@ def _build_dav2(letter):
     return make
 
 
-_BUILDERS = {1: _build_dpt_beit("beitl16_512", "dpt_beit_large_512.pt"), 2: _build_dpt_beit("beitl16_384", "dpt_beit_large_384.pt"),
+def _build_leres():
+    from lib.multi_depth_model_woauxi import RelDepthModel
+    return RelDepthModel(backbone='resnext101'), "res101.pth"
+
+
+_BUILDERS = {0: _build_leres, 1: _build_dpt_beit("beitl16_512", "dpt_beit_large_512.pt"), 2: _build_dpt_beit("beitl16_384", "dpt_beit_large_384.pt"),
              3: _build_dpt_beit("vitl16_384", "dpt_large-midas-2f21e586.pt"), 4: _build_dpt_beit("vitb_rn50_384", "dpt_hybrid-midas-501f0c75.pt"),
              12: _build_dav2('s'), 13: _build_dav2('b'), 14: _build_dav2('l')}
 
@@ -54,10 +60,14 @@ class _NetPredictor:
     def __init__(self, model_type, device, model_dir, allow_random_init, no_half):
         import torch
         net, filename = _BUILDERS[model_type]()
+        if model_type == 0 and os.path.basename(os.path.normpath(model_dir)) == "midas":
+            model_dir = os.path.join(os.path.dirname(os.path.normpath(model_dir)), "leres")    # reference :98
         path = os.path.join(model_dir, filename)
         if os.path.exists(path):
             sd = torch.load(path, map_location='cpu')
-            if "optimizer" in sd:
+            if model_type == 0:                              # reference :108-112: checkpoint['depth_model'], "module." stripped
+                sd = {(k[len("module."):] if k.startswith("module.") else k): v for k, v in sd['depth_model'].items()}
+            elif "optimizer" in sd:
                 sd = sd["model"]
             missing, unexpected = net.load_state_dict(sd, strict=False)
             # timm's index buffers / k_bias may or may not be stored; anything else missing is an error
@@ -70,7 +80,7 @@ class _NetPredictor:
         self.model_type = model_type
         self.net = net.eval().to(device)
         dev = torch.device(device)
-        if dev.type == 'cuda' and not no_half:              # reference :268-275
+        if dev.type == 'cuda' and not no_half and model_type != 0:   # reference :268-275 (LeReS stays float32)
             self.net = self.net.half()
 
     @property
@@ -82,6 +92,8 @@ class _NetPredictor:
         import torch
         img = torch.from_numpy(np.array(pil_image.convert("RGB"), dtype=np.uint8, order="C")).to(next(self.net.parameters()).device)
         batch = img.unsqueeze(0)
+        if self.model_type == 0:
+            return self.net.infer_batch(batch, int(net_width), int(net_height))[0]   # estimateleres (:406-421)
         if self.is_dav2:
             return self.net.infer_batch(batch, int(net_width))[0]          # reference passes net_width as input_size (:553)
         mode = "minimal"                                                    # resize_mode of ids 1-4 (:127, :141, :155, :168)
@@ -99,7 +111,7 @@ class ModelHolder:
         self.normalization = None
         self.tiling_mode = False
         self._predictors = {}
-        self.model_dir = "./models/midas"        # reference: src/depthmap_generation.py:95-99 (models/midas, models/leres, ...)
+        self.model_dir = "./models/midas"        # reference: src/depthmap_generation.py:95-99 (LeReS lives in ./models/leres)
         self.allow_random_init = False
         self.no_half = False
 

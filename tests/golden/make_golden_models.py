@@ -84,6 +84,17 @@ def main():
         l1, l2, l3, l4 = m.forward_transformer(m.pretrained, x4)
     out["dpt_hybrid_160x224_layer2"] = l2[:, ::8].numpy()
     out["dpt_hybrid_160x224_layer4"] = l4.numpy()
+    # LeReS res101 (model id 0, Boost's base estimator): the reference's lib/ is torch-only and imports as is
+    sys.path.insert(0, REF)
+    from lib.multi_depth_model_woauxi import RelDepthModel
+    sys.path.pop(0)
+    m = RelDepthModel(backbone='resnext101').eval()
+    m.load_state_dict(mw.fill_state_dict(m.state_dict()), strict=True)
+    x5 = mw.synthetic_image((2, 3, 96, 160), seed=15)
+    with torch.no_grad():
+        out["leres_96x160_out"] = m.depth_model(x5).numpy()
+        feats = m.depth_model.encoder_modules(x5)
+    out["leres_96x160_feat3"] = feats[3].numpy()
     np.savez_compressed(os.path.join(HERE, "model_cases.npz"), **out)
     for k, v in out.items():
         print(k, v.shape, float(np.abs(v).mean()))

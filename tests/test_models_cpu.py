@@ -152,3 +152,24 @@ def test_dpt_hybrid_forward_matches_reference_code(gold):
               "pretrained.act_postprocess4.4.weight", "scratch.layer1_rn.weight"):
         assert k in keys, k
     assert not any(k.startswith("pretrained.act_postprocess1") for k in keys)   # stem taps have no parameters (vit.py:148-150)
+
+
+def test_leres_forward_matches_reference_modules(gold):
+    """LeReS res101 (reference lib/: importable as is -> fully pinned).  BatchNorm folded into the convolutions here."""
+    from lib.multi_depth_model_woauxi import RelDepthModel
+    m = RelDepthModel('resnext101').eval()
+    m.load_state_dict(mw.fill_state_dict(m.state_dict()), strict=True)
+    x = mw.synthetic_image((2, 3, 96, 160), seed=15)
+    with torch.no_grad():
+        y = m.depth_model(x).numpy()
+        f3 = m.depth_model.encoder_modules(x)[3].numpy()
+    assert _rel(f3, gold["leres_96x160_feat3"]) < 1e-4
+    assert _rel(y, gold["leres_96x160_out"]) < 1e-4
+    keys = set(m.state_dict().keys())
+    for k in ("depth_model.encoder_modules.encoder.conv1.weight", "depth_model.encoder_modules.encoder.bn1.running_var",
+              "depth_model.encoder_modules.encoder.layer3.22.conv2.weight", "depth_model.encoder_modules.encoder.layer4.0.downsample.1.weight",
+              "depth_model.decoder_modules.conv.conv1.weight", "depth_model.decoder_modules.conv.conv_branch.2.running_mean",
+              "depth_model.decoder_modules.conv1.bias", "depth_model.decoder_modules.ffm2.ftb1.conv_branch.4.weight",
+              "depth_model.decoder_modules.ffm0.ftb2.conv1.weight", "depth_model.decoder_modules.outconv.adapt_conv.0.weight",
+              "depth_model.decoder_modules.outconv.adapt_conv.1.num_batches_tracked", "depth_model.decoder_modules.outconv.adapt_conv.3.bias"):
+        assert k in keys, k
