@@ -1,16 +1,14 @@
 export TMPDIR=/tmp
-mkdir -p gpurun_out/r1m
-for m in dav2_vitl dpt_beit_large_512; do python bench.py --model $m --steps 5 --warmup 2 --no-cpu-baseline 2>&1 | tail -1 | python -c "
-import sys,json; j=json.loads(sys.stdin.read()); r=j['roofline']; s=j['roofline_stereo']
-print(j['config']['model'], '%.1f pairs/s  %.1f ms/step | attn %.3f ms x%d = %.1f TF/s (frac %.3f) | stereo %.3f ms | encoder %.1f TFLOP/step' % (j['value'], j['ms_per_step'], r['avg_kernel_ms'], r['launches_per_step'], r['achieved'], r['frac'], s['avg_kernel_ms'], j['encoder_tflops_per_step']))"; done
-m=dav2_vitl
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/r1m/$m -o t -- python bench.py --model $m --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out/r1m/$m.log 2>&1
-python - "$m" <<'PY'
-import csv, sys
-m = sys.argv[1]
-rows = list(csv.DictReader(open(f'gpurun_out/r1m/{m}/t_kernel_stats.csv')))
-tot = sum(float(r['TotalDurationNs']) for r in rows)
-print(m, 'total kernel time %.1f ms' % (tot/1e6))
-for r in rows[:26]:
-    print('%6.2f%% %9.3f ms total %5d calls %9.1f us avg  %s' % (float(r['Percentage']), float(r['TotalDurationNs'])/1e6, int(r['Calls']), float(r['AverageNs'])/1e3, r['Name'][:100]))
-PY
+rm -rf gpurun_out/r1; mkdir -p gpurun_out/r1
+python __graft_entry__.py smoke 2>&1 | tail -2
+python -m pytest tests -m gpu -x -q 2>&1 | tail -3 | tee gpurun_out/r1/pytest_gpu.log
+python bench.py > gpurun_out/r1/bench_n1.json 2> gpurun_out/r1/bench_n1.err; python -c "
+import json; j=json.load(open('gpurun_out/r1/bench_n1.json')); print(j['value'], j['ms_per_step'], j['roofline']['achieved'], j['roofline']['frac'], j['roofline_stereo']['avg_kernel_ms'], j['cpu_baseline'])"
+python bench.py --model dpt_hybrid_384 --no-cpu-baseline > gpurun_out/r1/bench_n1_dpt_hybrid_384.json 2>/dev/null; python -c "
+import json; j=json.load(open('gpurun_out/r1/bench_n1_dpt_hybrid_384.json')); print('hybrid', j['value'], j['ms_per_step'], j['roofline']['achieved'])"
+python bench.py --model dav2_vitl --no-cpu-baseline > gpurun_out/r1/bench_n1_dav2_vitl.json 2>/dev/null; python -c "
+import json; j=json.load(open('gpurun_out/r1/bench_n1_dav2_vitl.json')); print('dav2', j['value'], j['ms_per_step'], j['roofline']['achieved'])"
+python bench.py --model none --no-cpu-baseline --steps 20 --warmup 3 > gpurun_out/r1/bench_n1_stereo_only.json 2>/dev/null; python -c "
+import json; j=json.load(open('gpurun_out/r1/bench_n1_stereo_only.json')); print('stereo only', j['value'], j['ms_per_step'], j['roofline']['achieved'])"
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/r1/trace -o t -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline > gpurun_out/r1/trace.log 2>&1
+head -12 gpurun_out/r1/trace/t_kernel_stats.csv | cut -c1-150

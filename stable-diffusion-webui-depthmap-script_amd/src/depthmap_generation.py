@@ -60,8 +60,9 @@ class _NetPredictor:
     def __init__(self, model_type, device, model_dir, allow_random_init, no_half):
         import torch
         net, filename = _BUILDERS[model_type]()
-        if model_type == 0 and os.path.basename(os.path.normpath(model_dir)) == "midas":
-            model_dir = os.path.join(os.path.dirname(os.path.normpath(model_dir)), "leres")    # reference :98
+        if model_dir is None:                                # reference :83-92
+            model_dir = {0: "./models/leres", 11: "./models/depth_anything", 12: "./models/depth_anything_v2",
+                         13: "./models/depth_anything_v2", 14: "./models/depth_anything_v2"}.get(model_type, "./models/midas")
         path = os.path.join(model_dir, filename)
         if os.path.exists(path):
             sd = torch.load(path, map_location='cpu')
@@ -111,7 +112,7 @@ class ModelHolder:
         self.normalization = None
         self.tiling_mode = False
         self._predictors = {}
-        self.model_dir = "./models/midas"        # reference: src/depthmap_generation.py:95-99 (LeReS lives in ./models/leres)
+        self.model_dir = None                    # None: the reference's per-family directories (:83-92); set to override
         self.allow_random_init = False
         self.no_half = False
 
