@@ -95,6 +95,18 @@ def main():
         out["leres_96x160_out"] = m.depth_model(x5).numpy()
         feats = m.depth_model.encoder_modules(x5)
     out["leres_96x160_feat3"] = feats[3].numpy()
+    # Boost merge network: pix2pix U-Net 'unet_1024', norm none (reference pix2pix/models/networks.py imports as is)
+    sys.path.insert(0, REF)
+    from pix2pix.models import networks as ref_networks
+    sys.path.pop(0)
+    g = ref_networks.UnetGenerator(2, 1, 10, 64, norm_layer=ref_networks.get_norm_layer('none'), use_dropout=False).eval()
+    sd = mw.fill_state_dict(g.state_dict())
+    g.load_state_dict(sd, strict=True)
+    x6 = mw.synthetic_image((1, 2, 1024, 1024), seed=16).clamp(-1, 1)
+    with torch.no_grad():
+        y6 = g(x6.clone())
+    out["unet1024_out_sample"] = y6[0, 0, ::8, ::8].numpy()
+    out["unet1024_out_mean_abs"] = np.array([float(y6.abs().mean()), float(y6.mean()), float(y6.std())])
     np.savez_compressed(os.path.join(HERE, "model_cases.npz"), **out)
     for k, v in out.items():
         print(k, v.shape, float(np.abs(v).mean()))

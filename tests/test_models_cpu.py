@@ -173,3 +173,17 @@ def test_leres_forward_matches_reference_modules(gold):
               "depth_model.decoder_modules.ffm0.ftb2.conv1.weight", "depth_model.decoder_modules.outconv.adapt_conv.0.weight",
               "depth_model.decoder_modules.outconv.adapt_conv.1.num_batches_tracked", "depth_model.decoder_modules.outconv.adapt_conv.3.bias"):
         assert k in keys, k
+
+
+def test_pix2pix_unet1024_matches_reference_module(gold):
+    """Boost's merge network (reference pix2pix/models/networks.py UnetGenerator, imported as is -> fully pinned),
+    including the in-place LeakyReLU quirk that makes the skip tensors the ACTIVATED block inputs."""
+    from pix2pix.models.networks import UnetGenerator
+    g = UnetGenerator(2, 1, 10, 64).eval()
+    g.load_state_dict(mw.fill_state_dict(g.state_dict()), strict=True)
+    x = mw.synthetic_image((1, 2, 1024, 1024), seed=16).clamp(-1, 1)
+    with torch.no_grad():
+        y = g(x)
+    assert _rel(y[0, 0, ::8, ::8].numpy(), gold["unet1024_out_sample"]) < 1e-4
+    st = gold["unet1024_out_mean_abs"]
+    assert abs(float(y.abs().mean()) - st[0]) < 1e-4 * max(1.0, abs(st[0]))
