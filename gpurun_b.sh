@@ -1,14 +1,18 @@
-export TMPDIR=/tmp
-rm -rf gpurun_out/r1; mkdir -p gpurun_out/r1
-python __graft_entry__.py smoke 2>&1 | tail -2
-python -m pytest tests -m gpu -x -q 2>&1 | tail -3 | tee gpurun_out/r1/pytest_gpu.log
-python bench.py > gpurun_out/r1/bench_n1.json 2> gpurun_out/r1/bench_n1.err; python -c "
-import json; j=json.load(open('gpurun_out/r1/bench_n1.json')); print(j['value'], j['ms_per_step'], j['roofline']['achieved'], j['roofline']['frac'], j['roofline_stereo']['avg_kernel_ms'], j['cpu_baseline'])"
-python bench.py --model dpt_hybrid_384 --no-cpu-baseline > gpurun_out/r1/bench_n1_dpt_hybrid_384.json 2>/dev/null; python -c "
-import json; j=json.load(open('gpurun_out/r1/bench_n1_dpt_hybrid_384.json')); print('hybrid', j['value'], j['ms_per_step'], j['roofline']['achieved'])"
-python bench.py --model dav2_vitl --no-cpu-baseline > gpurun_out/r1/bench_n1_dav2_vitl.json 2>/dev/null; python -c "
-import json; j=json.load(open('gpurun_out/r1/bench_n1_dav2_vitl.json')); print('dav2', j['value'], j['ms_per_step'], j['roofline']['achieved'])"
-python bench.py --model none --no-cpu-baseline --steps 20 --warmup 3 > gpurun_out/r1/bench_n1_stereo_only.json 2>/dev/null; python -c "
-import json; j=json.load(open('gpurun_out/r1/bench_n1_stereo_only.json')); print('stereo only', j['value'], j['ms_per_step'], j['roofline']['achieved'])"
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/r1/trace -o t -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline > gpurun_out/r1/trace.log 2>&1
-head -12 gpurun_out/r1/trace/t_kernel_stats.csv | cut -c1-150
+python -m pytest tests/test_gpu_models.py -x -q -k "boost" 2>&1 | tail -15
+python - <<'PY'
+import sys, time, torch, numpy as np
+sys.path.insert(0, 'stable-diffusion-webui-depthmap-script_amd')
+from src import boost
+from lib.multi_depth_model_woauxi import RelDepthModel
+from pix2pix.models.pix2pix4depth_model import Pix2Pix4DepthModel
+torch.manual_seed(0)
+net = RelDepthModel('resnext101').eval().cuda(); p2p = Pix2Pix4DepthModel().eval().cuda()
+rng = np.random.default_rng(1)
+yy, xx = np.mgrid[0:2160, 0:3840]
+img = (127 + 60*np.sin(xx/37.0)[...,None]*np.cos(yy/23.0)[...,None] + rng.normal(0,25,(2160,3840,3))).clip(0,255).astype(np.uint8)
+t = torch.from_numpy(img).cuda()
+for i in range(2):
+    st = {}; torch.cuda.synchronize(); t0 = time.perf_counter()
+    out = boost.estimateboost(t, net, 0, p2p, 1600, stats=st); torch.cuda.synchronize()
+    print('4K boost run', i, '%.2f s' % (time.perf_counter()-t0), st)
+PY

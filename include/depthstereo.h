@@ -175,6 +175,19 @@ int ds_residual_layernorm(ds_ctx *ctx, const void *x, const void *branch, const 
                           const void *ln_bias, void *x_out, void *h_out, int64_t rows, int channels, float eps, int dtype,
                           void *stream);
 
+/*
+ * ds_boost_blend -- the patch-merge step of Boost, all patches in one launch; replaces, per patch, np.polyval (:916),
+ * cv2.resize INTER_CUBIC of the merged patch (:918), cv2.resize INTER_LINEAR of the Gaussian mask (:930) and the blend
+ * `dst[rect] = dst[rect]*(1-mask) + merged*mask` (:936) of src/depthmap_generation.py:estimateboost.
+ *   dst            float32 [height, width] running estimate, updated in place (row stride in ELEMENTS)
+ *   patches        n_patches records {int32 x0, y0, w, h; float64 p0, p1} (32 bytes each, device memory), in BLEND ORDER
+ *   preds          float32 [n_patches, pred_size, pred_size]: (fake_B + 1)/2 of the merge network per patch
+ *   mask_template  float32 [mask_size, mask_size]: generatemask((3000, 3000)) (:944-953)
+ */
+int ds_boost_blend(ds_ctx *ctx, float *dst, int64_t dst_row_stride, int height, int width, const void *patches,
+                   int n_patches, const float *preds, int pred_size, const float *mask_template, int mask_size,
+                   void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -303,3 +303,71 @@ def depth_normalize01(raw_prediction, invert=False):
 
 def num_threads():
     return int(lib().orc_num_threads())
+
+
+# ---- Boost patch blend (src/depthmap_generation.py:915-937) --------------------------------------------------------------------
+def _cv_cubic_resize(src, out_hw):
+    """cv2.resize(src, (w, h), interpolation=cv2.INTER_CUBIC) restated from OpenCV's documentation: half-pixel centres,
+    4 taps with a = -0.75, replicated border, no antialiasing.  float64.  PARITY UNPINNED (cv2 is not installable here)."""
+    src = np.asarray(src, dtype=np.float64)
+    sh, sw = src.shape
+    oh, ow = out_hw
+
+    def taps(n_out, n_in):
+        f = (np.arange(n_out) + 0.5) * (n_in / n_out) - 0.5
+        i = np.floor(f).astype(np.int64)
+        t = f - i
+        A = -0.75
+        w = np.empty((n_out, 4))
+        w[:, 0] = ((A * (t + 1) - 5 * A) * (t + 1) + 8 * A) * (t + 1) - 4 * A
+        w[:, 1] = ((A + 2) * t - (A + 3)) * t * t + 1
+        w[:, 2] = ((A + 2) * (1 - t) - (A + 3)) * (1 - t) * (1 - t) + 1
+        w[:, 3] = 1.0 - w[:, 0] - w[:, 1] - w[:, 2]
+        idx = np.clip(i[:, None] - 1 + np.arange(4)[None, :], 0, n_in - 1)
+        return idx, w
+
+    iy, wy = taps(oh, sh)
+    ix, wx = taps(ow, sw)
+    rows = np.zeros((sh, ow))
+    for k in range(4):
+        rows += src[:, ix[:, k]] * wx[:, k][None, :]
+    out = np.zeros((oh, ow))
+    for k in range(4):
+        out += rows[iy[:, k], :] * wy[:, k][:, None]
+    return out
+
+
+def _cv_linear_resize(src, out_hw):
+    """cv2.resize INTER_LINEAR (half-pixel centres, edge clamp), float64 accumulation, float32 result.  UNPINNED."""
+    src = np.asarray(src, dtype=np.float64)
+    sh, sw = src.shape
+    oh, ow = out_hw
+
+    def taps(n_out, n_in):
+        f = (np.arange(n_out) + 0.5) * (n_in / n_out) - 0.5
+        i = np.floor(f).astype(np.int64)
+        t = f - i
+        t = np.where(i < 0, 0.0, t)
+        i = np.where(i < 0, 0, i)
+        t = np.where(i >= n_in - 1, 1.0, t)
+        i = np.where(i >= n_in - 1, n_in - 2, i)
+        return i, t
+
+    iy, ty = taps(oh, sh)
+    ix, tx = taps(ow, sw)
+    top = (1 - tx)[None, :] * src[iy][:, ix] + tx[None, :] * src[iy][:, ix + 1]
+    bot = (1 - tx)[None, :] * src[iy + 1][:, ix] + tx[None, :] * src[iy + 1][:, ix + 1]
+    return ((1 - ty)[:, None] * top + ty[:, None] * bot).astype(np.float32)
+
+
+def boost_blend(dst, rects, coefs, preds, mask_template):
+    """The per-patch loop of estimateboost (:915-937): polyval, cubic resize to the rectangle, bilinear resize of the mask
+    template, `dst[rect] = dst[rect] * (1 - mask) + merged * mask` with numpy's promotion (float32 * float32, float64 *
+    float32, float64 sum stored into the float32 image).  Returns a new float32 array."""
+    out = np.array(dst, dtype=np.float32, copy=True)
+    for (x0, y0, w, h), (p0, p1), pred in zip(rects, coefs, preds):
+        merged = _cv_cubic_resize(pred, (h, w)) * p0 + p1      # affine map and cubic resize commute (taps sum to one)
+        mask = _cv_linear_resize(mask_template, (h, w))
+        reg = out[y0:y0 + h, x0:x0 + w]
+        out[y0:y0 + h, x0:x0 + w] = np.multiply(reg, np.float32(1) - mask) + np.multiply(merged, mask)
+    return out

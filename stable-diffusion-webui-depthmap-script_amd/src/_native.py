@@ -20,7 +20,7 @@ FILL_IDS = {"none": 0, "naive": 1, "naive_interpolating": 2, "polylines_soft": 3
 EXPORTS = [
     "ds_version", "ds_last_error", "ds_ctx_create", "ds_ctx_destroy", "ds_stereo_warp", "ds_depth_minmax",
     "ds_stereo_last_exact_rows", "ds_copy_view", "ds_overlap_red_cyan", "ds_normalmap", "ds_depth_to_u16",
-    "ds_convert_to_i16", "ds_profile_enable", "ds_profile_last_ms", "ds_stereo_last_stats", "ds_attention_fwd", "ds_residual_layernorm",
+    "ds_convert_to_i16", "ds_profile_enable", "ds_profile_last_ms", "ds_stereo_last_stats", "ds_attention_fwd", "ds_residual_layernorm", "ds_boost_blend",
 ]
 
 
@@ -63,6 +63,7 @@ def lib():
             L.ds_stereo_last_stats.argtypes = [vp, ctypes.POINTER(i64), vp]
             L.ds_attention_fwd.argtypes = [vp, vp, vp, vp, vp, ci, ci, ci, ci, ctypes.c_float, ci, vp]
             L.ds_residual_layernorm.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, i64, ci, ctypes.c_float, ci, vp]
+            L.ds_boost_blend.argtypes = [vp, vp, i64, ci, ci, vp, ci, vp, ci, vp, ci, vp]
             L.ds_profile_enable.argtypes = [vp, ci]
             L.ds_profile_last_ms.argtypes = [vp, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float)]
             for name in EXPORTS:          # fail at load time, not at first use, if a symbol is missing
@@ -281,3 +282,26 @@ def residual_layernorm(x, branch, gamma, ln_weight, ln_bias, eps=1e-6):
                                        w.data_ptr(), b.data_ptr(), None if branch is None else x_out.data_ptr(), h.data_ptr(),
                                        rows, c, float(eps), dt, _stream(x)))
     return x_out, h
+
+
+def boost_blend(dst, rects, coefs, preds, mask_template):
+    """Blend all Boost patches into dst (float32 [H, W] CUDA, in place), in list order (include/depthstereo.h:
+    ds_boost_blend).  rects: list of (x0, y0, w, h); coefs: list of (p0, p1); preds float32 [P, S, S]; mask_template
+    float32 [M, M]."""
+    torch = require_gpu()
+    assert dst.is_cuda and dst.dtype == torch.float32 and dst.dim() == 2 and dst.stride(1) == 1
+    n = len(rects)
+    if n == 0:
+        return dst
+    preds = preds.contiguous()
+    mask_template = mask_template.contiguous()
+    assert preds.dtype == torch.float32 and preds.shape[0] == n and preds.shape[1] == preds.shape[2]
+    assert mask_template.dtype == torch.float32 and mask_template.shape[0] == mask_template.shape[1]
+    rec = np.zeros(n, dtype=[('x0', '<i4'), ('y0', '<i4'), ('w', '<i4'), ('h', '<i4'), ('p0', '<f8'), ('p1', '<f8')])
+    for i, (r, c) in enumerate(zip(rects, coefs)):
+        rec[i] = (int(r[0]), int(r[1]), int(r[2]), int(r[3]), float(c[0]), float(c[1]))
+    buf = torch.from_numpy(rec.view(np.uint8).copy()).to(dst.device)
+    _check(lib().ds_boost_blend(ctx_for(_dev_index(dst)), dst.data_ptr(), dst.stride(0), dst.shape[0], dst.shape[1],
+                                buf.data_ptr(), n, preds.data_ptr(), preds.shape[1], mask_template.data_ptr(),
+                                mask_template.shape[0], _stream(dst)))
+    return dst

@@ -27,7 +27,7 @@ SCRIPT_NAME = "DepthMap (MI355X-native hot path)"
 
 model_holder = ModelHolder()
 
-_OUT_OF_SCOPE = (go.GEN_REMBG, go.GEN_HEATMAP, go.GEN_SIMPLE_MESH, go.GEN_INPAINTED_MESH, go.BOOST)
+_OUT_OF_SCOPE = (go.GEN_REMBG, go.GEN_HEATMAP, go.GEN_SIMPLE_MESH, go.GEN_INPAINTED_MESH)
 
 
 def convert_to_i16(arr):

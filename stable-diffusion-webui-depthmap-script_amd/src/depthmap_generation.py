@@ -10,8 +10,9 @@ the reference.  Built model families:
 Checkpoints are looked up in ``model_dir`` under the reference's file names; the reference downloads them when missing
 (ensure_file_downloaded) -- this build has no network path and raises FileNotFoundError instead, unless
 ``allow_random_init`` is set (bench / tests: random weights of the same architecture).
-Other ids (midas_v21 5-6, ZoeDepth 7-9, Marigold 10, Depth-Anything v1 11) and Boost are
+Other ids (midas_v21 5-6, ZoeDepth 7-9, Marigold 10, Depth-Anything v1 11) are
 not built: ``ensure_models`` raises NotImplementedError unless a predictor was registered with ``register_predictor``.
+Boost (``boost=True``; src/boost.py + the pix2pix merge network + ds_boost_blend) is built for base models 0 and 12-14.
 Nothing ever falls back silently.
 """
 import gc
@@ -51,6 +52,18 @@ def _build_leres():
 _BUILDERS = {0: _build_leres, 1: _build_dpt_beit("beitl16_512", "dpt_beit_large_512.pt"), 2: _build_dpt_beit("beitl16_384", "dpt_beit_large_384.pt"),
              3: _build_dpt_beit("vitl16_384", "dpt_large-midas-2f21e586.pt"), 4: _build_dpt_beit("vitb_rn50_384", "dpt_hybrid-midas-501f0c75.pt"),
              12: _build_dav2('s'), 13: _build_dav2('b'), 14: _build_dav2('l')}
+
+
+def _load_pix2pix(device, allow_random_init):
+    """reference :287-299: './models/pix2pix/latest_net_G.pth' (downloaded there when missing)."""
+    from pix2pix.models.pix2pix4depth_model import Pix2Pix4DepthModel
+    m = Pix2Pix4DepthModel()
+    path = os.path.join(m.save_dir, 'latest_net_G.pth')
+    if os.path.exists(path):
+        m.load_networks('latest')
+    elif not allow_random_init:
+        raise FileNotFoundError(f"{path} not found (the reference would download it; this build has no network path)")
+    return m.eval().to(device)
 
 
 class _NetPredictor:
@@ -128,12 +141,20 @@ class ModelHolder:
     def ensure_models(self, model_type, device, boost: bool, tiling_mode: bool = False):
         """reference :60-74."""
         if boost:
-            raise NotImplementedError("Boost (res101 + pix2pix merge) is not built yet")
+            if model_type not in (0, 12, 13, 14):
+                raise NotImplementedError(f"Boost with depth model id {model_type!r} is not built (built: 0 LeReS, 12-14 "
+                                          "Depth-Anything-V2)")
+            if self.pix2pix_model is None:
+                self.pix2pix_model = _load_pix2pix(device, self.allow_random_init)
+        else:
+            self.pix2pix_model = None
         if model_type in self._predictors:
             self.depth_model = self._predictors[model_type]
         elif model_type in _BUILDERS:
             if self.depth_model is None or self.depth_model_type != model_type or not isinstance(self.depth_model, _NetPredictor):
-                self.depth_model = _NetPredictor(model_type, device, self.model_dir, self.allow_random_init, self.no_half)
+                # Boost never runs a MiDaS/LeReS base network in half precision (reference :271); DA-V2 stays half (:273-275)
+                self.depth_model = _NetPredictor(model_type, device, self.model_dir, self.allow_random_init,
+                                                 self.no_half or (boost and model_type not in (12, 13, 14)))
         else:
             raise NotImplementedError(
                 f"depth model {model_type!r} is not available in this build (built: ids {sorted(_BUILDERS)}); register a "
@@ -150,7 +171,15 @@ class ModelHolder:
 
     def get_raw_prediction(self, input, net_width, net_height):
         """reference :375-403 -> (prediction [H,W], invert?)."""
-        raw = self.depth_model(input, net_width, net_height, self.device)
+        if self.pix2pix_model is not None:                   # reference :399-401: net size is ignored with Boost
+            import numpy as np
+            import torch
+            from . import boost
+            img = torch.from_numpy(np.array(input.convert("RGB"), dtype=np.uint8, order="C")).to(self.device)
+            raw = boost.estimateboost(img, self.depth_model.net, self.depth_model_type, self.pix2pix_model,
+                                      int(getattr(self, "boost_rmax", 1600)))
+        else:
+            raw = self.depth_model(input, net_width, net_height, self.device)
         return raw, (self.depth_model_type in INVERTED_MODEL_IDS)
 
     def offload(self):

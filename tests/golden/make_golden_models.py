@@ -46,6 +46,36 @@ def reference_dpt(backbone):
     return DPTDepthModel(path=None, backbone=backbone, non_negative=True)
 
 
+def make_boost_selection_cases():
+    """Boost's patch selection (pure Python on an integral image) run with the REFERENCE's own functions."""
+    import json
+    for name in ("cv2", "skimage", "skimage.measure", "torchvision", "torchvision.transforms", "diffusers", "transformers",
+                 "dmarigold", "dmarigold.marigold", "dzoedepth", "dzoedepth.models", "dzoedepth.models.builder",
+                 "dzoedepth.utils", "dzoedepth.utils.config", "modules", "modules.shared", "modules.devices"):
+        if name not in sys.modules:
+            sys.modules[name] = mock.MagicMock()
+    import fake_timm
+    fake_timm.install()
+    sys.path.insert(0, REF)
+    import src.depthmap_generation as ref_dg
+    sys.path.pop(0)
+    H, W = 700, 1000
+    grad, integ = mw.boost_integral_image(5, H, W)
+    out = {"integral_checksum": np.array([float(integ[-1, -1]), float(integ[350, 500])])}
+    for name, (blsize, factor) in {"case_a": (112, 1.0), "case_b": (96, 0.45)}.items():
+        stride = int(round(blsize * 0.75))
+        img_stub = np.zeros((H, W, 3))
+        grid = ref_dg.applyGridpatch(blsize, stride, img_stub, [0, 0, 0, 0])
+        gf = float(grad.sum() / grad.size)
+        sel = ref_dg.adaptiveselection(integ, {k: {"rect": list(v["rect"]), "size": v["size"]} for k, v in grid.items()}, gf, factor)
+        meta = {"blsize": blsize, "stride": stride, "shape": [H, W, 3], "gf": gf, "factor": factor,
+                "grid_rects": [[int(x) for x in grid[str(i)]["rect"]] for i in range(len(grid))],
+                "selected_rects": [[int(x) for x in sel[str(i)]["rect"]] for i in range(len(sel))]}
+        out[name + "_meta"] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
+        print(name, len(grid), "grid patches ->", len(sel), "selected")
+    np.savez_compressed(os.path.join(HERE, "boost_selection_cases.npz"), **out)
+
+
 def main():
     out = {}
     torch.manual_seed(0)
@@ -108,6 +138,7 @@ def main():
     out["unet1024_out_sample"] = y6[0, 0, ::8, ::8].numpy()
     out["unet1024_out_mean_abs"] = np.array([float(y6.abs().mean()), float(y6.mean()), float(y6.std())])
     np.savez_compressed(os.path.join(HERE, "model_cases.npz"), **out)
+    make_boost_selection_cases()
     for k, v in out.items():
         print(k, v.shape, float(np.abs(v).mean()))
 

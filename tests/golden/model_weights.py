@@ -51,3 +51,14 @@ def fill_state_dict_beit(sd):
         if k.endswith("relative_position_bias_table"):
             out[k] = out[k] * 25.0
     return out
+
+
+def boost_integral_image(seed=5, H=700, W=1000):
+    """Deterministic gradient field + its integral image (cv2.integral layout) for the Boost patch-selection cases."""
+    import numpy as np
+    rng = np.random.default_rng(seed)
+    grad = rng.random((H, W)) * (rng.random((H, W)) > 0.6)
+    grad[200:420, 300:700] += 2.0                         # a dense-gradient region that the selection should grow around
+    integ = np.zeros((H + 1, W + 1))
+    integ[1:, 1:] = grad.cumsum(0).cumsum(1)
+    return grad, integ

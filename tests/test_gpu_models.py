@@ -147,3 +147,48 @@ def test_residual_layernorm_kernel(gpu, dtype):
         _, h0 = _native.residual_layernorm(x, None, None, w, b, 1e-6)
         h0r = torch.nn.functional.layer_norm(x.float(), (c,), w.float(), b.float(), 1e-6)
         assert (h0.float() - h0r).abs().max().item() < tol * (1 + h0r.abs().max().item())
+
+
+def test_boost_blend_kernel_vs_restatement(gpu, oracle):
+    """ds_boost_blend (all patches, one launch) against the sequential numpy restatement of estimateboost's per-patch loop
+    (oracle.boost_blend): overlapping rectangles in a fixed order, non-square rectangles, rectangles at the border."""
+    from src import _native
+    rng = np.random.default_rng(3)
+    H, W, S, M = 150, 220, 64, 97
+    dst = rng.random((H, W), dtype=np.float32)
+    rects = [(10, 5, 120, 120), (60, 20, 140, 100), (0, 0, 50, 70), (100, 90, 120, 60), (30, 40, 90, 90), (199, 129, 21, 21)]
+    coefs = [(float(rng.uniform(0.5, 1.5)), float(rng.uniform(-0.2, 0.2))) for _ in rects]
+    preds = rng.random((len(rects), S, S), dtype=np.float32)
+    yy, xx = np.mgrid[0:M, 0:M]
+    mask = np.exp(-(((xx - M / 2) ** 2 + (yy - M / 2) ** 2) / (2 * (M / 5) ** 2))).astype(np.float32)
+    want = oracle.boost_blend(dst, rects, coefs, preds, mask)
+    d = torch.from_numpy(dst.copy()).cuda()
+    _native.boost_blend(d, rects, coefs, torch.from_numpy(preds).cuda(), torch.from_numpy(mask).cuda())
+    got = d.cpu().numpy()
+    assert np.abs(got - want).max() < 2e-6, float(np.abs(got - want).max())
+    untouched = np.ones((H, W), bool)
+    for (x0, y0, w, h) in rects:
+        untouched[y0:y0 + h, x0:x0 + w] = False
+    assert np.array_equal(got[untouched], dst[untouched])
+    # order matters: reversing the list changes the result where rectangles overlap
+    d2 = torch.from_numpy(dst.copy()).cuda()
+    _native.boost_blend(d2, rects[::-1], coefs[::-1], torch.from_numpy(preds[::-1].copy()).cuda(), torch.from_numpy(mask).cuda())
+    assert np.abs(d2.cpu().numpy() - got).max() > 1e-3
+
+
+def test_boost_pipeline_runs_end_to_end(gpu):
+    """estimateboost with LeReS + the pix2pix merge network (random init: no checkpoints offline) on a 1200x1600 image:
+    resolution search, double estimation, patch selection, batched patch estimation, one-launch blend."""
+    from src import boost
+    from lib.multi_depth_model_woauxi import RelDepthModel
+    from pix2pix.models.pix2pix4depth_model import Pix2Pix4DepthModel
+    torch.manual_seed(0)
+    net = RelDepthModel('resnext101').eval().cuda()
+    p2p = Pix2Pix4DepthModel().eval().cuda()
+    rng = np.random.default_rng(1)
+    yy, xx = np.mgrid[0:1200, 0:1600]
+    img = (127 + 60 * np.sin(xx / 37.0)[..., None] * np.cos(yy / 23.0)[..., None] + rng.normal(0, 25, (1200, 1600, 3))).clip(0, 255).astype(np.uint8)
+    stats = {}
+    out = boost.estimateboost(torch.from_numpy(img).cuda(), net, 0, p2p, whole_size_threshold=1600, stats=stats)
+    assert tuple(out.shape) == (1200, 1600) and out.dtype == torch.float32 and torch.isfinite(out).all()
+    assert stats["patches"] >= 1 and 448 <= stats["whole_image_optimal_size"] <= 1600, stats

@@ -125,7 +125,9 @@ def test_model_holder_refuses_missing_models():
         mh.ensure_models(1, 'cpu', False)
     with pytest.raises(NotImplementedError):        # family that is not built
         mh.ensure_models(5, 'cpu', False)
-    with pytest.raises(NotImplementedError):        # Boost
+    with pytest.raises(NotImplementedError):        # Boost on a base model it is not built for
+        mh.ensure_models(1, 'cpu', True)
+    with pytest.raises(FileNotFoundError):          # Boost on LeReS is built, but the merge network's checkpoint is absent
         mh.ensure_models(0, 'cpu', True)
     mh.update_settings(boost_rmax=1600, no_half=True)
     assert mh.boost_rmax == 1600 and mh.no_half is True

@@ -187,3 +187,20 @@ def test_pix2pix_unet1024_matches_reference_module(gold):
     assert _rel(y[0, 0, ::8, ::8].numpy(), gold["unet1024_out_sample"]) < 1e-4
     st = gold["unet1024_out_mean_abs"]
     assert abs(float(y.abs().mean()) - st[0]) < 1e-4 * max(1.0, abs(st[0]))
+
+
+def test_boost_patch_selection_matches_reference_functions():
+    """applyGridpatch / adaptiveselection / getGF_fromintegral are pure Python on an integral image: the reference's own
+    functions (src/depthmap_generation.py:1102-1177, transcribed into tests/golden/boost_selection_cases.npz by
+    make_golden_models.py) against ours on the same inputs."""
+    import json
+    from src import boost
+    z = np.load(os.path.join(os.path.dirname(GOLD), "boost_selection_cases.npz"))
+    _, integ = mw.boost_integral_image(5, 700, 1000)
+    assert np.allclose(z["integral_checksum"], [integ[-1, -1], integ[350, 500]], rtol=1e-12)
+    for name in ("case_a", "case_b"):
+        meta = json.loads(bytes(z[name + "_meta"]).decode())
+        grid = boost.applyGridpatch(meta["blsize"], meta["stride"], tuple(meta["shape"]), [0, 0, 0, 0])
+        assert [grid[str(i)]["rect"] for i in range(len(grid))] == meta["grid_rects"]
+        sel = boost.adaptiveselection(integ, grid, meta["gf"], meta["factor"])
+        assert [sel[str(i)]["rect"] for i in range(len(sel))] == meta["selected_rects"]
