@@ -237,16 +237,16 @@ def main():
         npad = vm.pad_len(n_tok)
         qk = torch.randn(args.batch, npad, 2, minfo["heads"], 64, device=dev, dtype=torch.float16)
         vt = torch.randn(args.batch, minfo["heads"] * 64, npad, device=dev, dtype=torch.float16)
-        bias_t = None
+        bias = None
         if args.model == "dpt_beit_large_512":
-            bias_t = torch.randn(minfo["heads"], npad, npad, device=dev, dtype=torch.float16)
+            bias = torch.randn(minfo["heads"], npad, npad, device=dev, dtype=torch.float16)
         for _ in range(3):
-            nat.attention_fwd(qk, vt, n_tok, 0.125, bias_t=bias_t)
+            nat.attention_fwd(qk, vt, n_tok, 0.125, bias)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         reps = 20
         e0.record()
         for _ in range(reps):
-            nat.attention_fwd(qk, vt, n_tok, 0.125, bias_t=bias_t)
+            nat.attention_fwd(qk, vt, n_tok, 0.125, bias)
         e1.record()
         e1.synchronize()
         attn_ms = e0.elapsed_time(e1) / reps

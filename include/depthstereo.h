@@ -155,12 +155,12 @@ int ds_convert_to_i16(ds_ctx *ctx, const void *arr, int is_f64, int64_t count, u
  * :65-82) and of dmidas/backbones/beit.py:65-91 (attention_forward with relative position bias); head_dim = 64.
  *   qk      [B, Np, 2, H, 64]  Q (index 0) and K (index 1), token major, as the projection GEMM writes them
  *   vt      [B, H*64, Np]      V transposed (key index contiguous)
- *   bias_t  [H, Np, Np] or NULL: additive logits bias stored KEY-major: bias_t[h][key][query]
+ *   bias    [H, Np, Np] or NULL: additive logits bias, bias[h][query][key] (rows/columns >= n_valid are ignored)
  *   out     [B, Np, H*64]
  * Np is a multiple of 64 (the padded token count); keys >= n_valid are masked; query rows >= n_valid are computed
  * like any other row (they stay finite) and are never read as keys.  scale multiplies q.k before the bias is added.
  */
-int ds_attention_fwd(ds_ctx *ctx, const void *qk, const void *vt, const void *bias_t, void *out,
+int ds_attention_fwd(ds_ctx *ctx, const void *qk, const void *vt, const void *bias, void *out,
                      int B, int Np, int H, int n_valid, float scale, int dtype, void *stream);
 
 /*
@@ -174,6 +174,15 @@ int ds_attention_fwd(ds_ctx *ctx, const void *qk, const void *vt, const void *bi
 int ds_residual_layernorm(ds_ctx *ctx, const void *x, const void *branch, const void *gamma, const void *ln_weight,
                           const void *ln_bias, void *x_out, void *h_out, int64_t rows, int channels, float eps, int dtype,
                           void *stream);
+
+/*
+ * ds_upsample_bilinear_nhwc -- torch.nn.functional.interpolate(x, size, mode="bilinear", align_corners) for channels_last
+ * activations: the x2 upsamples of the DPT decoders (dmidas/blocks.py:429-431; ddepth_anything_v2/.../util/blocks.py:141-145;
+ * the heads' Interpolate, dmidas/dpt_depth.py:151, dpt.py:146).  in [batch, in_h, in_w, channels], out [batch, out_h, out_w,
+ * channels]; channels % 8 == 0; f16/bf16; float32 interpolation arithmetic like torch's.
+ */
+int ds_upsample_bilinear_nhwc(ds_ctx *ctx, const void *in, void *out, int batch, int channels, int in_h, int in_w,
+                              int out_h, int out_w, int align_corners, int dtype, void *stream);
 
 /*
  * ds_boost_blend -- the patch-merge step of Boost, all patches in one launch; replaces, per patch, np.polyval (:916),

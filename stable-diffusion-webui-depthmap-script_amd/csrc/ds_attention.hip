@@ -7,8 +7,8 @@
 // Operands (head_dim is 64 for every encoder the reference ships):
 //   qk   [B, Np, 2, H, 64]  f16/bf16   Q and K exactly as the projection GEMM writes them (token major)
 //   vt   [B, H*64, Np]      f16/bf16   V TRANSPOSED (key index contiguous), produced in that layout by its own GEMM
-//   bias [H, Np(key), Np(query)] optional, same dtype: additive logits bias, stored key-major so that the 32 lanes of
-//        a query block read 64 contiguous bytes per key
+//   bias [H, Np(query), Np(key)] optional, same dtype: additive logits bias; the 128 x 64 tile of a workgroup is staged
+//        through LDS with 16-byte loads and read back as 8-byte groups of 4 consecutive keys
 //   out  [B, Np, H*64]      f16/bf16
 // Np is a multiple of 64; keys >= n_valid are masked (pad rows of the padded token sequence).
 //
@@ -67,6 +67,7 @@ __global__ __launch_bounds__(AT_THREADS) void k_attention_fwd(AttnParams P)
     typedef typename TR::V8 V8;
     __shared__ __attribute__((aligned(16))) unsigned char s_k[AT_KB * 128];          // [key][64 d], chunk-swizzled
     __shared__ __attribute__((aligned(16))) unsigned char s_v[AT_D * AT_VROW];       // [d][64 keys], padded rows
+    __shared__ __attribute__((aligned(16))) unsigned char s_b[HAS_BIAS ? AT_QB * AT_VROW : 16];   // [query][64 keys], padded rows
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, hi = lane >> 5, l31 = lane & 31;
     const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * AT_QB + wave * AT_QW;
@@ -97,12 +98,22 @@ __global__ __launch_bounds__(AT_THREADS) void k_attention_fwd(AttnParams P)
     // staging assignment: K tile = 64 rows x 8 chunks of 16 B; V^T tile = 64 rows x 8 chunks: 512 chunks each, 2 per thread
     const int st_row = tid >> 3, st_chunk = tid & 7;                                  // rows st_row and st_row + 32
     uint4 kreg0, kreg1, vreg0, vreg1;
+    uint4 breg[HAS_BIAS ? 4 : 1];
+    const T *bias_base = nullptr;
+    if (HAS_BIAS) bias_base = (const T *)P.bias + (size_t)h * Np * (size_t)Np;
+    const int q0wg = blockIdx.x * AT_QB;
 #define AT_FETCH(kt_) do {                                                                                             \
         const int key0_ = (kt_) * AT_KB;                                                                                \
         kreg0 = *reinterpret_cast<const uint4 *>(k_base + (size_t)(key0_ + st_row) * tok_stride + 8 * st_chunk);        \
         kreg1 = *reinterpret_cast<const uint4 *>(k_base + (size_t)(key0_ + st_row + 32) * tok_stride + 8 * st_chunk);   \
         vreg0 = *reinterpret_cast<const uint4 *>(vt + (size_t)st_row * Np + key0_ + 8 * st_chunk);                      \
         vreg1 = *reinterpret_cast<const uint4 *>(vt + (size_t)(st_row + 32) * Np + key0_ + 8 * st_chunk);               \
+        if (HAS_BIAS) {                                                                                                  \
+            _Pragma("unroll") for (int p_ = 0; p_ < 4; p_++) {                                                          \
+                const int qr_ = min(q0wg + st_row + 32 * p_, Np - 1);                                                   \
+                breg[p_] = *reinterpret_cast<const uint4 *>(bias_base + (size_t)qr_ * Np + key0_ + 8 * st_chunk);       \
+            }                                                                                                            \
+        }                                                                                                                \
     } while (0)
 #define AT_STASH1(row_, kr_, vr_) do {                                                                                  \
         *reinterpret_cast<uint4 *>(s_k + (row_) * 128 + ((st_chunk ^ ((row_) & 7)) << 4)) = kr_;                        \
@@ -117,6 +128,14 @@ __global__ __launch_bounds__(AT_THREADS) void k_attention_fwd(AttnParams P)
         __syncthreads();                                    // everyone is done reading the previous tile
         AT_STASH1(st_row, kreg0, vreg0);
         AT_STASH1(st_row + 32, kreg1, vreg1);
+        if (HAS_BIAS) {
+#pragma unroll
+            for (int p = 0; p < 4; p++) {
+                uint2 *bd = reinterpret_cast<uint2 *>(s_b + (st_row + 32 * p) * AT_VROW + 16 * st_chunk);
+                bd[0] = make_uint2(breg[p].x, breg[p].y);
+                bd[1] = make_uint2(breg[p].z, breg[p].w);
+            }
+        }
         __syncthreads();
         if (kt + 1 < ntiles) AT_FETCH(kt + 1);              // in flight while this tile is computed
         if (!wave_live) continue;
@@ -140,14 +159,18 @@ __global__ __launch_bounds__(AT_THREADS) void k_attention_fwd(AttnParams P)
 #pragma unroll
         for (int kb = 0; kb < 2; kb++) {
 #pragma unroll
-            for (int r = 0; r < 16; r++) {
-                const int key = key0 + kb * 32 + at_crow(r, hi);
-                float v = s_acc[kb][r] * P.scale_log2e;
-                if (HAS_BIAS) {
-                    const T *bp = (const T *)P.bias + ((size_t)h * Np + key) * (size_t)Np + min(q0 + l31, Np - 1);
-                    v += TR::to_f32(*bp) * P.log2e;
+            for (int g = 0; g < 4; g++) {
+                T b4[4];
+                if (HAS_BIAS) {                     // keys kb*32 + 8g + 4hi + {0..3} of this lane's query row
+                    const uint2 raw = *reinterpret_cast<const uint2 *>(s_b + (wave * AT_QW + l31) * AT_VROW + 2 * (kb * 32 + 8 * g + 4 * hi));
+                    __builtin_memcpy(b4, &raw, 8);
                 }
-                s_acc[kb][r] = v;
+#pragma unroll
+                for (int t = 0; t < 4; t++) {
+                    float v = s_acc[kb][4 * g + t] * P.scale_log2e;
+                    if (HAS_BIAS) v += TR::to_f32(b4[t]) * P.log2e;
+                    s_acc[kb][4 * g + t] = v;
+                }
             }
         }
         if (key0 + AT_KB > P.n_valid) {                     // wave-uniform: only the last tile can hold pad keys
@@ -226,7 +249,7 @@ __global__ __launch_bounds__(AT_THREADS) void k_attention_fwd(AttnParams P)
     }
 }
 
-DS_API int ds_attention_fwd(ds_ctx *ctx, const void *qk, const void *vt, const void *bias_t, void *out,
+DS_API int ds_attention_fwd(ds_ctx *ctx, const void *qk, const void *vt, const void *bias, void *out,
                             int B, int Np, int H, int n_valid, float scale, int dtype, void *stream)
 {
     DS_REQUIRE(ctx && qk && vt && out, DS_EINVAL, "ds_attention_fwd: null argument");
@@ -234,21 +257,21 @@ DS_API int ds_attention_fwd(ds_ctx *ctx, const void *qk, const void *vt, const v
     DS_REQUIRE(n_valid > 0 && n_valid <= Np, DS_EINVAL, "ds_attention_fwd: n_valid %d outside 1..%d", n_valid, Np);
     DS_REQUIRE(dtype == DS_DTYPE_F16 || dtype == DS_DTYPE_BF16, DS_EINVAL, "ds_attention_fwd: dtype must be f16 or bf16");
     DS_REQUIRE(H <= 65535 && B <= 65535, DS_EUNSUPPORTED, "ds_attention_fwd: batch/heads too large for the grid");
-    DS_REQUIRE(((uintptr_t)qk & 15) == 0 && ((uintptr_t)vt & 15) == 0 && ((uintptr_t)out & 7) == 0, DS_EINVAL,
+    DS_REQUIRE(((uintptr_t)qk & 15) == 0 && ((uintptr_t)vt & 15) == 0 && ((uintptr_t)out & 7) == 0 && ((uintptr_t)bias & 15) == 0, DS_EINVAL,
                "ds_attention_fwd: operands must be 16-byte aligned");
     DS_HIP_CHECK(hipSetDevice(ctx->device));
     AttnParams P;
-    P.qk = qk; P.vt = vt; P.bias = bias_t; P.out = out;
+    P.qk = qk; P.vt = vt; P.bias = bias; P.out = out;
     P.B = B; P.Np = Np; P.H = H; P.n_valid = n_valid;
     P.log2e = 1.4426950408889634f;
     P.scale_log2e = scale * P.log2e;
     dim3 grid((Np + AT_QB - 1) / AT_QB, H, B);
     hipStream_t st = (hipStream_t)stream;
     if (dtype == DS_DTYPE_F16) {
-        if (bias_t) hipLaunchKernelGGL((k_attention_fwd<0, 1>), grid, dim3(AT_THREADS), 0, st, P);
+        if (bias) hipLaunchKernelGGL((k_attention_fwd<0, 1>), grid, dim3(AT_THREADS), 0, st, P);
         else hipLaunchKernelGGL((k_attention_fwd<0, 0>), grid, dim3(AT_THREADS), 0, st, P);
     } else {
-        if (bias_t) hipLaunchKernelGGL((k_attention_fwd<1, 1>), grid, dim3(AT_THREADS), 0, st, P);
+        if (bias) hipLaunchKernelGGL((k_attention_fwd<1, 1>), grid, dim3(AT_THREADS), 0, st, P);
         else hipLaunchKernelGGL((k_attention_fwd<1, 0>), grid, dim3(AT_THREADS), 0, st, P);
     }
     DS_HIP_CHECK(hipGetLastError());

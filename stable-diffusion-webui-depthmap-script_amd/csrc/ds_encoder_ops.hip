@@ -100,3 +100,68 @@ DS_API int ds_residual_layernorm(ds_ctx *ctx, const void *x, const void *branch,
     DS_HIP_CHECK(hipGetLastError());
     return DS_OK;
 }
+
+// ------------------------------------------------------------------------------------------------------------------------
+// ds_upsample_bilinear_nhwc: F.interpolate(x, size, mode="bilinear", align_corners=...) for channels_last activations of the
+// DPT decoders (dmidas/blocks.py:429-431, ddepth_anything_v2/.../util/blocks.py:141-145, the heads' Interpolate).  The
+// op is pure HBM streaming (the output is 4x the input); one lane produces 8 channels (16 bytes) of one output pixel from
+// four 16-byte reads that hit L1/L2, consecutive lanes walk the channel axis, so every store instruction writes whole lines.
+template <int BF16>
+__global__ __launch_bounds__(256) void k_upsample_bilinear_nhwc(const void *in_, void *out_, int C8, int ih, int iw, int oh, int ow,
+                                                                 float sy, float sx, int align_corners, long long total)
+{
+    typedef typename eo_traits<BF16>::T T;
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int c8 = (int)(idx % C8);
+    long long r = idx / C8;
+    const int ox = (int)(r % ow); r /= ow;
+    const int oy = (int)(r % oh);
+    const int b = (int)(r / oh);
+    float fy, fx;
+    if (align_corners) { fy = sy * oy; fx = sx * ox; }
+    else { fy = fmaxf(sy * (oy + 0.5f) - 0.5f, 0.f); fx = fmaxf(sx * (ox + 0.5f) - 0.5f, 0.f); }
+    const int y0 = min((int)fy, ih - 1), x0 = min((int)fx, iw - 1);
+    const int y1 = min(y0 + 1, ih - 1), x1 = min(x0 + 1, iw - 1);
+    const float ty = fy - y0, tx = fx - x0;
+    const T *in = (const T *)in_ + (size_t)b * ih * iw * C8 * 8 + (size_t)c8 * 8;
+    T a[8], bq[8], c[8], d[8], o[8];
+    __builtin_memcpy(a, in + ((size_t)y0 * iw + x0) * C8 * 8, 16);
+    __builtin_memcpy(bq, in + ((size_t)y0 * iw + x1) * C8 * 8, 16);
+    __builtin_memcpy(c, in + ((size_t)y1 * iw + x0) * C8 * 8, 16);
+    __builtin_memcpy(d, in + ((size_t)y1 * iw + x1) * C8 * 8, 16);
+    const float w00 = (1.f - ty) * (1.f - tx), w01 = (1.f - ty) * tx, w10 = ty * (1.f - tx), w11 = ty * tx;
+#pragma unroll
+    for (int k = 0; k < 8; k++)
+        o[k] = (T)(w00 * (float)a[k] + w01 * (float)bq[k] + w10 * (float)c[k] + w11 * (float)d[k]);
+    __builtin_memcpy((T *)out_ + (size_t)idx * 8, o, 16);
+}
+
+DS_API int ds_upsample_bilinear_nhwc(ds_ctx *ctx, const void *in, void *out, int batch, int channels, int in_h, int in_w,
+                                     int out_h, int out_w, int align_corners, int dtype, void *stream)
+{
+    DS_REQUIRE(ctx && in && out, DS_EINVAL, "ds_upsample_bilinear_nhwc: null argument");
+    DS_REQUIRE(batch > 0 && channels > 0 && (channels % 8) == 0 && in_h > 0 && in_w > 0 && out_h > 0 && out_w > 0, DS_EINVAL,
+               "ds_upsample_bilinear_nhwc: bad shape (channels must be a multiple of 8)");
+    DS_REQUIRE(dtype == DS_DTYPE_F16 || dtype == DS_DTYPE_BF16, DS_EINVAL, "ds_upsample_bilinear_nhwc: dtype must be f16 or bf16");
+    DS_REQUIRE(((uintptr_t)in & 15) == 0 && ((uintptr_t)out & 15) == 0, DS_EINVAL, "ds_upsample_bilinear_nhwc: 16-byte alignment");
+    DS_HIP_CHECK(hipSetDevice(ctx->device));
+    float sy, sx;
+    if (align_corners) {
+        sy = out_h > 1 ? (float)(in_h - 1) / (float)(out_h - 1) : 0.f;
+        sx = out_w > 1 ? (float)(in_w - 1) / (float)(out_w - 1) : 0.f;
+    } else {
+        sy = (float)in_h / (float)out_h;
+        sx = (float)in_w / (float)out_w;
+    }
+    const int C8 = channels / 8;
+    const long long total = (long long)batch * out_h * out_w * C8;
+    DS_REQUIRE((total + 255) / 256 < (1ll << 31), DS_EUNSUPPORTED, "ds_upsample_bilinear_nhwc: tensor too large");
+    dim3 grid((unsigned)((total + 255) / 256));
+    if (dtype == DS_DTYPE_F16)
+        hipLaunchKernelGGL((k_upsample_bilinear_nhwc<0>), grid, dim3(256), 0, (hipStream_t)stream, in, out, C8, in_h, in_w, out_h, out_w, sy, sx, align_corners, total);
+    else
+        hipLaunchKernelGGL((k_upsample_bilinear_nhwc<1>), grid, dim3(256), 0, (hipStream_t)stream, in, out, C8, in_h, in_w, out_h, out_w, sy, sx, align_corners, total);
+    DS_HIP_CHECK(hipGetLastError());
+    return DS_OK;
+}

@@ -10,6 +10,8 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from src import vit_mi355x as vm
+
 from .dinov2 import DINOv2
 
 
@@ -41,8 +43,8 @@ class FeatureFusionBlock(nn.Module):
         # so they commute (bias included): the conv runs on 4x fewer pixels and the upsample writes the final tensor
         output = self.out_conv(output)
         if size is None:
-            return F.interpolate(output, scale_factor=2, mode="bilinear", align_corners=True)
-        return F.interpolate(output, size=size, mode="bilinear", align_corners=True)
+            return vm.interpolate_bilinear(output, scale_factor=2, align_corners=True)
+        return vm.interpolate_bilinear(output, size=tuple(size), align_corners=True)
 
 
 class DPTHead(nn.Module):
@@ -85,7 +87,7 @@ class DPTHead(nn.Module):
         path_2 = s.refinenet2(path_3, l2, size=l1.shape[2:])
         path_1 = s.refinenet1(path_2, l1)
         out = s.output_conv1(path_1)
-        out = F.interpolate(out, (int(patch_h * 14), int(patch_w * 14)), mode="bilinear", align_corners=True)
+        out = vm.interpolate_bilinear(out, size=(int(patch_h * 14), int(patch_w * 14)), align_corners=True)
         return s.output_conv2(out)
 
 

@@ -12,7 +12,7 @@ gen_relative_position_index (timm is not installable in the build container).
 
 What is different from the reference on purpose:
   * the relative-position bias of a block depends only on (table, window): it is interpolated + gathered ONCE per
-    resolution and cached key-major ([H, Np, Np], the layout ds_attention_fwd reads), instead of in every block of every
+    resolution and cached as a padded [H, Np, Np] operand of ds_attention_fwd, instead of in every block of every
     forward (beit.py:29-62 runs F.interpolate + a 1M-element gather 24 times per image);
   * forward hooks and the module-global `activations` dict (utils.py:60-67,155-160) are replaced by returning the four
     taps from the block loop.
@@ -100,8 +100,8 @@ class Block(vm.EncoderBlock):
         bias = new_table[index.view(-1)].view(n, n, -1)
         return bias.permute(2, 0, 1).contiguous()
 
-    def attention_bias_t(self, n_pad, grid_hw, dtype, device):
-        """Key-major, padded: bias_t[h][key][query]; cached per (window, dtype) until the table changes."""
+    def attention_bias(self, n_pad, grid_hw, dtype, device):
+        """Padded [H, Np(query), Np(key)]; cached per (window, dtype) until the table changes."""
         a = self.attn
         key = (tuple(grid_hw), n_pad, dtype, device, a.relative_position_bias_table._version)
         hit = self._bias_cache.get(key)
@@ -111,7 +111,7 @@ class Block(vm.EncoderBlock):
             bias = self.rel_pos_bias(tuple(grid_hw))                                     # H, N, N (query, key)
             n = bias.shape[-1]
             bt = torch.zeros((bias.shape[0], n_pad, n_pad), dtype=dtype, device=device)
-            bt[:, :n, :n] = bias.transpose(1, 2).to(dtype)
+            bt[:, :n, :n] = bias.to(dtype)
         self._bias_cache.clear()
         self._bias_cache[key] = bt
         return bt

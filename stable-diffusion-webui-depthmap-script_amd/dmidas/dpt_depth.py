@@ -10,6 +10,8 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from src import vit_mi355x as vm
+
 from .backbones.beit import make_beit
 from .backbones.vit import make_vit
 
@@ -44,8 +46,8 @@ class FeatureFusionBlock_custom(nn.Module):
         # 1x1 out_conv and bilinear interpolation commute (linear, weights sum to one): conv first, on 4x fewer pixels
         output = self.out_conv(output)
         if size is None:
-            return F.interpolate(output, scale_factor=2, mode="bilinear", align_corners=True)
-        return F.interpolate(output, size=size, mode="bilinear", align_corners=True)
+            return vm.interpolate_bilinear(output, scale_factor=2, align_corners=True)
+        return vm.interpolate_bilinear(output, size=tuple(size), align_corners=True)
 
 
 class Interpolate(nn.Module):           # blocks.py:213-244 (no parameters; keeps the Sequential indices of the head)
@@ -54,6 +56,8 @@ class Interpolate(nn.Module):           # blocks.py:213-244 (no parameters; keep
         self.scale_factor, self.mode, self.align_corners = scale_factor, mode, align_corners
 
     def forward(self, x):
+        if self.mode == "bilinear":
+            return vm.interpolate_bilinear(x, scale_factor=self.scale_factor, align_corners=bool(self.align_corners))
         return F.interpolate(x, scale_factor=self.scale_factor, mode=self.mode, align_corners=self.align_corners)
 
 

@@ -20,7 +20,7 @@ FILL_IDS = {"none": 0, "naive": 1, "naive_interpolating": 2, "polylines_soft": 3
 EXPORTS = [
     "ds_version", "ds_last_error", "ds_ctx_create", "ds_ctx_destroy", "ds_stereo_warp", "ds_depth_minmax",
     "ds_stereo_last_exact_rows", "ds_copy_view", "ds_overlap_red_cyan", "ds_normalmap", "ds_depth_to_u16",
-    "ds_convert_to_i16", "ds_profile_enable", "ds_profile_last_ms", "ds_stereo_last_stats", "ds_attention_fwd", "ds_residual_layernorm", "ds_boost_blend",
+    "ds_convert_to_i16", "ds_profile_enable", "ds_profile_last_ms", "ds_stereo_last_stats", "ds_attention_fwd", "ds_residual_layernorm", "ds_boost_blend", "ds_upsample_bilinear_nhwc",
 ]
 
 
@@ -64,6 +64,7 @@ def lib():
             L.ds_attention_fwd.argtypes = [vp, vp, vp, vp, vp, ci, ci, ci, ci, ctypes.c_float, ci, vp]
             L.ds_residual_layernorm.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, i64, ci, ctypes.c_float, ci, vp]
             L.ds_boost_blend.argtypes = [vp, vp, i64, ci, ci, vp, ci, vp, ci, vp, ci, vp]
+            L.ds_upsample_bilinear_nhwc.argtypes = [vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, vp]
             L.ds_profile_enable.argtypes = [vp, ci]
             L.ds_profile_last_ms.argtypes = [vp, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float)]
             for name in EXPORTS:          # fail at load time, not at first use, if a symbol is missing
@@ -236,25 +237,22 @@ def convert_to_i16(arr):
     return out
 
 
-def attention_fwd(qk, vt, n_valid, scale, bias=None, bias_t=None):
+def attention_fwd(qk, vt, n_valid, scale, bias=None):
     """Fused MFMA attention (include/depthstereo.h: ds_attention_fwd).  qk [B,Np,2,H,64], vt [B,H*64,Np], float16 or
-    bfloat16 CUDA tensors; bias [H,Np(query),Np(key)] or, to skip the transpose, bias_t [H,Np(key),Np(query)].
-    Returns [B,Np,H*64]."""
+    bfloat16 CUDA tensors; bias [H,Np(query),Np(key)] or None.  Returns [B,Np,H*64]."""
     torch = require_gpu()
     assert qk.is_cuda and vt.is_cuda and qk.dtype == vt.dtype and qk.dtype in (torch.float16, torch.bfloat16)
     b, npad, two, h, d = qk.shape
     assert two == 2 and d == 64 and npad % 64 == 0 and tuple(vt.shape) == (b, h * 64, npad), (qk.shape, vt.shape)
     qk = qk.contiguous()
     vt = vt.contiguous()
-    if bias is not None and bias_t is None:
-        bias_t = bias.transpose(1, 2)
-    if bias_t is not None:
-        bias_t = bias_t.to(qk.dtype).contiguous()
-        assert tuple(bias_t.shape) == (h, npad, npad)
+    if bias is not None:
+        bias = bias.to(qk.dtype).contiguous()
+        assert tuple(bias.shape) == (h, npad, npad)
     out = torch.empty((b, npad, h * 64), dtype=qk.dtype, device=qk.device)
     dt = 1 if qk.dtype == torch.float16 else 2
     _check(lib().ds_attention_fwd(ctx_for(_dev_index(qk)), qk.data_ptr(), vt.data_ptr(),
-                                  bias_t.data_ptr() if bias_t is not None else None, out.data_ptr(),
+                                  bias.data_ptr() if bias is not None else None, out.data_ptr(),
                                   b, npad, h, int(n_valid), float(scale), dt, _stream(qk)))
     return out
 
@@ -305,3 +303,19 @@ def boost_blend(dst, rects, coefs, preds, mask_template):
                                 buf.data_ptr(), n, preds.data_ptr(), preds.shape[1], mask_template.data_ptr(),
                                 mask_template.shape[0], _stream(dst)))
     return dst
+
+
+def upsample_bilinear(x, size=None, scale_factor=None, align_corners=True):
+    """F.interpolate(x, mode="bilinear") for an NCHW-shaped float16/bfloat16 CUDA tensor in channels_last memory format
+    (include/depthstereo.h: ds_upsample_bilinear_nhwc).  Returns a channels_last tensor."""
+    torch = require_gpu()
+    b, c, ih, iw = x.shape
+    if size is None:
+        size = (int(ih * scale_factor), int(iw * scale_factor))
+    oh, ow = int(size[0]), int(size[1])
+    assert x.is_cuda and x.dtype in (torch.float16, torch.bfloat16) and c % 8 == 0
+    xin = x.contiguous(memory_format=torch.channels_last)
+    out = torch.empty((b, c, oh, ow), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+    _check(lib().ds_upsample_bilinear_nhwc(ctx_for(_dev_index(x)), xin.data_ptr(), out.data_ptr(), b, c, ih, iw, oh, ow,
+                                           1 if align_corners else 0, 1 if x.dtype == torch.float16 else 2, _stream(x)))
+    return out

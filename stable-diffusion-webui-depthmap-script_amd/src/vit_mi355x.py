@@ -77,12 +77,12 @@ def folded_proj_bias(proj, b_v):
     return proj.bias + F.linear(b_v.to(proj.weight.dtype), proj.weight)
 
 
-def fused_attention(qk, vt, n_valid, scale, bias_t=None):
-    """bias_t: key-major additive bias [H, Np(key), Np(query)] or None."""
+def fused_attention(qk, vt, n_valid, scale, bias=None):
+    """bias: additive logits bias [H, Np(query), Np(key)] or None."""
     if qk.dtype == torch.float32:
-        return attention_reference(qk, vt, n_valid, scale, None if bias_t is None else bias_t.transpose(1, 2))
+        return attention_reference(qk, vt, n_valid, scale, bias)
     from . import _native
-    return _native.attention_fwd(qk, vt, n_valid, scale, bias_t=bias_t)
+    return _native.attention_fwd(qk, vt, n_valid, scale, bias)
 
 
 class EncoderBlock(nn.Module):
@@ -90,7 +90,7 @@ class EncoderBlock(nn.Module):
     instantiates it: DINOv2 ``norm1/attn.qkv/attn.proj/ls1.gamma/norm2/mlp.fc1/mlp.fc2/ls2.gamma`` (dinov2_layers/
     block.py:60-83); the BEiT subclass keeps timm's ``gamma_1/gamma_2``, ``q_bias/v_bias`` and the bias table.
     Subclasses provide: norm1, norm2 (nn.LayerNorm), mlp, qkv_weights() -> (w_qk, b_qk, w_v, b_v),
-    proj(o, b_v), gammas() -> (g1, g2), and optionally attention_bias_t()."""
+    proj(o, b_v), gammas() -> (g1, g2), and optionally attention_bias()."""
 
     def __init__(self, dim, num_heads, mlp_ratio=4.0):
         super().__init__()
@@ -98,7 +98,7 @@ class EncoderBlock(nn.Module):
         self.dim, self.num_heads = dim, num_heads
         self.scale = HEAD_DIM ** -0.5
 
-    def attention_bias_t(self, n_pad, grid_hw, dtype, device):
+    def attention_bias(self, n_pad, grid_hw, dtype, device):
         return None
 
     def attend(self, h, n_valid, grid_hw):
@@ -107,7 +107,7 @@ class EncoderBlock(nn.Module):
         w_qk, b_qk, w_v, b_v = self.qkv_weights()
         qk = F.linear(h, w_qk, b_qk).view(b, npad, 2, self.num_heads, HEAD_DIM)
         vt = v_transposed(w_v, h)                               # [B, C, Np]: V transposed, straight out of the GEMM
-        o = fused_attention(qk, vt, n_valid, self.scale, self.attention_bias_t(npad, grid_hw, h.dtype, h.device))
+        o = fused_attention(qk, vt, n_valid, self.scale, self.attention_bias(npad, grid_hw, h.dtype, h.device))
         return self.proj(o, b_v)                                # V bias folded into the projection bias
 
     def forward_padded(self, x, n_valid, grid_hw=None):
@@ -147,6 +147,17 @@ def run_blocks(blocks, x, n_valid, grid_hw, take):
         if i in take:
             taps[i] = x[:, :n_valid]
     return x, taps
+
+
+def interpolate_bilinear(x, size=None, scale_factor=None, align_corners=True):
+    """F.interpolate(mode="bilinear") of the DPT decoders: the HIP kernel for half-precision channels_last activations on
+    the GPU (one pass at HBM speed), torch everywhere else (float32 parity path, CPU)."""
+    if x.is_cuda and x.dtype in (torch.float16, torch.bfloat16) and x.shape[1] % 8 == 0:
+        from . import _native
+        return _native.upsample_bilinear(x, size=size, scale_factor=scale_factor, align_corners=align_corners)
+    if size is not None:
+        return F.interpolate(x, size=size, mode="bilinear", align_corners=align_corners)
+    return F.interpolate(x, scale_factor=scale_factor, mode="bilinear", align_corners=align_corners)
 
 
 class Mlp(nn.Module):

@@ -192,3 +192,17 @@ def test_boost_pipeline_runs_end_to_end(gpu):
     out = boost.estimateboost(torch.from_numpy(img).cuda(), net, 0, p2p, whole_size_threshold=1600, stats=stats)
     assert tuple(out.shape) == (1200, 1600) and out.dtype == torch.float32 and torch.isfinite(out).all()
     assert stats["patches"] >= 1 and 448 <= stats["whole_image_optimal_size"] <= 1600, stats
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_upsample_bilinear_nhwc_kernel(gpu, dtype):
+    from src import _native
+    g = torch.Generator().manual_seed(8)
+    for (b, c, ih, iw, oh, ow, ac) in [(2, 64, 5, 7, 10, 14, True), (1, 256, 16, 16, 32, 32, True), (3, 8, 9, 13, 20, 27, True),
+                                        (2, 32, 10, 10, 37, 23, False), (1, 128, 37, 66, 518, 924, True)]:
+        x = torch.randn((b, c, ih, iw), generator=g).to(dtype).cuda().contiguous(memory_format=torch.channels_last)
+        got = _native.upsample_bilinear(x, size=(oh, ow), align_corners=ac)
+        want = torch.nn.functional.interpolate(x.float(), size=(oh, ow), mode="bilinear", align_corners=ac)
+        tol = 2e-3 if dtype == torch.float16 else 1.6e-2
+        assert got.shape == want.shape and got.is_contiguous(memory_format=torch.channels_last)
+        assert (got.float() - want).abs().max().item() < tol * (1 + want.abs().max().item())
