@@ -153,23 +153,22 @@ __global__ __launch_bounds__(AT_THREADS) void k_attention_fwd(AttnParams P)
                 s_acc[kb] = TR::mfma(kf, qf[s], s_acc[kb]);
             }
         }
-        // ---- logits (exp2 domain), bias, key mask, running max -------------------------------------------------
+        // ---- logits, bias, key mask, running max (exp2 domain) ---------------------------------------------------------
+        // Without a bias the raw accumulators are kept and the softmax scale is folded into the exponent's FMA:
+        // p = exp2(s*c - m*c) with m = max(s) (c > 0 commutes with max).  With a bias the logits are formed first.
         const int key0 = kt * AT_KB;
-        float m_loc = -__builtin_inff();
+        const float c_ = HAS_BIAS ? 1.0f : P.scale_log2e;   // factor still to be applied inside the exponent
+        if (HAS_BIAS) {
 #pragma unroll
-        for (int kb = 0; kb < 2; kb++) {
+            for (int kb = 0; kb < 2; kb++) {
 #pragma unroll
-            for (int g = 0; g < 4; g++) {
-                T b4[4];
-                if (HAS_BIAS) {                     // keys kb*32 + 8g + 4hi + {0..3} of this lane's query row
+                for (int g = 0; g < 4; g++) {
+                    T b4[4];                        // keys kb*32 + 8g + 4hi + {0..3} of this lane's query row
                     const uint2 raw = *reinterpret_cast<const uint2 *>(s_b + (wave * AT_QW + l31) * AT_VROW + 2 * (kb * 32 + 8 * g + 4 * hi));
                     __builtin_memcpy(b4, &raw, 8);
-                }
 #pragma unroll
-                for (int t = 0; t < 4; t++) {
-                    float v = s_acc[kb][4 * g + t] * P.scale_log2e;
-                    if (HAS_BIAS) v += TR::to_f32(b4[t]) * P.log2e;
-                    s_acc[kb][4 * g + t] = v;
+                    for (int t = 0; t < 4; t++)
+                        s_acc[kb][4 * g + t] = fmaf(TR::to_f32(b4[t]), P.log2e, s_acc[kb][4 * g + t] * P.scale_log2e);
                 }
             }
         }
@@ -180,16 +179,18 @@ __global__ __launch_bounds__(AT_THREADS) void k_attention_fwd(AttnParams P)
                 for (int r = 0; r < 16; r++)
                     if (key0 + kb * 32 + at_crow(r, hi) >= P.n_valid) s_acc[kb][r] = -__builtin_inff();
         }
+        float m_loc = -__builtin_inff();
 #pragma unroll
         for (int kb = 0; kb < 2; kb++)
 #pragma unroll
             for (int r = 0; r < 16; r++) m_loc = fmaxf(m_loc, s_acc[kb][r]);
         m_loc = fmaxf(m_loc, __shfl_xor(m_loc, 32, 64));    // the other half of this query's keys
-        const float m_new = fmaxf(m_run, m_loc);
-        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);   // v_exp_f32; first tile: exp2(-inf) = 0
+        const float m_new = fmaxf(m_run, m_loc);            // running max of the RAW values when c_ != 1
+        const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c_);   // first tile: exp2(-inf) = 0
         m_run = m_new;
+        const float mc = m_new * c_;
         float l_loc = 0.f;
-        // ---- P = exp2(S - m); P^T fragments for the four 16-key slices: registers 8j..8j+7 of key block kb ------
+        // ---- P = exp2(S*c - m*c); P^T fragments for the four 16-key slices: registers 8j..8j+7 of key block kb ------
         V8 pf[2][2];
 #pragma unroll
         for (int kb = 0; kb < 2; kb++) {
@@ -197,7 +198,7 @@ __global__ __launch_bounds__(AT_THREADS) void k_attention_fwd(AttnParams P)
             for (int j = 0; j < 2; j++) {
 #pragma unroll
                 for (int t = 0; t < 8; t++) {
-                    const float p = __builtin_amdgcn_exp2f(s_acc[kb][8 * j + t] - m_new);
+                    const float p = __builtin_amdgcn_exp2f(fmaf(s_acc[kb][8 * j + t], c_, -mc));
                     l_loc += p;
                     pf[kb][j][t] = TR::from_f32(p);
                 }
