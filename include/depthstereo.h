@@ -185,6 +185,20 @@ int ds_upsample_bilinear_nhwc(ds_ctx *ctx, const void *in, void *out, int batch,
                               int out_h, int out_w, int align_corners, int dtype, void *stream);
 
 /*
+ * ds_dpt_head_tail -- the tail of the DPT depth heads in one kernel: bilinear upsample (align_corners=True) ->
+ * conv3x3 128->32 (padding 1) -> ReLU -> conv1x1 32->1 -> optional ReLU (dmidas/dpt_depth.py:150-158 output_conv[1:6];
+ * ddepth_anything_v2/depth_anything_v2/dpt.py:146-147 with output_conv2 :105-111).
+ *   x            [batch, in_h, in_w, 128] f16/bf16, channels_last: the output of the head's first convolution
+ *   conv3_wfrag  the 3x3 weights [32, 128, 3, 3] rearranged as MFMA fragments [tap 9][k-slice 8][half 2][co 32][8 ci]
+ *                (ci = 16*slice + 8*half + j), same dtype as x
+ *   conv3_bias, conv1_weight  float32 [32];  conv1_bias scalar
+ *   out          [batch, out_h, out_w] same dtype as x
+ */
+int ds_dpt_head_tail(ds_ctx *ctx, const void *x, int batch, int in_h, int in_w, int out_h, int out_w,
+                     const void *conv3_wfrag, const float *conv3_bias, const float *conv1_weight, float conv1_bias,
+                     int relu_out, void *out, int dtype, void *stream);
+
+/*
  * ds_boost_blend -- the patch-merge step of Boost, all patches in one launch; replaces, per patch, np.polyval (:916),
  * cv2.resize INTER_CUBIC of the merged patch (:918), cv2.resize INTER_LINEAR of the Gaussian mask (:930) and the blend
  * `dst[rect] = dst[rect]*(1-mask) + merged*mask` (:936) of src/depthmap_generation.py:estimateboost.

@@ -165,3 +165,142 @@ DS_API int ds_upsample_bilinear_nhwc(ds_ctx *ctx, const void *in, void *out, int
     DS_HIP_CHECK(hipGetLastError());
     return DS_OK;
 }
+
+// ------------------------------------------------------------------------------------------------------------------------
+// ds_dpt_head_tail: the tail of the DPT depth heads, fused:
+//     bilinear upsample (align_corners=True) -> conv3x3 128->32 (pad 1) -> ReLU -> conv1x1 32->1 -> ReLU
+// (dmidas/dpt_depth.py:150-158: scratch.output_conv[1:6]; ddepth_anything_v2/.../dpt.py:146-147 + output_conv2, :105-111).
+// The reference materialises the upsampled 128-channel tensor (2.1 GB at batch 32, 512^2) and the 32-channel tensor; the
+// 3x3 convolution on it is the least efficient library call of the whole forward (MIOpen: 3.9 ms, 158 TF/s).  Here a
+// workgroup builds the upsampled activations of an 8 x 32 output tile (+1 halo) in LDS, runs the convolution as an
+// implicit GEMM on the matrix cores with the roles swapped (A = weights: 32 output channels, B = activations: 32 pixels
+// of one row), so that a lane ends up holding all 32 channels of ONE pixel (16 registers + the lane^32 partner) and the
+// ReLU + 1x1 convolution + ReLU is an in-lane dot product.  Nothing but the final 1-channel map is written.
+#define HT_TH 8
+#define HT_TW 32
+#define HT_PW (HT_TW + 2)
+#define HT_NPIX ((HT_TH + 2) * HT_PW)
+
+typedef _Float16 ht_f16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 ht_bf16x8 __attribute__((ext_vector_type(8)));
+typedef float ht_f32x16 __attribute__((ext_vector_type(16)));
+
+struct HeadTailParams {
+    const void *x;            // [B, ih, iw, 128]
+    const void *wfrag;        // conv3x3 weights as MFMA fragments: [tap 9][s 8][hi 2][co 32][8]
+    const float *b2, *w3;     // [32] conv3x3 bias, [32] conv1x1 weight
+    void *out;                // [B, oh, ow]
+    float b3;
+    int B, ih, iw, oh, ow, relu_out;
+    float sy, sx;
+};
+
+template <int BF16>
+__global__ __launch_bounds__(256) void k_dpt_head_tail(HeadTailParams P)
+{
+    typedef typename eo_traits<BF16>::T T;
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_act[];      // [HT_NPIX][16 chunks of 16 B], chunk ^ (pix & 15)
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, hi = lane >> 5, l31 = lane & 31;
+    const int b = blockIdx.z, ty0 = blockIdx.y * HT_TH, tx0 = blockIdx.x * HT_TW;
+    const T *x = (const T *)P.x + (size_t)b * P.ih * P.iw * 128;
+
+    // ---- upsampled activations of the tile + halo; outside the image = the convolution's zero padding -------------------
+    for (int i = tid; i < HT_NPIX * 16; i += 256) {
+        const int pix = i >> 4, chunk = i & 15;
+        const int r = pix / HT_PW, c = pix - r * HT_PW;
+        const int oy = ty0 - 1 + r, ox = tx0 - 1 + c;
+        T o[8];
+        if (oy < 0 || oy >= P.oh || ox < 0 || ox >= P.ow) {
+#pragma unroll
+            for (int k = 0; k < 8; k++) o[k] = (T)0.f;
+        } else {
+            const float fy = P.sy * oy, fx = P.sx * ox;
+            const int y0 = min((int)fy, P.ih - 1), x0 = min((int)fx, P.iw - 1);
+            const int y1 = min(y0 + 1, P.ih - 1), x1 = min(x0 + 1, P.iw - 1);
+            const float ty = fy - y0, tx = fx - x0;
+            T a[8], bq[8], cq[8], d[8];
+            __builtin_memcpy(a, x + ((size_t)y0 * P.iw + x0) * 128 + chunk * 8, 16);
+            __builtin_memcpy(bq, x + ((size_t)y0 * P.iw + x1) * 128 + chunk * 8, 16);
+            __builtin_memcpy(cq, x + ((size_t)y1 * P.iw + x0) * 128 + chunk * 8, 16);
+            __builtin_memcpy(d, x + ((size_t)y1 * P.iw + x1) * 128 + chunk * 8, 16);
+            const float w00 = (1.f - ty) * (1.f - tx), w01 = (1.f - ty) * tx, w10 = ty * (1.f - tx), w11 = ty * tx;
+#pragma unroll
+            for (int k = 0; k < 8; k++)
+                o[k] = (T)(w00 * (float)a[k] + w01 * (float)bq[k] + w10 * (float)cq[k] + w11 * (float)d[k]);
+        }
+        __builtin_memcpy(s_act + pix * 256 + ((chunk ^ (pix & 15)) << 4), o, 16);
+    }
+    __syncthreads();
+
+    // ---- implicit GEMM: D[co][pixel] += W[co][tap, ci] * act[pixel + tap][ci]; this wave: output rows 2*wave, 2*wave+1 ----
+    ht_f32x16 acc[2];
+#pragma unroll
+    for (int rr = 0; rr < 2; rr++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[rr][r] = 0.f;
+    const T *wf = (const T *)P.wfrag + ((size_t)hi * 32 + l31) * 8;
+#pragma unroll
+    for (int tap = 0; tap < 9; tap++) {
+        const int dy = tap / 3, dx = tap - dy * 3;
+#pragma unroll
+        for (int s = 0; s < 8; s++) {
+            uint4 wraw = *reinterpret_cast<const uint4 *>(wf + (size_t)(tap * 8 + s) * 2 * 32 * 8);
+#pragma unroll
+            for (int rr = 0; rr < 2; rr++) {
+                const int pix = (2 * wave + rr + dy) * HT_PW + l31 + dx;
+                const uint4 araw = *reinterpret_cast<const uint4 *>(s_act + pix * 256 + (((2 * s + hi) ^ (pix & 15)) << 4));
+                if (BF16) {
+                    union { uint4 u; ht_bf16x8 v; } wa, ab; wa.u = wraw; ab.u = araw;
+                    acc[rr] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa.v, ab.v, acc[rr], 0, 0, 0);
+                } else {
+                    union { uint4 u; ht_f16x8 v; } wa, ab; wa.u = wraw; ab.u = araw;
+                    acc[rr] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wa.v, ab.v, acc[rr], 0, 0, 0);
+                }
+            }
+        }
+    }
+    // ---- epilogue: lane holds channels crow(r, hi) of pixel l31: + bias, ReLU, dot with the 1x1 weights, + bias, ReLU ------
+#pragma unroll
+    for (int rr = 0; rr < 2; rr++) {
+        float part = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int ch = (r & 3) + 8 * (r >> 2) + 4 * hi;
+            const float v = fmaxf(acc[rr][r] + P.b2[ch], 0.f);
+            part += P.w3[ch] * v;
+        }
+        part += __shfl_xor(part, 32, 64);
+        float res = part + P.b3;
+        if (P.relu_out) res = fmaxf(res, 0.f);
+        const int oy = ty0 + 2 * wave + rr, ox = tx0 + l31;
+        if (hi == 0 && oy < P.oh && ox < P.ow) ((T *)P.out)[((size_t)b * P.oh + oy) * P.ow + ox] = (T)res;
+    }
+}
+
+DS_API int ds_dpt_head_tail(ds_ctx *ctx, const void *x, int batch, int in_h, int in_w, int out_h, int out_w,
+                            const void *conv3_wfrag, const float *conv3_bias, const float *conv1_weight, float conv1_bias,
+                            int relu_out, void *out, int dtype, void *stream)
+{
+    DS_REQUIRE(ctx && x && conv3_wfrag && conv3_bias && conv1_weight && out, DS_EINVAL, "ds_dpt_head_tail: null argument");
+    DS_REQUIRE(batch > 0 && batch <= 65535 && in_h > 0 && in_w > 0 && out_h > 0 && out_w > 0, DS_EINVAL, "ds_dpt_head_tail: bad shape");
+    DS_REQUIRE(dtype == DS_DTYPE_F16 || dtype == DS_DTYPE_BF16, DS_EINVAL, "ds_dpt_head_tail: dtype must be f16 or bf16");
+    DS_REQUIRE(((uintptr_t)x & 15) == 0 && ((uintptr_t)conv3_wfrag & 15) == 0, DS_EINVAL, "ds_dpt_head_tail: 16-byte alignment");
+    DS_HIP_CHECK(hipSetDevice(ctx->device));
+    HeadTailParams P;
+    P.x = x; P.wfrag = conv3_wfrag; P.b2 = conv3_bias; P.w3 = conv1_weight; P.b3 = conv1_bias; P.out = out;
+    P.B = batch; P.ih = in_h; P.iw = in_w; P.oh = out_h; P.ow = out_w; P.relu_out = relu_out;
+    P.sy = out_h > 1 ? (float)(in_h - 1) / (float)(out_h - 1) : 0.f;
+    P.sx = out_w > 1 ? (float)(in_w - 1) / (float)(out_w - 1) : 0.f;
+    const size_t lds = (size_t)HT_NPIX * 256;
+    dim3 grid((out_w + HT_TW - 1) / HT_TW, (out_h + HT_TH - 1) / HT_TH, batch);
+    DS_REQUIRE(grid.y <= 65535, DS_EUNSUPPORTED, "ds_dpt_head_tail: image too tall");
+    if (dtype == DS_DTYPE_F16) {
+        DS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_dpt_head_tail<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL((k_dpt_head_tail<0>), grid, dim3(256), lds, (hipStream_t)stream, P);
+    } else {
+        DS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_dpt_head_tail<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL((k_dpt_head_tail<1>), grid, dim3(256), lds, (hipStream_t)stream, P);
+    }
+    DS_HIP_CHECK(hipGetLastError());
+    return DS_OK;
+}

@@ -87,7 +87,12 @@ class DPTHead(nn.Module):
         path_2 = s.refinenet2(path_3, l2, size=l1.shape[2:])
         path_1 = s.refinenet1(path_2, l1)
         out = s.output_conv1(path_1)
-        out = vm.interpolate_bilinear(out, size=(int(patch_h * 14), int(patch_w * 14)), align_corners=True)
+        size = (int(patch_h * 14), int(patch_w * 14))
+        if out.is_cuda and out.dtype in (torch.float16, torch.bfloat16) and tuple(s.output_conv2[0].weight.shape) == (32, 128, 3, 3):
+            # upsample -> conv3x3 128->32 -> ReLU -> conv1x1 -> ReLU in one MFMA kernel (ds_dpt_head_tail)
+            from src import _native
+            return _native.dpt_head_tail(out, size, s.output_conv2[0], s.output_conv2[2], relu_out=True)
+        out = vm.interpolate_bilinear(out, size=size, align_corners=True)
         return s.output_conv2(out)
 
 

@@ -87,7 +87,15 @@ class DPT(nn.Module):
         path_3 = s.refinenet3(path_4, l3, size=l2.shape[2:])
         path_2 = s.refinenet2(path_3, l2, size=l1.shape[2:])
         path_1 = s.refinenet1(path_2, l1)
-        return s.output_conv(path_1)
+        head = s.output_conv
+        if (path_1.is_cuda and path_1.dtype in (torch.float16, torch.bfloat16) and isinstance(head[1], Interpolate)
+                and head[1].mode == "bilinear" and head[1].align_corners and tuple(head[2].weight.shape) == (32, 128, 3, 3)):
+            # upsample x2 -> conv3x3 128->32 -> ReLU -> conv1x1 -> ReLU in one MFMA kernel (ds_dpt_head_tail)
+            from src import _native
+            y = head[0](path_1)
+            size = (int(y.shape[2] * head[1].scale_factor), int(y.shape[3] * head[1].scale_factor))
+            return _native.dpt_head_tail(y, size, head[2], head[4], relu_out=isinstance(head[5], nn.ReLU))
+        return head(path_1)
 
 
 def _constrain(x, multiple, min_val=0, max_val=None):

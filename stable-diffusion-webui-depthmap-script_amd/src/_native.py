@@ -20,7 +20,7 @@ FILL_IDS = {"none": 0, "naive": 1, "naive_interpolating": 2, "polylines_soft": 3
 EXPORTS = [
     "ds_version", "ds_last_error", "ds_ctx_create", "ds_ctx_destroy", "ds_stereo_warp", "ds_depth_minmax",
     "ds_stereo_last_exact_rows", "ds_copy_view", "ds_overlap_red_cyan", "ds_normalmap", "ds_depth_to_u16",
-    "ds_convert_to_i16", "ds_profile_enable", "ds_profile_last_ms", "ds_stereo_last_stats", "ds_attention_fwd", "ds_residual_layernorm", "ds_boost_blend", "ds_upsample_bilinear_nhwc",
+    "ds_convert_to_i16", "ds_profile_enable", "ds_profile_last_ms", "ds_stereo_last_stats", "ds_attention_fwd", "ds_residual_layernorm", "ds_boost_blend", "ds_upsample_bilinear_nhwc", "ds_dpt_head_tail",
 ]
 
 
@@ -65,6 +65,7 @@ def lib():
             L.ds_residual_layernorm.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, i64, ci, ctypes.c_float, ci, vp]
             L.ds_boost_blend.argtypes = [vp, vp, i64, ci, ci, vp, ci, vp, ci, vp, ci, vp]
             L.ds_upsample_bilinear_nhwc.argtypes = [vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, vp]
+            L.ds_dpt_head_tail.argtypes = [vp, vp, ci, ci, ci, ci, ci, vp, vp, vp, ctypes.c_float, ci, vp, ci, vp]
             L.ds_profile_enable.argtypes = [vp, ci]
             L.ds_profile_last_ms.argtypes = [vp, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float)]
             for name in EXPORTS:          # fail at load time, not at first use, if a symbol is missing
@@ -318,4 +319,33 @@ def upsample_bilinear(x, size=None, scale_factor=None, align_corners=True):
     out = torch.empty((b, c, oh, ow), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
     _check(lib().ds_upsample_bilinear_nhwc(ctx_for(_dev_index(x)), xin.data_ptr(), out.data_ptr(), b, c, ih, iw, oh, ow,
                                            1 if align_corners else 0, 1 if x.dtype == torch.float16 else 2, _stream(x)))
+    return out
+
+
+_head_cache = {}
+
+
+def dpt_head_tail(x, size, conv3, conv1, relu_out=True):
+    """upsample(x, size, bilinear, align_corners=True) -> conv3 (3x3, 128->32) -> ReLU -> conv1 (1x1, 32->1) -> ReLU, fused
+    (include/depthstereo.h: ds_dpt_head_tail).  x: NCHW-shaped [B,128,h,w] float16/bfloat16 CUDA tensor (any memory format;
+    channels_last is zero-copy).  conv3 / conv1: the nn.Conv2d modules.  Returns [B, 1, H, W]."""
+    torch = require_gpu()
+    b, c, ih, iw = x.shape
+    assert c == 128 and tuple(conv3.weight.shape) == (32, 128, 3, 3) and tuple(conv1.weight.shape) == (1, 32, 1, 1)
+    xin = x.contiguous(memory_format=torch.channels_last)
+    key = (id(conv3), conv3.weight._version, conv3.bias._version, conv1.weight._version, conv1.bias._version, x.dtype, x.device)
+    hit = _head_cache.get(id(conv3))
+    if hit is None or hit[0] != key:
+        w = conv3.weight.detach().to(x.dtype)                                   # [co, ci, ky, kx]
+        # fragment order: [tap = ky*3+kx][slice s][half][co][j] with ci = 16 s + 8 half + j
+        wf = w.permute(2, 3, 1, 0).reshape(9, 8, 2, 8, 32).permute(0, 1, 2, 4, 3).contiguous()
+        hit = (key, wf, conv3.bias.detach().float().contiguous(), conv1.weight.detach().float().reshape(32).contiguous(),
+               float(conv1.bias.detach().float().item()))
+        _head_cache[id(conv3)] = hit
+    _, wf, b2, w3, b3 = hit
+    oh, ow = int(size[0]), int(size[1])
+    out = torch.empty((b, 1, oh, ow), dtype=x.dtype, device=x.device)
+    _check(lib().ds_dpt_head_tail(ctx_for(_dev_index(x)), xin.data_ptr(), b, ih, iw, oh, ow, wf.data_ptr(), b2.data_ptr(),
+                                  w3.data_ptr(), b3, 1 if relu_out else 0, out.data_ptr(),
+                                  1 if x.dtype == torch.float16 else 2, _stream(x)))
     return out

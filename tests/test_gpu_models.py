@@ -206,3 +206,29 @@ def test_upsample_bilinear_nhwc_kernel(gpu, dtype):
         tol = 2e-3 if dtype == torch.float16 else 1.6e-2
         assert got.shape == want.shape and got.is_contiguous(memory_format=torch.channels_last)
         assert (got.float() - want).abs().max().item() < tol * (1 + want.abs().max().item())
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float16, 4e-3), (torch.bfloat16, 3e-2)])
+def test_dpt_head_tail_kernel(gpu, dtype, tol):
+    """ds_dpt_head_tail against the torch sequence upsample -> conv3x3 -> ReLU -> conv1x1 -> ReLU in float32."""
+    from src import _native
+    import torch.nn as nn
+    import torch.nn.functional as F
+    torch.manual_seed(4)
+    conv3 = nn.Conv2d(128, 32, 3, padding=1).cuda()
+    conv1 = nn.Conv2d(32, 1, 1).cuda()
+    with torch.no_grad():
+        conv1.bias.fill_(0.05)
+    for (b, ih, iw, oh, ow, relu) in [(2, 9, 13, 18, 26, True), (1, 37, 37, 518 // 7, 518 // 7, True), (3, 16, 16, 32, 32, False),
+                                      (1, 20, 31, 33, 70, True)]:
+        x = torch.randn((b, 128, ih, iw), device='cuda')
+        with torch.no_grad():
+            up = F.interpolate(x.to(dtype).float(), size=(oh, ow), mode="bilinear", align_corners=True)
+            y = conv1(F.relu(conv3(up)))
+            want = F.relu(y) if relu else y
+            got = _native.dpt_head_tail(x.to(dtype).contiguous(memory_format=torch.channels_last), (oh, ow),
+                                        conv3.to(dtype), conv1.to(dtype), relu_out=relu).float()
+        conv3.float(); conv1.float()
+        assert got.shape == want.shape
+        err = (got - want).abs().max().item()
+        assert err < tol * (1 + want.abs().max().item()), (b, ih, iw, oh, ow, err)
