@@ -4,6 +4,8 @@
 // The reference runs LayerScale multiply, residual add and LayerNorm as three kernels (five tensor passes); here a row
 // is read once (x, branch), written once (x, h).  One wave per token row, float32 statistics on the ROUNDED residual
 // stream (so h is exactly LayerNorm of the x that is stored), two-pass variance in registers.
+#include <stdlib.h>
+
 #include "ds_common.h"
 
 template <int BF16> struct eo_traits;
@@ -176,10 +178,8 @@ DS_API int ds_upsample_bilinear_nhwc(ds_ctx *ctx, const void *in, void *out, int
 // implicit GEMM on the matrix cores with the roles swapped (A = weights: 32 output channels, B = activations: 32 pixels
 // of one row), so that a lane ends up holding all 32 channels of ONE pixel (16 registers + the lane^32 partner) and the
 // ReLU + 1x1 convolution + ReLU is an in-lane dot product.  Nothing but the final 1-channel map is written.
-#define HT_TH 8
 #define HT_TW 32
 #define HT_PW (HT_TW + 2)
-#define HT_NPIX ((HT_TH + 2) * HT_PW)
 
 typedef _Float16 ht_f16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 ht_bf16x8 __attribute__((ext_vector_type(8)));
@@ -195,47 +195,59 @@ struct HeadTailParams {
     float sy, sx;
 };
 
-template <int BF16>
+template <int BF16, int RPW>      // RPW = output rows per wave; tile = 4*RPW rows x 32 columns
 __global__ __launch_bounds__(256) void k_dpt_head_tail(HeadTailParams P)
 {
     typedef typename eo_traits<BF16>::T T;
+    constexpr int HT_TH = 4 * RPW;
+    constexpr int HT_NPIX = (HT_TH + 2) * HT_PW;
     extern __shared__ __attribute__((aligned(16))) unsigned char s_act[];      // [HT_NPIX][16 chunks of 16 B], chunk ^ (pix & 15)
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, hi = lane >> 5, l31 = lane & 31;
     const int b = blockIdx.z, ty0 = blockIdx.y * HT_TH, tx0 = blockIdx.x * HT_TW;
     const T *x = (const T *)P.x + (size_t)b * P.ih * P.iw * 128;
 
     // ---- upsampled activations of the tile + halo; outside the image = the convolution's zero padding -------------------
-    for (int i = tid; i < HT_NPIX * 16; i += 256) {
-        const int pix = i >> 4, chunk = i & 15;
-        const int r = pix / HT_PW, c = pix - r * HT_PW;
-        const int oy = ty0 - 1 + r, ox = tx0 - 1 + c;
-        T o[8];
-        if (oy < 0 || oy >= P.oh || ox < 0 || ox >= P.ow) {
+    for (int i0 = tid; i0 < HT_NPIX * 16; i0 += 256 * 4) {
+        T a[4][8], bq[4][8], cq[4][8], d[4][8];
+        float w00[4], w01[4], w10[4], w11[4];
+        bool inside[4], live[4];
 #pragma unroll
-            for (int k = 0; k < 8; k++) o[k] = (T)0.f;
-        } else {
-            const float fy = P.sy * oy, fx = P.sx * ox;
+        for (int u = 0; u < 4; u++) {                       // issue all 16 loads of four items before using any
+            const int i = i0 + u * 256;
+            live[u] = i < HT_NPIX * 16;
+            const int pix = min(i, HT_NPIX * 16 - 1) >> 4, chunk = i & 15;
+            const int r = pix / HT_PW, c = pix - r * HT_PW;
+            const int oy = ty0 - 1 + r, ox = tx0 - 1 + c;
+            inside[u] = live[u] && oy >= 0 && oy < P.oh && ox >= 0 && ox < P.ow;
+            const float fy = P.sy * max(oy, 0), fx = P.sx * max(ox, 0);
             const int y0 = min((int)fy, P.ih - 1), x0 = min((int)fx, P.iw - 1);
             const int y1 = min(y0 + 1, P.ih - 1), x1 = min(x0 + 1, P.iw - 1);
             const float ty = fy - y0, tx = fx - x0;
-            T a[8], bq[8], cq[8], d[8];
-            __builtin_memcpy(a, x + ((size_t)y0 * P.iw + x0) * 128 + chunk * 8, 16);
-            __builtin_memcpy(bq, x + ((size_t)y0 * P.iw + x1) * 128 + chunk * 8, 16);
-            __builtin_memcpy(cq, x + ((size_t)y1 * P.iw + x0) * 128 + chunk * 8, 16);
-            __builtin_memcpy(d, x + ((size_t)y1 * P.iw + x1) * 128 + chunk * 8, 16);
-            const float w00 = (1.f - ty) * (1.f - tx), w01 = (1.f - ty) * tx, w10 = ty * (1.f - tx), w11 = ty * tx;
+            w00[u] = (1.f - ty) * (1.f - tx); w01[u] = (1.f - ty) * tx; w10[u] = ty * (1.f - tx); w11[u] = ty * tx;
+            __builtin_memcpy(a[u], x + ((size_t)y0 * P.iw + x0) * 128 + chunk * 8, 16);
+            __builtin_memcpy(bq[u], x + ((size_t)y0 * P.iw + x1) * 128 + chunk * 8, 16);
+            __builtin_memcpy(cq[u], x + ((size_t)y1 * P.iw + x0) * 128 + chunk * 8, 16);
+            __builtin_memcpy(d[u], x + ((size_t)y1 * P.iw + x1) * 128 + chunk * 8, 16);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            if (!live[u]) continue;
+            const int i = i0 + u * 256;
+            const int pix = i >> 4, chunk = i & 15;
+            T o[8];
 #pragma unroll
             for (int k = 0; k < 8; k++)
-                o[k] = (T)(w00 * (float)a[k] + w01 * (float)bq[k] + w10 * (float)cq[k] + w11 * (float)d[k]);
+                o[k] = inside[u] ? (T)(w00[u] * (float)a[u][k] + w01[u] * (float)bq[u][k] + w10[u] * (float)cq[u][k] + w11[u] * (float)d[u][k])
+                                 : (T)0.f;
+            __builtin_memcpy(s_act + pix * 256 + ((chunk ^ (pix & 15)) << 4), o, 16);
         }
-        __builtin_memcpy(s_act + pix * 256 + ((chunk ^ (pix & 15)) << 4), o, 16);
     }
     __syncthreads();
 
-    // ---- implicit GEMM: D[co][pixel] += W[co][tap, ci] * act[pixel + tap][ci]; this wave: output rows 2*wave, 2*wave+1 ----
-    ht_f32x16 acc[2];
+    // ---- implicit GEMM: D[co][pixel] += W[co][tap, ci] * act[pixel + tap][ci]; this wave: output rows RPW*wave .. +RPW-1 ----
+    ht_f32x16 acc[RPW];
 #pragma unroll
-    for (int rr = 0; rr < 2; rr++)
+    for (int rr = 0; rr < RPW; rr++)
 #pragma unroll
         for (int r = 0; r < 16; r++) acc[rr][r] = 0.f;
     const T *wf = (const T *)P.wfrag + ((size_t)hi * 32 + l31) * 8;
@@ -246,8 +258,8 @@ __global__ __launch_bounds__(256) void k_dpt_head_tail(HeadTailParams P)
         for (int s = 0; s < 8; s++) {
             uint4 wraw = *reinterpret_cast<const uint4 *>(wf + (size_t)(tap * 8 + s) * 2 * 32 * 8);
 #pragma unroll
-            for (int rr = 0; rr < 2; rr++) {
-                const int pix = (2 * wave + rr + dy) * HT_PW + l31 + dx;
+            for (int rr = 0; rr < RPW; rr++) {
+                const int pix = (RPW * wave + rr + dy) * HT_PW + l31 + dx;
                 const uint4 araw = *reinterpret_cast<const uint4 *>(s_act + pix * 256 + (((2 * s + hi) ^ (pix & 15)) << 4));
                 if (BF16) {
                     union { uint4 u; ht_bf16x8 v; } wa, ab; wa.u = wraw; ab.u = araw;
@@ -261,7 +273,7 @@ __global__ __launch_bounds__(256) void k_dpt_head_tail(HeadTailParams P)
     }
     // ---- epilogue: lane holds channels crow(r, hi) of pixel l31: + bias, ReLU, dot with the 1x1 weights, + bias, ReLU ------
 #pragma unroll
-    for (int rr = 0; rr < 2; rr++) {
+    for (int rr = 0; rr < RPW; rr++) {
         float part = 0.f;
 #pragma unroll
         for (int r = 0; r < 16; r++) {
@@ -272,7 +284,7 @@ __global__ __launch_bounds__(256) void k_dpt_head_tail(HeadTailParams P)
         part += __shfl_xor(part, 32, 64);
         float res = part + P.b3;
         if (P.relu_out) res = fmaxf(res, 0.f);
-        const int oy = ty0 + 2 * wave + rr, ox = tx0 + l31;
+        const int oy = ty0 + RPW * wave + rr, ox = tx0 + l31;
         if (hi == 0 && oy < P.oh && ox < P.ow) ((T *)P.out)[((size_t)b * P.oh + oy) * P.ow + ox] = (T)res;
     }
 }
@@ -291,16 +303,20 @@ DS_API int ds_dpt_head_tail(ds_ctx *ctx, const void *x, int batch, int in_h, int
     P.B = batch; P.ih = in_h; P.iw = in_w; P.oh = out_h; P.ow = out_w; P.relu_out = relu_out;
     P.sy = out_h > 1 ? (float)(in_h - 1) / (float)(out_h - 1) : 0.f;
     P.sx = out_w > 1 ? (float)(in_w - 1) / (float)(out_w - 1) : 0.f;
-    const size_t lds = (size_t)HT_NPIX * 256;
-    dim3 grid((out_w + HT_TW - 1) / HT_TW, (out_h + HT_TH - 1) / HT_TH, batch);
+    static int s_rpw = 0;                                    // DS_HEAD_RPW: output rows per wave (tile height = 4x), 1 or 2
+    if (s_rpw == 0) { const char *e = getenv("DS_HEAD_RPW"); s_rpw = (e && atoi(e) == 2) ? 2 : 1; }
+    const int th = 4 * s_rpw;
+    const size_t lds = (size_t)(th + 2) * HT_PW * 256;
+    dim3 grid((out_w + HT_TW - 1) / HT_TW, (out_h + th - 1) / th, batch);
     DS_REQUIRE(grid.y <= 65535, DS_EUNSUPPORTED, "ds_dpt_head_tail: image too tall");
-    if (dtype == DS_DTYPE_F16) {
-        DS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_dpt_head_tail<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL((k_dpt_head_tail<0>), grid, dim3(256), lds, (hipStream_t)stream, P);
-    } else {
-        DS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_dpt_head_tail<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL((k_dpt_head_tail<1>), grid, dim3(256), lds, (hipStream_t)stream, P);
-    }
+#define HT_LAUNCH(BF, RP) do {                                                                                              \
+        DS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_dpt_head_tail<BF, RP>),                           \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                            \
+        hipLaunchKernelGGL((k_dpt_head_tail<BF, RP>), grid, dim3(256), lds, (hipStream_t)stream, P);                        \
+    } while (0)
+    if (dtype == DS_DTYPE_F16) { if (s_rpw == 2) HT_LAUNCH(0, 2); else HT_LAUNCH(0, 1); }
+    else { if (s_rpw == 2) HT_LAUNCH(1, 2); else HT_LAUNCH(1, 1); }
+#undef HT_LAUNCH
     DS_HIP_CHECK(hipGetLastError());
     return DS_OK;
 }

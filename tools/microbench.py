@@ -1,0 +1,74 @@
+#!/usr/bin/env python3
+"""Standalone timings of the hand-written HIP kernels at the shapes the default bench launches them with
+(dpt_beit_large_512, batch 32).  No library convolutions are involved, so it runs in seconds on a fresh box.
+
+    python tools/microbench.py [attention] [head] [rln] [upsample] [stereo]
+"""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "stable-diffusion-webui-depthmap-script_amd")):
+    sys.path.insert(0, p)
+
+import torch  # noqa: E402
+import torch.nn as nn  # noqa: E402
+from src import _native as nat  # noqa: E402
+
+
+def timeit(fn, reps=20, warm=3):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    e1.synchronize()
+    return e0.elapsed_time(e1) / reps
+
+
+def main():
+    which = set(sys.argv[1:]) or {"attention", "head", "rln", "upsample", "stereo"}
+    B = 32
+    dev = torch.device("cuda")
+    if "attention" in which:
+        for name, n, bias in (("beit-l 1025 +bias", 1025, True), ("dinov2-l 1370", 1370, False)):
+            npad = (n + 63) // 64 * 64
+            qk = torch.randn(B, npad, 2, 16, 64, device=dev, dtype=torch.float16)
+            vt = torch.randn(B, 1024, npad, device=dev, dtype=torch.float16)
+            bt = torch.randn(16, npad, npad, device=dev, dtype=torch.float16) if bias else None
+            ms = timeit(lambda: nat.attention_fwd(qk, vt, n, 0.125, bt))
+            print(f"attention {name}: {ms:.3f} ms  {4.0 * n * n * 1024 * B / ms / 1e9:.1f} TF/s")
+    if "head" in which:
+        conv3 = nn.Conv2d(128, 32, 3, padding=1).to(dev).half()
+        conv1 = nn.Conv2d(32, 1, 1).to(dev).half()
+        x = torch.randn(B, 128, 256, 256, device=dev, dtype=torch.float16).contiguous(memory_format=torch.channels_last)
+        ms = timeit(lambda: nat.dpt_head_tail(x, (512, 512), conv3, conv1, True))
+        print(f"dpt_head_tail 256^2 -> 512^2 x{B}: {ms:.3f} ms  {2.0 * 9 * 128 * 32 * 512 * 512 * B / ms / 1e9:.1f} TF/s")
+    if "rln" in which:
+        x = torch.randn(B * 1088, 1024, device=dev, dtype=torch.float16)
+        o = torch.randn_like(x)
+        g = torch.randn(1024, device=dev, dtype=torch.float16)
+        ms = timeit(lambda: nat.residual_layernorm(x, o, g, g, g, 1e-6))
+        print(f"residual_layernorm {B}x1088x1024: {ms * 1e3:.1f} us  {4 * x.numel() * 2 / ms / 1e6:.0f} GB/s")
+    if "upsample" in which:
+        x = torch.randn(B, 256, 128, 128, device=dev, dtype=torch.float16).contiguous(memory_format=torch.channels_last)
+        ms = timeit(lambda: nat.upsample_bilinear(x, scale_factor=2, align_corners=True))
+        print(f"upsample 128^2 -> 256^2 x256ch x{B}: {ms * 1e3:.1f} us  {5 * x.numel() * 2 / ms / 1e6:.0f} GB/s")
+    if "stereo" in which:
+        import numpy as np
+        import src.stereoimage_generation as sg
+        sys.path.insert(0, ROOT)
+        import bench
+        img_np, pred_np = bench.synth_batch(B, 1000)
+        img = torch.from_numpy(img_np).to(dev)
+        d16 = nat.depth_to_u16(torch.from_numpy(pred_np).to(dev), False)
+        ms = timeit(lambda: sg.create_stereoimages_batch(img, d16, 2.5, 0.0, ['left-right'], 0.0, 1.0, 'polylines_sharp'), reps=10)
+        print(f"create_stereoimages_batch polylines_sharp x{B} (1024^2): {ms:.3f} ms  {B / ms * 1e3:.0f} pairs/s")
+
+
+if __name__ == "__main__":
+    main()
