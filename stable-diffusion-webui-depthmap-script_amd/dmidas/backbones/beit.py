@@ -75,8 +75,15 @@ class Block(vm.EncoderBlock):
     def qkv_weights(self):
         c = self.dim
         w = self.attn.qkv.weight
-        b_qk = torch.cat((self.attn.q_bias, torch.zeros_like(self.attn.q_bias)))        # k_bias == 0 (beit.py:71)
-        return w[:2 * c], b_qk, w[2 * c:], self.attn.v_bias
+        qb = self.attn.q_bias
+        key = (qb._version, qb.data_ptr(), qb.dtype)
+        hit = getattr(self, "_bqk", None)
+        if hit is None or hit[0] != key:
+            b_qk = torch.cat((qb, torch.zeros_like(qb)))                                 # k_bias == 0 (beit.py:71)
+            hit = (key, b_qk)
+            if not torch.is_grad_enabled():
+                self._bqk = hit
+        return w[:2 * c], hit[1], w[2 * c:], self.attn.v_bias
 
     def proj(self, o, b_v=None):
         return F.linear(o, self.attn.proj.weight, vm.folded_proj_bias(self.attn.proj, b_v))

@@ -71,10 +71,18 @@ def v_transposed(w_v, h):
 
 def folded_proj_bias(proj, b_v):
     """softmax rows sum to one, so attn @ (v + b_v) = attn @ v + b_v: the V bias commutes with the attention and folds
-    into the output projection's bias, b_p + W_p . b_v -- one [C] vector per block instead of a pass over V^T."""
+    into the output projection's bias, b_p + W_p . b_v -- one [C] vector per block instead of a pass over V^T.
+    The folded vector depends only on parameters: cached on the module per parameter version (inference)."""
     if b_v is None:
         return proj.bias
-    return proj.bias + F.linear(b_v.to(proj.weight.dtype), proj.weight)
+    key = (proj.weight._version, proj.bias._version, b_v._version, b_v.data_ptr(), proj.weight.data_ptr(), proj.weight.dtype)
+    hit = getattr(proj, "_folded_bias", None)
+    if hit is not None and hit[0] == key:
+        return hit[1]
+    out = proj.bias + F.linear(b_v.to(proj.weight.dtype), proj.weight)
+    if not torch.is_grad_enabled():
+        proj._folded_bias = (key, out)
+    return out
 
 
 def fused_attention(qk, vt, n_valid, scale, bias=None):
