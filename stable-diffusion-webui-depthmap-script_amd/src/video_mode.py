@@ -1,0 +1,182 @@
+"""Video mode of the funnel, frame parallel.
+
+Reference: src/video_mode.py -- process_predicitons :103-128, gen_video :131-190 (first pass: raw predictions of all
+frames; global normalisation; second pass: the funnel again with the normalised predictions as custom depth maps).
+
+What is built: the COMPUTE of video mode on frame tensors --
+  * ``process_predicitons`` (same name, same semantics, numpy in / numpy out) and
+  * ``process_predictions_sharded``: the same normalisation when the frames are sharded over ranks (one process per
+    GPU): 'none' needs the global min/max -> ONE all-reduce(MIN) of the pair (min, -max); 'experimental' needs
+    +-2 frames of halo at the shard edges (an all-gather of every shard's first / last two frames) and the global
+    0.5 / 99.5 percentiles, found
+    EXACTLY by bisection on the float32 bit pattern with one all-reduce(SUM) of a counter per step (numpy's linear
+    interpolation between the two neighbouring order statistics reproduced) -- no rank ever holds all frames;
+  * ``gen_frames_sharded``: two passes over this rank's contiguous block of frames (network batched on the device,
+    normalisation with the collectives above, depth -> uint16 -> stereo on the device) and a single gather of the
+    collated output to rank 0 (src/multigpu.gather_units; RCCL over xGMI under the 'nccl' backend).
+Container I/O (moviepy / imageio-ffmpeg / av: open_path_as_images :13-64, frames_to_video :67-100) is outside the hot
+path and not built; callers hand in decoded frames.
+"""
+import numpy as np
+
+
+def process_predicitons(predictions, smoothening='none'):
+    """reference :103-128 (the spelling is the reference's)."""
+    def global_scaling(objs, a=None, b=None):
+        normalized = []
+        min_value = a if a is not None else min([obj.min() for obj in objs])
+        max_value = b if b is not None else max([obj.max() for obj in objs])
+        for obj in objs:
+            normalized += [(obj - min_value) / (max_value - min_value)]
+        return normalized
+
+    if smoothening == 'none':
+        return global_scaling(predictions)
+    elif smoothening == 'experimental':
+        processed = []
+        clip = lambda val: min(max(0, val), len(predictions) - 1)           # noqa: E731
+        for i in range(len(predictions)):
+            f = np.zeros_like(predictions[i])
+            for u, mul in enumerate([0.10, 0.20, 0.40, 0.20, 0.10]):
+                f += mul * predictions[clip(i + (u - 2))]
+            processed += [f]
+        a, b = np.percentile(np.stack(processed), [0.5, 99.5])
+        return global_scaling(predictions, a, b)
+    return predictions
+
+
+# ---- sharded over ranks -------------------------------------------------------------------------------------------------------
+def _f32_key(t):
+    """Order-preserving map float32 -> int64 (sign-magnitude bit pattern -> two's-complement order)."""
+    import torch
+    i = t.contiguous().view(torch.int32).to(torch.int64)
+    return torch.where(i < 0, -(i & 0x7fffffff) - 1, i)
+
+
+def _key_to_f32(k):
+    k = int(k)
+    bits = k if k >= 0 else ((-(k + 1)) | 0x80000000)
+    return float(np.array([bits], dtype=np.uint32).view(np.float32)[0])
+
+
+def _kth_smallest(keys, k, group):
+    """Exact k-th smallest (0-based) of the union of every rank's `keys` (int64 tensor): bisection on the value with one
+    all-reduce of a count per step (33 steps for the float32 key range)."""
+    import torch
+    import torch.distributed as dist
+    lo, hi = -(1 << 31) - 1, (1 << 31)
+    while hi - lo > 1:                                      # invariant: count(keys <= lo) <= k < count(keys <= hi)
+        mid = (lo + hi) // 2
+        c = (keys <= mid).sum().to(torch.int64).reshape(1)
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+            dist.all_reduce(c, op=dist.ReduceOp.SUM, group=group)
+        if int(c.item()) > k:
+            hi = mid
+        else:
+            lo = mid
+    return hi
+
+
+def _global_percentiles(local, qs, group):
+    """np.percentile(all values of all ranks, qs) with numpy's default linear interpolation, float32 data."""
+    import torch
+    import torch.distributed as dist
+    n = torch.tensor([local.numel()], dtype=torch.int64, device=local.device)
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(n, op=dist.ReduceOp.SUM, group=group)
+    n = int(n.item())
+    keys = _f32_key(local.reshape(-1).float())
+    out = []
+    for q in qs:
+        pos = (n - 1) * (q / 100.0)
+        i0 = int(np.floor(pos))
+        frac = pos - i0
+        v0 = _key_to_f32(_kth_smallest(keys, i0, group))
+        v1 = _key_to_f32(_kth_smallest(keys, min(i0 + 1, n - 1), group)) if frac > 0 else v0
+        # numpy (>= 1.22, method='linear') evaluates the lerp in the dtype of the data promoted with the weights
+        v0, v1 = np.float64(v0), np.float64(v1)
+        out.append(float(v0 + (v1 - v0) * frac))
+    return out
+
+
+def process_predictions_sharded(local, smoothening='none', group=None):
+    """The normalisation of process_predicitons for frames sharded in CONTIGUOUS blocks over the ranks.
+    local: float32 tensor [n_local, H, W] (this rank's frames, any device).  Returns the normalised tensor (float64 for
+    'experimental', like numpy's promotion with the float64 percentiles; float32 for 'none')."""
+    import torch
+    import torch.distributed as dist
+    multi = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+    if smoothening == 'none':
+        mm = torch.stack((local.min(), -local.max())) if local.numel() else torch.tensor([float('inf')] * 2, device=local.device)
+        if multi:
+            dist.all_reduce(mm, op=dist.ReduceOp.MIN, group=group)          # min and (negated) max in one collective
+        mn, mx = mm[0], -mm[1]
+        return (local - mn) / (mx - mn)
+    if smoothening != 'experimental':
+        return local
+    rank = dist.get_rank(group) if multi else 0
+    world = dist.get_world_size(group) if multi else 1
+    n_local = local.shape[0]
+    # halo: two frames from each neighbour (the global first / last frame is replicated: clip() of the reference)
+    if multi:
+        counts = [torch.zeros(1, dtype=torch.int64, device=local.device) for _ in range(world)]
+        dist.all_gather(counts, torch.tensor([n_local], dtype=torch.int64, device=local.device), group=group)
+        counts = [int(c.item()) for c in counts]
+        assert all(c >= 2 or c == 0 for c in counts), "frame shards must hold at least 2 frames for the +-2 halo"
+        head = local[:2].contiguous()
+        tail = local[-2:].contiguous()
+        heads = [torch.empty_like(head) for _ in range(world)]
+        tails = [torch.empty_like(tail) for _ in range(world)]
+        dist.all_gather(heads, head, group=group)
+        dist.all_gather(tails, tail, group=group)
+        prev_r = next((r for r in range(rank - 1, -1, -1) if counts[r] > 0), None)
+        next_r = next((r for r in range(rank + 1, world) if counts[r] > 0), None)
+        left = tails[prev_r] if prev_r is not None else local[:1].expand(2, -1, -1)
+        right = heads[next_r] if next_r is not None else local[-1:].expand(2, -1, -1)
+    else:
+        left = local[:1].expand(2, -1, -1)
+        right = local[-1:].expand(2, -1, -1)
+    ext = torch.cat((left, local, right), dim=0)
+    processed = torch.zeros_like(local)
+    for u, mul in enumerate([0.10, 0.20, 0.40, 0.20, 0.10]):                # same order of accumulation as the reference
+        processed += mul * ext[u:u + n_local]
+    a, b = _global_percentiles(processed, [0.5, 99.5], group)
+    return (local.double() - a) / (b - a)
+
+
+def gen_frames_sharded(frames_u8, predict_batch, inp, smoothening='none', group=None, batch=8, dst=0):
+    """Two-pass video pipeline on decoded frames, frame parallel.
+    frames_u8: uint8 tensor [F, H, W, 3] (every rank may hold the full clip or just index its block); predict_batch:
+    callable uint8 [b,H,W,3] -> float32 [b,H,W] raw prediction (e.g. DepthAnythingV2.infer_batch) on the rank's device.
+    Returns on rank `dst` a dict {mode: uint8 [F, ...]} for the requested stereo modes plus 'depth' (uint16 [F,H,W]);
+    None elsewhere."""
+    import torch
+    import torch.distributed as dist
+    from . import _native, multigpu
+    from .stereoimage_generation import create_stereoimages_batch
+    multi = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+    rank = dist.get_rank(group) if multi else 0
+    world = dist.get_world_size(group) if multi else 1
+    n = frames_u8.shape[0]
+    s, e = multigpu.my_shard(n, rank, world)
+    dev = torch.device('cuda', torch.cuda.current_device())
+    mine = frames_u8[s:e].to(dev)
+    preds = [predict_batch(mine[i:i + batch]) for i in range(0, e - s, batch)]                    # pass 1 (:139-150)
+    preds = torch.cat(preds) if preds else torch.empty((0,) + tuple(frames_u8.shape[1:3]), device=dev)
+    norm = process_predictions_sharded(preds, smoothening, group)                                 # :151
+    d16 = _native.convert_to_i16(norm.double() if norm.dtype != torch.float32 else norm)         # core.py:170-174,211
+    modes = list(inp.get('stereo_modes', ['left-right']))
+    outs = {'depth': d16}
+    if inp.get('gen_stereo', True) and e > s:                                                     # pass 2 (:160)
+        res = create_stereoimages_batch(mine, d16, inp.get('stereo_divergence', 2.5), inp.get('stereo_separation', 0.0), modes,
+                                        inp.get('stereo_balance', 0.0), inp.get('stereo_offset_exponent', 1.0),
+                                        inp.get('stereo_fill_algo', 'polylines_sharp'))
+        outs.update(dict(zip(modes, res)))
+    gathered = {}
+    for k, v in outs.items():                                                                     # ONE gather per output
+        if v.dtype == torch.uint16:                          # collectives have no uint16: same bits as int16
+            g = multigpu.gather_units(v.view(torch.int16), n, group=group, dst=dst)
+            gathered[k] = None if g is None else g.view(torch.uint16)
+        else:
+            gathered[k] = multigpu.gather_units(v, n, group=group, dst=dst)
+    return gathered if rank == dst else None

@@ -232,3 +232,23 @@ def test_dpt_head_tail_kernel(gpu, dtype, tol):
         assert got.shape == want.shape
         err = (got - want).abs().max().item()
         assert err < tol * (1 + want.abs().max().item()), (b, ih, iw, oh, ow, err)
+
+
+def test_video_two_pass_pipeline_single_rank(gpu, oracle):
+    """gen_frames_sharded on one rank: network -> global normalisation -> uint16 -> stereo, against the same steps done by
+    hand (process_predicitons on the host, the stereo oracle)."""
+    from src import video_mode
+    from ddepth_anything_v2 import DepthAnythingV2
+    torch.manual_seed(0)
+    net = DepthAnythingV2('vits', features=64, out_channels=[48, 96, 192, 384]).eval().cuda().half()
+    rng = np.random.default_rng(2)
+    frames = torch.from_numpy(rng.integers(0, 256, (5, 56, 84, 3), dtype=np.uint8))
+    res = video_mode.gen_frames_sharded(frames, lambda b: net.infer_batch(b, 70), {'stereo_modes': ['left-right']}, 'none', batch=2)
+    assert set(res.keys()) == {'depth', 'left-right'} and tuple(res['left-right'].shape) == (5, 56, 168, 3)
+    preds = torch.cat([net.infer_batch(frames[i:i + 2].cuda(), 70) for i in range(0, 5, 2)]).cpu().numpy()
+    norm = video_mode.process_predicitons([p for p in preds], 'none')
+    for i in range(5):
+        d16 = oracle.convert_to_i16(norm[i])
+        assert np.array_equal(res['depth'][i].cpu().numpy(), d16)
+        want = oracle.create_stereoimages_arrays(frames[i].numpy(), d16, 2.5, 0.0, ['left-right'], 0.0, 1.0, 'polylines_sharp')[0]
+        assert np.array_equal(res['left-right'][i].cpu().numpy(), want)

@@ -67,3 +67,44 @@ def test_two_rank_gather_equals_single_process(tmp_path, n_units):
     dep = torch.from_numpy(rng.integers(0, 65536, (n_units, 12, 40), dtype=np.uint16))
     want = _render_oracle(img, dep).numpy()
     assert np.array_equal(got, want)
+
+
+def _video_worker(rank, world, port, n_frames, mode, result_path):
+    for p in (conftest.ROOT, conftest.PKG):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from src import video_mode, multigpu
+    rng = np.random.default_rng(11)
+    preds = rng.normal(3.0, 2.0, (n_frames, 9, 14)).astype(np.float32)
+    s, e = multigpu.my_shard(n_frames, rank, world)
+    local = torch.from_numpy(preds[s:e])
+    out = video_mode.process_predictions_sharded(local, mode)
+    full = multigpu.gather_units(out.contiguous(), n_frames)
+    if rank == 0:
+        np.save(result_path, full.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("mode", ["none", "experimental"])
+@pytest.mark.parametrize("world,n_frames", [(2, 9), (3, 12)])
+def test_video_normalisation_sharded_equals_single_process(tmp_path, mode, world, n_frames):
+    """process_predicitons (reference src/video_mode.py:103-128) with the frames sharded over ranks: global min/max by
+    all-reduce, +-2-frame halo, exact global percentiles by bisection with all-reduced counts."""
+    for p in (conftest.ROOT, conftest.PKG):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    from src import video_mode
+    rng = np.random.default_rng(11)
+    preds = rng.normal(3.0, 2.0, (n_frames, 9, 14)).astype(np.float32)
+    want = np.stack(video_mode.process_predicitons([p for p in preds], mode))
+    path = str(tmp_path / "v.npy")
+    mp.spawn(_video_worker, args=(world, _free_port(), n_frames, mode, path), nprocs=world, join=True)
+    got = np.load(path)
+    assert got.shape == want.shape
+    assert np.allclose(got, want, rtol=1e-6, atol=1e-7), float(np.abs(got - want).max())
+    if mode == "none":
+        assert np.array_equal(got.astype(np.float32), want.astype(np.float32))
