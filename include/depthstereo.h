@@ -155,12 +155,13 @@ int ds_convert_to_i16(ds_ctx *ctx, const void *arr, int is_f64, int64_t count, u
  * :65-82) and of dmidas/backbones/beit.py:65-91 (attention_forward with relative position bias); head_dim = 64.
  *   qk      [B, Np, 2, H, 64]  Q (index 0) and K (index 1), token major, as the projection GEMM writes them
  *   vt      [B, H*64, Np]      V transposed (key index contiguous)
- *   bias    [H, Np, Np] or NULL: additive logits bias, bias[h][query][key] (rows/columns >= n_valid are ignored)
+ *   bias    [H, Np, Np] or NULL: additive logits bias, bias[h][query][key] (rows/columns >= n_valid are ignored);
+ *           bias_in_log2_units != 0: the caller stores bias * log2(e) (saves one multiply per logit)
  *   out     [B, Np, H*64]
  * Np is a multiple of 64 (the padded token count); keys >= n_valid are masked; query rows >= n_valid are computed
  * like any other row (they stay finite) and are never read as keys.  scale multiplies q.k before the bias is added.
  */
-int ds_attention_fwd(ds_ctx *ctx, const void *qk, const void *vt, const void *bias, void *out,
+int ds_attention_fwd(ds_ctx *ctx, const void *qk, const void *vt, const void *bias, int bias_in_log2_units, void *out,
                      int B, int Np, int H, int n_valid, float scale, int dtype, void *stream);
 
 /*

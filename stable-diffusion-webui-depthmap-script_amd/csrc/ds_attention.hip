@@ -56,7 +56,7 @@ struct AttnParams {
     void *out;
     int B, Np, H, n_valid;
     float scale_log2e;           // softmax scale * log2(e): logits are kept in the exp2 domain
-    float log2e;
+    float bias_mul;              // log2(e), or 1 when the caller already stores the bias in log2 units
 };
 
 template <int BF16, int HAS_BIAS>
@@ -167,8 +167,8 @@ __global__ __launch_bounds__(AT_THREADS) void k_attention_fwd(AttnParams P)
                     const uint2 raw = *reinterpret_cast<const uint2 *>(s_b + (wave * AT_QW + l31) * AT_VROW + 2 * (kb * 32 + 8 * g + 4 * hi));
                     __builtin_memcpy(b4, &raw, 8);
 #pragma unroll
-                    for (int t = 0; t < 4; t++)
-                        s_acc[kb][4 * g + t] = fmaf(TR::to_f32(b4[t]), P.log2e, s_acc[kb][4 * g + t] * P.scale_log2e);
+                    for (int t = 0; t < 4; t++)         // one mixed-precision FMA per logit: s*c + bias (bias already in log2 units)
+                        s_acc[kb][4 * g + t] = fmaf(s_acc[kb][4 * g + t], P.scale_log2e, TR::to_f32(b4[t]) * P.bias_mul);
                 }
             }
         }
@@ -250,7 +250,7 @@ __global__ __launch_bounds__(AT_THREADS) void k_attention_fwd(AttnParams P)
     }
 }
 
-DS_API int ds_attention_fwd(ds_ctx *ctx, const void *qk, const void *vt, const void *bias, void *out,
+DS_API int ds_attention_fwd(ds_ctx *ctx, const void *qk, const void *vt, const void *bias, int bias_in_log2_units, void *out,
                             int B, int Np, int H, int n_valid, float scale, int dtype, void *stream)
 {
     DS_REQUIRE(ctx && qk && vt && out, DS_EINVAL, "ds_attention_fwd: null argument");
@@ -264,8 +264,8 @@ DS_API int ds_attention_fwd(ds_ctx *ctx, const void *qk, const void *vt, const v
     AttnParams P;
     P.qk = qk; P.vt = vt; P.bias = bias; P.out = out;
     P.B = B; P.Np = Np; P.H = H; P.n_valid = n_valid;
-    P.log2e = 1.4426950408889634f;
-    P.scale_log2e = scale * P.log2e;
+    P.bias_mul = bias_in_log2_units ? 1.0f : 1.4426950408889634f;
+    P.scale_log2e = scale * 1.4426950408889634f;
     dim3 grid((Np + AT_QB - 1) / AT_QB, H, B);
     hipStream_t st = (hipStream_t)stream;
     if (dtype == DS_DTYPE_F16) {

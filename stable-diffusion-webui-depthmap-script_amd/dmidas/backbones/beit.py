@@ -118,7 +118,8 @@ class Block(vm.EncoderBlock):
             bias = self.rel_pos_bias(tuple(grid_hw))                                     # H, N, N (query, key)
             n = bias.shape[-1]
             bt = torch.zeros((bias.shape[0], n_pad, n_pad), dtype=dtype, device=device)
-            bt[:, :n, :n] = bias.to(dtype)
+            # half-precision operand of the HIP kernel: stored in log2 units (see vit_mi355x.fused_attention)
+            bt[:, :n, :n] = (bias.float() * vm.LOG2E).to(dtype) if dtype != torch.float32 else bias
         self._bias_cache.clear()
         self._bias_cache[key] = bt
         return bt

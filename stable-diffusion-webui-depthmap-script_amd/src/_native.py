@@ -61,7 +61,7 @@ def lib():
             L.ds_depth_to_u16.argtypes = [vp, vp, ci, ci, ci, ci, vp, vp, vp]
             L.ds_convert_to_i16.argtypes = [vp, vp, ci, i64, vp, vp]
             L.ds_stereo_last_stats.argtypes = [vp, ctypes.POINTER(i64), vp]
-            L.ds_attention_fwd.argtypes = [vp, vp, vp, vp, vp, ci, ci, ci, ci, ctypes.c_float, ci, vp]
+            L.ds_attention_fwd.argtypes = [vp, vp, vp, vp, ci, vp, ci, ci, ci, ci, ctypes.c_float, ci, vp]
             L.ds_residual_layernorm.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, i64, ci, ctypes.c_float, ci, vp]
             L.ds_boost_blend.argtypes = [vp, vp, i64, ci, ci, vp, ci, vp, ci, vp, ci, vp]
             L.ds_upsample_bilinear_nhwc.argtypes = [vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, vp]
@@ -238,9 +238,10 @@ def convert_to_i16(arr):
     return out
 
 
-def attention_fwd(qk, vt, n_valid, scale, bias=None):
+def attention_fwd(qk, vt, n_valid, scale, bias=None, bias_log2=False):
     """Fused MFMA attention (include/depthstereo.h: ds_attention_fwd).  qk [B,Np,2,H,64], vt [B,H*64,Np], float16 or
-    bfloat16 CUDA tensors; bias [H,Np(query),Np(key)] or None.  Returns [B,Np,H*64]."""
+    bfloat16 CUDA tensors; bias [H,Np(query),Np(key)] or None (bias_log2: it already holds bias * log2(e)).
+    Returns [B,Np,H*64]."""
     torch = require_gpu()
     assert qk.is_cuda and vt.is_cuda and qk.dtype == vt.dtype and qk.dtype in (torch.float16, torch.bfloat16)
     b, npad, two, h, d = qk.shape
@@ -253,7 +254,7 @@ def attention_fwd(qk, vt, n_valid, scale, bias=None):
     out = torch.empty((b, npad, h * 64), dtype=qk.dtype, device=qk.device)
     dt = 1 if qk.dtype == torch.float16 else 2
     _check(lib().ds_attention_fwd(ctx_for(_dev_index(qk)), qk.data_ptr(), vt.data_ptr(),
-                                  bias.data_ptr() if bias is not None else None, out.data_ptr(),
+                                  bias.data_ptr() if bias is not None else None, 1 if bias_log2 else 0, out.data_ptr(),
                                   b, npad, h, int(n_valid), float(scale), dt, _stream(qk)))
     return out
 

@@ -85,12 +85,16 @@ def folded_proj_bias(proj, b_v):
     return out
 
 
+LOG2E = 1.4426950408889634
+
+
 def fused_attention(qk, vt, n_valid, scale, bias=None):
-    """bias: additive logits bias [H, Np(query), Np(key)] or None."""
+    """bias: additive logits bias [H, Np(query), Np(key)] or None.  Half-precision bias operands are cached by the blocks
+    in log2 units (bias * log2 e: the kernel works in the exp2 domain), float32 ones in natural units."""
     if qk.dtype == torch.float32:
         return attention_reference(qk, vt, n_valid, scale, bias)
     from . import _native
-    return _native.attention_fwd(qk, vt, n_valid, scale, bias)
+    return _native.attention_fwd(qk, vt, n_valid, scale, bias, bias_log2=bias is not None)
 
 
 class EncoderBlock(nn.Module):

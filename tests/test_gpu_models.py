@@ -34,6 +34,10 @@ def test_attention_kernel_matches_definition(gpu, dtype, with_bias):
         qk, vt, bias, npad = _case(b, n_valid, h, dtype, seed, with_bias)
         got = _native.attention_fwd(qk, vt, n_valid, 0.125, bias)
         want = vm.attention_reference(qk.float(), vt.float(), n_valid, 0.125, None if bias is None else bias.float())
+        if bias is not None:        # the same bias handed over in log2 units
+            got2 = _native.attention_fwd(qk, vt, n_valid, 0.125, (bias.float() * vm.LOG2E).to(dtype), bias_log2=True)
+            # the rescaled bias is rounded once more to the operand type (11 / 8 bit mantissa on values of a few units)
+            assert (got2.float()[:, :n_valid] - want[:, :n_valid]).abs().max().item() < (5e-3 if dtype == torch.float16 else 8e-2)
         err = (got.float()[:, :n_valid] - want[:, :n_valid]).abs().max().item()
         tol = 2e-3 if dtype == torch.float16 else 1.6e-2       # P and the output are rounded to the 11 / 8 bit mantissa
         assert err < tol, (dtype, with_bias, b, n_valid, h, err)
