@@ -301,6 +301,23 @@ def depth_normalize01(raw_prediction, invert=False):
     return out
 
 
+def depth_postprocess(raw_prediction, invert=False, clipdepth=False, clipdepth_mode='Range', far=0.0, near=1.0):
+    """core.py:189-206 with the clipping branches (:196-201), plain numpy (NumPy >= 2 promotion rules: the float64
+    percentile bounds of 'Outliers' promote the float32 prediction to float64; the python-float bounds of 'Range' do not)."""
+    raw = np.asarray(raw_prediction)
+    if not abs(raw.max() - raw.min()) > np.finfo("float").eps:
+        return np.zeros(raw.shape)
+    d = -raw if invert else raw.copy()
+    if clipdepth and clipdepth_mode == 'Range':
+        lo, hi = d.min(), d.max()
+        d = np.clip((d - lo) / (hi - lo), far, near)
+    elif clipdepth and clipdepth_mode == 'Outliers':
+        bounds = np.percentile(d, [far * 100.0, near * 100.0])
+        d = np.clip(d, bounds[0], bounds[1])
+    lo, hi = d.min(), d.max()
+    return (d - lo) / (hi - lo)
+
+
 def num_threads():
     return int(lib().orc_num_threads())
 

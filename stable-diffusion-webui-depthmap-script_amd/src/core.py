@@ -121,8 +121,12 @@ def _postprocess_prediction(pred, invert, inp):
         if inp[go.CLIPDEPTH_MODE] == 'Range':
             out = (out - out.min()) / (out.max() - out.min())
             out = torch.clamp(out, min=float(inp[go.CLIPDEPTH_FAR]), max=float(inp[go.CLIPDEPTH_NEAR]))
-        elif inp[go.CLIPDEPTH_MODE] == 'Outliers':
-            raise NotImplementedError("CLIPDEPTH_MODE 'Outliers' (np.percentile clipping, core.py:200-202) is not built yet")
+        elif inp[go.CLIPDEPTH_MODE] == 'Outliers':                                              # :199-201
+            # np.percentile on the device: exact order statistics by bisection on the float32 bit pattern, numpy's
+            # linear interpolation; np.clip(float32 array, float64 bounds) promotes to float64 (NumPy >= 2)
+            from .video_mode import _global_percentiles
+            fb, nb = _global_percentiles(out, [float(inp[go.CLIPDEPTH_FAR]) * 100.0, float(inp[go.CLIPDEPTH_NEAR]) * 100.0], None)
+            out = torch.clamp(out.double(), min=fb, max=nb)
     return out, prediction_copy, False
 
 
@@ -177,7 +181,11 @@ def core_generation_funnel(outpath, inputimages, inputdepthmaps, inputnames, inp
                     if not broken:
                         if inp[go.DO_OUTPUT_DEPTH_PREDICTION]:
                             yield count, 'depth_prediction', prediction_copy.cpu().numpy().copy()
-                        img_output_t = _native.depth_to_u16(out_t.to(torch.float32).unsqueeze(0), False)[0]   # :203,:211
+                        if out_t.dtype == torch.float64:                                        # 'Outliers': numpy promoted
+                            out_t = (out_t - out_t.min()) / (out_t.max() - out_t.min())                 # :202
+                            img_output_t = _native.convert_to_i16(out_t.contiguous())                   # :211
+                        else:
+                            img_output_t = _native.depth_to_u16(out_t.to(torch.float32).unsqueeze(0), False)[0]   # :202,:211
                     else:
                         img_output_t = torch.zeros(pred_t.shape, dtype=torch.uint16, device=device)          # :206
 

@@ -93,9 +93,12 @@ def _global_percentiles(local, qs, group):
         frac = pos - i0
         v0 = _key_to_f32(_kth_smallest(keys, i0, group))
         v1 = _key_to_f32(_kth_smallest(keys, min(i0 + 1, n - 1), group)) if frac > 0 else v0
-        # numpy (>= 1.22, method='linear') evaluates the lerp in the dtype of the data promoted with the weights
+        # numpy (>= 1.22, method='linear'; lib/_function_base_impl._lerp): the difference of the two order statistics is
+        # taken in the dtype of the data (float32), the product with the float64 weight and the sum in float64, and from the
+        # right end when the weight is >= 0.5
+        d = np.float64(np.float32(v1) - np.float32(v0))
         v0, v1 = np.float64(v0), np.float64(v1)
-        out.append(float(v0 + (v1 - v0) * frac))
+        out.append(float(v1 - d * (1 - frac)) if frac >= 0.5 else float(v0 + d * frac))
     return out
 
 

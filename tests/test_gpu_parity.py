@@ -249,6 +249,14 @@ def test_funnel_model_branch_with_registered_predictor(gpu, oracle):
         sbs = oracle.create_stereoimages_arrays(img, d16, 2.5, 0.0, ['left-right'], 0.0, 1.0, 'polylines_sharp')[0]
         assert np.array_equal(np.asarray(got[1][2]), sbs)
         assert np.array_equal(np.asarray(got[2][2]), oracle.create_normalmap_array(d16))
+    for opts in ({'clipdepth': True, 'clipdepth_mode': 'Range', 'clipdepth_far': 0.1, 'clipdepth_near': 0.8},
+                 {'clipdepth': True, 'clipdepth_mode': 'Outliers', 'clipdepth_far': 0.02, 'clipdepth_near': 0.97},
+                 {'clipdepth': True, 'clipdepth_mode': 'Outliers', 'clipdepth_far': 0.0, 'clipdepth_near': 0.6}):
+        for mt, inv in ((4, False), (0, True)):                                                  # core.py:196-201
+            got = list(core.core_generation_funnel(None, [Image.fromarray(img)], None, None, dict(opts, model_type=mt)))
+            want = oracle.convert_to_i16(oracle.depth_postprocess(pred, inv, True, opts['clipdepth_mode'],
+                                                                  opts['clipdepth_far'], opts['clipdepth_near']))
+            assert [k for _, k, _ in got] == ['depth'] and np.array_equal(np.asarray(got[0][2]), want), opts
     with pytest.raises(NotImplementedError):        # midas_v21 (id 5): a family that is not built
         list(core.core_generation_funnel(None, [Image.fromarray(img)], None, None, {'model_type': 5}))
     with pytest.raises(FileNotFoundError):          # dpt_beit_large_512 (id 1) is built, but there is no checkpoint offline

@@ -108,3 +108,22 @@ def test_video_normalisation_sharded_equals_single_process(tmp_path, mode, world
     assert np.allclose(got, want, rtol=1e-6, atol=1e-7), float(np.abs(got - want).max())
     if mode == "none":
         assert np.array_equal(got.astype(np.float32), want.astype(np.float32))
+
+
+def test_percentiles_match_numpy_single_process():
+    """video_mode._global_percentiles (also behind CLIPDEPTH_MODE 'Outliers', core.py:199-201) against np.percentile:
+    float32 data, both halves of numpy's two-sided lerp, ties, negative values, tiny and odd sizes."""
+    import torch
+    from src import video_mode as vm
+    rng = np.random.default_rng(11)
+    for n in (1, 2, 3, 17, 1000, 4099):
+        for kind in range(3):
+            a = rng.standard_normal(n).astype(np.float32)
+            if kind == 1:
+                a = np.round(a * 4) / 4                     # many ties
+            if kind == 2:
+                a = np.abs(a) * 1e-3
+            qs = [0.0, 0.5, 2.0, 33.3, 50.0, 60.0, 97.0, 99.5, 100.0]
+            got = vm._global_percentiles(torch.from_numpy(a), qs, None)
+            want = np.percentile(a, qs)
+            assert np.array_equal(np.asarray(got), want), (n, kind, got, want)
