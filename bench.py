@@ -151,6 +151,9 @@ def main():
     ap.add_argument("--depth", default="steps", choices=["steps", "smooth"],
                     help="--model none only: synthetic prediction with steps + occluders (default), or smooth only")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--tune-gemms", default=None, metavar="CSV",
+                    help="run with TunableOp tuning ON and accumulate the winners in CSV (maintenance: regenerates "
+                         "src/tunableop_gfx950.csv); the default run only READS the shipped file")
     ap.add_argument("--cpu-sample", type=int, default=4, help="distinct units of the CPU baseline sample")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="minimum wall time of the CPU baseline leg")
     args = ap.parse_args()
@@ -180,6 +183,11 @@ def main():
     nat.profile_enable(local_rank, True)
     model, minfo = (None, None)
     if args.model != "none":
+        from src import gemm_tuning
+        if args.tune_gemms:
+            gemm_tuning.enable(tune=True, results=os.path.abspath(args.tune_gemms))
+        else:
+            gemm_tuning.enable()
         model, minfo = build_model(args.model)
         model = model.to(dev).half()                       # the reference's default on a GPU (depthmap_generation.py:268-275)
 

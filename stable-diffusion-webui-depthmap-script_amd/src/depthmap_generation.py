@@ -151,6 +151,8 @@ class ModelHolder:
         if model_type in self._predictors:
             self.depth_model = self._predictors[model_type]
         elif model_type in _BUILDERS:
+            from . import gemm_tuning
+            gemm_tuning.enable()                      # tuned hipBLASLt / rocBLAS solutions for the transformer linears
             if self.depth_model is None or self.depth_model_type != model_type or not isinstance(self.depth_model, _NetPredictor):
                 # Boost never runs a MiDaS/LeReS base network in half precision (reference :271); DA-V2 stays half (:273-275)
                 self.depth_model = _NetPredictor(model_type, device, self.model_dir, self.allow_random_init,
