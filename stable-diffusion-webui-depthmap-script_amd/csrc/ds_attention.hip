@@ -26,6 +26,8 @@
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 #define AT_THREADS 256
 #define AT_QW 32                 // query rows per wave
@@ -55,12 +57,14 @@ struct AttnParams {
     const void *qk, *vt, *bias;
     void *out;
     int B, Np, H, n_valid;
-    float scale_log2e;           // softmax scale * log2(e): logits are kept in the exp2 domain
-    float bias_mul;              // log2(e), or 1 when the caller already stores the bias in log2 units
+    int nq, total, chunk;        // query blocks per (b,h); B*H*nq; ceil(total / 8) (XCD-aware work order, see the kernel)
+    float k_logit;               // bias: scale*log2(e)/c_exp, the factor of the raw accumulator in  x = s*k_logit + bias
+    float c_exp;                 // factor inside the exponent, p = exp2((x - max x)*c_exp): scale*log2(e) without a bias;
+                                 // with one, 1 when the caller stores it in log2 units, else log2(e)
 };
 
 template <int BF16, int HAS_BIAS>
-__global__ __launch_bounds__(AT_THREADS) void k_attention_fwd(AttnParams P)
+__global__ __launch_bounds__(AT_THREADS, 3) void k_attention_fwd(AttnParams P)
 {
     typedef at_traits<BF16> TR;
     typedef typename TR::T T;
@@ -70,7 +74,17 @@ __global__ __launch_bounds__(AT_THREADS) void k_attention_fwd(AttnParams P)
     __shared__ __attribute__((aligned(16))) unsigned char s_b[HAS_BIAS ? AT_QB * AT_VROW : 16];   // [query][64 keys], padded rows
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, hi = lane >> 5, l31 = lane & 31;
-    const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * AT_QB + wave * AT_QW;
+    // Work order.  Workgroups are dealt round-robin to the 8 XCDs (id & 7), each with its own 4 MB L2.  Work items are
+    // numbered head-major, L = (h*B + b)*nq + qblock, and XCD j takes the contiguous range [j*chunk, (j+1)*chunk) in order:
+    // the query blocks of one (b, h) -- which all stream the same K / V^T -- run on ONE L2 at the same time, and a head's
+    // bias table (2.4 MB at 1088 tokens) is read by one XCD only.  With chunk == 0 the launch falls back to the plain order.
+    int L = blockIdx.x;
+    if (P.chunk > 0) {
+        L = (int)(blockIdx.x & 7) * P.chunk + (int)(blockIdx.x >> 3);
+        if (L >= P.total) return;                              // grid = 8*chunk >= total: the tail of the last XCD's range
+    }
+    const int qblk = L % P.nq, bh = L / P.nq;
+    const int b = bh % P.B, h = bh / P.B, q0 = qblk * AT_QB + wave * AT_QW;
     const int Np = P.Np, H = P.H;
     const size_t tok_stride = (size_t)2 * H * AT_D;                                   // elements between tokens in qk
     const T *qk = (const T *)P.qk + (size_t)b * Np * tok_stride;
@@ -97,26 +111,38 @@ __global__ __launch_bounds__(AT_THREADS) void k_attention_fwd(AttnParams P)
 
     // staging assignment: K tile = 64 rows x 8 chunks of 16 B; V^T tile = 64 rows x 8 chunks: 512 chunks each, 2 per thread
     const int st_row = tid >> 3, st_chunk = tid & 7;                                  // rows st_row and st_row + 32
-    uint4 kreg0, kreg1, vreg0, vreg1;
-    uint4 breg[HAS_BIAS ? 4 : 1];
-    const T *bias_base = nullptr;
-    if (HAS_BIAS) bias_base = (const T *)P.bias + (size_t)h * Np * (size_t)Np;
-    const int q0wg = blockIdx.x * AT_QB;
+    // Tile fetches go through buffer descriptors: the per-lane part of every address is ONE loop-invariant 32-bit byte
+    // offset per operand, the tile / row-group part a scalar offset -- no 64-bit address arithmetic in the loop.
+    // Rows of the bias tile beyond the padded sequence (query blocks that overhang Np) are not clamped: they belong to
+    // waves that never store, and the descriptor's range check returns zeros past the end of the table.
+    u32x4 kreg0, kreg1, vreg0, vreg1;
+    u32x4 breg[HAS_BIAS ? 4 : 1];
+    const int q0wg = qblk * AT_QB;
+    const __amdgpu_buffer_rsrc_t rs_k = __builtin_amdgcn_make_buffer_rsrc(
+        (void *)k_base, 0, (int)(((size_t)Np * tok_stride - (size_t)(H + h) * AT_D) * sizeof(T)), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_v = __builtin_amdgcn_make_buffer_rsrc((void *)vt, 0, (int)((size_t)AT_D * Np * sizeof(T)), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc(
+        (void *)(HAS_BIAS ? (const T *)P.bias + (size_t)h * Np * (size_t)Np : (const T *)P.qk), 0,
+        (int)((size_t)Np * Np * sizeof(T)), 0x00020000);
+    const int vo_k = (int)((st_row * tok_stride + 8 * st_chunk) * sizeof(T));
+    const int vo_v = (int)((st_row * Np + 8 * st_chunk) * sizeof(T));
+    const int vo_b = (int)((((size_t)q0wg + st_row) * Np + 8 * st_chunk) * sizeof(T));
+    const int so_k32 = (int)(32 * tok_stride * sizeof(T)), so_r32 = (int)(32 * Np * sizeof(T));
 #define AT_FETCH(kt_) do {                                                                                             \
         const int key0_ = (kt_) * AT_KB;                                                                                \
-        kreg0 = *reinterpret_cast<const uint4 *>(k_base + (size_t)(key0_ + st_row) * tok_stride + 8 * st_chunk);        \
-        kreg1 = *reinterpret_cast<const uint4 *>(k_base + (size_t)(key0_ + st_row + 32) * tok_stride + 8 * st_chunk);   \
-        vreg0 = *reinterpret_cast<const uint4 *>(vt + (size_t)st_row * Np + key0_ + 8 * st_chunk);                      \
-        vreg1 = *reinterpret_cast<const uint4 *>(vt + (size_t)(st_row + 32) * Np + key0_ + 8 * st_chunk);               \
+        const int sk_ = __builtin_amdgcn_readfirstlane(key0_ * (int)(tok_stride * sizeof(T)));  /* provably scalar */    \
+        const int sv_ = __builtin_amdgcn_readfirstlane(key0_ * (int)sizeof(T));                                         \
+        kreg0 = __builtin_amdgcn_raw_buffer_load_b128(rs_k, vo_k, sk_, 0);                                              \
+        kreg1 = __builtin_amdgcn_raw_buffer_load_b128(rs_k, vo_k, sk_ + so_k32, 0);                                     \
+        vreg0 = __builtin_amdgcn_raw_buffer_load_b128(rs_v, vo_v, sv_, 0);                                              \
+        vreg1 = __builtin_amdgcn_raw_buffer_load_b128(rs_v, vo_v, sv_ + so_r32, 0);                                     \
         if (HAS_BIAS) {                                                                                                  \
-            _Pragma("unroll") for (int p_ = 0; p_ < 4; p_++) {                                                          \
-                const int qr_ = min(q0wg + st_row + 32 * p_, Np - 1);                                                   \
-                breg[p_] = *reinterpret_cast<const uint4 *>(bias_base + (size_t)qr_ * Np + key0_ + 8 * st_chunk);       \
-            }                                                                                                            \
+            _Pragma("unroll") for (int p_ = 0; p_ < 4; p_++)                                                            \
+                breg[p_] = __builtin_amdgcn_raw_buffer_load_b128(rs_b, vo_b, sv_ + p_ * so_r32, 0);                     \
         }                                                                                                                \
     } while (0)
 #define AT_STASH1(row_, kr_, vr_) do {                                                                                  \
-        *reinterpret_cast<uint4 *>(s_k + (row_) * 128 + ((st_chunk ^ ((row_) & 7)) << 4)) = kr_;                        \
+        *reinterpret_cast<u32x4 *>(s_k + (row_) * 128 + ((st_chunk ^ ((row_) & 7)) << 4)) = kr_;                        \
         uint2 *vd_ = reinterpret_cast<uint2 *>(s_v + (row_) * AT_VROW + 16 * st_chunk);                                 \
         vd_[0] = make_uint2(vr_.x, vr_.y);                                                                              \
         vd_[1] = make_uint2(vr_.z, vr_.w);                                                                              \
@@ -154,10 +180,13 @@ __global__ __launch_bounds__(AT_THREADS) void k_attention_fwd(AttnParams P)
             }
         }
         // ---- logits, bias, key mask, running max (exp2 domain) ---------------------------------------------------------
-        // Without a bias the raw accumulators are kept and the softmax scale is folded into the exponent's FMA:
-        // p = exp2(s*c - m*c) with m = max(s) (c > 0 commutes with max).  With a bias the logits are formed first.
+        // x = the value the max runs over; p = exp2(x*c - m*c) with m = max(x) (c > 0 commutes with max).
+        //   no bias:  x = raw accumulator,                 c = scale*log2(e)
+        //   bias:     x = s*(scale*log2e/bmul) + bias,      c = bmul  (1 when the bias is stored in log2 units, else log2 e)
+        // so a logit costs one FMA for the bias (the f16 operand converted in the same instruction where the ISA has
+        // v_fma_mix), half a packed FMA for the exponent's argument, one exp2, half a packed add, half a packed convert.
         const int key0 = kt * AT_KB;
-        const float c_ = HAS_BIAS ? 1.0f : P.scale_log2e;   // factor still to be applied inside the exponent
+        const float c_ = P.c_exp;
         if (HAS_BIAS) {
 #pragma unroll
             for (int kb = 0; kb < 2; kb++) {
@@ -167,12 +196,13 @@ __global__ __launch_bounds__(AT_THREADS) void k_attention_fwd(AttnParams P)
                     const uint2 raw = *reinterpret_cast<const uint2 *>(s_b + (wave * AT_QW + l31) * AT_VROW + 2 * (kb * 32 + 8 * g + 4 * hi));
                     __builtin_memcpy(b4, &raw, 8);
 #pragma unroll
-                    for (int t = 0; t < 4; t++)         // one mixed-precision FMA per logit: s*c + bias (bias already in log2 units)
-                        s_acc[kb][4 * g + t] = fmaf(s_acc[kb][4 * g + t], P.scale_log2e, TR::to_f32(b4[t]) * P.bias_mul);
+                    for (int t = 0; t < 4; t++)
+                        s_acc[kb][4 * g + t] = __builtin_fmaf(s_acc[kb][4 * g + t], P.k_logit, TR::to_f32(b4[t]));
                 }
             }
         }
         if (key0 + AT_KB > P.n_valid) {                     // wave-uniform: only the last tile can hold pad keys
+            asm volatile("; pad-key mask (kept out of the steady-state tiles: not a candidate for if-conversion)" ::: "memory");
 #pragma unroll
             for (int kb = 0; kb < 2; kb++)
 #pragma unroll
@@ -185,25 +215,30 @@ __global__ __launch_bounds__(AT_THREADS) void k_attention_fwd(AttnParams P)
 #pragma unroll
             for (int r = 0; r < 16; r++) m_loc = fmaxf(m_loc, s_acc[kb][r]);
         m_loc = fmaxf(m_loc, __shfl_xor(m_loc, 32, 64));    // the other half of this query's keys
-        const float m_new = fmaxf(m_run, m_loc);            // running max of the RAW values when c_ != 1
+        const float m_new = fmaxf(m_run, m_loc);
         const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c_);   // first tile: exp2(-inf) = 0
         m_run = m_new;
-        const float mc = m_new * c_;
-        float l_loc = 0.f;
-        // ---- P = exp2(S*c - m*c); P^T fragments for the four 16-key slices: registers 8j..8j+7 of key block kb ------
+        const f32x2 c2 = {c_, c_};
+        const f32x2 mc2 = {-m_new * c_, -m_new * c_};
+        f32x2 l2 = {0.f, 0.f};
+        // ---- P = exp2(x*c - m*c); P^T fragments for the four 16-key slices: registers 8j..8j+7 of key block kb -------
         V8 pf[2][2];
 #pragma unroll
         for (int kb = 0; kb < 2; kb++) {
 #pragma unroll
             for (int j = 0; j < 2; j++) {
 #pragma unroll
-                for (int t = 0; t < 8; t++) {
-                    const float p = __builtin_amdgcn_exp2f(fmaf(s_acc[kb][8 * j + t], c_, -mc));
-                    l_loc += p;
-                    pf[kb][j][t] = TR::from_f32(p);
+                for (int t = 0; t < 8; t += 2) {
+                    const f32x2 x2 = {s_acc[kb][8 * j + t], s_acc[kb][8 * j + t + 1]};
+                    const f32x2 a2 = __builtin_elementwise_fma(x2, c2, mc2);
+                    const f32x2 p2 = {__builtin_amdgcn_exp2f(a2[0]), __builtin_amdgcn_exp2f(a2[1])};
+                    l2 += p2;
+                    pf[kb][j][t] = TR::from_f32(p2[0]);
+                    pf[kb][j][t + 1] = TR::from_f32(p2[1]);
                 }
             }
         }
+        const float l_loc = l2[0] + l2[1];
         l_run = l_run * alpha + l_loc;
         if (!__all(alpha == 1.0f)) {                         // the running max moved for some query of this wave
 #pragma unroll
@@ -257,16 +292,21 @@ DS_API int ds_attention_fwd(ds_ctx *ctx, const void *qk, const void *vt, const v
     DS_REQUIRE(B > 0 && H > 0 && Np > 0 && (Np % 64) == 0, DS_EINVAL, "ds_attention_fwd: Np must be a positive multiple of 64 (got %d)", Np);
     DS_REQUIRE(n_valid > 0 && n_valid <= Np, DS_EINVAL, "ds_attention_fwd: n_valid %d outside 1..%d", n_valid, Np);
     DS_REQUIRE(dtype == DS_DTYPE_F16 || dtype == DS_DTYPE_BF16, DS_EINVAL, "ds_attention_fwd: dtype must be f16 or bf16");
-    DS_REQUIRE(H <= 65535 && B <= 65535, DS_EUNSUPPORTED, "ds_attention_fwd: batch/heads too large for the grid");
+    DS_REQUIRE((long long)B * H * ((Np + AT_QB - 1) / AT_QB) < (1ll << 30), DS_EUNSUPPORTED, "ds_attention_fwd: batch x heads too large for the grid");
     DS_REQUIRE(((uintptr_t)qk & 15) == 0 && ((uintptr_t)vt & 15) == 0 && ((uintptr_t)out & 7) == 0 && ((uintptr_t)bias & 15) == 0, DS_EINVAL,
                "ds_attention_fwd: operands must be 16-byte aligned");
     DS_HIP_CHECK(hipSetDevice(ctx->device));
     AttnParams P;
     P.qk = qk; P.vt = vt; P.bias = bias; P.out = out;
     P.B = B; P.Np = Np; P.H = H; P.n_valid = n_valid;
-    P.bias_mul = bias_in_log2_units ? 1.0f : 1.4426950408889634f;
-    P.scale_log2e = scale * 1.4426950408889634f;
-    dim3 grid((Np + AT_QB - 1) / AT_QB, H, B);
+    const float log2e = 1.4426950408889634f;
+    P.c_exp = bias ? (bias_in_log2_units ? 1.0f : log2e) : scale * log2e;
+    P.k_logit = scale * log2e / P.c_exp;
+    P.nq = (Np + AT_QB - 1) / AT_QB;
+    P.total = P.nq * H * B;
+    static const int plain_order = getenv("DS_ATT_PLAIN_ORDER") ? atoi(getenv("DS_ATT_PLAIN_ORDER")) : 0;   // A/B switch
+    P.chunk = plain_order ? 0 : (P.total + 7) / 8;
+    dim3 grid(plain_order ? P.total : 8 * P.chunk);
     hipStream_t st = (hipStream_t)stream;
     if (dtype == DS_DTYPE_F16) {
         if (bias) hipLaunchKernelGGL((k_attention_fwd<0, 1>), grid, dim3(AT_THREADS), 0, st, P);
