@@ -248,14 +248,14 @@ def main():
         vt = torch.randn(args.batch, minfo["heads"] * 64, npad, device=dev, dtype=torch.float16)
         bias = None
         if args.model == "dpt_beit_large_512":
-            bias = torch.randn(minfo["heads"], npad, npad, device=dev, dtype=torch.float16)
+            bias = nat.attention_bias_pack(torch.randn(minfo["heads"], n_tok, n_tok, device=dev), npad, torch.float16)
         for _ in range(3):
-            nat.attention_fwd(qk, vt, n_tok, 0.125, bias, bias_log2=bias is not None)
+            nat.attention_fwd(qk, vt, n_tok, 0.125, bias)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         reps = 20
         e0.record()
         for _ in range(reps):
-            nat.attention_fwd(qk, vt, n_tok, 0.125, bias, bias_log2=bias is not None)
+            nat.attention_fwd(qk, vt, n_tok, 0.125, bias)
         e1.record()
         e1.synchronize()
         attn_ms = e0.elapsed_time(e1) / reps

@@ -155,14 +155,24 @@ int ds_convert_to_i16(ds_ctx *ctx, const void *arr, int is_f64, int64_t count, u
  * :65-82) and of dmidas/backbones/beit.py:65-91 (attention_forward with relative position bias); head_dim = 64.
  *   qk      [B, Np, 2, H, 64]  Q (index 0) and K (index 1), token major, as the projection GEMM writes them
  *   vt      [B, H*64, Np]      V transposed (key index contiguous)
- *   bias    [H, Np, Np] or NULL: additive logits bias, bias[h][query][key] (rows/columns >= n_valid are ignored);
- *           bias_in_log2_units != 0: the caller stores bias * log2(e) (saves one multiply per logit)
+ *   bias_packed  NULL, or the operand made by ds_attention_bias_pack for this (H, Np) in the same dtype
  *   out     [B, Np, H*64]
  * Np is a multiple of 64 (the padded token count); keys >= n_valid are masked; query rows >= n_valid are computed
  * like any other row (they stay finite) and are never read as keys.  scale multiplies q.k before the bias is added.
  */
-int ds_attention_fwd(ds_ctx *ctx, const void *qk, const void *vt, const void *bias, int bias_in_log2_units, void *out,
+int ds_attention_fwd(ds_ctx *ctx, const void *qk, const void *vt, const void *bias_packed, void *out,
                      int B, int Np, int H, int n_valid, float scale, int dtype, void *stream);
+
+/*
+ * ds_attention_bias_pack -- prepares the additive logits bias of ds_attention_fwd (the relative position bias of
+ * dmidas/backbones/beit.py:29-62,84-88: bias[h][query][key], one table per block, constant per input resolution).
+ *   bias    [H, n, n] float32, natural units (what the reference adds to q.k*scale)
+ *   packed  H*Np*Np elements of dtype: the same values times log2(e) (the kernel works in the exp2 domain), zero padded
+ *           to Np x Np and reordered to [H][Np/32 query blocks][Np/64 key tiles][4][64 lanes][8] -- the register order of
+ *           the kernel's logits tile, so that a wave reads its 32 x 64 bias tile with four coalesced 16-byte loads.
+ * Run once per (block, resolution); the packed operand is reused by every forward.
+ */
+int ds_attention_bias_pack(ds_ctx *ctx, const float *bias, int H, int n, int Np, int dtype, void *packed, void *stream);
 
 /*
  * ds_residual_layernorm -- the element-wise part of a transformer block between two GEMMs, fused:

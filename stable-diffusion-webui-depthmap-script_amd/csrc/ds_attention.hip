@@ -57,10 +57,11 @@ struct AttnParams {
     const void *qk, *vt, *bias;
     void *out;
     int B, Np, H, n_valid;
+    int flags;                   // bit 0: raise the wave priority around the MFMA clusters (experiment switch)
     int nq, total, chunk;        // query blocks per (b,h); B*H*nq; ceil(total / 8) (XCD-aware work order, see the kernel)
-    float k_logit;               // bias: scale*log2(e)/c_exp, the factor of the raw accumulator in  x = s*k_logit + bias
-    float c_exp;                 // factor inside the exponent, p = exp2((x - max x)*c_exp): scale*log2(e) without a bias;
-                                 // with one, 1 when the caller stores it in log2 units, else log2(e)
+    float k_logit;               // scale*log2(e): with a bias, the factor of the raw accumulator in  x = s*k_logit + bias
+    float c_exp;                 // factor inside the exponent, p = exp2((x - max x)*c_exp): scale*log2(e) without a bias,
+                                 // 1 with one (the packed bias is in log2 units)
 };
 
 template <int BF16, int HAS_BIAS>
@@ -69,9 +70,9 @@ __global__ __launch_bounds__(AT_THREADS, 3) void k_attention_fwd(AttnParams P)
     typedef at_traits<BF16> TR;
     typedef typename TR::T T;
     typedef typename TR::V8 V8;
-    __shared__ __attribute__((aligned(16))) unsigned char s_k[AT_KB * 128];          // [key][64 d], chunk-swizzled
-    __shared__ __attribute__((aligned(16))) unsigned char s_v[AT_D * AT_VROW];       // [d][64 keys], padded rows
-    __shared__ __attribute__((aligned(16))) unsigned char s_b[HAS_BIAS ? AT_QB * AT_VROW : 16];   // [query][64 keys], padded rows
+    // two tile buffers: tile t+1 is stashed while tile t is still being read -> ONE barrier per tile
+    __shared__ __attribute__((aligned(16))) unsigned char s_kbuf[2][AT_KB * 128];    // [key][64 d], chunk-swizzled
+    __shared__ __attribute__((aligned(16))) unsigned char s_vbuf[2][AT_D * AT_VROW]; // [d][64 keys], padded rows
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, hi = lane >> 5, l31 = lane & 31;
     // Work order.  Workgroups are dealt round-robin to the 8 XCDs (id & 7), each with its own 4 MB L2.  Work items are
@@ -112,21 +113,13 @@ __global__ __launch_bounds__(AT_THREADS, 3) void k_attention_fwd(AttnParams P)
     // staging assignment: K tile = 64 rows x 8 chunks of 16 B; V^T tile = 64 rows x 8 chunks: 512 chunks each, 2 per thread
     const int st_row = tid >> 3, st_chunk = tid & 7;                                  // rows st_row and st_row + 32
     // Tile fetches go through buffer descriptors: the per-lane part of every address is ONE loop-invariant 32-bit byte
-    // offset per operand, the tile / row-group part a scalar offset -- no 64-bit address arithmetic in the loop.
-    // Rows of the bias tile beyond the padded sequence (query blocks that overhang Np) are not clamped: they belong to
-    // waves that never store, and the descriptor's range check returns zeros past the end of the table.
+    // offset per operand, the tile part a scalar offset -- no 64-bit address arithmetic in the loop.
     u32x4 kreg0, kreg1, vreg0, vreg1;
-    u32x4 breg[HAS_BIAS ? 4 : 1];
-    const int q0wg = qblk * AT_QB;
     const __amdgpu_buffer_rsrc_t rs_k = __builtin_amdgcn_make_buffer_rsrc(
         (void *)k_base, 0, (int)(((size_t)Np * tok_stride - (size_t)(H + h) * AT_D) * sizeof(T)), 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_v = __builtin_amdgcn_make_buffer_rsrc((void *)vt, 0, (int)((size_t)AT_D * Np * sizeof(T)), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc(
-        (void *)(HAS_BIAS ? (const T *)P.bias + (size_t)h * Np * (size_t)Np : (const T *)P.qk), 0,
-        (int)((size_t)Np * Np * sizeof(T)), 0x00020000);
     const int vo_k = (int)((st_row * tok_stride + 8 * st_chunk) * sizeof(T));
     const int vo_v = (int)((st_row * Np + 8 * st_chunk) * sizeof(T));
-    const int vo_b = (int)((((size_t)q0wg + st_row) * Np + 8 * st_chunk) * sizeof(T));
     const int so_k32 = (int)(32 * tok_stride * sizeof(T)), so_r32 = (int)(32 * Np * sizeof(T));
 #define AT_FETCH(kt_) do {                                                                                             \
         const int key0_ = (kt_) * AT_KB;                                                                                \
@@ -136,38 +129,43 @@ __global__ __launch_bounds__(AT_THREADS, 3) void k_attention_fwd(AttnParams P)
         kreg1 = __builtin_amdgcn_raw_buffer_load_b128(rs_k, vo_k, sk_ + so_k32, 0);                                     \
         vreg0 = __builtin_amdgcn_raw_buffer_load_b128(rs_v, vo_v, sv_, 0);                                              \
         vreg1 = __builtin_amdgcn_raw_buffer_load_b128(rs_v, vo_v, sv_ + so_r32, 0);                                     \
-        if (HAS_BIAS) {                                                                                                  \
-            _Pragma("unroll") for (int p_ = 0; p_ < 4; p_++)                                                            \
-                breg[p_] = __builtin_amdgcn_raw_buffer_load_b128(rs_b, vo_b, sv_ + p_ * so_r32, 0);                     \
-        }                                                                                                                \
     } while (0)
-#define AT_STASH1(row_, kr_, vr_) do {                                                                                  \
-        *reinterpret_cast<u32x4 *>(s_k + (row_) * 128 + ((st_chunk ^ ((row_) & 7)) << 4)) = kr_;                        \
-        uint2 *vd_ = reinterpret_cast<uint2 *>(s_v + (row_) * AT_VROW + 16 * st_chunk);                                 \
+    // Bias: the packed operand (ds_attention_bias_pack) is laid out in the register order of the S^T accumulators,
+    // [head][32-query block][64-key tile][4 chunks][64 lanes][8 values]: a wave's 32 x 64 tile is four fully coalesced
+    // 16-byte loads per lane straight into registers -- no LDS round trip, nothing shared between waves.
+    u32x4 breg[HAS_BIAS ? 4 : 1];
+    const int n_kt = Np / AT_KB;
+    const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc(
+        (void *)(HAS_BIAS ? (const T *)P.bias + (size_t)h * Np * (size_t)Np : (const T *)P.qk), 0,
+        (int)((size_t)Np * Np * sizeof(T)), 0x00020000);
+    const int vo_b = (int)((((size_t)(q0 / AT_QW) * n_kt) * 2048 + (size_t)lane * 8) * sizeof(T));
+#define AT_FETCH_BIAS(kt_) do {                                                                                        \
+        const int sb_ = __builtin_amdgcn_readfirstlane((kt_) * (int)(2048 * sizeof(T)));                                \
+        _Pragma("unroll") for (int c_i = 0; c_i < 4; c_i++)                                                             \
+            breg[c_i] = __builtin_amdgcn_raw_buffer_load_b128(rs_b, vo_b + c_i * 1024, sb_, 0);                         \
+    } while (0)
+#define AT_STASH1(buf_, row_, kr_, vr_) do {                                                                            \
+        *reinterpret_cast<u32x4 *>(s_kbuf[buf_] + (row_) * 128 + ((st_chunk ^ ((row_) & 7)) << 4)) = kr_;               \
+        uint2 *vd_ = reinterpret_cast<uint2 *>(s_vbuf[buf_] + (row_) * AT_VROW + 16 * st_chunk);                        \
         vd_[0] = make_uint2(vr_.x, vr_.y);                                                                              \
         vd_[1] = make_uint2(vr_.z, vr_.w);                                                                              \
     } while (0)
 
     const int ntiles = (P.n_valid + AT_KB - 1) / AT_KB;
     AT_FETCH(0);
+    if (HAS_BIAS && wave_live) AT_FETCH_BIAS(0);
+    AT_STASH1(0, st_row, kreg0, vreg0);
+    AT_STASH1(0, st_row + 32, kreg1, vreg1);
+    __syncthreads();
     for (int kt = 0; kt < ntiles; kt++) {
-        __syncthreads();                                    // everyone is done reading the previous tile
-        AT_STASH1(st_row, kreg0, vreg0);
-        AT_STASH1(st_row + 32, kreg1, vreg1);
-        if (HAS_BIAS) {
-#pragma unroll
-            for (int p = 0; p < 4; p++) {
-                uint2 *bd = reinterpret_cast<uint2 *>(s_b + (st_row + 32 * p) * AT_VROW + 16 * st_chunk);
-                bd[0] = make_uint2(breg[p].x, breg[p].y);
-                bd[1] = make_uint2(breg[p].z, breg[p].w);
-            }
-        }
-        __syncthreads();
-        if (kt + 1 < ntiles) AT_FETCH(kt + 1);              // in flight while this tile is computed
-        if (!wave_live) continue;
-
-        // ---- S^T = K . Q^T for the 64 keys of the tile: 2 key blocks of 32 -----------------------------------
+        const int cur = kt & 1;
+        const unsigned char *s_k = s_kbuf[cur], *s_v = s_vbuf[cur];
+        const bool more = kt + 1 < ntiles;
+        if (more) AT_FETCH(kt + 1);                         // in flight while this tile is computed
         f32x16 s_acc[2];
+        if (wave_live) {
+        // ---- S^T = K . Q^T for the 64 keys of the tile: 2 key blocks of 32 -----------------------------------
+        if (P.flags & 1) __builtin_amdgcn_s_setprio(2);
 #pragma unroll
         for (int kb = 0; kb < 2; kb++) {
 #pragma unroll
@@ -179,6 +177,7 @@ __global__ __launch_bounds__(AT_THREADS, 3) void k_attention_fwd(AttnParams P)
                 s_acc[kb] = TR::mfma(kf, qf[s], s_acc[kb]);
             }
         }
+        if (P.flags & 1) __builtin_amdgcn_s_setprio(0);
         // ---- logits, bias, key mask, running max (exp2 domain) ---------------------------------------------------------
         // x = the value the max runs over; p = exp2(x*c - m*c) with m = max(x) (c > 0 commutes with max).
         //   no bias:  x = raw accumulator,                 c = scale*log2(e)
@@ -189,18 +188,15 @@ __global__ __launch_bounds__(AT_THREADS, 3) void k_attention_fwd(AttnParams P)
         const float c_ = P.c_exp;
         if (HAS_BIAS) {
 #pragma unroll
-            for (int kb = 0; kb < 2; kb++) {
+            for (int c = 0; c < 4; c++) {               // chunk c = accumulator registers 8(c&1) .. +7 of key block c>>1
+                T b8[8];
+                __builtin_memcpy(b8, &breg[c], 16);
 #pragma unroll
-                for (int g = 0; g < 4; g++) {
-                    T b4[4];                        // keys kb*32 + 8g + 4hi + {0..3} of this lane's query row
-                    const uint2 raw = *reinterpret_cast<const uint2 *>(s_b + (wave * AT_QW + l31) * AT_VROW + 2 * (kb * 32 + 8 * g + 4 * hi));
-                    __builtin_memcpy(b4, &raw, 8);
-#pragma unroll
-                    for (int t = 0; t < 4; t++)
-                        s_acc[kb][4 * g + t] = __builtin_fmaf(s_acc[kb][4 * g + t], P.k_logit, TR::to_f32(b4[t]));
-                }
+                for (int t = 0; t < 8; t++)
+                    s_acc[c >> 1][8 * (c & 1) + t] = __builtin_fmaf(s_acc[c >> 1][8 * (c & 1) + t], P.k_logit, TR::to_f32(b8[t]));
             }
-        }
+            if (more) AT_FETCH_BIAS(kt + 1);                // the registers are free again: next tile's bias lands under the
+        }                                                   // softmax / P.V of this one and the S^T of the next
         if (key0 + AT_KB > P.n_valid) {                     // wave-uniform: only the last tile can hold pad keys
             asm volatile("; pad-key mask (kept out of the steady-state tiles: not a candidate for if-conversion)" ::: "memory");
 #pragma unroll
@@ -247,6 +243,7 @@ __global__ __launch_bounds__(AT_THREADS, 3) void k_attention_fwd(AttnParams P)
                 for (int r = 0; r < 16; r++) o_acc[d][r] *= alpha;
         }
         // ---- O^T += V^T . P^T : A = V^T[d][key slots], slot t of half hi = key 16j + (t&3) + 8(t>>2) + 4hi -------
+        if (P.flags & 1) __builtin_amdgcn_s_setprio(2);
 #pragma unroll
         for (int d = 0; d < 2; d++) {
             const unsigned char *vrow = s_v + (d * 32 + l31) * AT_VROW;
@@ -263,6 +260,13 @@ __global__ __launch_bounds__(AT_THREADS, 3) void k_attention_fwd(AttnParams P)
                 }
             }
         }
+        if (P.flags & 1) __builtin_amdgcn_s_setprio(0);
+        }   // wave_live
+        if (more) {
+            AT_STASH1(cur ^ 1, st_row, kreg0, vreg0);
+            AT_STASH1(cur ^ 1, st_row + 32, kreg1, vreg1);
+        }
+        __syncthreads();                                    // tile kt is read, tile kt+1 is in place
     }
     if (!wave_live) return;
 
@@ -285,10 +289,46 @@ __global__ __launch_bounds__(AT_THREADS, 3) void k_attention_fwd(AttnParams P)
     }
 }
 
-DS_API int ds_attention_fwd(ds_ctx *ctx, const void *qk, const void *vt, const void *bias, int bias_in_log2_units, void *out,
+// ---- bias operand: [H, n, n] float32 (natural units) -> packed register order, log2 units, zero padded to Np ----------
+template <int BF16>
+__global__ void k_attention_bias_pack(const float *__restrict__ bias, typename at_traits<BF16>::T *__restrict__ out,
+                                      int H, int n, int Np, float mul)
+{
+    typedef at_traits<BF16> TR;
+    const long long total = (long long)H * Np * Np;
+    const int n_kt = Np / AT_KB, nq32 = Np / AT_QW;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+        const int j = (int)(idx & 7), lane = (int)((idx >> 3) & 63), c = (int)((idx >> 9) & 3);
+        const long long tile = idx >> 11;
+        const int kt = (int)(tile % n_kt), qb = (int)((tile / n_kt) % nq32), h = (int)(tile / ((long long)n_kt * nq32));
+        const int q = qb * AT_QW + (lane & 31);
+        const int k = kt * AT_KB + (c >> 1) * 32 + at_crow(8 * (c & 1) + j, lane >> 5);
+        const float v = (q < n && k < n) ? bias[((size_t)h * n + q) * n + k] * mul : 0.f;
+        out[idx] = TR::from_f32(v);
+    }
+}
+
+DS_API int ds_attention_bias_pack(ds_ctx *ctx, const float *bias, int H, int n, int Np, int dtype, void *packed, void *stream)
+{
+    DS_REQUIRE(ctx && bias && packed, DS_EINVAL, "ds_attention_bias_pack: null argument");
+    DS_REQUIRE(H > 0 && n > 0 && Np >= n && (Np % 64) == 0, DS_EINVAL, "ds_attention_bias_pack: need 0 < n <= Np, Np a multiple of 64 (n %d, Np %d)", n, Np);
+    DS_REQUIRE(dtype == DS_DTYPE_F16 || dtype == DS_DTYPE_BF16, DS_EINVAL, "ds_attention_bias_pack: dtype must be f16 or bf16");
+    DS_HIP_CHECK(hipSetDevice(ctx->device));
+    const long long total = (long long)H * Np * Np;
+    const int blocks = (int)std::min<long long>((total + 255) / 256, 65536);
+    hipStream_t st = (hipStream_t)stream;
+    const float log2e = 1.4426950408889634f;
+    if (dtype == DS_DTYPE_F16) hipLaunchKernelGGL((k_attention_bias_pack<0>), dim3(blocks), dim3(256), 0, st, bias, (_Float16 *)packed, H, n, Np, log2e);
+    else hipLaunchKernelGGL((k_attention_bias_pack<1>), dim3(blocks), dim3(256), 0, st, bias, (__bf16 *)packed, H, n, Np, log2e);
+    DS_HIP_CHECK(hipGetLastError());
+    return DS_OK;
+}
+
+DS_API int ds_attention_fwd(ds_ctx *ctx, const void *qk, const void *vt, const void *bias_packed, void *out,
                             int B, int Np, int H, int n_valid, float scale, int dtype, void *stream)
 {
     DS_REQUIRE(ctx && qk && vt && out, DS_EINVAL, "ds_attention_fwd: null argument");
+    const void *bias = bias_packed;
     DS_REQUIRE(B > 0 && H > 0 && Np > 0 && (Np % 64) == 0, DS_EINVAL, "ds_attention_fwd: Np must be a positive multiple of 64 (got %d)", Np);
     DS_REQUIRE(n_valid > 0 && n_valid <= Np, DS_EINVAL, "ds_attention_fwd: n_valid %d outside 1..%d", n_valid, Np);
     DS_REQUIRE(dtype == DS_DTYPE_F16 || dtype == DS_DTYPE_BF16, DS_EINVAL, "ds_attention_fwd: dtype must be f16 or bf16");
@@ -300,8 +340,10 @@ DS_API int ds_attention_fwd(ds_ctx *ctx, const void *qk, const void *vt, const v
     P.qk = qk; P.vt = vt; P.bias = bias; P.out = out;
     P.B = B; P.Np = Np; P.H = H; P.n_valid = n_valid;
     const float log2e = 1.4426950408889634f;
-    P.c_exp = bias ? (bias_in_log2_units ? 1.0f : log2e) : scale * log2e;
-    P.k_logit = scale * log2e / P.c_exp;
+    P.c_exp = bias ? 1.0f : scale * log2e;                  // the packed bias is in log2 units
+    P.k_logit = scale * log2e;
+    static const int att_flags = getenv("DS_ATT_FLAGS") ? atoi(getenv("DS_ATT_FLAGS")) : 1;   // setprio around the MFMA clusters: +2.5 % with bias
+    P.flags = att_flags;
     P.nq = (Np + AT_QB - 1) / AT_QB;
     P.total = P.nq * H * B;
     static const int plain_order = getenv("DS_ATT_PLAIN_ORDER") ? atoi(getenv("DS_ATT_PLAIN_ORDER")) : 0;   // A/B switch

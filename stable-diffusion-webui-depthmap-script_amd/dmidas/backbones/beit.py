@@ -117,9 +117,12 @@ class Block(vm.EncoderBlock):
         with torch.no_grad():
             bias = self.rel_pos_bias(tuple(grid_hw))                                     # H, N, N (query, key)
             n = bias.shape[-1]
-            bt = torch.zeros((bias.shape[0], n_pad, n_pad), dtype=dtype, device=device)
-            # half-precision operand of the HIP kernel: stored in log2 units (see vit_mi355x.fused_attention)
-            bt[:, :n, :n] = (bias.float() * vm.LOG2E).to(dtype) if dtype != torch.float32 else bias
+            if dtype == torch.float32 or not bias.is_cuda:
+                bt = torch.zeros((bias.shape[0], n_pad, n_pad), dtype=dtype, device=device)
+                bt[:, :n, :n] = bias
+            else:                                   # operand of the HIP kernel (register order, log2 units)
+                from src import _native
+                bt = _native.attention_bias_pack(bias.to(device), n_pad, dtype)
         self._bias_cache.clear()
         self._bias_cache[key] = bt
         return bt

@@ -20,7 +20,7 @@ FILL_IDS = {"none": 0, "naive": 1, "naive_interpolating": 2, "polylines_soft": 3
 EXPORTS = [
     "ds_version", "ds_last_error", "ds_ctx_create", "ds_ctx_destroy", "ds_stereo_warp", "ds_depth_minmax",
     "ds_stereo_last_exact_rows", "ds_copy_view", "ds_overlap_red_cyan", "ds_normalmap", "ds_depth_to_u16",
-    "ds_convert_to_i16", "ds_profile_enable", "ds_profile_last_ms", "ds_stereo_last_stats", "ds_attention_fwd", "ds_residual_layernorm", "ds_boost_blend", "ds_upsample_bilinear_nhwc", "ds_dpt_head_tail",
+    "ds_convert_to_i16", "ds_profile_enable", "ds_profile_last_ms", "ds_stereo_last_stats", "ds_attention_fwd", "ds_attention_bias_pack", "ds_residual_layernorm", "ds_boost_blend", "ds_upsample_bilinear_nhwc", "ds_dpt_head_tail",
 ]
 
 
@@ -61,7 +61,8 @@ def lib():
             L.ds_depth_to_u16.argtypes = [vp, vp, ci, ci, ci, ci, vp, vp, vp]
             L.ds_convert_to_i16.argtypes = [vp, vp, ci, i64, vp, vp]
             L.ds_stereo_last_stats.argtypes = [vp, ctypes.POINTER(i64), vp]
-            L.ds_attention_fwd.argtypes = [vp, vp, vp, vp, ci, vp, ci, ci, ci, ci, ctypes.c_float, ci, vp]
+            L.ds_attention_fwd.argtypes = [vp, vp, vp, vp, vp, ci, ci, ci, ci, ctypes.c_float, ci, vp]
+            L.ds_attention_bias_pack.argtypes = [vp, vp, ci, ci, ci, ci, vp, vp]
             L.ds_residual_layernorm.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, i64, ci, ctypes.c_float, ci, vp]
             L.ds_boost_blend.argtypes = [vp, vp, i64, ci, ci, vp, ci, vp, ci, vp, ci, vp]
             L.ds_upsample_bilinear_nhwc.argtypes = [vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, vp]
@@ -238,9 +239,33 @@ def convert_to_i16(arr):
     return out
 
 
-def attention_fwd(qk, vt, n_valid, scale, bias=None, bias_log2=False):
+class PackedAttentionBias:
+    """The bias operand of attention_fwd: made by attention_bias_pack, opaque to the host code."""
+
+    def __init__(self, data, heads, n, npad):
+        self.data, self.heads, self.n, self.npad = data, heads, n, npad
+
+    @property
+    def dtype(self):
+        return self.data.dtype
+
+
+def attention_bias_pack(bias, npad, dtype):
+    """bias [H, n, n] (CUDA tensor, any float dtype, natural units) -> PackedAttentionBias for sequences padded to npad
+    (include/depthstereo.h: ds_attention_bias_pack)."""
+    torch = require_gpu()
+    assert bias.is_cuda and bias.dim() == 3 and bias.shape[1] == bias.shape[2] and dtype in (torch.float16, torch.bfloat16)
+    h, n = int(bias.shape[0]), int(bias.shape[1])
+    src = bias.detach().float().contiguous()
+    out = torch.empty((h * npad * npad,), dtype=dtype, device=bias.device)
+    _check(lib().ds_attention_bias_pack(ctx_for(_dev_index(src)), src.data_ptr(), h, n, int(npad),
+                                        1 if dtype == torch.float16 else 2, out.data_ptr(), _stream(src)))
+    return PackedAttentionBias(out, h, n, int(npad))
+
+
+def attention_fwd(qk, vt, n_valid, scale, bias=None):
     """Fused MFMA attention (include/depthstereo.h: ds_attention_fwd).  qk [B,Np,2,H,64], vt [B,H*64,Np], float16 or
-    bfloat16 CUDA tensors; bias [H,Np(query),Np(key)] or None (bias_log2: it already holds bias * log2(e)).
+    bfloat16 CUDA tensors; bias: None or a PackedAttentionBias (attention_bias_pack) for the same H, Np and dtype.
     Returns [B,Np,H*64]."""
     torch = require_gpu()
     assert qk.is_cuda and vt.is_cuda and qk.dtype == vt.dtype and qk.dtype in (torch.float16, torch.bfloat16)
@@ -249,12 +274,12 @@ def attention_fwd(qk, vt, n_valid, scale, bias=None, bias_log2=False):
     qk = qk.contiguous()
     vt = vt.contiguous()
     if bias is not None:
-        bias = bias.to(qk.dtype).contiguous()
-        assert tuple(bias.shape) == (h, npad, npad)
+        assert isinstance(bias, PackedAttentionBias), "bias must come from attention_bias_pack"
+        assert (bias.heads, bias.npad, bias.dtype) == (h, npad, qk.dtype) and bias.data.device == qk.device
     out = torch.empty((b, npad, h * 64), dtype=qk.dtype, device=qk.device)
     dt = 1 if qk.dtype == torch.float16 else 2
     _check(lib().ds_attention_fwd(ctx_for(_dev_index(qk)), qk.data_ptr(), vt.data_ptr(),
-                                  bias.data_ptr() if bias is not None else None, 1 if bias_log2 else 0, out.data_ptr(),
+                                  bias.data.data_ptr() if bias is not None else None, out.data_ptr(),
                                   b, npad, h, int(n_valid), float(scale), dt, _stream(qk)))
     return out
 

@@ -89,12 +89,12 @@ LOG2E = 1.4426950408889634
 
 
 def fused_attention(qk, vt, n_valid, scale, bias=None):
-    """bias: additive logits bias [H, Np(query), Np(key)] or None.  Half-precision bias operands are cached by the blocks
-    in log2 units (bias * log2 e: the kernel works in the exp2 domain), float32 ones in natural units."""
+    """bias: None, or what the block's attention_bias() cached for this dtype: the packed operand of the HIP kernel
+    (_native.attention_bias_pack) for float16 / bfloat16, a padded [H, Np(query), Np(key)] tensor for float32."""
     if qk.dtype == torch.float32:
         return attention_reference(qk, vt, n_valid, scale, bias)
     from . import _native
-    return _native.attention_fwd(qk, vt, n_valid, scale, bias, bias_log2=bias is not None)
+    return _native.attention_fwd(qk, vt, n_valid, scale, bias)
 
 
 class EncoderBlock(nn.Module):

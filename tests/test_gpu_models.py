@@ -19,8 +19,8 @@ def _case(b, n_valid, h, dtype, seed, with_bias):
     npad = vm.pad_len(n_valid)
     qk = (torch.randn((b, npad, 2, h, 64), generator=g) * 1.5).to(dtype).cuda()
     vt = torch.randn((b, h * 64, npad), generator=g).to(dtype).cuda()
-    # pad rows hold finite garbage, as they do in a real forward
-    bias = (torch.randn((h, npad, npad), generator=g) * 2.0).to(dtype).cuda() if with_bias else None
+    # the bias is defined on the valid tokens only ([H, n, n], natural units), like the reference's relative position bias
+    bias = (torch.randn((h, n_valid, n_valid), generator=g) * 2.0).cuda() if with_bias else None
     return qk, vt, bias, npad
 
 
@@ -32,14 +32,32 @@ def test_attention_kernel_matches_definition(gpu, dtype, with_bias):
     for (b, n_valid, h, seed) in [(1, 1, 1, 1), (2, 63, 2, 2), (1, 64, 3, 3), (2, 131, 6, 4), (1, 577, 12, 5), (1, 1370, 16, 6),
                                   (3, 200, 1, 7)]:
         qk, vt, bias, npad = _case(b, n_valid, h, dtype, seed, with_bias)
-        got = _native.attention_fwd(qk, vt, n_valid, 0.125, bias)
-        want = vm.attention_reference(qk.float(), vt.float(), n_valid, 0.125, None if bias is None else bias.float())
-        if bias is not None:        # the same bias handed over in log2 units
-            got2 = _native.attention_fwd(qk, vt, n_valid, 0.125, (bias.float() * vm.LOG2E).to(dtype), bias_log2=True)
-            # the rescaled bias is rounded once more to the operand type (11 / 8 bit mantissa on values of a few units)
-            assert (got2.float()[:, :n_valid] - want[:, :n_valid]).abs().max().item() < (5e-3 if dtype == torch.float16 else 8e-2)
+        packed, padded = None, None
+        if bias is not None:
+            packed = _native.attention_bias_pack(bias, npad, dtype)
+            padded = torch.zeros((h, npad, npad), device='cuda')
+            padded[:, :n_valid, :n_valid] = bias
+            # the pack kernel against its layout definition (include/depthstereo.h): [H][Np/32][Np/64][4][64 lanes][8]
+            t = packed.data.float().view(h, npad // 32, npad // 64, 4, 64, 8)
+            lane = torch.arange(64, device='cuda')
+            c = torch.arange(4, device='cuda')
+            j = torch.arange(8, device='cuda')
+            r = 8 * (c[:, None, None] & 1) + j[None, None, :]                                   # accumulator register
+            key = (c[:, None, None] >> 1) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane[None, :, None] >> 5)
+            qq = (lane & 31)[None, :, None].expand(4, 64, 8)
+            for qb in (0, npad // 32 - 1):
+                for kt in (0, npad // 64 - 1):
+                    exact = (padded[:, qb * 32:(qb + 1) * 32, kt * 64:(kt + 1) * 64] * vm.LOG2E)[:, qq, key.expand(4, 64, 8)]
+                    # correctly rounded to the operand type (the kernel rounds the product once; float32 -> half of
+                    # a float32 product rounds twice and differs by one ulp in ~1e-4 of the cases)
+                    ulp = 2.0 ** (-10 if dtype == torch.float16 else -7)
+                    assert ((t[:, qb, kt] - exact).abs() <= 0.5 * ulp * exact.abs() * 1.001 + 1e-30).all()
+        got = _native.attention_fwd(qk, vt, n_valid, 0.125, packed)
+        want = vm.attention_reference(qk.float(), vt.float(), n_valid, 0.125, padded)
         err = (got.float()[:, :n_valid] - want[:, :n_valid]).abs().max().item()
-        tol = 2e-3 if dtype == torch.float16 else 1.6e-2       # P and the output are rounded to the 11 / 8 bit mantissa
+        # P and the output are rounded to the 11 / 8 bit mantissa; the bias operand (values of a few units, in log2
+        # units) is rounded to it as well
+        tol = (2e-3 if dtype == torch.float16 else 1.6e-2) if bias is None else (5e-3 if dtype == torch.float16 else 8e-2)
         assert err < tol, (dtype, with_bias, b, n_valid, h, err)
         assert torch.isfinite(got.float()).all()               # pad query rows must stay finite
 

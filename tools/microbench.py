@@ -39,8 +39,8 @@ def main():
             npad = (n + 63) // 64 * 64
             qk = torch.randn(B, npad, 2, 16, 64, device=dev, dtype=torch.float16)
             vt = torch.randn(B, 1024, npad, device=dev, dtype=torch.float16)
-            bt = torch.randn(16, npad, npad, device=dev, dtype=torch.float16) if bias else None
-            ms = timeit(lambda: nat.attention_fwd(qk, vt, n, 0.125, bt, bias_log2=bias))
+            bt = nat.attention_bias_pack(torch.randn(16, n, n, device=dev), npad, torch.float16) if bias else None
+            ms = timeit(lambda: nat.attention_fwd(qk, vt, n, 0.125, bt))
             print(f"attention {name}: {ms:.3f} ms  {4.0 * n * n * 1024 * B / ms / 1e9:.1f} TF/s")
     if "head" in which:
         conv3 = nn.Conv2d(128, 32, 3, padding=1).to(dev).half()
