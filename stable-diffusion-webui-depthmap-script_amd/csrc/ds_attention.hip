@@ -84,8 +84,13 @@ __global__ __launch_bounds__(AT_THREADS, 3) void k_attention_fwd(AttnParams P)
         L = (int)(blockIdx.x & 7) * P.chunk + (int)(blockIdx.x >> 3);
         if (L >= P.total) return;                              // grid = 8*chunk >= total: the tail of the last XCD's range
     }
-    const int qblk = L % P.nq, bh = L / P.nq;
-    const int b = bh % P.B, h = bh / P.B, q0 = qblk * AT_QB + wave * AT_QW;
+    int qblk, b, h;
+    if (P.flags & 2) {                                          // batch fastest: concurrent workgroups share the bias tiles
+        b = L % P.B; qblk = (L / P.B) % P.nq; h = L / (P.B * P.nq);
+    } else {                                                    // query block fastest: they share K / V^T
+        qblk = L % P.nq; b = (L / P.nq) % P.B; h = L / (P.nq * P.B);
+    }
+    const int q0 = qblk * AT_QB + wave * AT_QW;
     const int Np = P.Np, H = P.H;
     const size_t tok_stride = (size_t)2 * H * AT_D;                                   // elements between tokens in qk
     const T *qk = (const T *)P.qk + (size_t)b * Np * tok_stride;
