@@ -297,7 +297,7 @@ def main():
             "config": {"workload": f"{wl}depth->u16 + create_stereoimages({args.fill}, left-right, divergence 2.5%) on "
                                    f"{args.batch} x 1024x1024 RGB per GPU, inputs resident in HBM"
                                    + ("" if model is not None else "; float32 depth prediction is a synthetic input (--model none)"),
-                       "model": args.model, "global_batch": args.batch * world, "height": H, "width": W,
+                       "depth_network": args.model, "units_per_step": args.batch * world, "height": H, "width": W,
                        "parallelism": f"units sharded over {world} GPU(s), no data-path collective"
                                       + (", RCCL gather to rank 0 overlapped" if gather_ok else "")},
             # the dominant hand-written kernel of the step: the fused attention when a network runs, else the stereo kernel

@@ -142,6 +142,18 @@ int ds_normalmap(ds_ctx *ctx, const uint16_t *depth, int n, int h, int w, int pr
 int ds_depth_to_u16(ds_ctx *ctx, const float *pred, int n, int h, int w, int invert,
                     uint16_t *out, float *norm_out, void *stream);
 
+/*
+ * ds_colorize_u16 -- the heat map output of core_generation_funnel (src/core.py:271-274), i.e.
+ * dzoedepth/utils/misc.py:97-150 colorize(depth, cmap=...) with its default arguments: per image
+ *     value = (depth - vmin) / (vmax - vmin)   in float64 (zeros when vmin == vmax, :124-127)
+ *     index = trunc(value * lut_n), below 0 -> entry 0, >= lut_n -> the last entry (matplotlib Colormap.__call__)
+ *     out   = lut_rgba[index]
+ *   depth      n*h*w uint16;  vmin_vmax  n*2 doubles (device): the reference's np.percentile(depth, 2 / 85);
+ *   lut_rgba   lut_n*4 bytes (device), the colormap's bytes=True table;  out  n*h*w*4 bytes (RGBA).
+ */
+int ds_colorize_u16(ds_ctx *ctx, const uint16_t *depth, int n, int h, int w, const double *vmin_vmax,
+                    const uint8_t *lut_rgba, int lut_n, uint8_t *out, void *stream);
+
 /* convert_to_i16 alone (src/core.py:44-50): float32 or float64 input already in [0,1]. */
 int ds_convert_to_i16(ds_ctx *ctx, const void *arr, int is_f64, int64_t count, uint16_t *out, void *stream);
 

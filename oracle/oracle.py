@@ -318,6 +318,19 @@ def depth_postprocess(raw_prediction, invert=False, clipdepth=False, clipdepth_m
     return (d - lo) / (hi - lo)
 
 
+def colorize_u16(depth, lut_rgba, lo=2.0, hi=85.0):
+    """dzoedepth/utils/misc.py:97-150 (colorize with default arguments, as src/core.py:271-274 calls it) on a uint16
+    depth; lut_rgba = the colormap's bytes=True table [N, 4].  Percentile normalisation (:121-127) in float64, then
+    matplotlib's Colormap.__call__ on floats: index = trunc(value * N), negative -> first entry, >= N -> last."""
+    d = np.asarray(depth).squeeze()
+    n = lut_rgba.shape[0]
+    vmin, vmax = np.percentile(d, lo), np.percentile(d, hi)
+    v = (d - vmin) / (vmax - vmin) if vmin != vmax else d * 0.0
+    x = v * n
+    idx = np.where(x < 0, 0, np.where(x >= n, n - 1, np.minimum(x, n - 1).astype(np.int64)))
+    return lut_rgba[idx]
+
+
 def num_threads():
     return int(lib().orc_num_threads())
 

@@ -20,7 +20,7 @@ FILL_IDS = {"none": 0, "naive": 1, "naive_interpolating": 2, "polylines_soft": 3
 EXPORTS = [
     "ds_version", "ds_last_error", "ds_ctx_create", "ds_ctx_destroy", "ds_stereo_warp", "ds_depth_minmax",
     "ds_stereo_last_exact_rows", "ds_copy_view", "ds_overlap_red_cyan", "ds_normalmap", "ds_depth_to_u16",
-    "ds_convert_to_i16", "ds_profile_enable", "ds_profile_last_ms", "ds_stereo_last_stats", "ds_attention_fwd", "ds_attention_bias_pack", "ds_residual_layernorm", "ds_boost_blend", "ds_upsample_bilinear_nhwc", "ds_dpt_head_tail",
+    "ds_convert_to_i16", "ds_profile_enable", "ds_profile_last_ms", "ds_stereo_last_stats", "ds_attention_fwd", "ds_attention_bias_pack", "ds_colorize_u16", "ds_residual_layernorm", "ds_boost_blend", "ds_upsample_bilinear_nhwc", "ds_dpt_head_tail",
 ]
 
 
@@ -63,6 +63,7 @@ def lib():
             L.ds_stereo_last_stats.argtypes = [vp, ctypes.POINTER(i64), vp]
             L.ds_attention_fwd.argtypes = [vp, vp, vp, vp, vp, ci, ci, ci, ci, ctypes.c_float, ci, vp]
             L.ds_attention_bias_pack.argtypes = [vp, vp, ci, ci, ci, ci, vp, vp]
+            L.ds_colorize_u16.argtypes = [vp, vp, ci, ci, ci, vp, vp, ci, vp, vp]
             L.ds_residual_layernorm.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, i64, ci, ctypes.c_float, ci, vp]
             L.ds_boost_blend.argtypes = [vp, vp, i64, ci, ci, vp, ci, vp, ci, vp, ci, vp]
             L.ds_upsample_bilinear_nhwc.argtypes = [vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, vp]
@@ -236,6 +237,21 @@ def convert_to_i16(arr):
     out = torch.empty(arr.shape, dtype=torch.uint16, device=arr.device)
     _check(lib().ds_convert_to_i16(ctx_for(_dev_index(arr)), arr.data_ptr(), 1 if arr.dtype == torch.float64 else 0,
                                    arr.numel(), out.data_ptr(), _stream(arr)))
+    return out
+
+
+def colorize_u16(depth, vmin_vmax, lut_rgba):
+    """Heat map (include/depthstereo.h: ds_colorize_u16).  depth [n,h,w] uint16, vmin_vmax [n,2] float64, lut_rgba
+    [N<=256, 4] uint8, all CUDA tensors.  Returns [n,h,w,4] uint8."""
+    torch = require_gpu()
+    assert depth.is_cuda and depth.dtype == torch.uint16 and depth.dim() == 3 and depth.is_contiguous()
+    n, h, w = depth.shape
+    vmm = vmin_vmax.to(device=depth.device, dtype=torch.float64).contiguous()
+    lut = lut_rgba.to(device=depth.device, dtype=torch.uint8).contiguous()
+    assert tuple(vmm.shape) == (n, 2) and lut.dim() == 2 and lut.shape[1] == 4
+    out = torch.empty((n, h, w, 4), dtype=torch.uint8, device=depth.device)
+    _check(lib().ds_colorize_u16(ctx_for(_dev_index(depth)), depth.data_ptr(), n, h, w, vmm.data_ptr(), lut.data_ptr(),
+                                 int(lut.shape[0]), out.data_ptr(), _stream(depth)))
     return out
 
 

@@ -8,7 +8,7 @@ depth post-processing, uint16 quantisation, stereo views and normal maps run as 
 MI355X (``libdepthstereo_hip.so``) and stay in HBM between stages; host code only converts to PIL at
 the moment a result is yielded.
 
-Out of scope here: background removal, heatmap, meshes / 3D-photo inpainting and
+Out of scope here: background removal, meshes / 3D-photo inpainting and
 video assembly.  Asking for them raises NotImplementedError instead of silently doing nothing.
 """
 import gc
@@ -27,7 +27,7 @@ SCRIPT_NAME = "DepthMap (MI355X-native hot path)"
 
 model_holder = ModelHolder()
 
-_OUT_OF_SCOPE = (go.GEN_REMBG, go.GEN_HEATMAP, go.GEN_SIMPLE_MESH, go.GEN_INPAINTED_MESH)
+_OUT_OF_SCOPE = (go.GEN_REMBG, go.GEN_SIMPLE_MESH, go.GEN_INPAINTED_MESH)
 
 
 def convert_to_i16(arr):
@@ -222,6 +222,10 @@ def core_generation_funnel(outpath, inputimages, inputdepthmaps, inputnames, inp
                     inp[go.NORMALMAP_POST_BLUR_KERNEL] if inp[go.NORMALMAP_POST_BLUR] else None,
                     inp[go.NORMALMAP_INVERT])
                 yield count, 'normalmap', Image.fromarray(nm[0].cpu().numpy())
+
+            if inp[go.GEN_HEATMAP]:                                                            # :271-274
+                from .heatmap import colorize_batch
+                yield count, 'heatmap', Image.fromarray(colorize_batch(img_output_t.unsqueeze(0))[0].cpu().numpy())
     except Exception as e:
         if 'out of memory' in str(e).lower():                                                  # :308-326
             suggestion = "out of GPU memory, could not generate depthmap! " \

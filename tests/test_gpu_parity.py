@@ -265,6 +265,36 @@ def test_funnel_model_branch_with_registered_predictor(gpu, oracle):
         list(core.core_generation_funnel(None, [Image.fromarray(img)], [pred], None, {'gen_rembg': True}))
 
 
+def test_heatmap_vs_reference_and_oracle(gpu, oracle):
+    """GEN_HEATMAP (core.py:271-274): ds_colorize_u16 + device percentiles against the reference's own colorize outputs
+    (golden) and, on larger seeded inputs, against the oracle; then through the funnel."""
+    import os
+    from PIL import Image
+    import src.core as core
+    from src import heatmap
+    torch = gpu
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'heatmap_cases.npz'))
+    lut = heatmap.colormap_table('inferno')
+    assert np.array_equal(lut, z['inferno_lut']), "this box's matplotlib builds a different inferno table than the golden run"
+    for name in sorted(k[:-7] for k in z.files if k.endswith('__depth')):
+        d = torch.from_numpy(z[f'{name}__depth'].copy()).cuda()
+        got = heatmap.colorize_batch(d.unsqueeze(0))[0].cpu().numpy()
+        assert np.array_equal(got, z[f'{name}__rgba']), name
+    rng = np.random.default_rng(12)
+    batch = np.stack([rng.integers(0, 65536, (301, 517), dtype=np.uint16),
+                      (util.smooth_depth(301, 517, 3) * 65535).astype(np.uint16),
+                      np.full((301, 517), 7, np.uint16)])
+    got = heatmap.colorize_batch(torch.from_numpy(batch).cuda()).cpu().numpy()
+    for i in range(3):
+        assert np.array_equal(got[i], oracle.colorize_u16(batch[i], lut)), i
+    img = rng.integers(0, 256, (48, 80, 3), dtype=np.uint8)
+    dep = z['smooth__depth'].astype(np.float64) / 65536.0          # custom depth in [0,1): u16 = trunc(x*65536 + 1e-4)
+    res = list(core.core_generation_funnel(None, [Image.fromarray(img)], [dep], None,
+                                           {'gen_heatmap': True, 'do_output_depth': False}))
+    assert [k for _, k, _ in res] == ['heatmap'] and res[0][2].mode == 'RGBA'
+    assert np.array_equal(np.asarray(res[0][2]), oracle.colorize_u16(oracle.convert_to_i16(dep), lut))
+
+
 def test_full_size_properties(sg, native, oracle, gpu):
     """BASELINE size (1024x1024): size-independent properties on the whole batch, plus the oracle on a subset of rows
     (row 500 is made to hold the image's min and max so the subset normalises like the full image)."""

@@ -92,3 +92,16 @@ def test_oracle_depth_normalize(oracle):
         ref = (out - out.min()) / (out.max() - out.min())
         assert np.array_equal(oracle.depth_normalize01(p, inv), ref)
     assert not oracle.depth_normalize01(np.full((4, 4), 3.0, np.float32)).any()
+
+
+def test_heatmap_oracle_matches_reference_colorize():
+    """oracle.colorize_u16 against the reference's own colorize outputs (tests/golden/make_golden_heatmap.py)."""
+    import os
+    from oracle import oracle as orc
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'heatmap_cases.npz'))
+    lut = z['inferno_lut']
+    names = sorted(k[:-7] for k in z.files if k.endswith('__depth'))
+    assert len(names) == 7
+    for name in names:
+        got = orc.colorize_u16(z[f'{name}__depth'], lut)
+        assert got.dtype == np.uint8 and np.array_equal(got, z[f'{name}__rgba']), name
