@@ -125,8 +125,8 @@ def cpu_baseline(model_name, distinct_units, seed, min_seconds=12.0):
                       f"with the gcc -O2 -fopenmp restatement of the reference's numba kernels, {dt:.2f} s"}
 
 
-def pmc_traffic(batch):
-    """HBM bytes per k_polylines launch from the committed rocprofv3 PMC summary (separate --pmc passes, FETCH_SIZE
+def pmc_traffic(batch, kernel="k_polylines"):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC summary (separate --pmc passes, FETCH_SIZE
     doubled as MI355X_MICROARCH.md prescribes for gfx950): profiles/round1_pmc_summary.json.  None when the summary is
     missing or was taken at another batch size -- bench.py cannot read PMC counters itself."""
     try:
@@ -134,7 +134,7 @@ def pmc_traffic(batch):
             j = json.load(f)
         if int(j.get("batch", -1)) != int(batch):
             return None
-        return float(j["k_polylines"]["hbm_bytes_per_launch"])
+        return float(j[kernel]["hbm_bytes_per_launch"])
     except Exception:
         return None
 
@@ -262,7 +262,9 @@ def main():
         attn_flops = 4.0 * n_tok * n_tok * minfo["dim"] * args.batch          # QK^T + PV, 2 flops per MAC
         attn = {"bound": "mfma", "kernel": "k_attention_fwd", "achieved": attn_flops / (attn_ms * 1e-3) / 1e12,
                 "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": attn_flops / (attn_ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS,
-                "traffic": None, "algorithmic_flops_per_launch": attn_flops, "avg_kernel_ms": attn_ms,
+                # HBM bytes per launch (PMC, committed summary): only measured for the default network's shape
+                "traffic": pmc_traffic(args.batch, "k_attention_fwd") if args.model == "dpt_beit_large_512" else None,
+                "algorithmic_flops_per_launch": attn_flops, "avg_kernel_ms": attn_ms,
                 "launches_per_step": minfo["depth"], "shape": {"batch": args.batch, "tokens": n_tok, "heads": minfo["heads"]}}
     torch.cuda.synchronize()
 
