@@ -7,8 +7,8 @@
 // Operands (head_dim is 64 for every encoder the reference ships):
 //   qk   [B, Np, 2, H, 64]  f16/bf16   Q and K exactly as the projection GEMM writes them (token major)
 //   vt   [B, H*64, Np]      f16/bf16   V TRANSPOSED (key index contiguous), produced in that layout by its own GEMM
-//   bias [H, Np(query), Np(key)] optional, same dtype: additive logits bias; the 128 x 64 tile of a workgroup is staged
-//        through LDS with 16-byte loads and read back as 8-byte groups of 4 consecutive keys
+//   bias optional: the operand made by ds_attention_bias_pack (this file) from the [H, n, n] table -- x log2(e), zero
+//        padded, stored in the register order of the logits tile, so a wave loads its 32 x 64 tile straight into registers
 //   out  [B, Np, H*64]      f16/bf16
 // Np is a multiple of 64; keys >= n_valid are masked (pad rows of the padded token sequence).
 //
@@ -20,7 +20,9 @@
 //                   from the S^T accumulators: the accumulator's row order fixes which keys sit in which k-slot, and
 //                   the V^T reads use the same order, so no cross-lane traffic is needed between the two GEMMs.
 // K tiles sit in LDS XOR-swizzled by 16-byte chunk (conflict-free ds_read_b128 of 32 rows x 128 B); V^T rows are padded
-// to 136 B (conflict-free ds_read_b64).  The next tile is fetched into registers while the current one is computed.
+// to 136 B (conflict-free ds_read_b64).  The next tile is fetched into registers (buffer loads through descriptors) while
+// the current one is computed and stashed into the other of two LDS buffers: one barrier per tile.  Workgroups are
+// ordered so that one XCD's L2 serves all query blocks of a (batch, head) and one head's bias (see the kernel).
 #include "ds_common.h"
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
