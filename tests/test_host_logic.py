@@ -153,3 +153,18 @@ def test_u16_normalisation_identity_exhaustive(oracle):
     subprocess.check_call(["make", "-C", here, "-s", "check_u16_division"])
     out = subprocess.run([os.path.join(here, "check_u16_division")], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and out.stdout.startswith("bad=0 of 4294901760"), out.stdout
+
+
+def test_heatmap_table_and_gemm_tuning_host_side():
+    """The colour table the heat map uploads is the one the golden run saw (same matplotlib in the image), and the GEMM
+    tuning switch is a no-op without a GPU; its results file carries the validator header torch checks."""
+    import os
+    from src import gemm_tuning, heatmap
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'heatmap_cases.npz'))
+    lut = heatmap.colormap_table('inferno')
+    assert lut.shape == (256, 4) and lut.dtype == np.uint8 and np.array_equal(lut, z['inferno_lut'])
+    import torch
+    if not torch.cuda.is_available():
+        assert gemm_tuning.enable() is False
+    lines = open(gemm_tuning.RESULTS).read().splitlines()
+    assert lines[0].startswith('Validator,PT_VERSION') and any(l.startswith('GemmAndBiasTunableOp_Half_TN') for l in lines)
