@@ -79,7 +79,10 @@ class DPT(nn.Module):
         scratch.output_conv = head
         self.scratch = scratch
 
-    def forward(self, x):               # dpt_depth.py:110-139
+    def forward(self, x, features=None):               # dpt_depth.py:110-139
+        """features: None, or a dict that receives what ZoeDepth's MidasCore taps with forward hooks
+        (dzoedepth/models/base_models/midas.py:307-331): 'l4_rn', 'r4'..'r1' and 'out_conv' (the 32-channel activation
+        after the head's second convolution + ReLU)."""
         l1, l2, l3, l4 = self.pretrained(x)
         s = self.scratch
         l1, l2, l3, l4 = s.layer1_rn(l1), s.layer2_rn(l2), s.layer3_rn(l3), s.layer4_rn(l4)
@@ -88,6 +91,14 @@ class DPT(nn.Module):
         path_2 = s.refinenet2(path_3, l2, size=l1.shape[2:])
         path_1 = s.refinenet1(path_2, l1)
         head = s.output_conv
+        if features is not None:
+            features.update(l4_rn=l4, r4=path_4, r3=path_3, r2=path_2, r1=path_1)
+            y = path_1
+            for i, layer in enumerate(head):
+                y = layer(y)
+                if i == 3:
+                    features['out_conv'] = y
+            return y
         if (path_1.is_cuda and path_1.dtype in (torch.float16, torch.bfloat16) and isinstance(head[1], Interpolate)
                 and head[1].mode == "bilinear" and head[1].align_corners and tuple(head[2].weight.shape) == (32, 128, 3, 3)):
             # upsample x2 -> conv3x3 128->32 -> ReLU -> conv1x1 -> ReLU in one MFMA kernel (ds_dpt_head_tail)
@@ -151,8 +162,8 @@ class DPTDepthModel(DPT):
             parameters = parameters["model"]
         self.load_state_dict(parameters, strict=False)     # timm's non-persistent buffers may or may not be in the file
 
-    def forward(self, x):
-        return super().forward(x).squeeze(dim=1)
+    def forward(self, x, features=None):
+        return super().forward(x, features).squeeze(dim=1)
 
     # ---- device-resident pre/post of estimatemidas (src/depthmap_generation.py:455-499) ------------------
     @torch.no_grad()

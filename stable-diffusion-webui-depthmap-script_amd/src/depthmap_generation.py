@@ -6,11 +6,12 @@ the reference.  Built model families:
     id  0           LeReS res101 (ResNeXt101-32x8d)      (lib.multi_depth_model_woauxi.RelDepthModel; reference :101-114)
     ids 1, 2        MiDaS 3.1 DPT BEiT-L/16 512 / 384   (dmidas.dpt_depth.DPTDepthModel; reference :116-146)
     ids 3, 4        MiDaS 3.0 dpt_large_384 (ViT-L/16) / dpt_hybrid_384 (ViT-B/16 + ResNetV2-50 stem)   (reference :147-170)
+    ids 7, 8, 9     ZoeDepth N / K / NK on the DPT BEiT-L/16 384 core   (dzoedepth.zoedepth; reference :196-209, :443-452)
     ids 12, 13, 14  Depth-Anything-V2 small/base/large   (ddepth_anything_v2.DepthAnythingV2; reference :237-248)
 Checkpoints are looked up in ``model_dir`` under the reference's file names; the reference downloads them when missing
 (ensure_file_downloaded) -- this build has no network path and raises FileNotFoundError instead, unless
 ``allow_random_init`` is set (bench / tests: random weights of the same architecture).
-Other ids (midas_v21 5-6, ZoeDepth 7-9, Marigold 10, Depth-Anything v1 11) are
+Other ids (midas_v21 5-6, Marigold 10, Depth-Anything v1 11: their networks are not vendored by the reference) are
 not built: ``ensure_models`` raises NotImplementedError unless a predictor was registered with ``register_predictor``.
 Boost (``boost=True``; src/boost.py + the pix2pix merge network + ds_boost_blend) is built for base models 0 and 12-14.
 Nothing ever falls back silently.
@@ -23,7 +24,7 @@ INVERTED_MODEL_IDS = (0, 7, 8, 9, 10)
 
 DEFAULT_NET_SIZES = {          # src/depthmap_generation.py:323-339
     0: [448, 448], 1: [512, 512], 2: [384, 384], 3: [384, 384], 4: [384, 384], 5: [384, 384], 6: [256, 256],
-    7: [512, 384], 8: [768, 384], 9: [512, 384], 10: [768, 768], 11: [518, 518], 12: [518, 518], 13: [518, 518],
+    7: [384, 512], 8: [384, 768], 9: [384, 512], 10: [768, 768], 11: [518, 518], 12: [518, 518], 13: [518, 518],
     14: [518, 518],
 }
 
@@ -44,6 +45,13 @@ def _build_dav2(letter):
     return make
 
 
+def _build_zoe(kind):
+    def make():
+        from dzoedepth import build_zoedepth
+        return build_zoedepth(kind)
+    return make
+
+
 def _build_leres():
     from lib.multi_depth_model_woauxi import RelDepthModel
     return RelDepthModel(backbone='resnext101'), "res101.pth"
@@ -51,6 +59,7 @@ def _build_leres():
 
 _BUILDERS = {0: _build_leres, 1: _build_dpt_beit("beitl16_512", "dpt_beit_large_512.pt"), 2: _build_dpt_beit("beitl16_384", "dpt_beit_large_384.pt"),
              3: _build_dpt_beit("vitl16_384", "dpt_large-midas-2f21e586.pt"), 4: _build_dpt_beit("vitb_rn50_384", "dpt_hybrid-midas-501f0c75.pt"),
+             7: _build_zoe("zoedepth_n"), 8: _build_zoe("zoedepth_k"), 9: _build_zoe("zoedepth_nk"),
              12: _build_dav2('s'), 13: _build_dav2('b'), 14: _build_dav2('l')}
 
 
@@ -73,12 +82,19 @@ class _NetPredictor:
     def __init__(self, model_type, device, model_dir, allow_random_init, no_half):
         import torch
         net, filename = _BUILDERS[model_type]()
+        self_model_dir_unset = model_dir is None
         if model_dir is None:                                # reference :83-92
             model_dir = {0: "./models/leres", 11: "./models/depth_anything", 12: "./models/depth_anything_v2",
                          13: "./models/depth_anything_v2", 14: "./models/depth_anything_v2"}.get(model_type, "./models/midas")
+        if model_type in (7, 8, 9) and self_model_dir_unset:
+            # the reference lets torch.hub.load_state_dict_from_url cache ZoeD_M12_*.pt (dzoedepth/models/model_io.py:62-64)
+            model_dir = os.path.join(torch.hub.get_dir(), "checkpoints")
         path = os.path.join(model_dir, filename)
         if os.path.exists(path):
             sd = torch.load(path, map_location='cpu')
+            if model_type in (7, 8, 9):                      # model_io.py:34-50: optional 'model' wrapper, DataParallel prefix
+                sd = sd.get('model', sd)
+                sd = {(k[len("module."):] if k.startswith("module.") else k): v for k, v in sd.items()}
             if model_type == 0:                              # reference :108-112: checkpoint['depth_model'], "module." stripped
                 sd = {(k[len("module."):] if k.startswith("module.") else k): v for k, v in sd['depth_model'].items()}
             elif "optimizer" in sd:
@@ -94,7 +110,8 @@ class _NetPredictor:
         self.model_type = model_type
         self.net = net.eval().to(device)
         dev = torch.device(device)
-        if dev.type == 'cuda' and not no_half and model_type != 0:   # reference :268-275 (LeReS stays float32)
+        # reference :266-275: LeReS stays float32, and so does zoedepth_n ("completely trips and generates black images")
+        if dev.type == 'cuda' and not no_half and model_type not in (0, 7):
             self.net = self.net.half()
 
     @property
@@ -108,6 +125,8 @@ class _NetPredictor:
         batch = img.unsqueeze(0)
         if self.model_type == 0:
             return self.net.infer_batch(batch, int(net_width), int(net_height))[0]   # estimateleres (:406-421)
+        if self.model_type in (7, 8, 9):
+            return self.net.infer_batch(batch, int(net_width), int(net_height))[0]   # estimatezoedepth (:443-452)
         if self.is_dav2:
             return self.net.infer_batch(batch, int(net_width))[0]          # reference passes net_width as input_size (:553)
         mode = "minimal"                                                    # resize_mode of ids 1-4 (:127, :141, :155, :168)

@@ -53,6 +53,15 @@ def fill_state_dict_beit(sd):
     return out
 
 
+def fill_state_dict_zoe(sd):
+    """fill_state_dict_beit for ZoeDepth: the float buffer K_minus_1 of the log-binomial layer is a constant, not a weight."""
+    out = fill_state_dict_beit(sd)
+    for k in sd:
+        if k.endswith("K_minus_1"):
+            out[k] = sd[k].clone()
+    return out
+
+
 def boost_integral_image(seed=5, H=700, W=1000):
     """Deterministic gradient field + its integral image (cv2.integral layout) for the Boost patch-selection cases."""
     import numpy as np

@@ -274,3 +274,48 @@ def test_video_two_pass_pipeline_single_rank(gpu, oracle):
         assert np.array_equal(res['depth'][i].cpu().numpy(), d16)
         want = oracle.create_stereoimages_arrays(frames[i].numpy(), d16, 2.5, 0.0, ['left-right'], 0.0, 1.0, 'polylines_sharp')[0]
         assert np.array_equal(res['left-right'][i].cpu().numpy(), want)
+
+
+@pytest.mark.parametrize("tag,kind", [("k", "zoedepth_k"), ("nk", "zoedepth_nk")])
+def test_zoedepth_gpu_vs_reference_fp32(gpu, tag, kind):
+    """ZoeDepth (ids 8, 9 run in half on a GPU, src/depthmap_generation.py:266-272) on the device: float32 against the
+    outputs of the reference's own ZoeDepth code (tests/golden/zoedepth_cases.npz; 1e-4 is the CPU bar, the GPU's
+    float32 convolutions / GEMMs sum in another order), then float16 with the fused kernels inside the DPT core."""
+    from dzoedepth import build_zoedepth
+    z = np.load(os.path.join(os.path.dirname(GOLD), "zoedepth_cases.npz"))
+    m, _ = build_zoedepth(kind, midas_model_type="DPT_BEiT_B_384")
+    m = m.eval()
+    m.load_state_dict(mw.fill_state_dict_zoe(m.state_dict()), strict=True)
+    m = m.cuda()
+    x = torch.rand((1, 3, 88, 120), generator=torch.Generator().manual_seed(21)).cuda()
+    m.core.set_net_size(160, 128)
+    ref = z[f"{tag}_88x120_infer"]
+    with torch.no_grad():
+        y32 = m.infer(x).cpu().numpy()
+    assert np.abs(y32 - ref).max() / np.abs(ref).max() < 5e-4
+    with torch.no_grad():
+        y16 = m.half().infer(x.half()).float().cpu().numpy()
+    assert np.isfinite(y16).all()
+    assert np.abs(y16 - ref).max() / np.abs(ref).max() < 5e-2
+
+
+def test_funnel_with_zoedepth(gpu):
+    """ids 7 (float32 by the reference's rule) and 9 through ModelHolder / the funnel with random weights: plumbing only
+    (PIL -> ToTensor scaling -> padded + flipped inference -> inverted depth -> uint16)."""
+    from PIL import Image
+    import src.core as core
+    core.model_holder.allow_random_init = True
+    try:
+        rng = np.random.default_rng(3)
+        img = Image.fromarray(rng.integers(0, 256, (96, 128, 3), dtype=np.uint8))
+        for mt in (7, 9):
+            got = list(core.core_generation_funnel(None, [img], None, None,
+                                                   {'model_type': mt, 'net_width': 128, 'net_height': 96, 'net_size_match': False}))
+            assert [k for _, k, _ in got] == ['depth']
+            d = np.asarray(got[0][2])
+            assert d.shape == (96, 128) and d.dtype == np.uint16 and d.max() > d.min()
+            net = core.model_holder.depth_model.net
+            assert next(net.parameters()).dtype == (torch.float32 if mt == 7 else torch.float16)
+    finally:
+        core.model_holder.allow_random_init = False
+        core.model_holder.unload_models()

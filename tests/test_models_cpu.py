@@ -204,3 +204,50 @@ def test_boost_patch_selection_matches_reference_functions():
         assert [grid[str(i)]["rect"] for i in range(len(grid))] == meta["grid_rects"]
         sel = boost.adaptiveselection(integ, grid, meta["gf"], meta["factor"])
         assert [sel[str(i)]["rect"] for i in range(len(sel))] == meta["selected_rects"]
+
+
+# ---- ZoeDepth (ids 7, 8, 9): our dzoedepth/zoedepth.py against the reference's own ZoeDepth / ZoeDepthNK / MidasCore / layers --
+ZGOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "zoedepth_cases.npz")
+
+
+@pytest.mark.parametrize("tag,kind", [("n", "zoedepth_n"), ("k", "zoedepth_k"), ("nk", "zoedepth_nk")])
+def test_zoedepth_matches_reference_modules(tag, kind):
+    """Same name-seeded weights (strict load = same state-dict layout), same inputs, the reference's augmented `infer`
+    (reflect padding, bicubic resize back, crop, horizontal-flip average) and the plain forward."""
+    from dzoedepth import build_zoedepth
+    z = np.load(ZGOLD)
+    m, _ = build_zoedepth(kind, midas_model_type="DPT_BEiT_B_384")
+    m = m.eval()
+    res = m.load_state_dict(mw.fill_state_dict_zoe(m.state_dict()), strict=True)
+    assert not res.missing_keys and not res.unexpected_keys
+    x = torch.rand((1, 3, 88, 120), generator=torch.Generator().manual_seed(21))
+    m.core.set_net_size(160, 128)
+    with torch.no_grad():
+        full = m.infer(x).numpy()
+        raw = m(x)
+    assert full.shape == z[f"{tag}_88x120_infer"].shape
+    assert _rel(raw['metric_depth'].numpy(), z[f"{tag}_88x120_forward"]) < 1e-4
+    assert _rel(full, z[f"{tag}_88x120_infer"]) < 1e-4
+    # the output must not be (numerically) constant, or the comparison above would say little
+    assert float(np.std(z[f"{tag}_88x120_infer"])) > 20 * 1e-4 * float(np.abs(z[f"{tag}_88x120_infer"]).max())
+    if tag == "nk":
+        assert _rel(raw['domain_logits'].numpy(), z["nk_88x120_domain_logits"]) < 1e-4
+    x2 = torch.rand((2, 3, 70, 150), generator=torch.Generator().manual_seed(22))
+    m.core.set_net_size(224, 96)
+    with torch.no_grad():
+        assert _rel(m.infer(x2).numpy(), z[f"{tag}_70x150_infer"]) < 1e-4
+
+
+@pytest.mark.parametrize("tag,kind", [("n", "zoedepth_n"), ("nk", "zoedepth_nk")])
+def test_zoedepth_default_build_has_the_reference_checkpoint_layout(tag, kind):
+    """Names and shapes of every non-encoder tensor of the DEFAULT (BEiT-L core) build, as the reference's own
+    get_config + build_model produce them: ZoeD_M12_{N,NK}.pt load by name."""
+    from dzoedepth import build_zoedepth
+    z = np.load(ZGOLD)
+    with torch.device("meta"):
+        m, ckpt = build_zoedepth(kind)
+    sd = m.state_dict()
+    mine = sorted(f"{k}:{tuple(v.shape)}" for k, v in sd.items() if not k.startswith("core.core.pretrained"))
+    assert mine == list(z[f"{tag}_head_names"])
+    assert len(sd) == int(z[f"{tag}_n_tensors"][0])
+    assert ckpt == {"n": "ZoeD_M12_N.pt", "nk": "ZoeD_M12_NK.pt"}[tag]
