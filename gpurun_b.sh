@@ -1,1 +1,1 @@
-timeout 400 python -m pytest tests/test_gpu_models.py -x -q -k "zoedepth" 2>&1 | grep -v "Warning\|warn\|^$" | tail -15
+timeout 500 python -m pytest tests -x -q -m gpu 2>&1 | grep -v "Warning\|warn\|^$\|TransformerEncoder" | tail -6
