@@ -215,7 +215,30 @@ def _single_estimates(patches, msize, net, model_type, chunk):
             u8 = (p * 255.1).clamp(0, 255).to(torch.uint8).flip(-1)    # (:550) the second channel swap; net swaps again
             outs.append(net.infer_batch(u8.unsqueeze(0), int(msize))[0])
         return outs
-    raise NotImplementedError(f"Boost with depth model id {model_type} is not built (built: 0 LeReS, 12-14 Depth-Anything-V2)")
+    if model_type in (1, 2, 3, 4):                           # estimatemidasBoost (:1180-1220)
+        from dmidas.dpt_depth import midas_net_size
+        mean = torch.tensor([0.485, 0.456, 0.406], device=dev).view(1, 3, 1, 1)      # ImageNet statistics for EVERY MiDaS
+        std = torch.tensor([0.229, 0.224, 0.225], device=dev).view(1, 3, 1, 1)       # model here, unlike estimatemidas
+        for p in patches:
+            h, w = p.shape[:2]
+            nw, nh = midas_net_size(w, h, msize, msize, "upper_bound")              # keep aspect, multiple of 32 (:1184-1191)
+            x = _resize(p.permute(2, 0, 1), (nh, nw), 'bicubic').unsqueeze(0).float()
+            pred = net((x - mean) / std).float()[0]                                   # float32: Boost never runs half (:271)
+            pred = _resize(pred, (h, w), 'bicubic')                                   # cv2.resize INTER_CUBIC (:1209)
+            lo, hi = pred.min(), pred.max()
+            if float(hi - lo) > float(np.finfo("float").eps):                         # :1212-1218
+                pred = (pred - lo) / (hi - lo)
+            else:
+                pred = torch.zeros_like(pred)
+            outs.append(pred)
+        return outs
+    if model_type in (7, 8, 9):                              # estimatezoedepth on np.uint8(img * 255) (:1062-1064)
+        for p in patches:
+            u8 = (p * 255).to(torch.uint8)                   # truncation like np.uint8; no channel swap on this path
+            outs.append(net.infer_batch(u8.unsqueeze(0), int(msize), int(msize))[0])
+        return outs
+    raise NotImplementedError(f"Boost with depth model id {model_type} is not built (built: 0 LeReS, 1-4 MiDaS DPT, 7-9 ZoeDepth, "
+                              "12-14 Depth-Anything-V2)")
 
 
 def doubleestimate(patches, size1, size2, net, model_type, pix2pix, chunk=8):

@@ -13,7 +13,7 @@ Checkpoints are looked up in ``model_dir`` under the reference's file names; the
 ``allow_random_init`` is set (bench / tests: random weights of the same architecture).
 Other ids (midas_v21 5-6, Marigold 10, Depth-Anything v1 11: their networks are not vendored by the reference) are
 not built: ``ensure_models`` raises NotImplementedError unless a predictor was registered with ``register_predictor``.
-Boost (``boost=True``; src/boost.py + the pix2pix merge network + ds_boost_blend) is built for base models 0 and 12-14.
+Boost (``boost=True``; src/boost.py + the pix2pix merge network + ds_boost_blend) runs on every built base model.
 Nothing ever falls back silently.
 """
 import gc
@@ -108,6 +108,7 @@ class _NetPredictor:
             raise FileNotFoundError(f"{path} not found (the reference would download it; this build has no network path). "
                                     "Place the checkpoint there or set ModelHolder.allow_random_init for a dry run")
         self.model_type = model_type
+        self.no_half = bool(no_half)
         self.net = net.eval().to(device)
         dev = torch.device(device)
         # reference :266-275: LeReS stays float32, and so does zoedepth_n ("completely trips and generates black images")
@@ -160,9 +161,9 @@ class ModelHolder:
     def ensure_models(self, model_type, device, boost: bool, tiling_mode: bool = False):
         """reference :60-74."""
         if boost:
-            if model_type not in (0, 12, 13, 14):
-                raise NotImplementedError(f"Boost with depth model id {model_type!r} is not built (built: 0 LeReS, 12-14 "
-                                          "Depth-Anything-V2)")
+            if model_type not in (0, 1, 2, 3, 4, 7, 8, 9, 12, 13, 14):
+                raise NotImplementedError(f"Boost with depth model id {model_type!r} is not built (built: 0 LeReS, 1-4 MiDaS "
+                                          "DPT, 7-9 ZoeDepth, 12-14 Depth-Anything-V2)")
             if self.pix2pix_model is None:
                 self.pix2pix_model = _load_pix2pix(device, self.allow_random_init)
         else:
@@ -172,10 +173,12 @@ class ModelHolder:
         elif model_type in _BUILDERS:
             from . import gemm_tuning
             gemm_tuning.enable()                      # tuned hipBLASLt / rocBLAS solutions for the transformer linears
-            if self.depth_model is None or self.depth_model_type != model_type or not isinstance(self.depth_model, _NetPredictor):
-                # Boost never runs a MiDaS/LeReS base network in half precision (reference :271); DA-V2 stays half (:273-275)
-                self.depth_model = _NetPredictor(model_type, device, self.model_dir, self.allow_random_init,
-                                                 self.no_half or (boost and model_type not in (12, 13, 14)))
+            # Boost never runs a MiDaS/LeReS/ZoeDepth base network in half precision (reference :271); DA-V2 stays half
+            # (:273-275).  The reference reloads whenever the boost switch changes (:62-72); here only if the precision does.
+            no_half = bool(self.no_half or (boost and model_type not in (12, 13, 14)))
+            if (self.depth_model is None or self.depth_model_type != model_type or not isinstance(self.depth_model, _NetPredictor)
+                    or self.depth_model.no_half != no_half):
+                self.depth_model = _NetPredictor(model_type, device, self.model_dir, self.allow_random_init, no_half)
         else:
             raise NotImplementedError(
                 f"depth model {model_type!r} is not available in this build (built: ids {sorted(_BUILDERS)}); register a "

@@ -251,3 +251,42 @@ def test_zoedepth_default_build_has_the_reference_checkpoint_layout(tag, kind):
     assert mine == list(z[f"{tag}_head_names"])
     assert len(sd) == int(z[f"{tag}_n_tensors"][0])
     assert ckpt == {"n": "ZoeD_M12_N.pt", "nk": "ZoeD_M12_NK.pt"}[tag]
+
+
+def test_boost_single_estimates_for_midas_and_zoedepth_base_models():
+    """singleestimate's MiDaS branch (estimatemidasBoost, src/depthmap_generation.py:1180-1220: upper_bound resize,
+    ImageNet statistics, min-max normalised output) and ZoeDepth branch (:1062-1064) on CPU tensors with small random
+    networks: executes end to end, output at patch size, the MiDaS one in [0, 1] touching both ends, and equal to the
+    same steps written out by hand."""
+    import torch.nn.functional as F
+    from dmidas.dpt_depth import DPTDepthModel, midas_net_size
+    from dzoedepth import build_zoedepth
+    from src import boost
+    torch.manual_seed(3)
+    patches = [torch.rand((70, 100, 3), dtype=torch.float64), torch.rand((90, 64, 3), dtype=torch.float64)]
+    net = DPTDepthModel(path=None, backbone="vitb_rn50_384", non_negative=True).eval()
+    net.load_state_dict(mw.fill_state_dict(net.state_dict()), strict=True)
+    with torch.no_grad():
+        outs = boost._single_estimates(patches, 96, net, 4, 8)
+        p = patches[0]
+        nw, nh = midas_net_size(100, 70, 96, 96, "upper_bound")
+        assert nw <= 96 and nh <= 96 and nw % 32 == 0 and nh % 32 == 0
+        x = F.interpolate(p.permute(2, 0, 1)[None].reshape(3, 1, 70, 100), size=(nh, nw), mode='bicubic', align_corners=False)
+        x = x.reshape(1, 3, nh, nw).float()
+        mean = torch.tensor([0.485, 0.456, 0.406]).view(1, 3, 1, 1)
+        std = torch.tensor([0.229, 0.224, 0.225]).view(1, 3, 1, 1)
+        want = F.interpolate(net((x - mean) / std)[:, None].float(), size=(70, 100), mode='bicubic', align_corners=False)[0, 0]
+        want = (want - want.min()) / (want.max() - want.min())
+    assert [tuple(o.shape) for o in outs] == [(70, 100), (90, 64)]
+    assert float(outs[0].min()) == 0.0 and float(outs[0].max()) == 1.0
+    assert torch.allclose(outs[0], want, atol=1e-6)
+    zoe, _ = build_zoedepth("zoedepth_n", midas_model_type="DPT_BEiT_B_384")
+    zoe = zoe.eval()
+    zoe.load_state_dict(mw.fill_state_dict_zoe(zoe.state_dict()), strict=True)
+    with torch.no_grad():
+        zo = boost._single_estimates(patches[:1], 96, zoe, 7, 8)
+        u8 = (patches[0] * 255).to(torch.uint8)
+        direct = zoe.infer_batch(u8[None], 96, 96)[0]
+    assert tuple(zo[0].shape) == (70, 100) and torch.equal(zo[0], direct) and torch.isfinite(zo[0]).all()
+    with pytest.raises(NotImplementedError):
+        boost._single_estimates(patches, 96, net, 5, 8)
