@@ -125,8 +125,11 @@ def test_model_holder_refuses_missing_models():
         mh.ensure_models(1, 'cpu', False)
     with pytest.raises(NotImplementedError):        # family that is not built
         mh.ensure_models(5, 'cpu', False)
-    with pytest.raises(NotImplementedError):        # Boost on a base model it is not built for
+    with pytest.raises(NotImplementedError):        # Boost on a base model that is not built
+        mh.ensure_models(5, 'cpu', True)
+    with pytest.raises(FileNotFoundError):          # Boost on a MiDaS DPT base model is built; checkpoints are absent
         mh.ensure_models(1, 'cpu', True)
+    assert mh.get_default_net_size(7) == [384, 512] and mh.get_default_net_size(8) == [384, 768]   # reference :323-339
     with pytest.raises(FileNotFoundError):          # Boost on LeReS is built, but the merge network's checkpoint is absent
         mh.ensure_models(0, 'cpu', True)
     mh.update_settings(boost_rmax=1600, no_half=True)
