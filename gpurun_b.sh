@@ -1,1 +1,1 @@
-timeout 500 python -m pytest tests -x -q -m gpu 2>&1 | grep -v "Warning\|warn\|^$\|TransformerEncoder" | tail -6
+timeout 100 python -m pytest tests/test_gpu_parity.py -x -q -k "simple_mesh or heatmap" 2>&1 | tail -8

@@ -8,7 +8,7 @@ depth post-processing, uint16 quantisation, stereo views and normal maps run as 
 MI355X (``libdepthstereo_hip.so``) and stay in HBM between stages; host code only converts to PIL at
 the moment a result is yielded.
 
-Out of scope here: background removal, meshes / 3D-photo inpainting and
+Out of scope here: background removal, the inpainted (3D-photo) mesh and
 video assembly.  Asking for them raises NotImplementedError instead of silently doing nothing.
 """
 import gc
@@ -27,7 +27,7 @@ SCRIPT_NAME = "DepthMap (MI355X-native hot path)"
 
 model_holder = ModelHolder()
 
-_OUT_OF_SCOPE = (go.GEN_REMBG, go.GEN_SIMPLE_MESH, go.GEN_INPAINTED_MESH)
+_OUT_OF_SCOPE = (go.GEN_REMBG, go.GEN_INPAINTED_MESH)
 
 
 def convert_to_i16(arr):
@@ -159,10 +159,12 @@ def core_generation_funnel(outpath, inputimages, inputdepthmaps, inputnames, inp
                 inputimages[count] = inputimages[count].convert('RGB')
 
             image = inputimages[count]
+            mesh_source = None      # what :281 calls depthi: the raw prediction, or the custom depth map
             if inputdepthmaps is not None and inputdepthmaps[count] is not None:
                 out = _custom_depth_to_float(inputdepthmaps[count], image)                     # :145-174
                 out_t = torch.from_numpy(np.array(out, dtype=np.float64, order='C')).to(device)
                 img_output_t = _native.convert_to_i16(out_t)                                   # :211
+                mesh_source = out_t
             else:
                 if inp[go.NET_SIZE_MATCH]:                                                     # :177-184
                     net_width = (image.width + 31) // 32 * 32
@@ -173,6 +175,7 @@ def core_generation_funnel(outpath, inputimages, inputdepthmaps, inputnames, inp
                 raw_prediction, raw_prediction_invert = model_holder.get_raw_prediction(image, net_width, net_height)
                 pred_t = raw_prediction if torch.is_tensor(raw_prediction) else torch.from_numpy(np.asarray(raw_prediction))
                 pred_t = pred_t.to(device=device, dtype=torch.float32)
+                mesh_source = pred_t
                 if not inp[go.CLIPDEPTH] and not inp[go.DO_OUTPUT_DEPTH_PREDICTION]:
                     # fused device path: min/max -> normalise -> uint16 in one pass (:189-211)
                     img_output_t = _native.depth_to_u16(pred_t.unsqueeze(0), raw_prediction_invert)[0]
@@ -226,6 +229,16 @@ def core_generation_funnel(outpath, inputimages, inputdepthmaps, inputnames, inp
             if inp[go.GEN_HEATMAP]:                                                            # :271-274
                 from .heatmap import colorize_batch
                 yield count, 'heatmap', Image.fromarray(colorize_batch(img_output_t.unsqueeze(0))[0].cpu().numpy())
+
+            if inp[go.GEN_SIMPLE_MESH]:                                                        # :277-306
+                from . import mesh_generation as mg
+                custom = inputdepthmaps[count] is not None
+                depthi = mg.mesh_depth(mesh_source, int(inp[go.MODEL_TYPE]), bool(inp[go.BOOST]), custom)
+                rgb_t = torch.from_numpy(np.array(image.convert('RGB'), dtype=np.uint8, order='C')).to(device)
+                verts, faces, colors = mg.create_mesh_arrays(rgb_t, depthi, keep_edges=not inp[go.SIMPLE_MESH_OCCLUDE],
+                                                             spherical=bool(inp[go.SIMPLE_MESH_SPHERICAL]))
+                fn = mg.unique_filename(outpath, 'depthmap', 'obj', 'simple')
+                yield count, 'simple_mesh', mg.write_obj(fn, verts.cpu().numpy(), faces.cpu().numpy(), colors.cpu().numpy())
     except Exception as e:
         if 'out of memory' in str(e).lower():                                                  # :308-326
             suggestion = "out of GPU memory, could not generate depthmap! " \

@@ -295,6 +295,29 @@ def test_heatmap_vs_reference_and_oracle(gpu, oracle):
     assert np.array_equal(np.asarray(res[0][2]), oracle.colorize_u16(oracle.convert_to_i16(dep), lut))
 
 
+def test_funnel_simple_mesh(gpu, tmp_path):
+    """GEN_SIMPLE_MESH (core.py:277-306) through the funnel with a custom depth map: the geometry computed on the device
+    equals the same tensor ops on the CPU, which tests/test_host_logic.py pins to the reference's own functions."""
+    import os
+    from PIL import Image
+    import src.core as core
+    from src import mesh_generation as mg
+    torch = gpu
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'mesh_cases.npz'))
+    dep = z['c__depth'].astype(np.float64) / 4.0
+    img = np.random.default_rng(2).integers(0, 256, (24, 24, 3), dtype=np.uint8)
+    res = list(core.core_generation_funnel(str(tmp_path), [Image.fromarray(img)], [dep], None,
+                                           {'gen_simple_mesh': True, 'do_output_depth': False}))
+    assert [k for _, k, _ in res] == ['simple_mesh'] and os.path.exists(res[0][2])
+    d = torch.from_numpy(dep)
+    v, f, c = mg.create_mesh_arrays(torch.from_numpy(img), mg.mesh_depth(d, 0, False, True), keep_edges=False)
+    want = mg.write_obj(str(tmp_path / 'cpu.obj'), v.numpy(), f.numpy(), c.numpy())
+    assert open(res[0][2]).read() == open(want).read()
+    v2 = mg.create_mesh_arrays(torch.from_numpy(img).cuda(), mg.mesh_depth(d.cuda(), 0, False, True), keep_edges=True, spherical=True)[0]
+    v2c = mg.create_mesh_arrays(torch.from_numpy(img), mg.mesh_depth(d, 0, False, True), keep_edges=True, spherical=True)[0]
+    assert np.allclose(v2.cpu().numpy(), v2c.numpy(), rtol=0, atol=1e-12)
+
+
 def test_full_size_properties(sg, native, oracle, gpu):
     """BASELINE size (1024x1024): size-independent properties on the whole batch, plus the oracle on a subset of rows
     (row 500 is made to hold the image's min and max so the subset normalises like the full image)."""

@@ -171,3 +171,38 @@ def test_heatmap_table_and_gemm_tuning_host_side():
         assert gemm_tuning.enable() is False
     lines = open(gemm_tuning.RESULTS).read().splitlines()
     assert lines[0].startswith('Validator,PT_VERSION') and any(l.startswith('GemmAndBiasTunableOp_Half_TN') for l in lines)
+
+
+def test_simple_mesh_geometry_matches_reference_functions(tmp_path):
+    """src/mesh_generation.py (device tensor ops, run here on CPU tensors) against outputs of the reference's own
+    depth_to_points / create_triangles / depth_edges_mask / pano_depth_to_world_points (tests/golden/make_golden_mesh.py):
+    vertices bit for bit, faces and masks identical; then the .obj writer."""
+    import torch
+    from src import mesh_generation as mg
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'mesh_cases.npz'))
+    for name in "abc":
+        d = torch.from_numpy(z[f"{name}__depth"].copy())
+        h, w = d.shape
+        pts = mg.depth_to_points(d)
+        assert pts.dtype == torch.float64 and np.array_equal(pts.numpy(), z[f"{name}__points"]), name
+        assert np.array_equal(mg.depth_edges_mask(d).numpy(), z[f"{name}__edges"]), name
+        assert np.array_equal(mg.create_triangles(h, w).numpy(), z[f"{name}__tri_all"]), name
+        masked = mg.create_triangles(h, w, mask=~mg.depth_edges_mask(d))
+        assert np.array_equal(masked.numpy(), z[f"{name}__tri_masked"]), name
+        pano = mg.pano_depth_to_world_points(d).numpy()
+        assert np.allclose(pano, z[f"{name}__pano"], rtol=0, atol=1e-12 if d.dtype == torch.float64 else 1e-6), name
+    d = torch.from_numpy(z["c__depth"].copy())
+    img = torch.from_numpy(np.random.default_rng(1).integers(0, 256, (24, 24, 3), dtype=np.uint8))
+    v, f, c = mg.create_mesh_arrays(img, mg.mesh_depth(d, 1, False, False), keep_edges=False)
+    assert v.shape == (576, 3) and c.shape == (576, 3) and f.shape[1] == 3 and 0 < f.shape[0] < 1058
+    path = mg.write_obj(mg.unique_filename(str(tmp_path), 'depthmap', 'obj', 'simple'), v, f, c)
+    lines = open(path).read().splitlines()
+    assert path.endswith('depthmap-0000-simple.obj') and sum(l.startswith('v ') for l in lines) == 576
+    assert sum(l.startswith('f ') for l in lines) == f.shape[0] and lines[-1].split()[0] == 'f'
+    assert mg.unique_filename(str(tmp_path), 'depthmap', 'obj', 'simple').endswith('depthmap-0001-simple.obj')
+    # mesh_depth: ZoeDepth predictions pass through untouched, everything else is inverted / shifted / offset (core.py:283-303)
+    zd = torch.tensor([[2.0, 3.0]])
+    assert torch.equal(mg.mesh_depth(zd, 7, False, False), zd)
+    assert torch.equal(mg.mesh_depth(zd, 1, False, False), torch.tensor([[4.0, 3.0]]))
+    # the rescale uses the min / max from BEFORE the shift (reference quirk): 4 * ([0, 21] + 1) / 21 + 1
+    assert torch.allclose(mg.mesh_depth(torch.tensor([[-1.0, 20.0]]), 0, False, False), torch.tensor([[1.0 + 4 / 21, 1.0 + 88 / 21]]))
