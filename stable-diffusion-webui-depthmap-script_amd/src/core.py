@@ -233,7 +233,8 @@ def core_generation_funnel(outpath, inputimages, inputdepthmaps, inputnames, inp
             if inp[go.GEN_SIMPLE_MESH]:                                                        # :277-306
                 from . import mesh_generation as mg
                 custom = inputdepthmaps[count] is not None
-                depthi = mg.mesh_depth(mesh_source, int(inp[go.MODEL_TYPE]), bool(inp[go.BOOST]), custom)
+                mt = inp[go.MODEL_TYPE]          # callers pass the numeric id; the option's default is a display name
+                depthi = mg.mesh_depth(mesh_source, mt if isinstance(mt, int) else -1, bool(inp[go.BOOST]), custom)
                 rgb_t = torch.from_numpy(np.array(image.convert('RGB'), dtype=np.uint8, order='C')).to(device)
                 verts, faces, colors = mg.create_mesh_arrays(rgb_t, depthi, keep_edges=not inp[go.SIMPLE_MESH_OCCLUDE],
                                                              spherical=bool(inp[go.SIMPLE_MESH_SPHERICAL]))

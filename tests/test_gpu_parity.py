@@ -310,11 +310,11 @@ def test_funnel_simple_mesh(gpu, tmp_path):
                                            {'gen_simple_mesh': True, 'do_output_depth': False}))
     assert [k for _, k, _ in res] == ['simple_mesh'] and os.path.exists(res[0][2])
     d = torch.from_numpy(dep)
-    v, f, c = mg.create_mesh_arrays(torch.from_numpy(img), mg.mesh_depth(d, 0, False, True), keep_edges=False)
+    v, f, c = mg.create_mesh_arrays(torch.from_numpy(img), mg.mesh_depth(d, -1, False, True), keep_edges=False)
     want = mg.write_obj(str(tmp_path / 'cpu.obj'), v.numpy(), f.numpy(), c.numpy())
     assert open(res[0][2]).read() == open(want).read()
-    v2 = mg.create_mesh_arrays(torch.from_numpy(img).cuda(), mg.mesh_depth(d.cuda(), 0, False, True), keep_edges=True, spherical=True)[0]
-    v2c = mg.create_mesh_arrays(torch.from_numpy(img), mg.mesh_depth(d, 0, False, True), keep_edges=True, spherical=True)[0]
+    v2 = mg.create_mesh_arrays(torch.from_numpy(img).cuda(), mg.mesh_depth(d.cuda(), -1, False, True), keep_edges=True, spherical=True)[0]
+    v2c = mg.create_mesh_arrays(torch.from_numpy(img), mg.mesh_depth(d, -1, False, True), keep_edges=True, spherical=True)[0]
     assert np.allclose(v2.cpu().numpy(), v2c.numpy(), rtol=0, atol=1e-12)
 
 
