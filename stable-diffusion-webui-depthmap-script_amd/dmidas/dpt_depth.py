@@ -100,7 +100,8 @@ class DPT(nn.Module):
                     features['out_conv'] = y
             return y
         if (path_1.is_cuda and path_1.dtype in (torch.float16, torch.bfloat16) and isinstance(head[1], Interpolate)
-                and head[1].mode == "bilinear" and head[1].align_corners and tuple(head[2].weight.shape) == (32, 128, 3, 3)):
+                and head[1].mode == "bilinear" and head[1].align_corners and tuple(head[2].weight.shape) == (32, 128, 3, 3)
+                and head[2].padding_mode == 'zeros'):          # TILING_MODE makes the convolutions circular: library path
             # upsample x2 -> conv3x3 128->32 -> ReLU -> conv1x1 -> ReLU in one MFMA kernel (ds_dpt_head_tail)
             from src import _native
             y = head[0](path_1)

@@ -37,7 +37,11 @@ def _folded(conv, bn, cache_holder):
 def conv_bn(x, conv, bn, relu=False):
     """BatchNorm(conv(x)) in inference mode as one convolution with folded weights."""
     w, b = _folded(conv, bn, conv)
-    y = F.conv2d(x, w, b, conv.stride, conv.padding, conv.dilation, conv.groups)
+    if conv.padding_mode != 'zeros':       # TILING_MODE (src/depthmap_generation.py:250-260): what nn.Conv2d._conv_forward does
+        x = F.pad(x, conv._reversed_padding_repeated_twice, mode=conv.padding_mode)
+        y = F.conv2d(x, w, b, conv.stride, 0, conv.dilation, conv.groups)
+    else:
+        y = F.conv2d(x, w, b, conv.stride, conv.padding, conv.dilation, conv.groups)
     return F.relu(y) if relu else y
 
 

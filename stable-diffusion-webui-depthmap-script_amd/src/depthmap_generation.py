@@ -63,6 +63,19 @@ _BUILDERS = {0: _build_leres, 1: _build_dpt_beit("beitl16_512", "dpt_beit_large_
              12: _build_dav2('s'), 13: _build_dav2('b'), 14: _build_dav2('l')}
 
 
+def apply_tiling_mode(net):
+    """reference :250-260: every module whose type is EXACTLY nn.Conv2d / nn.Conv1d (subclasses such as the hybrid stem's
+    weight-standardised convolutions are left alone, like in the reference) pads circularly, so that the depth map of a
+    tileable texture tiles.  Returns the number of layers switched."""
+    import torch
+    n = 0
+    for m in net.modules():
+        if type(m) is torch.nn.Conv2d or type(m) is torch.nn.Conv1d:
+            m.padding_mode = 'circular'
+            n += 1
+    return n
+
+
 def _load_pix2pix(device, allow_random_init):
     """reference :287-299: './models/pix2pix/latest_net_G.pth' (downloaded there when missing)."""
     from pix2pix.models.pix2pix4depth_model import Pix2Pix4DepthModel
@@ -79,9 +92,12 @@ class _NetPredictor:
     """One loaded network + its device-resident pre/post-processing (estimatemidas :455-499 / estimatedepthanything_v2
     :548-559).  Callable like a registered predictor: (pil_image, net_width, net_height, device) -> float32 tensor [H,W]."""
 
-    def __init__(self, model_type, device, model_dir, allow_random_init, no_half):
+    def __init__(self, model_type, device, model_dir, allow_random_init, no_half, tiling_mode=False):
         import torch
         net, filename = _BUILDERS[model_type]()
+        self.tiling_mode = bool(tiling_mode)
+        if tiling_mode:
+            apply_tiling_mode(net)
         self_model_dir_unset = model_dir is None
         if model_dir is None:                                # reference :83-92
             model_dir = {0: "./models/leres", 11: "./models/depth_anything", 12: "./models/depth_anything_v2",
@@ -177,8 +193,8 @@ class ModelHolder:
             # (:273-275).  The reference reloads whenever the boost switch changes (:62-72); here only if the precision does.
             no_half = bool(self.no_half or (boost and model_type not in (12, 13, 14)))
             if (self.depth_model is None or self.depth_model_type != model_type or not isinstance(self.depth_model, _NetPredictor)
-                    or self.depth_model.no_half != no_half):
-                self.depth_model = _NetPredictor(model_type, device, self.model_dir, self.allow_random_init, no_half)
+                    or self.depth_model.no_half != no_half or self.depth_model.tiling_mode != bool(tiling_mode)):
+                self.depth_model = _NetPredictor(model_type, device, self.model_dir, self.allow_random_init, no_half, tiling_mode)
         else:
             raise NotImplementedError(
                 f"depth model {model_type!r} is not available in this build (built: ids {sorted(_BUILDERS)}); register a "

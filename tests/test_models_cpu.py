@@ -290,3 +290,34 @@ def test_boost_single_estimates_for_midas_and_zoedepth_base_models():
     assert tuple(zo[0].shape) == (70, 100) and torch.equal(zo[0], direct) and torch.isfinite(zo[0]).all()
     with pytest.raises(NotImplementedError):
         boost._single_estimates(patches, 96, net, 5, 8)
+
+
+def test_tiling_mode_matches_reference_modules():
+    """TILING_MODE (src/depthmap_generation.py:250-260): the same layers switch to circular padding as in the reference's
+    own modules (count of exact-type nn.Conv2d) and the outputs match its hijacked modules to 1e-4
+    (tests/golden/make_golden_tiling.py)."""
+    from ddepth_anything_v2 import DepthAnythingV2
+    from dmidas.dpt_depth import DPTDepthModel
+    from lib.multi_depth_model_woauxi import RelDepthModel
+    from src.depthmap_generation import apply_tiling_mode
+    z = np.load(os.path.join(os.path.dirname(GOLD), "tiling_cases.npz"))
+    m = DPTDepthModel(path=None, backbone="beitb16_384", non_negative=True).eval()
+    m.load_state_dict(mw.fill_state_dict_beit(m.state_dict()), strict=True)
+    assert apply_tiling_mode(m) == int(z["dpt_beitb_n_convs"][0])
+    with torch.no_grad():
+        assert _rel(m(mw.synthetic_image((2, 3, 160, 224), seed=13)).numpy(), z["dpt_beitb_160x224_out"]) < 1e-4
+    m = DPTDepthModel(path=None, backbone="vitb_rn50_384", non_negative=True).eval()
+    m.load_state_dict(mw.fill_state_dict(m.state_dict()), strict=True)
+    assert apply_tiling_mode(m) == int(z["dpt_hybrid_n_convs"][0])
+    with torch.no_grad():
+        assert _rel(m(mw.synthetic_image((2, 3, 160, 224), seed=14)).numpy(), z["dpt_hybrid_160x224_out"]) < 1e-4
+    m = DepthAnythingV2('vits', features=64, out_channels=[48, 96, 192, 384]).eval()
+    m.load_state_dict(mw.fill_state_dict(m.state_dict()), strict=True)
+    assert apply_tiling_mode(m) == int(z["dav2_vits_n_convs"][0])
+    with torch.no_grad():
+        assert _rel(m(mw.synthetic_image((2, 3, 140, 182), seed=11)).numpy(), z["dav2_vits_140x182_out"]) < 1e-4
+    m = RelDepthModel(backbone='resnext101').eval()
+    m.load_state_dict(mw.fill_state_dict(m.state_dict()), strict=True)
+    assert apply_tiling_mode(m) == int(z["leres_n_convs"][0])
+    with torch.no_grad():
+        assert _rel(m.depth_model(mw.synthetic_image((2, 3, 96, 160), seed=15)).numpy(), z["leres_96x160_out"]) < 1e-4
