@@ -223,9 +223,13 @@ class ModelHolder:
         return raw, (self.depth_model_type in INVERTED_MODEL_IDS)
 
     def offload(self):
+        """reference :341-350 moves the networks to host RAM between runs to spare a consumer card's VRAM.  On a 288 GB
+        MI355X the largest built set (BEiT-L + pix2pix, < 2 GB in float32) stays resident: the call only records the
+        state, so the next run starts without a 1-2 GB host -> device copy."""
         self.offloaded = True
 
     def reload(self):
+        """reference :352-360 (counterpart of offload)."""
         self.offloaded = False
 
     def unload_models(self):
