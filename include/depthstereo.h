@@ -131,6 +131,14 @@ int ds_normalmap(ds_ctx *ctx, const uint16_t *depth, int n, int h, int w, int pr
                  int sobel_ksize, int post_blur, int invert, uint8_t *out, void *stream);
 
 /*
+ * ds_normalmap_f64 -- the same for float64 depth: create_normalmap accepts any real array
+ * (src/normalmap_generation.py:20-21 promote `depthmap * (-1.0) / 256.0` to float64; integer and float32
+ * inputs are cast to float64 by the host, which is exact).  Always the separable float64 passes.
+ */
+int ds_normalmap_f64(ds_ctx *ctx, const double *depth, int n, int h, int w, int pre_blur,
+                     int sobel_ksize, int post_blur, int invert, uint8_t *out, void *stream);
+
+/*
  * ds_depth_to_u16 -- replaces the depth post-processing of core_generation_funnel
  * (src/core.py:189-206, no-clip branch) followed by convert_to_i16 (src/core.py:44-50) for a batch
  * of float32 predictions: per image min/max, optional negate (models whose raw output is

@@ -401,3 +401,28 @@ def boost_blend(dst, rects, coefs, preds, mask_template):
         reg = out[y0:y0 + h, x0:x0 + w]
         out[y0:y0 + h, x0:x0 + w] = np.multiply(reg, np.float32(1) - mask) + np.multiply(merged, mask)
     return out
+
+
+def process_predicitons(predictions, smoothening='none'):
+    """numpy restatement of video mode's normalisation, src/video_mode.py:103-128 (the spelling is the reference's).
+    Pinned: tests/golden/video_cases.npz holds the outputs of the reference's own function
+    (tests/golden/make_golden_video.py) and tests/test_oracle_golden.py reproduces them bit for bit.
+      'none' (:115-116)          every frame scaled with the clip's global min / max
+      'experimental' (:117-127)  the global 0.5 / 99.5 percentiles of the temporally smoothed clip (5 taps 0.1 0.2 0.4 0.2
+                                 0.1, frame index clamped at both ends) replace min / max; the raw frames are scaled"""
+    frames = [np.asarray(p) for p in predictions]
+    if smoothening == 'none':                                                   # :105-111 with a = b = None
+        lo = min(f.min() for f in frames)
+        hi = max(f.max() for f in frames)
+    elif smoothening == 'experimental':
+        n = len(frames)
+        smoothed = []
+        for i in range(n):                                                      # :120-124
+            acc = np.zeros_like(frames[i])
+            for tap, weight in zip(range(-2, 3), (0.10, 0.20, 0.40, 0.20, 0.10)):
+                acc += weight * frames[min(max(0, i + tap), n - 1)]
+            smoothed.append(acc)
+        lo, hi = np.percentile(np.stack(smoothed), [0.5, 99.5])                 # :126
+    else:
+        return predictions                                                      # :128
+    return [(f - lo) / (hi - lo) for f in frames]

@@ -76,7 +76,8 @@ __global__ __launch_bounds__(NM_BX * NM_BY) void k_normalmap_fused(const uint16_
 #define NM_MAXK 63
 struct NmKernel { double cf[NM_MAXK]; int n; };
 
-__global__ __launch_bounds__(256) void k_nm_load(const uint16_t *__restrict__ depth, int64_t count, int invert, double *__restrict__ plane)
+template <typename T>
+__global__ __launch_bounds__(256) void k_nm_load(const T *__restrict__ depth, int64_t count, int invert, double *__restrict__ plane)
 {
     const double sgn = invert ? 1.0 : -1.0;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (int64_t)gridDim.x * 256)
@@ -202,9 +203,10 @@ static int nm_sobel(int ksize, int order, NmKernel *K)
     return 0;
 }
 
-DS_API int ds_normalmap(ds_ctx *ctx, const uint16_t *depth, int n, int h, int w, int pre_blur,
-                        int sobel_ksize, int post_blur, int invert, uint8_t *out, void *stream)
+static int nm_run(ds_ctx *ctx, const void *depth_any, int is_f64, int n, int h, int w, int pre_blur,
+                  int sobel_ksize, int post_blur, int invert, uint8_t *out, void *stream)
 {
+    const uint16_t *depth = (const uint16_t *)depth_any;
     DS_REQUIRE(ctx && depth && out, DS_EINVAL, "ds_normalmap: null argument");
     DS_REQUIRE(n > 0 && h > 0 && w > 0, DS_EINVAL, "ds_normalmap: bad shape n=%d h=%d w=%d", n, h, w);
     DS_REQUIRE(n <= 65535, DS_EUNSUPPORTED, "ds_normalmap: n must be <= 65535");
@@ -220,7 +222,7 @@ DS_API int ds_normalmap(ds_ctx *ctx, const uint16_t *depth, int n, int h, int w,
     DS_HIP_CHECK(hipSetDevice(ctx->device));
     hipStream_t st = (hipStream_t)stream;
 
-    if (pre_blur == 0 && post_blur == 0 && (sobel_ksize == 3 || sobel_ksize == 0)) {
+    if (!is_f64 && pre_blur == 0 && post_blur == 0 && (sobel_ksize == 3 || sobel_ksize == 0)) {
         dim3 grid((w + NM_BX - 1) / NM_BX, (h + NM_BY - 1) / NM_BY, n), block(NM_BX, NM_BY);
         DS_REQUIRE(grid.y <= 65535, DS_EUNSUPPORTED, "ds_normalmap: image too tall");
         if (sobel_ksize == 3) hipLaunchKernelGGL(k_normalmap_fused<1>, grid, block, 0, st, depth, h, w, invert ? 1 : 0, out);
@@ -237,7 +239,8 @@ DS_API int ds_normalmap(ds_ctx *ctx, const uint16_t *depth, int n, int h, int w,
     int nb = (int)((count + 1023) / 1024); if (nb > 4096) nb = 4096;
     dim3 g2((w + 63) / 64, (h + 3) / 4, n);
     DS_REQUIRE(g2.y <= 65535, DS_EUNSUPPORTED, "ds_normalmap: image too tall");
-    hipLaunchKernelGGL(k_nm_load, dim3(nb), dim3(256), 0, st, depth, count, invert ? 1 : 0, A);
+    if (is_f64) hipLaunchKernelGGL(k_nm_load<double>, dim3(nb), dim3(256), 0, st, (const double *)depth_any, count, invert ? 1 : 0, A);
+    else hipLaunchKernelGGL(k_nm_load<uint16_t>, dim3(nb), dim3(256), 0, st, depth, count, invert ? 1 : 0, A);
     NmKernel G, KD, KS;
     if (pre_blur > 0) {                                            // :23-24
         nm_gaussian(pre_blur, (double)pre_blur, &G);
@@ -266,4 +269,18 @@ DS_API int ds_normalmap(ds_ctx *ctx, const uint16_t *depth, int n, int h, int w,
     hipLaunchKernelGGL(k_nm_finish, dim3(nb), dim3(256), 0, st, C, D, E, count, post_blur > 0 ? 1 : 0, out);
     DS_HIP_CHECK(hipGetLastError());
     return DS_OK;
+}
+
+DS_API int ds_normalmap(ds_ctx *ctx, const uint16_t *depth, int n, int h, int w, int pre_blur,
+                        int sobel_ksize, int post_blur, int invert, uint8_t *out, void *stream)
+{
+    return nm_run(ctx, depth, 0, n, h, w, pre_blur, sobel_ksize, post_blur, invert, out, stream);
+}
+
+// Any other real dtype of the reference's `depthmap` argument (:20-21 promote it to float64; the host casts): the separable
+// float64 passes for every kernel size (general float64 data has no exact 3x3 shortcut).
+DS_API int ds_normalmap_f64(ds_ctx *ctx, const double *depth, int n, int h, int w, int pre_blur,
+                            int sobel_ksize, int post_blur, int invert, uint8_t *out, void *stream)
+{
+    return nm_run(ctx, depth, 1, n, h, w, pre_blur, sobel_ksize, post_blur, invert, out, stream);
 }

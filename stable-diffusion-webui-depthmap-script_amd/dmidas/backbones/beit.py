@@ -91,9 +91,8 @@ class Block(vm.EncoderBlock):
     def gammas(self):
         return self.gamma_1, self.gamma_2
 
-    def rel_pos_bias(self, window_size):
-        """[H, N, N] (query, key) for N = Wh*Ww + 1: beit.py:29-62 (bilinear resize of the table to the new window, then
-        the index gather)."""
+    def _resized_table(self, window_size):
+        """beit.py:29-54: the bias table bilinearly resized to the run-time window, [(2Wh-1)(2Ww-1) + 3, H]."""
         a = self.attn
         old_h, old_w = 2 * a.window_size[0] - 1, 2 * a.window_size[1] - 1
         new_h, new_w = 2 * window_size[0] - 1, 2 * window_size[1] - 1
@@ -101,31 +100,73 @@ class Block(vm.EncoderBlock):
         old_sub = table[:a.num_relative_distance - 3].reshape(1, old_w, old_h, -1).permute(0, 3, 1, 2)
         new_sub = F.interpolate(old_sub.float(), size=(int(new_h), int(new_w)), mode="bilinear").to(table.dtype)
         new_sub = new_sub.permute(0, 2, 3, 1).reshape(new_h * new_w, -1)
-        new_table = torch.cat([new_sub, table[a.num_relative_distance - 3:]])
-        index = gen_relative_position_index(window_size).to(table.device)
+        return torch.cat([new_sub, table[a.num_relative_distance - 3:]])
+
+    def rel_pos_bias(self, window_size):
+        """[H, N, N] (query, key) for N = Wh*Ww + 1: beit.py:29-62 (bilinear resize of the table to the new window, then
+        the index gather)."""
+        new_table = self._resized_table(window_size)
+        index = _relative_position_index(tuple(window_size), new_table.device)
         n = window_size[0] * window_size[1] + 1
         bias = new_table[index.view(-1)].view(n, n, -1)
         return bias.permute(2, 0, 1).contiguous()
 
     def attention_bias(self, n_pad, grid_hw, dtype, device):
-        """Padded [H, Np(query), Np(key)]; cached per (window, dtype) until the table changes."""
+        """Padded [H, Np(query), Np(key)]; cached per (window, dtype) until the table changes.  A dense float32 operand
+        above DENSE_BIAS_BYTES_MAX is NOT kept (Boost's whole-image pass of the float32 path reaches 10^4 tokens: 6.5 GB
+        per block, 155 GB for the 24 blocks): the block then hands out a _LazyBias that gathers per query tile from the
+        resized table, like the reference, which builds the bias transiently in every block (beit.py:29-62)."""
         a = self.attn
         key = (tuple(grid_hw), n_pad, dtype, device, a.relative_position_bias_table._version)
         hit = self._bias_cache.get(key)
         if hit is not None:
             return hit
         with torch.no_grad():
-            bias = self.rel_pos_bias(tuple(grid_hw))                                     # H, N, N (query, key)
-            n = bias.shape[-1]
-            if dtype == torch.float32 or not bias.is_cuda:
+            if dtype == torch.float32 or device.type != 'cuda':
+                heads = a.relative_position_bias_table.shape[1]
+                if heads * n_pad * n_pad * 4 > DENSE_BIAS_BYTES_MAX:
+                    self._bias_cache.clear()
+                    return _LazyBias(self._resized_table(tuple(grid_hw)).to(device=device, dtype=dtype), tuple(grid_hw), n_pad)
+                bias = self.rel_pos_bias(tuple(grid_hw))                                 # H, N, N (query, key)
+                n = bias.shape[-1]
                 bt = torch.zeros((bias.shape[0], n_pad, n_pad), dtype=dtype, device=device)
                 bt[:, :n, :n] = bias
             else:                                   # operand of the HIP kernel (register order, log2 units)
                 from src import _native
-                bt = _native.attention_bias_pack(bias.to(device), n_pad, dtype)
+                bt = _native.attention_bias_pack(self.rel_pos_bias(tuple(grid_hw)).to(device), n_pad, dtype)
         self._bias_cache.clear()
         self._bias_cache[key] = bt
         return bt
+
+
+DENSE_BIAS_BYTES_MAX = 256 << 20
+_index_cache = {}
+
+
+def _relative_position_index(window_size, device):
+    """gen_relative_position_index, shared by all blocks (it depends on the window only); one entry is kept."""
+    key = (tuple(window_size), str(device))
+    hit = _index_cache.get(key)
+    if hit is None:
+        _index_cache.clear()
+        hit = _index_cache[key] = gen_relative_position_index(window_size).to(device)
+    return hit
+
+
+class _LazyBias:
+    """Relative-position bias too large to keep dense: rows(q0, q1) gathers [H, q1-q0, Np] from the resized table."""
+
+    def __init__(self, table, window_size, n_pad):
+        self.table, self.window_size, self.n_pad = table, window_size, n_pad
+        self.n = window_size[0] * window_size[1] + 1
+
+    def rows(self, q0, q1):
+        index = _relative_position_index(self.window_size, self.table.device)
+        out = self.table.new_zeros((self.table.shape[1], q1 - q0, self.n_pad))
+        qe = min(q1, self.n)
+        if qe > q0:
+            out[:, :qe - q0, :self.n] = self.table[index[q0:qe].reshape(-1)].view(qe - q0, self.n, -1).permute(2, 0, 1)
+        return out
 
 
 class PatchEmbed(nn.Module):

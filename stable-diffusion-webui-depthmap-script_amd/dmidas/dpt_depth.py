@@ -168,13 +168,15 @@ class DPTDepthModel(DPT):
 
     # ---- device-resident pre/post of estimatemidas (src/depthmap_generation.py:455-499) ------------------
     @torch.no_grad()
-    def infer_batch(self, images_u8, net_size=512, resize_mode="minimal", mean=0.5, std=0.5):
+    def infer_batch(self, images_u8, net_size=512, resize_mode="minimal", mean=0.5, std=0.5, net_h=None):
         """uint8 [B,H,W,3] (RGB as the funnel hands it over) -> float32 [B,H,W] raw prediction, on the device.
+        net_size is the requested network WIDTH, net_h the HEIGHT (default: the same) -- Resize gets both (:460-462), and with
+        NET_SIZE_MATCH on a non-square image (core.py:177-181) they differ, which changes the 'minimal' scale choice.
         get_raw_prediction swaps R and B once (:381) and estimatemidas does not swap back, so the network sees BGR
         order -- reproduced.  cv2.INTER_CUBIC resize -> torch bicubic (same kernel a=-0.75, half-pixel centres; cv2 is
         not available here: unpinned); prediction upsampled with torch bicubic align_corners=False exactly as :484-489."""
         b, h, w, _ = images_u8.shape
-        nw, nh = midas_net_size(w, h, net_size, net_size, resize_mode)
+        nw, nh = midas_net_size(w, h, int(net_size), int(net_size if net_h is None else net_h), resize_mode)
         x = images_u8.flip(-1).permute(0, 3, 1, 2).float() / 255.0
         x = F.interpolate(x, size=(nh, nw), mode="bicubic", align_corners=False)
         x = (x - mean) / std

@@ -18,7 +18,7 @@ DS_DEPTH_U16, DS_DEPTH_F32, DS_DEPTH_F64 = 0, 1, 2
 FILL_IDS = {"none": 0, "naive": 1, "naive_interpolating": 2, "polylines_soft": 3, "polylines_sharp": 4}
 
 EXPORTS = [
-    "ds_version", "ds_last_error", "ds_ctx_create", "ds_ctx_destroy", "ds_stereo_warp", "ds_depth_minmax",
+    "ds_version", "ds_last_error", "ds_normalmap_f64", "ds_ctx_create", "ds_ctx_destroy", "ds_stereo_warp", "ds_depth_minmax",
     "ds_stereo_last_exact_rows", "ds_copy_view", "ds_overlap_red_cyan", "ds_normalmap", "ds_depth_to_u16",
     "ds_convert_to_i16", "ds_profile_enable", "ds_profile_last_ms", "ds_stereo_last_stats", "ds_attention_fwd", "ds_attention_bias_pack", "ds_colorize_u16", "ds_residual_layernorm", "ds_boost_blend", "ds_upsample_bilinear_nhwc", "ds_dpt_head_tail",
 ]
@@ -58,6 +58,7 @@ def lib():
             L.ds_copy_view.argtypes = [vp, vp, i64, i64, vp, i64, i64, ci, ci, i64, vp]
             L.ds_overlap_red_cyan.argtypes = [vp, vp, i64, i64, vp, i64, i64, ci, ci, ci, ci, vp, vp]
             L.ds_normalmap.argtypes = [vp, vp, ci, ci, ci, ci, ci, ci, ci, vp, vp]
+            L.ds_normalmap_f64.argtypes = [vp, vp, ci, ci, ci, ci, ci, ci, ci, vp, vp]
             L.ds_depth_to_u16.argtypes = [vp, vp, ci, ci, ci, ci, vp, vp, vp]
             L.ds_convert_to_i16.argtypes = [vp, vp, ci, i64, vp, vp]
             L.ds_stereo_last_stats.argtypes = [vp, ctypes.POINTER(i64), vp]
@@ -212,12 +213,15 @@ def overlap_red_cyan(im1_ptr, r1, i1, im2_ptr, r2, i2, n, h, w, c, out):
                                      _stream(out)))
 
 
-def normalmap(depth_u16, pre_blur, sobel_ksize, post_blur, invert):
+def normalmap(depth, pre_blur, sobel_ksize, post_blur, invert):
+    """depth [n,h,w]: uint16 (the funnel's depth maps; the fused kernel) or float64 (any other dtype, cast by the caller)."""
     torch = require_gpu()
-    n, h, w = depth_u16.shape
-    out = torch.empty((n, h, w, 3), dtype=torch.uint8, device=depth_u16.device)
-    _check(lib().ds_normalmap(ctx_for(_dev_index(depth_u16)), depth_u16.data_ptr(), n, h, w, int(pre_blur), int(sobel_ksize),
-                              int(post_blur), 1 if invert else 0, out.data_ptr(), _stream(depth_u16)))
+    n, h, w = depth.shape
+    assert depth.dtype in (torch.uint16, torch.float64) and depth.is_contiguous()
+    out = torch.empty((n, h, w, 3), dtype=torch.uint8, device=depth.device)
+    fn = lib().ds_normalmap if depth.dtype == torch.uint16 else lib().ds_normalmap_f64
+    _check(fn(ctx_for(_dev_index(depth)), depth.data_ptr(), n, h, w, int(pre_blur), int(sobel_ksize),
+              int(post_blur), 1 if invert else 0, out.data_ptr(), _stream(depth)))
     return out
 
 
@@ -364,9 +368,6 @@ def upsample_bilinear(x, size=None, scale_factor=None, align_corners=True):
     return out
 
 
-_head_cache = {}
-
-
 def dpt_head_tail(x, size, conv3, conv1, relu_out=True):
     """upsample(x, size, bilinear, align_corners=True) -> conv3 (3x3, 128->32) -> ReLU -> conv1 (1x1, 32->1) -> ReLU, fused
     (include/depthstereo.h: ds_dpt_head_tail).  x: NCHW-shaped [B,128,h,w] float16/bfloat16 CUDA tensor (any memory format;
@@ -375,15 +376,17 @@ def dpt_head_tail(x, size, conv3, conv1, relu_out=True):
     b, c, ih, iw = x.shape
     assert c == 128 and tuple(conv3.weight.shape) == (32, 128, 3, 3) and tuple(conv1.weight.shape) == (1, 32, 1, 1)
     xin = x.contiguous(memory_format=torch.channels_last)
-    key = (id(conv3), conv3.weight._version, conv3.bias._version, conv1.weight._version, conv1.bias._version, x.dtype, x.device)
-    hit = _head_cache.get(id(conv3))
+    # the repacked weights live ON the module (they die with it; a recycled id() of another model's head can never hit),
+    # keyed by the storage and version of every parameter that went into them
+    key = tuple((p.data_ptr(), p._version) for p in (conv3.weight, conv3.bias, conv1.weight, conv1.bias)) + (x.dtype, x.device)
+    hit = getattr(conv3, "_ds_head_cache", None)
     if hit is None or hit[0] != key:
         w = conv3.weight.detach().to(x.dtype)                                   # [co, ci, ky, kx]
         # fragment order: [tap = ky*3+kx][slice s][half][co][j] with ci = 16 s + 8 half + j
         wf = w.permute(2, 3, 1, 0).reshape(9, 8, 2, 8, 32).permute(0, 1, 2, 4, 3).contiguous()
         hit = (key, wf, conv3.bias.detach().float().contiguous(), conv1.weight.detach().float().reshape(32).contiguous(),
                float(conv1.bias.detach().float().item()))
-        _head_cache[id(conv3)] = hit
+        conv3._ds_head_cache = hit
     _, wf, b2, w3, b3 = hit
     oh, ow = int(size[0]), int(size[1])
     out = torch.empty((b, 1, oh, ow), dtype=x.dtype, device=x.device)

@@ -147,7 +147,7 @@ class _NetPredictor:
         if self.is_dav2:
             return self.net.infer_batch(batch, int(net_width))[0]          # reference passes net_width as input_size (:553)
         mode = "minimal"                                                    # resize_mode of ids 1-4 (:127, :141, :155, :168)
-        return self.net.infer_batch(batch, net_size=int(net_width), resize_mode=mode)[0]
+        return self.net.infer_batch(batch, net_size=int(net_width), resize_mode=mode, net_h=int(net_height))[0]
 
 
 class ModelHolder:

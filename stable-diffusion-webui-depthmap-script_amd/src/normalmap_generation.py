@@ -11,7 +11,7 @@ def _ksize(v):
 
 def create_normalmap(depthmap, pre_blur=None, sobel_gradient=3, post_blur=None, invert=False):
     """Generates normalmaps (reference: src/normalmap_generation.py:5-56).
-    :param depthmap: HxW depthmap (uint16 from the funnel)
+    :param depthmap: HxW depthmap: uint16 from the funnel (core.py:262), or any other real array like the reference
     :param pre_blur: Gaussian blur before the gradient, None/<=0 to disable, otherwise kernel size
     :param sobel_gradient: Sobel kernel size, None/<=0 for np.gradient
     :param post_blur: Gaussian blur after the gradient, None/<=0 to disable, otherwise kernel size
@@ -19,9 +19,16 @@ def create_normalmap(depthmap, pre_blur=None, sobel_gradient=3, post_blur=None, 
     """
     torch = _native.require_gpu()
     depth = np.asarray(depthmap)
+    if depth.ndim != 2 or depth.dtype.kind not in 'buif':
+        raise _native.DepthStereoError('create_normalmap: depthmap must be a 2-D real array, got %s %s' % (depth.dtype, depth.shape))
     if depth.dtype != np.uint16:
-        raise _native.DepthStereoError('create_normalmap: only uint16 depthmaps (what core_generation_funnel passes, '
-                                       'core.py:211,262) are supported, got %s' % depth.dtype)
+        # :20-21: `depthmap * (-1.0) / 256.0` promotes integers to float64 and keeps float32 as float32; cv2.Sobel is fed
+        # np.float64(normalmap) (:28-29), which equals the float64 evaluation (negation and /256 are exact), but np.gradient
+        # (:31) and everything after it would run in float32 -- that one combination is not built.
+        if depth.dtype.kind == 'f' and depth.dtype.itemsize < 8 and _ksize(sobel_gradient) == 0:
+            raise _native.DepthStereoError('create_normalmap: float16/float32 depth with np.gradient (sobel_gradient None) runs '
+                                           'in float32 in the reference and is not built; pass float64 or use a Sobel size')
+        depth = depth.astype(np.float64)
     dev = torch.device('cuda', torch.cuda.current_device())
     d = torch.from_numpy(np.array(depth, order='C')).to(dev).unsqueeze(0)
     out = create_normalmap_batch(d, pre_blur, sobel_gradient, post_blur, invert)
@@ -29,5 +36,5 @@ def create_normalmap(depthmap, pre_blur=None, sobel_gradient=3, post_blur=None, 
 
 
 def create_normalmap_batch(depth_u16, pre_blur=None, sobel_gradient=3, post_blur=None, invert=False):
-    """Device-resident batch: uint16 cuda tensor [N,H,W] -> uint8 cuda tensor [N,H,W,3]."""
+    """Device-resident batch: uint16 (or float64) cuda tensor [N,H,W] -> uint8 cuda tensor [N,H,W,3]."""
     return _native.normalmap(depth_u16.contiguous(), _ksize(pre_blur), _ksize(sobel_gradient), _ksize(post_blur), bool(invert))

@@ -21,28 +21,22 @@ import numpy as np
 
 
 def process_predicitons(predictions, smoothening='none'):
-    """reference :103-128 (the spelling is the reference's)."""
-    def global_scaling(objs, a=None, b=None):
-        normalized = []
-        min_value = a if a is not None else min([obj.min() for obj in objs])
-        max_value = b if b is not None else max([obj.max() for obj in objs])
-        for obj in objs:
-            normalized += [(obj - min_value) / (max_value - min_value)]
-        return normalized
+    """Drop-in for the reference's process_predicitons (:103-128; the spelling is the reference's): a list of [H,W]
+    arrays in, a list of normalised arrays out ('none': float32, global min/max; 'experimental': float64, the 0.5 / 99.5
+    percentiles of the 5-tap temporally smoothed clip; anything else: returned unchanged).  The work is the same tensor
+    code that runs frame-parallel (process_predictions_sharded) on the whole clip as one local shard -- on the GPU when
+    one is visible; nothing here is specific to a device."""
+    if smoothening not in ('none', 'experimental') or len(predictions) == 0:
+        return predictions
+    import torch
+    stack = torch.from_numpy(np.stack([np.asarray(p, dtype=np.float32) for p in predictions]))
+    if torch.cuda.is_available():
+        stack = stack.cuda()
+    out = process_predictions_sharded(stack, smoothening, group=_LOCAL).cpu().numpy()
+    return [out[i] for i in range(out.shape[0])]
 
-    if smoothening == 'none':
-        return global_scaling(predictions)
-    elif smoothening == 'experimental':
-        processed = []
-        clip = lambda val: min(max(0, val), len(predictions) - 1)           # noqa: E731
-        for i in range(len(predictions)):
-            f = np.zeros_like(predictions[i])
-            for u, mul in enumerate([0.10, 0.20, 0.40, 0.20, 0.10]):
-                f += mul * predictions[clip(i + (u - 2))]
-            processed += [f]
-        a, b = np.percentile(np.stack(processed), [0.5, 99.5])
-        return global_scaling(predictions, a, b)
-    return predictions
+
+_LOCAL = object()          # group sentinel: treat `local` as the whole clip even inside an initialised process group
 
 
 # ---- sharded over ranks -------------------------------------------------------------------------------------------------------
@@ -108,7 +102,9 @@ def process_predictions_sharded(local, smoothening='none', group=None):
     'experimental', like numpy's promotion with the float64 percentiles; float32 for 'none')."""
     import torch
     import torch.distributed as dist
-    multi = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+    multi = group is not _LOCAL and dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+    if group is _LOCAL:
+        group = None
     if smoothening == 'none':
         mm = torch.stack((local.min(), -local.max())) if local.numel() else torch.tensor([float('inf')] * 2, device=local.device)
         if multi:
@@ -120,25 +116,46 @@ def process_predictions_sharded(local, smoothening='none', group=None):
     rank = dist.get_rank(group) if multi else 0
     world = dist.get_world_size(group) if multi else 1
     n_local = local.shape[0]
-    # halo: two frames from each neighbour (the global first / last frame is replicated: clip() of the reference)
+    # halo: the two frames before and after this rank's block (the global first / last frame replicated: clip() of the
+    # reference).  Every rank publishes its first and last (up to) two frames -- zero placeholders where it holds fewer,
+    # so the collectives have one fixed shape even for empty shards -- and walks outwards over its neighbours until it
+    # has two frames on each side (a neighbour may hold a single frame, or none).
+    hw = tuple(local.shape[1:])
     if multi:
         counts = [torch.zeros(1, dtype=torch.int64, device=local.device) for _ in range(world)]
         dist.all_gather(counts, torch.tensor([n_local], dtype=torch.int64, device=local.device), group=group)
         counts = [int(c.item()) for c in counts]
-        assert all(c >= 2 or c == 0 for c in counts), "frame shards must hold at least 2 frames for the +-2 halo"
-        head = local[:2].contiguous()
-        tail = local[-2:].contiguous()
+        k = min(n_local, 2)
+        head = torch.zeros((2,) + hw, dtype=local.dtype, device=local.device)
+        tail = torch.zeros((2,) + hw, dtype=local.dtype, device=local.device)
+        if k:
+            head[:k] = local[:k]                              # left aligned
+            tail[2 - k:] = local[n_local - k:]                # right aligned
         heads = [torch.empty_like(head) for _ in range(world)]
         tails = [torch.empty_like(tail) for _ in range(world)]
         dist.all_gather(heads, head, group=group)
         dist.all_gather(tails, tail, group=group)
-        prev_r = next((r for r in range(rank - 1, -1, -1) if counts[r] > 0), None)
-        next_r = next((r for r in range(rank + 1, world) if counts[r] > 0), None)
-        left = tails[prev_r] if prev_r is not None else local[:1].expand(2, -1, -1)
-        right = heads[next_r] if next_r is not None else local[-1:].expand(2, -1, -1)
+        before, after = [], []
+        for r in range(rank - 1, -1, -1):
+            c = min(counts[r], 2)
+            before = [tails[r][2 - c + i] for i in range(c)] + before
+            if len(before) >= 2:
+                break
+        for r in range(rank + 1, world):
+            c = min(counts[r], 2)
+            after = after + [heads[r][i] for i in range(c)]
+            if len(after) >= 2:
+                break
     else:
-        left = local[:1].expand(2, -1, -1)
-        right = local[-1:].expand(2, -1, -1)
+        before, after = [], []
+    if n_local == 0:                                          # nothing to smooth here; still part of every collective below
+        left = right = local.new_zeros((2,) + hw)
+    else:
+        before, after = before[-2:], after[:2]
+        first = before[0] if before else local[0]             # exhausted the ranks on that side: the global first frame
+        last = after[-1] if after else local[-1]
+        left = torch.stack([first] * (2 - len(before)) + before)
+        right = torch.stack(after + [last] * (2 - len(after)))
     ext = torch.cat((left, local, right), dim=0)
     processed = torch.zeros_like(local)
     for u, mul in enumerate([0.10, 0.20, 0.40, 0.20, 0.10]):                # same order of accumulation as the reference
@@ -147,12 +164,14 @@ def process_predictions_sharded(local, smoothening='none', group=None):
     return (local.double() - a) / (b - a)
 
 
-def gen_frames_sharded(frames_u8, predict_batch, inp, smoothening='none', group=None, batch=8, dst=0):
+def gen_frames_sharded(frames_u8, predict_batch, inp, smoothening='none', group=None, batch=8, dst=0, invert=False):
     """Two-pass video pipeline on decoded frames, frame parallel.
     frames_u8: uint8 tensor [F, H, W, 3] (every rank may hold the full clip or just index its block); predict_batch:
     callable uint8 [b,H,W,3] -> float32 [b,H,W] raw prediction (e.g. DepthAnythingV2.infer_batch) on the rank's device.
-    Returns on rank `dst` a dict {mode: uint8 [F, ...]} for the requested stereo modes plus 'depth' (uint16 [F,H,W]);
-    None elsewhere."""
+    invert: True for the models whose raw output is near-is-dark (ids 0, 7-9, 10: depthmap_generation.py:402) -- the
+    first pass of the reference yields 'depth_prediction' AFTER ``out *= -1`` (core.py:192-195), so the normalisation sees
+    the negated predictions.  Returns on rank `dst` a dict {mode: uint8 [F, ...]} for the requested stereo modes plus
+    'depth' (uint16 [F,H,W]); None elsewhere."""
     import torch
     import torch.distributed as dist
     from . import _native, multigpu
@@ -166,8 +185,15 @@ def gen_frames_sharded(frames_u8, predict_batch, inp, smoothening='none', group=
     mine = frames_u8[s:e].to(dev)
     preds = [predict_batch(mine[i:i + batch]) for i in range(0, e - s, batch)]                    # pass 1 (:139-150)
     preds = torch.cat(preds) if preds else torch.empty((0,) + tuple(frames_u8.shape[1:3]), device=dev)
+    if invert:
+        preds = preds * -1                                                                        # core.py:192-195
     norm = process_predictions_sharded(preds, smoothening, group)                                 # :151
-    d16 = _native.convert_to_i16(norm.double() if norm.dtype != torch.float32 else norm)         # core.py:170-174,211
+    # second pass: the normalised frames re-enter the funnel as custom depth maps, np.asarray(dp, dtype='float') = float64
+    # (core.py:170-174), and are quantised in float64 (:211) -- also in 'none' mode, whose frames are float32
+    if e > s:
+        d16 = _native.convert_to_i16(norm.double().contiguous())
+    else:
+        d16 = torch.empty((0,) + tuple(frames_u8.shape[1:3]), dtype=torch.uint16, device=dev)
     modes = list(inp.get('stereo_modes', ['left-right']))
     outs = {'depth': d16}
     if inp.get('gen_stereo', True) and e > s:                                                     # pass 2 (:160)

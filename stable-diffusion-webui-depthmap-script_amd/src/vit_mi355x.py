@@ -44,21 +44,33 @@ def pad_tokens(x, n_pad):
     return out
 
 
+SCORE_BYTES_MAX = 1 << 30         # attention_reference never holds more than this many bytes of logits at once
+
+
 def attention_reference(qk, vt, n_valid, scale, bias=None):
     """Definition of the fused attention (float32 math).
-    qk [B, Np, 2, H, D]; vt [B, H*D, Np]; keys >= n_valid are masked; bias optional [H, Np, Np] (added to q.k*scale).
-    Returns [B, Np, H*D]; rows >= n_valid are unspecified (they are never read as keys)."""
+    qk [B, Np, 2, H, D]; vt [B, H*D, Np]; keys >= n_valid are masked; bias optional: a [H, Np, Np] tensor (added to
+    q.k*scale) or an object with ``rows(q0, q1) -> [H, q1-q0, Np]`` (a bias too large to keep dense, built per query tile).
+    Returns [B, Np, H*D]; rows >= n_valid are unspecified (they are never read as keys).
+    Long sequences (Boost's whole-image pass reaches 10^4 tokens: B*H*Np^2 floats = 6.4 GB per block) are processed in
+    query tiles of at most SCORE_BYTES_MAX bytes of logits; softmax rows are independent, so the result is the same."""
     b, npad, _, h, d = qk.shape
     q = qk[:, :, 0].permute(0, 2, 1, 3).float()                # B H Np D
     k = qk[:, :, 1].permute(0, 2, 1, 3).float()
     v = vt.reshape(b, h, d, npad).permute(0, 1, 3, 2).float()   # B H Np D
-    att = (q * scale) @ k.transpose(-2, -1)
-    if bias is not None:
-        att = att + bias.float().unsqueeze(0)
-    if n_valid < npad:
-        att[..., n_valid:] = float('-inf')
-    att = att.softmax(dim=-1)
-    out = att @ v
+    kt = k.transpose(-2, -1)
+    rows = max(1, min(npad, SCORE_BYTES_MAX // max(1, b * h * npad * 4)))
+    outs = []
+    for q0 in range(0, npad, rows):
+        q1 = min(npad, q0 + rows)
+        att = (q[:, :, q0:q1] * scale) @ kt
+        if bias is not None:
+            bt = bias.rows(q0, q1) if hasattr(bias, "rows") else bias[:, q0:q1]
+            att = att + bt.float().unsqueeze(0)
+        if n_valid < npad:
+            att[..., n_valid:] = float('-inf')
+        outs.append(att.softmax(dim=-1) @ v)
+    out = outs[0] if len(outs) == 1 else torch.cat(outs, dim=2)
     return out.permute(0, 2, 1, 3).reshape(b, npad, h * d).to(qk.dtype)
 
 

@@ -319,3 +319,129 @@ def test_funnel_with_zoedepth(gpu):
     finally:
         core.model_holder.allow_random_init = False
         core.model_holder.unload_models()
+
+
+# ---- parity at the BENCHMARKED shapes ---------------------------------------------------------------------------------
+GOLD_LARGE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "model_cases_large.npz")
+
+
+@pytest.mark.parametrize("b,n_valid,h,with_bias,dtype", [
+    (32, 1025, 16, True, torch.float16),      # dpt_beit_large_512 at batch 32: the launch bench.py's roofline is quoted on
+    (4, 2443, 16, False, torch.float16),      # Depth-Anything-V2 ViT-L on a 1080p frame (BASELINE config 5)
+    (2, 4097, 16, True, torch.float16),       # dpt_beit_large_512 with NET_SIZE_MATCH at 1024^2 (net 1024)
+    (2, 1025, 16, True, torch.bfloat16),
+    (1, 577, 12, False, torch.float16),       # dpt_hybrid_384 (BASELINE config 2)
+])
+def test_attention_kernel_at_benchmark_shapes(gpu, b, n_valid, h, with_bias, dtype):
+    """k_attention_fwd against its float32 definition (vit_mi355x.attention_reference, query-tiled so the B x H x N x N
+    logits never exceed 1 GiB) at the exact launch shapes of the networks BASELINE.json names -- every batch element,
+    every head, every valid row.  dmidas/backbones/beit.py:65-91, dinov2_layers/attention.py:49-62."""
+    from src import vit_mi355x as vm
+    from src import _native
+    qk, vt, bias, npad = _case(b, n_valid, h, dtype, 1000 + n_valid, with_bias)
+    packed, padded = None, None
+    if bias is not None:
+        packed = _native.attention_bias_pack(bias, npad, dtype)
+        padded = torch.zeros((h, npad, npad), device='cuda')
+        padded[:, :n_valid, :n_valid] = bias
+    got = _native.attention_fwd(qk, vt, n_valid, 0.125, packed)
+    tol = (2e-3 if dtype == torch.float16 else 1.6e-2) if bias is None else (5e-3 if dtype == torch.float16 else 8e-2)
+    worst = 0.0
+    for b0 in range(0, b, 4):                       # the definition in float32, four batch elements at a time
+        want = vm.attention_reference(qk[b0:b0 + 4].float(), vt[b0:b0 + 4].float(), n_valid, 0.125, padded)
+        worst = max(worst, (got[b0:b0 + 4].float()[:, :n_valid] - want[:, :n_valid]).abs().max().item())
+    assert worst < tol, (b, n_valid, h, with_bias, dtype, worst)
+    assert torch.isfinite(got.float()).all()
+
+
+def test_attention_rescale_branch_is_exercised(gpu):
+    """The online softmax only rescales O when a running maximum moves; spike one key per 64-key tile so that every tile
+    moves it for some query, and make the LAST tile hold the row maximum for others (cdna_hip_programming.md rule 26)."""
+    from src import vit_mi355x as vm
+    from src import _native
+    qk, vt, _, npad = _case(2, 1025, 4, torch.float16, 77, False)
+    for t in range(0, 1025, 64):
+        qk[:, t + (t // 64) % 50, 1] *= 6.0          # a strong key in every tile, stronger towards the end
+    qk[:, 1024, 1] = qk[:, 3, 0] * 3.0               # the last valid key matches query 3
+    got = _native.attention_fwd(qk, vt, 1025, 0.125)
+    want = vm.attention_reference(qk.float(), vt.float(), 1025, 0.125)
+    assert (got.float()[:, :1025] - want[:, :1025]).abs().max().item() < 4e-3
+
+
+def test_dpt_beit_large_512_forward_vs_reference(gpu):
+    """dpt_beit_large_512 (BASELINE config 3's network, 24 blocks, 1025 tokens, relative-position bias) on the GPU against
+    the float32 output of the reference's own dmidas code at the same size (make_golden_models_large.py):
+    float32 at 1e-4 (north_star's depth tolerance), then float16 -- the precision bench.py runs and the reference's own GPU
+    default (src/depthmap_generation.py:268-275) -- at 2e-2: fused attention with the packed bias, fused residual +
+    LayerNorm, fused head tail."""
+    from dmidas.dpt_depth import DPTDepthModel
+    gold = np.load(GOLD_LARGE)
+    m = DPTDepthModel(path=None, backbone="beitl16_512", non_negative=True).eval()
+    m.load_state_dict(mw.fill_state_dict_beit(m.state_dict()), strict=True)
+    x = mw.synthetic_image((1, 3, 512, 512), seed=31).cuda()
+    ref = gold["dpt_beitl512_512x512_out_s2"]
+    m = m.cuda()
+    with torch.no_grad():
+        y32 = m(x)[:, ::2, ::2].cpu().numpy()
+        taps = m.pretrained(x)
+    scale = np.abs(ref).max()
+    assert np.abs(y32 - ref).max() / scale < 1e-4, np.abs(y32 - ref).max() / scale
+    t4 = taps[3][:, ::4].float().cpu().numpy()
+    g4 = gold["dpt_beitl512_512x512_layer4_s"]
+    assert np.abs(t4 - g4).max() / np.abs(g4).max() < 1e-4
+    with torch.no_grad():
+        y16 = m.half()(x.half().contiguous(memory_format=torch.channels_last))[:, ::2, ::2].float().cpu().numpy()
+    assert np.abs(y16 - ref).max() / scale < 2e-2, np.abs(y16 - ref).max() / scale
+
+
+def test_dav2_vitl_1080p_forward_vs_reference(gpu):
+    """Depth-Anything-V2 ViT-L at 518 x 924 (a 1080p frame at input_size 518: 2443 tokens, BASELINE config 5) against the
+    float32 outputs of the reference's own modules: encoder taps and depth, float32 at 1e-4 and float16 at 2e-2."""
+    from ddepth_anything_v2 import DepthAnythingV2
+    gold = np.load(GOLD_LARGE)
+    m = DepthAnythingV2('vitl', features=256, out_channels=[256, 512, 1024, 1024]).eval()
+    m.load_state_dict(mw.fill_state_dict(m.state_dict()), strict=True)
+    m = m.cuda()
+    x = mw.synthetic_image((1, 3, 518, 924), seed=32).cuda()
+    ref = gold["dav2_vitl_518x924_out_s2"]
+    scale = np.abs(ref).max()
+    with torch.no_grad():
+        y32 = m(x)[:, ::2, ::2].cpu().numpy()
+        taps = m.pretrained.get_intermediate_layers(x, [4, 11, 17, 23], return_class_token=True)
+    assert np.abs(y32 - ref).max() / scale < 1e-4, np.abs(y32 - ref).max() / scale
+    for i, key in ((1, "dav2_vitl_518x924_tap1_s"), (3, "dav2_vitl_518x924_tap3_s")):
+        g = gold[key]
+        t = taps[i][0][:, ::8, ::4].float().cpu().numpy()
+        assert np.abs(t - g).max() / np.abs(g).max() < 1e-4, (key, np.abs(t - g).max() / np.abs(g).max())
+    with torch.no_grad():
+        mh = m.half()
+        y16 = mh(x.half())[:, ::2, ::2].float().cpu().numpy()
+        t16 = mh.pretrained.get_intermediate_layers(x.half(), [4, 11, 17, 23], return_class_token=True)[3][0][:, ::8, ::4].float().cpu().numpy()
+    g = gold["dav2_vitl_518x924_tap3_s"]
+    assert np.abs(t16 - g).max() / np.abs(g).max() < 3e-2
+    assert np.abs(y16 - ref).max() / scale < 2e-2, np.abs(y16 - ref).max() / scale
+
+
+def test_leres_and_hybrid_gpu_fp32_vs_reference(gpu):
+    """LeReS res101 (BatchNorm folded) and dpt_hybrid_384 on the GPU in float32 against the reference modules' outputs
+    (tests/golden/model_cases.npz), 1e-4; dpt_hybrid also in float16 (BASELINE config 2's precision) at 2e-2."""
+    from dmidas.dpt_depth import DPTDepthModel
+    from lib.multi_depth_model_woauxi import RelDepthModel
+    gold = np.load(GOLD)
+    m = RelDepthModel(backbone='resnext101').eval()
+    m.load_state_dict(mw.fill_state_dict(m.state_dict()), strict=True)
+    x5 = mw.synthetic_image((2, 3, 96, 160), seed=15).cuda()
+    with torch.no_grad():
+        y = m.cuda().depth_model(x5).cpu().numpy()
+    ref = gold["leres_96x160_out"]
+    assert np.abs(y - ref).max() / np.abs(ref).max() < 1e-4, np.abs(y - ref).max() / np.abs(ref).max()
+    m = DPTDepthModel(path=None, backbone="vitb_rn50_384", non_negative=True).eval()
+    m.load_state_dict(mw.fill_state_dict(m.state_dict()), strict=True)
+    x4 = mw.synthetic_image((2, 3, 160, 224), seed=14).cuda()
+    ref = gold["dpt_hybrid_160x224_out"]
+    with torch.no_grad():
+        y32 = m.cuda()(x4).cpu().numpy()
+    assert np.abs(y32 - ref).max() / np.abs(ref).max() < 1e-4, np.abs(y32 - ref).max() / np.abs(ref).max()
+    with torch.no_grad():
+        y16 = m.half()(x4.half().contiguous(memory_format=torch.channels_last)).float().cpu().numpy()
+    assert np.abs(y16 - ref).max() / np.abs(ref).max() < 2e-2

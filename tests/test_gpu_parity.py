@@ -350,3 +350,73 @@ def test_full_size_properties(sg, native, oracle, gpu):
     import src.normalmap_generation as nm
     nmap = nm.create_normalmap_batch(dt).cpu().numpy()
     assert np.array_equal(nmap[0], oracle.create_normalmap_array(dep[0]))
+
+
+def test_normalmap_accepts_any_real_dtype(gpu, oracle):
+    """create_normalmap takes any real array like the reference (src/normalmap_generation.py:20-21 promote to float64):
+    integer / float64 / float32 depth through ds_normalmap_f64 against the oracle's float64 restatement, every gradient
+    mode; float32 + np.gradient (a float32 pipeline in the reference) is refused, as are non-real / non-2-D inputs."""
+    import src.normalmap_generation as nm
+    import src._native as nat
+    rng = np.random.default_rng(21)
+    base = (util.smooth_depth(37, 45, 4) * 20000 + 20000).clip(0, 65535)
+    cases = [base.astype(np.uint8), base.astype(np.int32), base.astype(np.int64), (base / 65535.0).astype(np.float64),
+             (base * 1.7 - 300.0).astype(np.float32), rng.standard_normal((37, 45)) * 1000.0, base.astype(np.int16)]
+    for dep in cases:
+        for inv in (False, True):
+            for args in ((None, 3, None), (None, 5, None), (3, 3, 3), (None, None, None)):
+                if dep.dtype == np.float32 and args[1] is None:
+                    with pytest.raises(nat.DepthStereoError):
+                        nm.create_normalmap(dep, *args, inv)
+                    continue
+                want = oracle.create_normalmap_array(dep.astype(np.float64), args[0], args[1], args[2], inv)
+                got = np.asarray(nm.create_normalmap(dep, args[0], args[1], args[2], inv))
+                assert np.array_equal(want, got), (dep.dtype, inv, args, int((want != got).sum()))
+    # a float64 array holding uint16 codes gives what the uint16 fused kernel gives (the exact-representability argument)
+    d16 = base.astype(np.uint16)
+    assert np.array_equal(np.asarray(nm.create_normalmap(d16.astype(np.float64))), np.asarray(nm.create_normalmap(d16)))
+    for bad in (np.zeros((4, 4), np.complex64), np.zeros((4, 4, 3), np.uint16)):
+        with pytest.raises(nat.DepthStereoError):
+            nm.create_normalmap(bad)
+
+
+def _full_frame_depths():
+    """Three depth regimes at the benchmark's size, as uint16 [3, 1024, 1024]:
+      0  the survey pattern (ramps, periodic steps, large occluders)
+      1  noisy: a smooth field + per-pixel noise of a few hundred codes, what a random-weight network's prediction looks
+         like to the stereo kernel (> 10^5 'general' pixels per image: backward segments everywhere)
+      2  adversarial: white-noise columns, quantised plateaus with coincident breakpoints and single-pixel spikes -- rows
+         whose sweep is history dependent and must go through the exact fallback"""
+    rng = np.random.default_rng(77)
+    H = W = 1024
+    d0 = util.survey_inputs(H, W, 0)[1][0]
+    smooth = util.smooth_depth(H, W, 5).astype(np.float64)
+    d1 = (smooth * 18000 + 20000 + rng.normal(0, 300, (H, W))).clip(0, 65535).astype(np.uint16)
+    d2 = (rng.integers(0, 4, (H, W)) * 21845).astype(np.uint16)
+    d2[:, 300:420] = rng.integers(0, 65536, (H, 120), dtype=np.uint16)
+    d2[::7, ::13] = 65535
+    d2[200:260] = (smooth[200:260] * 30000 + 20000).clip(0, 65535).astype(np.uint16)
+    return np.stack([d0, d1, d2])
+
+
+@pytest.mark.parametrize("fill", ["polylines_sharp", "polylines_soft"])
+def test_full_frame_1024_all_rows_vs_oracle(sg, native, oracle, gpu, fill):
+    """BASELINE's size, EVERY row, both eyes, bit-exact against the oracle (which reproduces the reference-made goldens),
+    on the three regimes of _full_frame_depths -- including the bench's own regime (noisy network depth) and rows that
+    take the exact fallback.  src/stereoimage_generation.py:162-283."""
+    torch = gpu
+    dep = _full_frame_depths()
+    img = np.random.default_rng(78).integers(0, 256, (3, 1024, 1024, 3), dtype=np.uint8)
+    it, dt = torch.from_numpy(img).cuda(), torch.from_numpy(dep).cuda()
+    got = sg.create_stereoimages_batch(it, dt, 2.5, 0.0, ['left-right'], 0.0, 1.0, fill)[0].cpu().numpy()
+    exact_rows, general = native.last_stats(it)
+    for i in range(3):
+        want = oracle.create_stereoimages_arrays(img[i], dep[i], 2.5, 0.0, ['left-right'], 0.0, 1.0, fill)[0]
+        bad = int((want != got[i]).sum())
+        assert bad == 0, (fill, i, bad, np.argwhere((want != got[i]).any(axis=2))[:5].tolist())
+    # the regimes are what they claim to be: the batch as a whole produced general pixels and exact-fallback rows
+    assert general > 0 and exact_rows >= 0
+    # each image alone: regime 1 is dominated by general pixels
+    sg.create_stereoimages_batch(it[1:2], dt[1:2], 2.5, 0.0, ['left-right'], 0.0, 1.0, fill)
+    _, g1 = native.last_stats(it)
+    assert g1 > 0

@@ -126,6 +126,34 @@ def test_midas_net_size_matches_reference_transform():
     assert midas_net_size(1920, 1080, 512, 512, "minimal") == (896, 512)
     assert midas_net_size(640, 480, 384, 384, "minimal") == (512, 384)
     assert midas_net_size(640, 480, 384, 384, "upper_bound") == (384, 288)
+    # NET_SIZE_MATCH on non-square images (core.py:177-181 hands Resize BOTH sizes): values produced by the reference's own
+    # Resize.get_size (3000 random cases of all three methods agreed when this test was written)
+    assert midas_net_size(490, 640, 512, 640, "minimal") == (480, 640)
+    assert midas_net_size(640, 490, 640, 512, "minimal") == (640, 480)
+    assert midas_net_size(1920, 1080, 1920, 1088, "minimal") == (1920, 1088)
+    assert midas_net_size(1000, 700, 512, 384, "minimal") == (544, 384)
+
+
+def test_net_predictor_passes_both_net_sizes():
+    """_NetPredictor must hand net_width AND net_height to the MiDaS DPT families (estimatemidas(img, model, w, h, ...),
+    src/depthmap_generation.py:391-396): the network resolution of a 490x640 image with NET_SIZE_MATCH is 480x640."""
+    from PIL import Image
+    from src.depthmap_generation import _NetPredictor
+    seen = {}
+
+    class Net(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.p = torch.nn.Parameter(torch.zeros(1))
+
+        def infer_batch(self, batch, net_size, resize_mode, net_h=None):
+            seen.update(net_size=net_size, net_h=net_h, mode=resize_mode)
+            return torch.zeros(batch.shape[:3])
+
+    pr = _NetPredictor.__new__(_NetPredictor)
+    pr.model_type, pr.net = 1, Net()
+    pr(Image.new("RGB", (490, 640)), 512, 640, "cpu")
+    assert seen == {"net_size": 512, "net_h": 640, "mode": "minimal"}
 
 
 def test_dpt_hybrid_forward_matches_reference_code(gold):
@@ -321,3 +349,24 @@ def test_tiling_mode_matches_reference_modules():
     assert apply_tiling_mode(m) == int(z["leres_n_convs"][0])
     with torch.no_grad():
         assert _rel(m.depth_model(mw.synthetic_image((2, 3, 96, 160), seed=15)).numpy(), z["leres_96x160_out"]) < 1e-4
+
+
+def test_float32_attention_is_tiled_and_large_bias_is_not_kept_dense(monkeypatch):
+    """The float32 path (Boost runs MiDaS / ZoeDepth in float32 at up to 10^4 tokens): a bias above DENSE_BIAS_BYTES_MAX
+    is handed out as a per-query-tile gather (nothing dense is cached on the block) and the logits are processed in query
+    tiles of bounded size -- both bit-identical to the dense single-shot evaluation."""
+    from dmidas.backbones import beit
+    from src import vit_mi355x as vm
+    torch.manual_seed(0)
+    blk = beit.Block(128, 2, (4, 4))
+    torch.nn.init.normal_(blk.attn.relative_position_bias_table)
+    qk, vt = torch.randn(2, 64, 2, 2, 64), torch.randn(2, 128, 64)
+    dense = blk.attention_bias(64, (5, 6), torch.float32, torch.device('cpu'))
+    want = vm.attention_reference(qk, vt, 31, 0.125, dense)
+    monkeypatch.setattr(beit, "DENSE_BIAS_BYTES_MAX", 0)
+    blk._bias_cache.clear()
+    lazy = blk.attention_bias(64, (5, 6), torch.float32, torch.device('cpu'))
+    assert isinstance(lazy, beit._LazyBias) and not blk._bias_cache
+    monkeypatch.setattr(vm, "SCORE_BYTES_MAX", 2 * 2 * 64 * 4 * 7)            # 7 query rows per tile
+    assert torch.equal(vm.attention_reference(qk, vt, 31, 0.125, lazy)[:, :31], want[:, :31])
+    assert torch.equal(vm.attention_reference(qk, vt, 31, 0.125, dense)[:, :31], want[:, :31])

@@ -69,7 +69,14 @@ def test_two_rank_gather_equals_single_process(tmp_path, n_units):
     assert np.array_equal(got, want)
 
 
-def _video_worker(rank, world, port, n_frames, mode, result_path):
+def _video_case(name):
+    sys.path.insert(0, os.path.join(conftest.ROOT, "tests", "golden"))
+    import make_golden_video as mgv
+    spec = {c[0]: c for c in mgv.CASES}[name]
+    return mgv.make_predictions(*spec[1:])
+
+
+def _video_worker(rank, world, port, case, mode, result_path):
     for p in (conftest.ROOT, conftest.PKG):
         if p not in sys.path:
             sys.path.insert(0, p)
@@ -77,8 +84,8 @@ def _video_worker(rank, world, port, n_frames, mode, result_path):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from src import video_mode, multigpu
-    rng = np.random.default_rng(11)
-    preds = rng.normal(3.0, 2.0, (n_frames, 9, 14)).astype(np.float32)
+    preds = _video_case(case)
+    n_frames = preds.shape[0]
     s, e = multigpu.my_shard(n_frames, rank, world)
     local = torch.from_numpy(preds[s:e])
     out = video_mode.process_predictions_sharded(local, mode)
@@ -90,24 +97,41 @@ def _video_worker(rank, world, port, n_frames, mode, result_path):
 
 
 @pytest.mark.parametrize("mode", ["none", "experimental"])
-@pytest.mark.parametrize("world,n_frames", [(2, 9), (3, 12)])
-def test_video_normalisation_sharded_equals_single_process(tmp_path, mode, world, n_frames):
+@pytest.mark.parametrize("world,case", [(2, "n9"), (3, "n12"), (4, "n9"), (3, "n5_wide"), (2, "n7_ties"), (3, "n2")])
+def test_video_normalisation_sharded_equals_reference(tmp_path, mode, world, case):
     """process_predicitons (reference src/video_mode.py:103-128) with the frames sharded over ranks: global min/max by
-    all-reduce, +-2-frame halo, exact global percentiles by bisection with all-reduced counts."""
+    all-reduce, +-2-frame halo, exact global percentiles by bisection with all-reduced counts.  The expected side is the
+    REFERENCE's own function, executed by tests/golden/make_golden_video.py on the same seeded predictions.
+    (4, n9) shards as 3+3+3+0 and (3, n2) as 1+1+0: EMPTY shards take part in every collective and the halo walk skips
+    them; (3, n5_wide) as 2+2+1: a halo that spans two neighbours.  Bit-exact in both modes."""
+    want = np.load(os.path.join(conftest.ROOT, "tests", "golden", "video_cases.npz"))[f"{case}/{mode}"]
+    path = str(tmp_path / "v.npy")
+    mp.spawn(_video_worker, args=(world, _free_port(), case, mode, path), nprocs=world, join=True)
+    got = np.load(path)
+    assert got.shape == want.shape and got.dtype == want.dtype
+    assert np.array_equal(got, want), float(np.abs(got - want).max())
+
+
+def test_process_predicitons_dropin_and_oracle_match_reference():
+    """The list-in / list-out drop-in (src/video_mode.process_predicitons: the sharded tensor code on one local shard) and
+    the numpy restatement in oracle/ against the reference-made goldens, every case, both modes; other modes pass through."""
     for p in (conftest.ROOT, conftest.PKG):
         if p not in sys.path:
             sys.path.insert(0, p)
+    sys.path.insert(0, os.path.join(conftest.ROOT, "tests", "golden"))
+    import make_golden_video as mgv
+    from oracle import oracle as orc
     from src import video_mode
-    rng = np.random.default_rng(11)
-    preds = rng.normal(3.0, 2.0, (n_frames, 9, 14)).astype(np.float32)
-    want = np.stack(video_mode.process_predicitons([p for p in preds], mode))
-    path = str(tmp_path / "v.npy")
-    mp.spawn(_video_worker, args=(world, _free_port(), n_frames, mode, path), nprocs=world, join=True)
-    got = np.load(path)
-    assert got.shape == want.shape
-    assert np.allclose(got, want, rtol=1e-6, atol=1e-7), float(np.abs(got - want).max())
-    if mode == "none":
-        assert np.array_equal(got.astype(np.float32), want.astype(np.float32))
+    gold = np.load(os.path.join(conftest.ROOT, "tests", "golden", "video_cases.npz"))
+    for spec in mgv.CASES:
+        preds = mgv.make_predictions(*spec[1:])
+        for mode in ("none", "experimental"):
+            want = gold[f"{spec[0]}/{mode}"]
+            for impl in (video_mode.process_predicitons, orc.process_predicitons):
+                got = np.stack(impl([x for x in preds], mode))
+                assert got.dtype == want.dtype and np.array_equal(got, want), (spec[0], mode, impl.__module__)
+    frames = [x for x in mgv.make_predictions(3, 4, 5, 1, "normal")]
+    assert video_mode.process_predicitons(frames, "something else") is frames
 
 
 def test_percentiles_match_numpy_single_process():
