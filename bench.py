@@ -1,26 +1,33 @@
 #!/usr/bin/env python3
 """bench.py -- depth + stereo pairs/sec @1024x1024 on MI355X (BASELINE.json's metric).
 
-One *unit* = one 1024x1024 RGB image -> one uint16 depth map + one side-by-side stereo pair (both eyes), SURVEY.md 8(d).
-One *step* = one pass of the hot path over a batch of `--batch` units already resident in HBM:
+One *unit* = one RGB image -> one uint16 depth map + one side-by-side stereo pair (both eyes) + one normal map
+(BASELINE config 3 is "depth + normalmap" at the metric's 1024x1024).  One *step* = one pass of the hot
+path over a batch of `--batch` units already resident in HBM:
 
     uint8 RGB batch    --model forward (fp16, MFMA)-->  float32 depth prediction   (depthmap_generation.py:375-403 +
                                                                                     the model family's estimate*())
     float32 prediction --ds_depth_to_u16-------------->  uint16 depth              (core.py:189-211)
     RGB + uint16 depth --ds_stereo_warp--------------->  left-right pair           (stereoimage_generation.py:13-92,
                                                                                     polylines_sharp, divergence 2.5 %)
+    uint16 depth       --ds_normalmap----------------->  normal map                (normalmap_generation.py:5-56)
+
+fp16 is the reference's own GPU default for these networks (src/depthmap_generation.py:268-275); the GPU tests hold the
+fp16 forward to 2e-2 of the reference's float32 output and the float32 forward to 1e-4 (tests/test_gpu_models.py).
 
 `--model` picks the depth network (random-init weights of the named architecture -- there are no checkpoints offline):
-    dav2_vitl            Depth-Anything-V2 ViT-L/14, net 518 (reference model id 14; BASELINE config 5's network)
-    dpt_beit_large_512   MiDaS 3.1 DPT BEiT-L/16, net 512   (reference model id 1;  BASELINE config 3's network) [default]
-    dpt_hybrid_384       MiDaS 3.0 ViT-B/16 + ResNetV2-50, net 384 (reference model id 4; BASELINE config 2's network)
-    none                 no network: the float32 prediction is a synthetic INPUT and only the per-pixel path is timed
-                         (what round 1 measured first; kept to track the stereo kernels on their own)
+    dpt_beit_large_512   MiDaS 3.1 DPT BEiT-L/16, net 512   (reference model id 1;  BASELINE config 3) [default]
+    dav2_vitl            Depth-Anything-V2 ViT-L/14, net 518 (reference model id 14; BASELINE config 5)
+    dpt_hybrid_384       MiDaS 3.0 ViT-B/16 + ResNetV2-50, net 384 (reference model id 4; BASELINE config 2)
+    none                 no network: the float32 prediction is a synthetic INPUT, only the per-pixel path is timed
+`--config` presets: c2 (dpt_hybrid_384, batch 1, 512x512: latency), c3 (default), c3match (config 3 with NET_SIZE_MATCH:
+net 1024, 4097 tokens), c5 (dav2_vitl on 1920x1080 frames, 2443 tokens).  Only c3 is the metric's line; the others are
+kept profile lines (profiles/round2_*).
 
 Contract: `python bench.py --gpus N --steps K --warmup W`; for N > 1 the driver launches one rank per GPU with
 torch.distributed.run.  Units are sharded across ranks (weak scaling: every rank renders its own batch, no data-path
-collective); with --gather the collated outputs are gathered to rank 0 with one RCCL gather per step, overlapped with
-the next step's kernels.  Rank 0 prints ONE JSON line.
+collective) and the collated stereo pairs are gathered to rank 0 with ONE RCCL gather per step, overlapped with the next
+step's kernels (--no-gather to leave it out).  Rank 0 prints ONE JSON line.
 """
 import argparse
 import json
@@ -39,9 +46,17 @@ import numpy as np  # noqa: E402
 H = W = 1024
 HBM_PEAK_GBPS = 8000.0            # MI355X HBM3E spec peak (guides/MI355X_MICROARCH.md)
 MFMA_PEAK_TFLOPS = 2500.0         # dense f16/bf16 MFMA peak (same guide)
-ALGO_BYTES_PER_UNIT = 11 * H * W  # read RGB 3HW + depth u16 2HW, write two eyes 6HW
+PMC_SUMMARY = "profiles/round2_pmc_summary.json"
 
 DEPTH_KIND = "steps"
+
+
+def algo_bytes_stereo():
+    return 11 * H * W             # read RGB 3HW + depth u16 2HW, write two eyes 6HW
+
+
+def algo_bytes_normalmap():
+    return 5 * H * W              # uint16 in 2HW + RGB out 3HW
 
 
 def synth_batch(batch, seed):
@@ -63,7 +78,7 @@ def synth_batch(batch, seed):
     return img, pred
 
 
-def model_input_size(model_name):
+def default_net_size(model_name):
     return {"dav2_vitl": 518, "dpt_beit_large_512": 512, "dpt_hybrid_384": 384}.get(model_name, 0)
 
 
@@ -74,41 +89,63 @@ def build_model(name, seed=0):
     if name == "dav2_vitl":
         from ddepth_anything_v2 import DepthAnythingV2
         m = DepthAnythingV2(encoder='vitl', features=256, out_channels=[256, 512, 1024, 1024])
-        info = {"name": "Depth-Anything-V2 ViT-L/14", "net": 518, "tokens": 37 * 37 + 1, "dim": 1024, "depth": 24, "heads": 16}
+        info = {"name": "Depth-Anything-V2 ViT-L/14", "patch": 14, "dim": 1024, "depth": 24, "heads": 16, "bias": False}
     elif name == "dpt_beit_large_512":
         from dmidas.dpt_depth import DPTDepthModel
         m = DPTDepthModel(path=None, backbone="beitl16_512", non_negative=True)
-        info = {"name": "MiDaS 3.1 DPT BEiT-L/16 512", "net": 512, "tokens": 32 * 32 + 1, "dim": 1024, "depth": 24, "heads": 16}
+        info = {"name": "MiDaS 3.1 DPT BEiT-L/16 512", "patch": 16, "dim": 1024, "depth": 24, "heads": 16, "bias": True}
     elif name == "dpt_hybrid_384":
         from dmidas.dpt_depth import DPTDepthModel
         m = DPTDepthModel(path=None, backbone="vitb_rn50_384", non_negative=True)
-        info = {"name": "MiDaS 3.0 dpt_hybrid_384 (ViT-B/16 + ResNetV2-50)", "net": 384, "tokens": 24 * 24 + 1, "dim": 768, "depth": 12, "heads": 12}
+        info = {"name": "MiDaS 3.0 dpt_hybrid_384 (ViT-B/16 + ResNetV2-50)", "patch": 16, "dim": 768, "depth": 12, "heads": 12, "bias": False}
     else:
         raise SystemExit(f"unknown --model {name}")
     return m.eval(), info
 
 
-def cpu_baseline(model_name, distinct_units, seed, min_seconds=12.0):
+def net_grid(model_name, net_size, net_h=None):
+    """(rows, cols) of the token grid the network runs at for an H x W image -- the same size rules the product applies."""
+    if model_name == "dav2_vitl":
+        from ddepth_anything_v2.depth_anything_v2.dpt import lower_bound_size
+        nw, nh = lower_bound_size(W, H, net_size)
+        return nh // 14, nw // 14
+    from dmidas.dpt_depth import midas_net_size
+    nw, nh = midas_net_size(W, H, net_size, net_size if net_h is None else net_h, "minimal")
+    return nh // 16, nw // 16
+
+
+def run_forward(model, model_name, img, net_size, net_h=None):
+    if model_name == "dav2_vitl":
+        return model.infer_batch(img, net_size)
+    return model.infer_batch(img, net_size=net_size, resize_mode="minimal", net_h=net_h)
+
+
+# ---- CPU baseline -------------------------------------------------------------------------------------------------------
+def cpu_baseline(model_name, net_size, net_h, distinct_units, seed, min_seconds, normalmap, python_unit, init_seed=0):
     """The same workload on this host's cores, bounded: the float32 torch-eager forward of the same network (what the
     reference runs on a CPU device) + the CPU oracle (C restatement of the reference's numba kernels, OpenMP over rows
-    like numba's prange).  `distinct_units` units are processed round-robin until `min_seconds` have been spent."""
+    like numba's prange) + the numpy normal map.  `distinct_units` units are processed round-robin until `min_seconds`
+    have been spent.  Beside it: one unit of `python_unit`^2 through the pure-Python restatement of the reference's
+    numba-less fallback (what the reference runs when numba is missing, src/stereoimage_generation.py:1-8), 1 core."""
     import torch
     from oracle import oracle as orc
     orc.build()
     img, pred = synth_batch(distinct_units, seed)
     model = None
     if model_name != "none":
-        model, _ = build_model(model_name)
+        model, _ = build_model(model_name, init_seed)
         model = model.float()
 
     def one(i):
         if model is not None:
             with torch.no_grad():
-                p = model.infer_batch(torch.from_numpy(img[i:i + 1]), model_input_size(model_name)).numpy()[0]
+                p = run_forward(model, model_name, torch.from_numpy(img[i:i + 1]), net_size, net_h).numpy()[0]
         else:
             p = pred[i]
         d16 = orc.convert_to_i16(orc.depth_normalize01(p, False))
         orc.create_stereoimages_arrays(img[i], d16, 2.5, 0.0, ['left-right'], 0.0, 1.0, 'polylines_sharp')
+        if normalmap:
+            orc.create_normalmap_array(d16)
 
     one(0)
     done = 0
@@ -117,37 +154,58 @@ def cpu_baseline(model_name, distinct_units, seed, min_seconds=12.0):
         one(done % distinct_units)
         done += 1
         dt = time.perf_counter() - t0
-        if dt >= min_seconds and done >= min(distinct_units, 2):
+        if dt >= min_seconds and done >= min(distinct_units, 4):
             break
     what = "torch-eager float32 forward of the same network on the CPU + " if model is not None else ""
-    return {"value": done / dt, "unit": "pairs/s", "cores": max(orc.num_threads(), torch.get_num_threads()), "kind": "port",
-            "sample": f"{done} units of 1024x1024 ({distinct_units} distinct): {what}depth->u16 + polylines_sharp left-right "
-                      f"with the gcc -O2 -fopenmp restatement of the reference's numba kernels, {dt:.2f} s"}
+    out = {"value": done / dt, "unit": "pairs/s", "cores": max(orc.num_threads(), torch.get_num_threads()), "kind": "port",
+           "sample": f"{done} units of {H}x{W} ({distinct_units} distinct): {what}depth->u16 + polylines_sharp left-right "
+                     f"with the gcc -O2 -fopenmp restatement of the reference's numba kernels"
+                     + (" + the numpy normal map" if normalmap else "") + f", {dt:.2f} s"}
+    if python_unit > 0:
+        from oracle import oracle_py
+        s = int(python_unit)
+        sub, sd = img[0, :s, :s], orc.convert_to_i16(orc.depth_normalize01(pred[0, :s, :s], False))
+        t1 = time.perf_counter()
+        got = oracle_py.create_stereoimages_arrays(sub, sd, 2.5, 0.0, ['left-right'], 0.0, 1.0, 'polylines_sharp')[0]
+        dt1 = time.perf_counter() - t1
+        same = bool(np.array_equal(got, orc.create_stereoimages_arrays(sub, sd, 2.5, 0.0, ['left-right'], 0.0, 1.0, 'polylines_sharp')[0]))
+        out["python_fallback"] = {"value": 1.0 / dt1, "unit": "pairs/s", "cores": 1, "kind": "port",
+                                  "sample": f"1 unit of {s}x{s} (BASELINE config 1's size), polylines_sharp left-right, pure-Python "
+                                            f"restatement of the reference's numba-less fallback, {dt1:.2f} s; stereo stage only",
+                                  "identical_to_c_port": same}
+    return out
 
 
-def pmc_traffic(batch, kernel="k_polylines"):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC summary (separate --pmc passes, FETCH_SIZE
-    doubled as MI355X_MICROARCH.md prescribes for gfx950): profiles/round1_pmc_summary.json.  None when the summary is
-    missing or was taken at another batch size -- bench.py cannot read PMC counters itself."""
+def traffic_from_profile(kernel, batch):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC summary (separate --pmc passes, FETCH_SIZE doubled
+    as MI355X_MICROARCH.md prescribes for gfx950).  bench.py cannot read PMC counters itself: this is a figure FROM A
+    PROFILE of the same command, labelled as such; None when the summary is missing or was taken at another batch size."""
     try:
-        with open(os.path.join(ROOT, "profiles", "round1_pmc_summary.json")) as f:
+        with open(os.path.join(ROOT, PMC_SUMMARY)) as f:
             j = json.load(f)
         if int(j.get("batch", -1)) != int(batch):
             return None
-        return float(j[kernel]["hbm_bytes_per_launch"])
+        return {"hbm_bytes_per_launch": float(j[kernel]["hbm_bytes_per_launch"]), "source": PMC_SUMMARY}
     except Exception:
         return None
 
 
 def main():
+    global H, W, DEPTH_KIND
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=32, help="units per GPU per step")
-    ap.add_argument("--model", default="dpt_beit_large_512", choices=["dav2_vitl", "dpt_beit_large_512", "dpt_hybrid_384", "none"])
+    ap.add_argument("--config", default="c3", choices=["c2", "c3", "c3match", "c5"], help="BASELINE.json config preset (see the header)")
+    ap.add_argument("--batch", type=int, default=None, help="units per GPU per step")
+    ap.add_argument("--model", default=None, choices=["dav2_vitl", "dpt_beit_large_512", "dpt_hybrid_384", "none"])
+    ap.add_argument("--height", type=int, default=None)
+    ap.add_argument("--width", type=int, default=None)
+    ap.add_argument("--net-size", type=int, default=None, help="network input size (default: the model's; 0 = NET_SIZE_MATCH)")
     ap.add_argument("--fill", default="polylines_sharp")
-    ap.add_argument("--gather", action="store_true", help="gather the collated outputs to rank 0 (N > 1)")
+    ap.add_argument("--no-normalmap", action="store_true", help="leave the normal map out of the step (round-1 workload)")
+    ap.add_argument("--no-gather", action="store_true", help="N > 1: do not gather the collated outputs to rank 0")
+    ap.add_argument("--funnel", action="store_true", help="also time the drop-in funnel (PIL in -> PIL out) on the same batch")
     ap.add_argument("--depth", default="steps", choices=["steps", "smooth"],
                     help="--model none only: synthetic prediction with steps + occluders (default), or smooth only")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -155,10 +213,23 @@ def main():
                     help="run with TunableOp tuning ON and accumulate the winners in CSV (maintenance: regenerates "
                          "src/tunableop_gfx950.csv); the default run only READS the shipped file")
     ap.add_argument("--cpu-sample", type=int, default=4, help="distinct units of the CPU baseline sample")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="minimum wall time of the CPU baseline leg")
+    ap.add_argument("--cpu-seconds", type=float, default=20.0, help="minimum wall time of the CPU baseline leg")
+    ap.add_argument("--cpu-python-unit", type=int, default=512, help="side of the one unit timed through the pure-Python port (0 = skip)")
     args = ap.parse_args()
-    global DEPTH_KIND
+    preset = {"c2": ("dpt_hybrid_384", 1, 512, 512, None), "c3": ("dpt_beit_large_512", 32, 1024, 1024, None),
+              "c3match": ("dpt_beit_large_512", 8, 1024, 1024, 0), "c5": ("dav2_vitl", 8, 1080, 1920, None)}[args.config]
+    model_name = args.model or preset[0]
+    batch = args.batch or preset[1]
+    H = args.height or preset[2]
+    W = args.width or preset[3]
+    net_size = args.net_size if args.net_size is not None else preset[4]
+    net_h = None
+    if net_size is None:
+        net_size = default_net_size(model_name)
+    elif net_size == 0:                                            # NET_SIZE_MATCH (core.py:177-181)
+        net_size, net_h = (W + 31) // 32 * 32, (H + 31) // 32 * 32
     DEPTH_KIND = args.depth
+    normalmap = not args.no_normalmap
 
     import torch
     import torch.distributed as dist
@@ -174,36 +245,56 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
 
     import src._native as nat
+    import src.normalmap_generation as nmg
     import src.stereoimage_generation as sg
     from src import vit_mi355x as vm
 
-    img_np, pred_np = synth_batch(args.batch, seed=1000 + rank)
+    img_np, pred_np = synth_batch(batch, seed=1000 + rank)
     img = torch.from_numpy(img_np).to(dev)
     pred_in = torch.from_numpy(pred_np).to(dev)
     nat.profile_enable(local_rank, True)
     model, minfo = (None, None)
-    if args.model != "none":
+    if model_name != "none":
         from src import gemm_tuning
         if args.tune_gemms:
             gemm_tuning.enable(tune=True, results=os.path.abspath(args.tune_gemms))
         else:
             gemm_tuning.enable()
-        model, minfo = build_model(args.model)
-        model = model.to(dev).half()                       # the reference's default on a GPU (depthmap_generation.py:268-275)
+        # a random-init network may emit a (near-)constant map (dead final ReLUs): such a step would render a degenerate
+        # stereo pair and time nothing real -- take the first seed whose prediction varies on every unit, else stop
+        for seed in range(8):
+            model, minfo = build_model(model_name, seed)
+            model = model.to(dev).half()                   # the reference's default on a GPU (depthmap_generation.py:268-275)
+            p = run_forward(model, model_name, img, net_size, net_h)
+            lo, hi = p.flatten(1).min(1).values, p.flatten(1).max(1).values
+            if bool(((hi - lo) > 1e-3 * hi.abs().clamp_min(1e-6)).all()):
+                minfo["init_seed"] = seed
+                break
+            model = None
+        if model is None:
+            raise SystemExit(f"{model_name}: 8 random initialisations all gave a constant depth map on some unit; refusing to "
+                             "time a degenerate stereo workload")
+        gh, gw = net_grid(model_name, net_size, net_h)
+        minfo["tokens"] = gh * gw + 1
+        minfo["net"] = f"{gw * minfo['patch']}x{gh * minfo['patch']}"
 
-    gather_ok = args.gather and world > 1
+    gather_ok = world > 1 and not args.no_gather
     side = torch.cuda.Stream(device=dev) if gather_ok else None
     gathered = None
     if gather_ok and rank == 0:
-        gathered = [torch.empty((args.batch, H, 2 * W, 3), dtype=torch.uint8, device=dev) for _ in range(world)]
+        gathered = [torch.empty((batch, H, 2 * W, 3), dtype=torch.uint8, device=dev) for _ in range(world)]
 
-    def step():
+    def step(check=False):
         if model is not None:
-            pred = model.infer_batch(img, model_input_size(args.model))
+            pred = run_forward(model, model_name, img, net_size, net_h)
         else:
             pred = pred_in
+        if check:                                            # outside the timed region: every unit's prediction varies
+            lo, hi = pred.flatten(1).min(1).values, pred.flatten(1).max(1).values
+            assert bool((hi > lo).all()), "degenerate (constant) depth prediction: the stereo leg would be meaningless"
         d16 = nat.depth_to_u16(pred, False)
         sbs = sg.create_stereoimages_batch(img, d16, 2.5, 0.0, ['left-right'], 0.0, 1.0, args.fill)[0]
+        nmap = nmg.create_normalmap_batch(d16) if normalmap else None
         if gather_ok:
             ev = torch.cuda.Event()
             ev.record()
@@ -211,9 +302,9 @@ def main():
                 side.wait_event(ev)
                 dist.gather(sbs, gathered if rank == 0 else None, dst=0)
                 sbs.record_stream(side)
-        return sbs
+        return sbs, nmap, d16
 
-    step()                      # priming pass, never timed: library kernel selection (MIOpen find), bias operands, allocator
+    step(check=True)            # priming pass, never timed: library kernel selection (MIOpen find), bias operands, allocator
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
@@ -230,24 +321,31 @@ def main():
     elapsed = time.perf_counter() - t0
 
     # per-kernel timing in separate untimed passes (event synchronisation must not perturb the throughput measurement):
-    # k_polylines via HIP events recorded inside the C ABI on the launch stream ...
-    render_ms, exact_ms = [], []
+    # k_polylines via HIP events recorded inside the C ABI on the launch stream, ds_normalmap via events on torch's current
+    # stream (which IS the launch stream of the ctypes call) ...
+    render_ms, exact_ms, nm_ms = [], [], []
     for _ in range(min(args.steps, 5)):
-        step()
+        _, _, d16 = step()
         r, e = nat.profile_last_ms(local_rank)
         render_ms.append(r)
         exact_ms.append(e)
+        if normalmap:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            nmg.create_normalmap_batch(d16)
+            e1.record()
+            e1.synchronize()
+            nm_ms.append(e0.elapsed_time(e1))
     exact_rows, general_px = nat.last_stats(img)
-    # ... and the fused attention kernel at exactly the shape one encoder block launches it with (torch's current stream
-    # IS the launch stream of the ctypes call, so torch events bracket it)
+    # ... and the fused attention kernel at exactly the shape one encoder block launches it with
     attn = None
     if model is not None:
         n_tok = minfo["tokens"]
         npad = vm.pad_len(n_tok)
-        qk = torch.randn(args.batch, npad, 2, minfo["heads"], 64, device=dev, dtype=torch.float16)
-        vt = torch.randn(args.batch, minfo["heads"] * 64, npad, device=dev, dtype=torch.float16)
+        qk = torch.randn(batch, npad, 2, minfo["heads"], 64, device=dev, dtype=torch.float16)
+        vt = torch.randn(batch, minfo["heads"] * 64, npad, device=dev, dtype=torch.float16)
         bias = None
-        if args.model == "dpt_beit_large_512":
+        if minfo["bias"]:
             bias = nat.attention_bias_pack(torch.randn(minfo["heads"], n_tok, n_tok, device=dev), npad, torch.float16)
         for _ in range(3):
             nat.attention_fwd(qk, vt, n_tok, 0.125, bias)
@@ -259,14 +357,18 @@ def main():
         e1.record()
         e1.synchronize()
         attn_ms = e0.elapsed_time(e1) / reps
-        attn_flops = 4.0 * n_tok * n_tok * minfo["dim"] * args.batch          # QK^T + PV, 2 flops per MAC
+        attn_flops = 4.0 * n_tok * n_tok * minfo["dim"] * batch            # QK^T + PV, 2 flops per MAC
         attn = {"bound": "mfma", "kernel": "k_attention_fwd", "achieved": attn_flops / (attn_ms * 1e-3) / 1e12,
                 "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": attn_flops / (attn_ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS,
-                # HBM bytes per launch (PMC, committed summary): only measured for the default network's shape
-                "traffic": pmc_traffic(args.batch, "k_attention_fwd") if args.model == "dpt_beit_large_512" else None,
-                "algorithmic_flops_per_launch": attn_flops, "avg_kernel_ms": attn_ms,
-                "launches_per_step": minfo["depth"], "shape": {"batch": args.batch, "tokens": n_tok, "heads": minfo["heads"]}}
+                "traffic": None,                          # PMC counters cannot be read from inside the run ...
+                "traffic_from_profile": traffic_from_profile("k_attention_fwd", batch) if args.config == "c3" else None,
+                "algorithmic_flops_per_launch": attn_flops, "avg_kernel_ms": attn_ms, "operands": "random (randn)",
+                "launches_per_step": minfo["depth"], "shape": {"batch": batch, "tokens": n_tok, "heads": minfo["heads"], "bias": minfo["bias"]}}
     torch.cuda.synchronize()
+
+    funnel = None
+    if args.funnel and rank == 0 and model is not None:
+        funnel = funnel_leg(model, model_name, img_np, net_size, net_h, normalmap)
 
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if world > 1:
@@ -274,17 +376,22 @@ def main():
     elapsed = float(t.item())
 
     if rank == 0:
-        units = args.batch * world * args.steps
+        units = batch * world * args.steps
         avg_render_s = float(np.mean(render_ms)) * 1e-3
-        achieved = args.batch * ALGO_BYTES_PER_UNIT / avg_render_s / 1e9
+        achieved = batch * algo_bytes_stereo() / avg_render_s / 1e9
         stereo_roof = {"bound": "hbm", "kernel": "k_polylines", "achieved": achieved, "peak": HBM_PEAK_GBPS,
-                       "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": pmc_traffic(args.batch),
-                       "algorithmic_bytes_per_launch": args.batch * ALGO_BYTES_PER_UNIT,
+                       "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                       "traffic_from_profile": traffic_from_profile("k_polylines", batch) if (H, W) == (1024, 1024) else None,
+                       "algorithmic_bytes_per_launch": batch * algo_bytes_stereo(),
                        "avg_kernel_ms": float(np.mean(render_ms)), "exact_fallback_ms": float(np.mean(exact_ms)),
-                       "exact_fallback_rows": exact_rows, "general_pixels": general_px}
-        wl = (f"{minfo['name']} forward (fp16, random-init weights, net {minfo['net']}) + " if model is not None else "")
+                       "exact_fallback_rows": exact_rows, "general_pixels": general_px,
+                       # what actually bounds it: float64 VALU issue (bit-exactness forces binary64 in the reference's order)
+                       "fp64_valu": {"peak_tflops": 78.6, "note": "see DESIGN.md 3.1: instruction count per 64 pixel-eyes from "
+                                                                  "the committed PMC profile"}}
+        wl = (f"{minfo['name']} forward (fp16, random-init weights seed {minfo['init_seed']}, net {minfo['net']}, "
+              f"{minfo['tokens']} tokens) + " if model is not None else "")
         out = {
-            "metric": "depth+stereo pairs/sec @1024x1024",
+            "metric": "depth+stereo pairs/sec @1024x1024" if (H, W) == (1024, 1024) else f"depth+stereo pairs/sec @{W}x{H}",
             "value": units / elapsed,
             "unit": "pairs/s",
             "n_gpus": world,
@@ -294,26 +401,71 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f16 (network) / f64 (stereo)" if model is not None else "f64",
+            "dtype": "f16 (network) / f64 (stereo, normal map)" if model is not None else "f64",
             "data": "synthetic",
-            "config": {"workload": f"{wl}depth->u16 + create_stereoimages({args.fill}, left-right, divergence 2.5%) on "
-                                   f"{args.batch} x 1024x1024 RGB per GPU, inputs resident in HBM"
+            "config": {"workload": f"BASELINE config {args.config}: {wl}depth->u16 + create_stereoimages({args.fill}, left-right, "
+                                   f"divergence 2.5%)" + (" + create_normalmap (Sobel 3)" if normalmap else "")
+                                   + f" on {batch} x {W}x{H} RGB per GPU, inputs resident in HBM"
                                    + ("" if model is not None else "; float32 depth prediction is a synthetic input (--model none)"),
-                       "depth_network": args.model, "units_per_step": args.batch * world, "height": H, "width": W,
+                       "depth_network": model_name, "units_per_step": batch * world, "height": H, "width": W,
+                       "network_precision_vs_reference": "fp16 = the reference's GPU default; held to 2e-2 of its float32 output "
+                                                         "(float32 path: 1e-4), tests/test_gpu_models.py",
                        "parallelism": f"units sharded over {world} GPU(s), no data-path collective"
-                                      + (", RCCL gather to rank 0 overlapped" if gather_ok else "")},
+                                      + (", ONE RCCL gather of the stereo pairs to rank 0 per step, overlapped" if gather_ok else "")},
             # the dominant hand-written kernel of the step: the fused attention when a network runs, else the stereo kernel
             "roofline": attn if attn is not None else stereo_roof,
         }
         if attn is not None:
             out["roofline_stereo"] = stereo_roof
-            enc = vm.count_encoder_flops(minfo["depth"], minfo["tokens"], minfo["dim"]) * args.batch
+            enc = vm.count_encoder_flops(minfo["depth"], minfo["tokens"], minfo["dim"]) * batch
             out["encoder_tflops_per_step"] = enc / 1e12
+        if normalmap and nm_ms:
+            a = batch * algo_bytes_normalmap() / (float(np.mean(nm_ms)) * 1e-3) / 1e9
+            out["roofline_normalmap"] = {"bound": "hbm", "kernel": "k_normalmap_fused", "achieved": a, "peak": HBM_PEAK_GBPS,
+                                         "unit": "GB/s", "frac": a / HBM_PEAK_GBPS, "traffic": None,
+                                         "algorithmic_bytes_per_launch": batch * algo_bytes_normalmap(),
+                                         "avg_kernel_ms": float(np.mean(nm_ms))}
+        if funnel is not None:
+            out["funnel"] = funnel
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(args.model, args.cpu_sample, seed=1000, min_seconds=args.cpu_seconds)
+            out["cpu_baseline"] = cpu_baseline(model_name, net_size, net_h, args.cpu_sample, seed=1000, min_seconds=args.cpu_seconds,
+                                               normalmap=normalmap, python_unit=args.cpu_python_unit,
+                                               init_seed=minfo["init_seed"] if minfo else 0)
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
+
+
+def funnel_leg(model, model_name, img_np, net_size, net_h, normalmap):
+    """The same batch through the DROP-IN boundary: core_generation_funnel(PIL images in -> PIL results out), host copies,
+    PIL conversion and all (what a reference caller actually gets; never `value`)."""
+    import torch
+    from PIL import Image
+    import src.core as core
+    mt = {"dpt_beit_large_512": 1, "dpt_hybrid_384": 4, "dav2_vitl": 14}[model_name]
+
+    class _Pred:                                             # the bench's random-init network behind the predictor hook
+        def __call__(self, pil, nw, nh, device):
+            return self.batch([pil], nw, nh, device)[0]
+
+        def batch(self, pils, nw, nh, device):
+            t = torch.from_numpy(np.stack([np.asarray(p.convert("RGB")) for p in pils])).to(device)
+            return run_forward(model, model_name, t, net_size, net_h)
+
+    core.model_holder.register_predictor(mt, _Pred())
+    pils = [Image.fromarray(a) for a in img_np]
+    opts = {"model_type": mt, "gen_stereo": True, "stereo_modes": ["left-right"], "gen_normalmap": normalmap,
+            "net_width": net_size, "net_height": net_size if net_h is None else net_h}
+    for _ in range(2):
+        n_out = sum(1 for _ in core.core_generation_funnel(None, list(pils), None, None, opts))
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    n_out = sum(1 for _ in core.core_generation_funnel(None, list(pils), None, None, opts))
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    return {"value": len(pils) / dt, "unit": "pairs/s", "results": n_out, "seconds": dt,
+            "what": "core_generation_funnel: PIL in -> uint16 depth, left-right pair" + (", normal map" if normalmap else "")
+                    + " as PIL out (host<->device copies and PIL conversion included)"}
 
 
 if __name__ == "__main__":

@@ -105,33 +105,217 @@ def _custom_depth_to_float(dp, image):
     return out
 
 
-def _postprocess_prediction(pred, invert, inp):
-    """Depth post-processing of src/core.py:189-206 on the device.
-    pred: float32 cuda tensor [H,W].  Returns (out_f32 [H,W] in [0,1], prediction_copy or None)."""
+import os as _os
+
+# device batch of the funnel: up to this many pixels (36 x 1024^2 by default), at most 64 images
+FUNNEL_BATCH_PIXELS = int(_os.environ.get("DS_FUNNEL_BATCH_PIXELS", 36 << 20))
+
+
+def _postprocess_batch(pred, invert, inp):
+    """Depth post-processing of src/core.py:189-206 for a batch of same-size predictions, on the device.
+    pred: float32 cuda tensor [B,H,W].  Returns (out [B,H,W] float32 or float64 in [0,1] ready for convert_to_i16 -- None
+    for the fused no-clip branch --, prediction_copy [B,H,W] or None, broken: list of bool, one host sync per BATCH)."""
     torch = _native._torch()
     pred = pred.contiguous()
-    pmin, pmax = pred.min(), pred.max()
-    if not bool(abs(float(pmax) - float(pmin)) > np.finfo("float").eps):
-        return torch.zeros(pred.shape, dtype=torch.float64, device=pred.device), None, True
-    out = pred.clone()
-    if invert:
-        out = out * -1
+    flat = pred.flatten(1)
+    pmin, pmax = flat.min(1).values, flat.max(1).values
+    broken = [not bool(v) for v in ((pmax - pmin).abs() > np.finfo("float").eps).cpu().tolist()]      # :190
+    out = pred * -1 if invert else pred.clone()                                                  # :192-195
     prediction_copy = out
     if inp[go.CLIPDEPTH]:
-        if inp[go.CLIPDEPTH_MODE] == 'Range':
-            out = (out - out.min()) / (out.max() - out.min())
+        if inp[go.CLIPDEPTH_MODE] == 'Range':                                                    # :197-198
+            omin = out.flatten(1).min(1).values.view(-1, 1, 1)
+            omax = out.flatten(1).max(1).values.view(-1, 1, 1)
+            out = (out - omin) / (omax - omin)
             out = torch.clamp(out, min=float(inp[go.CLIPDEPTH_FAR]), max=float(inp[go.CLIPDEPTH_NEAR]))
-        elif inp[go.CLIPDEPTH_MODE] == 'Outliers':                                              # :199-201
+        elif inp[go.CLIPDEPTH_MODE] == 'Outliers':                                               # :199-201
             # np.percentile on the device: exact order statistics by bisection on the float32 bit pattern, numpy's
             # linear interpolation; np.clip(float32 array, float64 bounds) promotes to float64 (NumPy >= 2)
             from .video_mode import _global_percentiles
-            fb, nb = _global_percentiles(out, [float(inp[go.CLIPDEPTH_FAR]) * 100.0, float(inp[go.CLIPDEPTH_NEAR]) * 100.0], None)
-            out = torch.clamp(out.double(), min=fb, max=nb)
-    return out, prediction_copy, False
+            rows = []
+            for i in range(out.shape[0]):
+                if broken[i]:
+                    rows.append(out[i].double())
+                    continue
+                fb, nb = _global_percentiles(out[i], [float(inp[go.CLIPDEPTH_FAR]) * 100.0, float(inp[go.CLIPDEPTH_NEAR]) * 100.0], None)
+                rows.append(torch.clamp(out[i].double(), min=fb, max=nb))
+            out = torch.stack(rows)
+    return out, prediction_copy, broken
+
+
+class _HostStaging:
+    """Pinned host buffers of the funnel, two generations (the results of group k are converted to PIL while group k+1
+    runs on the device).  A buffer is (re)allocated only when a larger one is needed."""
+
+    def __init__(self):
+        self.buf = {}
+
+    def get(self, gen, tag, shape, dtype):
+        torch = _native._torch()
+        n = int(np.prod(shape)) * torch.empty((), dtype=dtype).element_size()
+        key = (gen, tag)
+        b = self.buf.get(key)
+        if b is None or b.numel() < n:
+            b = self.buf[key] = torch.empty((max(n, 1),), dtype=torch.uint8, pin_memory=True)
+        return b[:n].view(dtype).view(shape)
+
+
+_staging = _HostStaging()
+
+
+def _plan_groups(inputimages, inputdepthmaps, batchable):
+    """Consecutive images of one size and mode (and one kind of depth source) form a device batch."""
+    groups, cur, key = [], [], None
+    for i, im in enumerate(inputimages):
+        k = (im.size, im.mode, inputdepthmaps[i] is not None)
+        limit = max(1, min(64, FUNNEL_BATCH_PIXELS // max(1, im.size[0] * im.size[1]))) if batchable else 1
+        if cur and (k != key or len(cur) >= limit):
+            groups.append(cur)
+            cur = []
+        key = k
+        cur.append(i)
+    if cur:
+        groups.append(cur)
+    return groups
+
+
+def _launch_group(gen, idxs, inputimages, inputdepthmaps, inp, device):
+    """Enqueue everything a group needs on the current stream -- H2D, network, post-processing, stereo, normal map, heat
+    map, D2H into pinned buffers -- and return the handles; nothing here waits for the device except the post-processing
+    branches that must know which predictions are flat (one sync per batch) and the percentile bisection of 'Outliers'."""
+    torch = _native._torch()
+    b = len(idxs)
+    images = [inputimages[i] for i in idxs]
+    w, h = images[0].size
+    g = {"idxs": idxs, "images": images, "host": {}, "pred_host": None, "broken": [False] * b}
+    custom = inputdepthmaps[idxs[0]] is not None
+    want_stereo = inp[go.GEN_STEREO]
+
+    def upload(arrays, tag, dtype):
+        st = _staging.get(gen, tag, (b,) + arrays[0].shape, dtype)
+        stn = st.numpy()
+        for j, a in enumerate(arrays):
+            np.copyto(stn[j], a)
+        return st.to(device, non_blocking=True)
+
+    img_t = None
+    if want_stereo:
+        arrs = [np.asarray(im, dtype=np.uint8) for im in images]                                 # :252 np.array(image)
+        if arrs[0].ndim != 3:
+            raise ValueError('not enough values to unpack (expected 3, got %d)' % arrs[0].ndim)
+        img_t = upload(arrs, "img", torch.uint8)
+    mesh_source = None
+    if custom:
+        outs = [_custom_depth_to_float(inputdepthmaps[i], inputimages[i]) for i in idxs]         # :145-174 (host: PIL)
+        out_t = upload([np.asarray(o, dtype=np.float64) for o in outs], "cdepth", torch.float64)
+        d16 = _native.convert_to_i16(out_t)                                                      # :211
+        mesh_source = out_t
+    else:
+        if inp[go.NET_SIZE_MATCH]:                                                               # :177-184
+            net_width, net_height = (w + 31) // 32 * 32, (h + 31) // 32 * 32
+        else:
+            net_width, net_height = inp[go.NET_WIDTH], inp[go.NET_HEIGHT]
+        if images[0].mode == "RGB" and img_t is not None:
+            rgb_t = img_t
+        else:
+            rgb_t = upload([np.asarray(im.convert("RGB"), dtype=np.uint8) for im in images], "rgb", torch.uint8)
+        pred, invert = model_holder.get_raw_prediction_batch(images, rgb_t, net_width, net_height)
+        pred = pred.to(device=device, dtype=torch.float32)
+        mesh_source = pred
+        if not inp[go.CLIPDEPTH] and not inp[go.DO_OUTPUT_DEPTH_PREDICTION]:
+            d16 = _native.depth_to_u16(pred, invert)         # fused: per-image min/max -> normalise -> uint16 (:189-211)
+        else:
+            out_t, prediction_copy, broken = _postprocess_batch(pred, invert, inp)
+            g["broken"] = broken
+            if inp[go.DO_OUTPUT_DEPTH_PREDICTION]:
+                ph = _staging.get(gen, "pred", tuple(prediction_copy.shape), torch.float32)
+                ph.copy_(prediction_copy, non_blocking=True)
+                g["pred_host"] = ph
+            if out_t.dtype == torch.float64:                                                     # 'Outliers': numpy promoted
+                omin = out_t.flatten(1).min(1).values.view(-1, 1, 1)
+                omax = out_t.flatten(1).max(1).values.view(-1, 1, 1)
+                d16 = _native.convert_to_i16(((out_t - omin) / (omax - omin)).contiguous())      # :202, :211
+            else:
+                d16 = _native.depth_to_u16(out_t.to(torch.float32).contiguous(), False)          # :202, :211
+            if any(broken):                                                                      # :203-206 zeros
+                keep = torch.tensor([0 if x else 1 for x in broken], device=device, dtype=torch.int16).view(-1, 1, 1)
+                d16 = (d16.view(torch.int16) * keep).view(torch.uint16)
+    g["d16"], g["mesh_source"], g["img_t"], g["custom"] = d16, mesh_source, img_t, custom
+
+    def download(t, tag):
+        hbuf = _staging.get(gen, tag, tuple(t.shape), t.dtype)
+        hbuf.copy_(t, non_blocking=True)
+        g["host"][tag] = hbuf
+
+    if inp[go.DO_OUTPUT_DEPTH]:
+        download(d16, "depth")
+    if want_stereo:                                                                              # :251-259
+        modes = inp[go.STEREO_MODES]
+        stereo = create_stereoimages_batch(img_t, d16, inp[go.STEREO_DIVERGENCE], inp[go.STEREO_SEPARATION], modes,
+                                           inp[go.STEREO_BALANCE], inp[go.STEREO_OFFSET_EXPONENT], inp[go.STEREO_FILL_ALGO])
+        for c in range(len(stereo)):
+            download(stereo[c], "stereo%d" % c)
+        g["n_stereo"] = len(stereo)
+    if inp[go.GEN_NORMALMAP]:                                                                    # :261-269
+        download(create_normalmap_batch(
+            d16,
+            inp[go.NORMALMAP_PRE_BLUR_KERNEL] if inp[go.NORMALMAP_PRE_BLUR] else None,
+            inp[go.NORMALMAP_SOBEL_KERNEL] if inp[go.NORMALMAP_SOBEL] else None,
+            inp[go.NORMALMAP_POST_BLUR_KERNEL] if inp[go.NORMALMAP_POST_BLUR] else None,
+            inp[go.NORMALMAP_INVERT]), "normalmap")
+    if inp[go.GEN_HEATMAP]:                                                                      # :271-274
+        from .heatmap import colorize_batch
+        download(colorize_batch(d16), "heatmap")
+    g["done"] = torch.cuda.Event()
+    g["done"].record()
+    return g
+
+
+def _emit_group(g, outpath, inp, device):
+    """Yield a finished group's results image by image in the reference's order (:208-306).  The pinned buffers are reused
+    two groups later, so every result is copied out of them (PIL owns its pixels)."""
+    torch = _native._torch()
+    g["done"].synchronize()
+    host = {k: v.numpy() for k, v in g["host"].items()}
+    for j, count in enumerate(g["idxs"]):
+        image = g["images"][j]
+        if g["pred_host"] is not None and not g["broken"][j]:
+            yield count, 'depth_prediction', g["pred_host"][j].numpy().copy()
+        if inp[go.DO_OUTPUT_DEPTH]:                                                              # :240-249
+            img_output = host["depth"][j]
+            img_depth = np.bitwise_not(img_output) if inp[go.OUTPUT_DEPTH_INVERT] else img_output   # cv2.bitwise_not
+            if inp[go.OUTPUT_DEPTH_COMBINE]:
+                axis = 1 if inp[go.OUTPUT_DEPTH_COMBINE_AXIS] == 'Horizontal' else 0
+                yield count, 'concat_depth', Image.fromarray(np.concatenate(
+                    (image, convert_i16_to_rgb(img_depth, np.asarray(image))), axis=axis))
+            else:
+                yield count, 'depth', Image.fromarray(img_depth.copy())
+        if inp[go.GEN_STEREO]:
+            for c in range(g["n_stereo"]):
+                yield count, inp[go.STEREO_MODES][c], Image.fromarray(host["stereo%d" % c][j].copy())
+        if inp[go.GEN_NORMALMAP]:
+            yield count, 'normalmap', Image.fromarray(host["normalmap"][j].copy())
+        if inp[go.GEN_HEATMAP]:
+            yield count, 'heatmap', Image.fromarray(host["heatmap"][j].copy())
+        if inp[go.GEN_SIMPLE_MESH]:                                                              # :277-306
+            from . import mesh_generation as mg
+            mt = inp[go.MODEL_TYPE]              # callers pass the numeric id; the option's default is a display name
+            depthi = mg.mesh_depth(g["mesh_source"][j], mt if isinstance(mt, int) else -1, bool(inp[go.BOOST]), g["custom"])
+            rgb_t = torch.from_numpy(np.array(image.convert('RGB'), dtype=np.uint8, order='C')).to(device)
+            verts, faces, colors = mg.create_mesh_arrays(rgb_t, depthi, keep_edges=not inp[go.SIMPLE_MESH_OCCLUDE],
+                                                         spherical=bool(inp[go.SIMPLE_MESH_SPHERICAL]))
+            fn = mg.unique_filename(outpath, 'depthmap', 'obj', 'simple')
+            yield count, 'simple_mesh', mg.write_obj(fn, verts.cpu().numpy(), faces.cpu().numpy(), colors.cpu().numpy())
 
 
 def core_generation_funnel(outpath, inputimages, inputdepthmaps, inputnames, inp, ops=None):
-    """Generator yielding ``(input_index, kind, result)`` (reference: src/core.py:83-349)."""
+    """Generator yielding ``(input_index, kind, result)`` (reference: src/core.py:83-349).
+
+    Same signature, same triples in the same order as the reference's per-image loop (:133); what differs is the schedule:
+    consecutive images of one size form a device batch (H2D of the uint8 pixels through pinned memory, ONE batched network
+    forward, batched depth -> uint16 -> stereo / normal map / heat map kernels, asynchronous D2H into pinned buffers), and
+    the next batch is enqueued before the results of the current one are converted to PIL, so host conversion and device
+    work overlap.  COMPUTE_DEVICE is accepted and ignored: the hot path exists on the GPU only."""
     if len(inputimages) == 0 or inputimages[0] is None:
         return
     if inputdepthmaps is None or len(inputdepthmaps) == 0:
@@ -157,89 +341,16 @@ def core_generation_funnel(outpath, inputimages, inputdepthmaps, inputnames, inp
             if inputimages[count].mode == 'I':                      # :135-137
                 inputimages[count].point(lambda p: p * 0.0039063096, mode='RGB')
                 inputimages[count] = inputimages[count].convert('RGB')
-
-            image = inputimages[count]
-            mesh_source = None      # what :281 calls depthi: the raw prediction, or the custom depth map
-            if inputdepthmaps is not None and inputdepthmaps[count] is not None:
-                out = _custom_depth_to_float(inputdepthmaps[count], image)                     # :145-174
-                out_t = torch.from_numpy(np.array(out, dtype=np.float64, order='C')).to(device)
-                img_output_t = _native.convert_to_i16(out_t)                                   # :211
-                mesh_source = out_t
-            else:
-                if inp[go.NET_SIZE_MATCH]:                                                     # :177-184
-                    net_width = (image.width + 31) // 32 * 32
-                    net_height = (image.height + 31) // 32 * 32
-                else:
-                    net_width = inp[go.NET_WIDTH]
-                    net_height = inp[go.NET_HEIGHT]
-                raw_prediction, raw_prediction_invert = model_holder.get_raw_prediction(image, net_width, net_height)
-                pred_t = raw_prediction if torch.is_tensor(raw_prediction) else torch.from_numpy(np.asarray(raw_prediction))
-                pred_t = pred_t.to(device=device, dtype=torch.float32)
-                mesh_source = pred_t
-                if not inp[go.CLIPDEPTH] and not inp[go.DO_OUTPUT_DEPTH_PREDICTION]:
-                    # fused device path: min/max -> normalise -> uint16 in one pass (:189-211)
-                    img_output_t = _native.depth_to_u16(pred_t.unsqueeze(0), raw_prediction_invert)[0]
-                else:
-                    out_t, prediction_copy, broken = _postprocess_prediction(pred_t, raw_prediction_invert, inp)
-                    if not broken:
-                        if inp[go.DO_OUTPUT_DEPTH_PREDICTION]:
-                            yield count, 'depth_prediction', prediction_copy.cpu().numpy().copy()
-                        if out_t.dtype == torch.float64:                                        # 'Outliers': numpy promoted
-                            out_t = (out_t - out_t.min()) / (out_t.max() - out_t.min())                 # :202
-                            img_output_t = _native.convert_to_i16(out_t.contiguous())                   # :211
-                        else:
-                            img_output_t = _native.depth_to_u16(out_t.to(torch.float32).unsqueeze(0), False)[0]   # :202,:211
-                    else:
-                        img_output_t = torch.zeros(pred_t.shape, dtype=torch.uint16, device=device)          # :206
-
-            img_output = None       # host copy of the uint16 depth, made only if a host consumer needs it
-
-            if inp[go.DO_OUTPUT_DEPTH]:                                                        # :240-249
-                img_output = img_output_t.cpu().numpy()
-                img_depth = np.bitwise_not(img_output) if inp[go.OUTPUT_DEPTH_INVERT] else img_output   # cv2.bitwise_not
-                if inp[go.OUTPUT_DEPTH_COMBINE]:
-                    axis = 1 if inp[go.OUTPUT_DEPTH_COMBINE_AXIS] == 'Horizontal' else 0
-                    img_concat = Image.fromarray(np.concatenate(
-                        (image, convert_i16_to_rgb(img_depth, np.asarray(image))), axis=axis))
-                    yield count, 'concat_depth', img_concat
-                else:
-                    yield count, 'depth', Image.fromarray(img_depth)
-
-            if inp[go.GEN_STEREO]:                                                             # :251-259
-                modes = inp[go.STEREO_MODES]
-                img_t = torch.from_numpy(np.array(image, dtype=np.uint8, order='C')).to(device)
-                if img_t.dim() != 3:
-                    raise ValueError('not enough values to unpack (expected 3, got %d)' % img_t.dim())
-                stereo = create_stereoimages_batch(
-                    img_t.unsqueeze(0), img_output_t.unsqueeze(0),
-                    inp[go.STEREO_DIVERGENCE], inp[go.STEREO_SEPARATION], modes,
-                    inp[go.STEREO_BALANCE], inp[go.STEREO_OFFSET_EXPONENT], inp[go.STEREO_FILL_ALGO])
-                for c in range(0, len(stereo)):
-                    yield count, inp[go.STEREO_MODES][c], Image.fromarray(stereo[c][0].cpu().numpy())
-
-            if inp[go.GEN_NORMALMAP]:                                                          # :261-269
-                nm = create_normalmap_batch(
-                    img_output_t.unsqueeze(0),
-                    inp[go.NORMALMAP_PRE_BLUR_KERNEL] if inp[go.NORMALMAP_PRE_BLUR] else None,
-                    inp[go.NORMALMAP_SOBEL_KERNEL] if inp[go.NORMALMAP_SOBEL] else None,
-                    inp[go.NORMALMAP_POST_BLUR_KERNEL] if inp[go.NORMALMAP_POST_BLUR] else None,
-                    inp[go.NORMALMAP_INVERT])
-                yield count, 'normalmap', Image.fromarray(nm[0].cpu().numpy())
-
-            if inp[go.GEN_HEATMAP]:                                                            # :271-274
-                from .heatmap import colorize_batch
-                yield count, 'heatmap', Image.fromarray(colorize_batch(img_output_t.unsqueeze(0))[0].cpu().numpy())
-
-            if inp[go.GEN_SIMPLE_MESH]:                                                        # :277-306
-                from . import mesh_generation as mg
-                custom = inputdepthmaps[count] is not None
-                mt = inp[go.MODEL_TYPE]          # callers pass the numeric id; the option's default is a display name
-                depthi = mg.mesh_depth(mesh_source, mt if isinstance(mt, int) else -1, bool(inp[go.BOOST]), custom)
-                rgb_t = torch.from_numpy(np.array(image.convert('RGB'), dtype=np.uint8, order='C')).to(device)
-                verts, faces, colors = mg.create_mesh_arrays(rgb_t, depthi, keep_edges=not inp[go.SIMPLE_MESH_OCCLUDE],
-                                                             spherical=bool(inp[go.SIMPLE_MESH_SPHERICAL]))
-                fn = mg.unique_filename(outpath, 'depthmap', 'obj', 'simple')
-                yield count, 'simple_mesh', mg.write_obj(fn, verts.cpu().numpy(), faces.cpu().numpy(), colors.cpu().numpy())
+        # Boost renders one image at a time by construction (its own patch batches inside estimateboost)
+        groups = _plan_groups(inputimages, inputdepthmaps, batchable=not inp[go.BOOST])
+        pending = None
+        for gi, idxs in enumerate(groups):
+            launched = _launch_group(gi & 1, idxs, inputimages, inputdepthmaps, inp, device)
+            if pending is not None:
+                yield from _emit_group(pending, outpath, inp, device)
+            pending = launched
+        if pending is not None:
+            yield from _emit_group(pending, outpath, inp, device)
     except Exception as e:
         if 'out of memory' in str(e).lower():                                                  # :308-326
             suggestion = "out of GPU memory, could not generate depthmap! " \

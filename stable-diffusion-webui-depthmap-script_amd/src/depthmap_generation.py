@@ -139,15 +139,18 @@ class _NetPredictor:
         import numpy as np
         import torch
         img = torch.from_numpy(np.array(pil_image.convert("RGB"), dtype=np.uint8, order="C")).to(next(self.net.parameters()).device)
-        batch = img.unsqueeze(0)
+        return self.predict_batch(img.unsqueeze(0), net_width, net_height)[0]
+
+    def predict_batch(self, batch, net_width, net_height):
+        """uint8 RGB [B,H,W,3] on the network's device -> float32 [B,H,W] raw predictions: ONE forward for the batch."""
         if self.model_type == 0:
-            return self.net.infer_batch(batch, int(net_width), int(net_height))[0]   # estimateleres (:406-421)
+            return self.net.infer_batch(batch, int(net_width), int(net_height))      # estimateleres (:406-421)
         if self.model_type in (7, 8, 9):
-            return self.net.infer_batch(batch, int(net_width), int(net_height))[0]   # estimatezoedepth (:443-452)
+            return self.net.infer_batch(batch, int(net_width), int(net_height))      # estimatezoedepth (:443-452)
         if self.is_dav2:
-            return self.net.infer_batch(batch, int(net_width))[0]          # reference passes net_width as input_size (:553)
+            return self.net.infer_batch(batch, int(net_width))             # reference passes net_width as input_size (:553)
         mode = "minimal"                                                    # resize_mode of ids 1-4 (:127, :141, :155, :168)
-        return self.net.infer_batch(batch, net_size=int(net_width), resize_mode=mode, net_h=int(net_height))[0]
+        return self.net.infer_batch(batch, net_size=int(net_width), resize_mode=mode, net_h=int(net_height))
 
 
 class ModelHolder:
@@ -221,6 +224,29 @@ class ModelHolder:
         else:
             raw = self.depth_model(input, net_width, net_height, self.device)
         return raw, (self.depth_model_type in INVERTED_MODEL_IDS)
+
+    def get_raw_prediction_batch(self, pil_images, rgb_u8, net_width, net_height):
+        """get_raw_prediction for a device batch of same-size images (the funnel's unit of work on an MI355X).
+        pil_images: the PIL inputs; rgb_u8: the same pixels as a uint8 [B,H,W,3] tensor on the device.
+        -> (float32 [B,H,W] on the device, invert?).  A built network runs ONE forward for the batch; a registered predictor
+        is called through its optional ``batch(pils, net_width, net_height, device)`` or image by image; Boost renders image
+        by image (estimateboost batches its own patches)."""
+        import torch
+        invert = self.depth_model_type in INVERTED_MODEL_IDS
+        if self.pix2pix_model is not None:
+            from . import boost
+            outs = [boost.estimateboost(rgb_u8[i], self.depth_model.net, self.depth_model_type, self.pix2pix_model,
+                                        int(getattr(self, "boost_rmax", 1600))) for i in range(rgb_u8.shape[0])]
+            return torch.stack([torch.as_tensor(o) for o in outs]), invert
+        if isinstance(self.depth_model, _NetPredictor):
+            return self.depth_model.predict_batch(rgb_u8, net_width, net_height), invert
+        if hasattr(self.depth_model, "batch"):
+            return torch.as_tensor(self.depth_model.batch(pil_images, net_width, net_height, self.device)), invert
+        outs = []
+        for im in pil_images:
+            r = self.depth_model(im, net_width, net_height, self.device)
+            outs.append(r if torch.is_tensor(r) else torch.from_numpy(__import__("numpy").asarray(r)))
+        return torch.stack([o.to(self.device) for o in outs]), invert
 
     def offload(self):
         """reference :341-350 moves the networks to host RAM between runs to spare a consumer card's VRAM.  On a 288 GB

@@ -420,3 +420,82 @@ def test_full_frame_1024_all_rows_vs_oracle(sg, native, oracle, gpu, fill):
     sg.create_stereoimages_batch(it[1:2], dt[1:2], 2.5, 0.0, ['left-right'], 0.0, 1.0, fill)
     _, g1 = native.last_stats(it)
     assert g1 > 0
+
+
+def test_funnel_batched_schedule_equals_image_by_image(gpu, oracle, monkeypatch):
+    """The funnel groups consecutive same-size images into device batches and pipelines the groups; the yielded triples
+    must be exactly what one funnel call per image yields (and what the oracle says), in the reference's order
+    (src/core.py:133-306): mixed sizes and modes, a flat prediction in the middle of a batch (zeros, no
+    'depth_prediction'), every post-processing branch, custom depth maps, and groups split by the pixel budget."""
+    from PIL import Image
+    import src.core as core
+    torch = gpu
+    rng = np.random.default_rng(31)
+    sizes = [(48, 72), (48, 72), (48, 72), (40, 64), (40, 64), (48, 72), (48, 72)]
+    imgs = [rng.integers(0, 256, (h, w, 3), dtype=np.uint8) for h, w in sizes]
+    preds = [util.smooth_depth(h, w, 40 + i) * (i + 1) - i for i, (h, w) in enumerate(sizes)]
+    preds[1][:] = 3.25                                       # flat: broken prediction inside a batch
+    pils = [Image.fromarray(a) for a in imgs]
+    pils[5] = pils[5].convert("RGBA")                        # another mode: its own group, 4-channel stereo
+    lookup = {id(p): preds[i] for i, p in enumerate(pils)}
+
+    class Pred:
+        calls = []
+
+        def __call__(self, pil, nw, nh, dev):
+            return torch.from_numpy(lookup[id(pil)]).to(dev)
+
+        def batch(self, plist, nw, nh, dev):
+            Pred.calls.append(len(plist))
+            return torch.stack([torch.from_numpy(lookup[id(p)]) for p in plist]).to(dev)
+
+    core.model_holder.register_predictor(4, Pred())
+    core.model_holder.register_predictor(0, Pred())
+    option_sets = [
+        {'gen_stereo': True, 'gen_normalmap': True, 'stereo_modes': ['left-right', 'red-cyan-anaglyph']},
+        {'do_output_depth_prediction': True, 'gen_stereo': True, 'stereo_modes': ['top-bottom']},
+        {'clipdepth': True, 'clipdepth_mode': 'Range', 'clipdepth_far': 0.1, 'clipdepth_near': 0.8, 'gen_normalmap': True},
+        {'clipdepth': True, 'clipdepth_mode': 'Outliers', 'clipdepth_far': 0.02, 'clipdepth_near': 0.97, 'output_depth_invert': True},
+        {'output_depth_combine': True, 'gen_heatmap': True},
+    ]
+    for mt in (4, 0):
+        for opts in option_sets:
+            o = dict(opts, model_type=mt)
+            Pred.calls.clear()
+            got = list(core.core_generation_funnel(None, list(pils), None, None, o))
+            assert Pred.calls == [3, 2, 1, 1], Pred.calls           # 3 x 48x72 | 2 x 40x64 | RGBA | RGB
+            want = []
+            for i, p in enumerate(pils):
+                want += [(i, k, r) for _, k, r in core.core_generation_funnel(None, [p], None, None, o)]
+            assert [(i, k) for i, k, _ in got] == [(i, k) for i, k, _ in want], opts
+            for (i, k, a), (_, _, b) in zip(got, want):
+                assert np.array_equal(np.asarray(a), np.asarray(b)), (mt, opts, i, k)
+            if 'do_output_depth_prediction' in opts:
+                assert (1, 'depth_prediction') not in [(i, k) for i, k, _ in got]
+                d1 = [r for i, k, r in got if i == 1 and k == 'depth'][0]
+                assert not np.asarray(d1).any()
+    # the oracle on one option set (the per-image runs above could share a mistake with the batched ones)
+    got = list(core.core_generation_funnel(None, list(pils[:3]), None, None, dict(option_sets[0], model_type=0)))
+    for i in (0, 2):
+        d16 = oracle.convert_to_i16(oracle.depth_normalize01(preds[i], True))
+        r = {k: np.asarray(x) for j, k, x in got if j == i}
+        assert np.array_equal(r['depth'], d16)
+        sbs, ana = oracle.create_stereoimages_arrays(imgs[i], d16, 2.5, 0.0, ['left-right', 'red-cyan-anaglyph'], 0.0, 1.0, 'polylines_sharp')
+        assert np.array_equal(r['left-right'], sbs) and np.array_equal(r['red-cyan-anaglyph'], ana)
+        assert np.array_equal(r['normalmap'], oracle.create_normalmap_array(d16))
+    # the pixel budget splits a run of same-size images into several pipelined groups, results unchanged
+    monkeypatch.setattr(core, "FUNNEL_BATCH_PIXELS", 48 * 72)
+    Pred.calls.clear()
+    one = list(core.core_generation_funnel(None, list(pils[:3]), None, None, dict(option_sets[0], model_type=0)))
+    assert Pred.calls == [1, 1, 1]
+    for (i, k, a), (j, l, b) in zip(one, got):
+        assert (i, k) == (j, l) and np.array_equal(np.asarray(a), np.asarray(b))
+    # custom depth maps are batched too
+    deps = [rng.random((48, 72)) for _ in range(3)]
+    res = list(core.core_generation_funnel(None, list(pils[:3]), deps, None, {'gen_stereo': True, 'stereo_modes': ['left-right']}))
+    assert [(i, k) for i, k, _ in res] == [(0, 'depth'), (0, 'left-right'), (1, 'depth'), (1, 'left-right'), (2, 'depth'), (2, 'left-right')]
+    for i in range(3):
+        d16 = oracle.convert_to_i16(deps[i])
+        assert np.array_equal(np.asarray(res[2 * i][2]), d16)
+        assert np.array_equal(np.asarray(res[2 * i + 1][2]),
+                              oracle.create_stereoimages_arrays(imgs[i], d16, 2.5, 0.0, ['left-right'], 0.0, 1.0, 'polylines_sharp')[0])

@@ -206,3 +206,29 @@ def test_simple_mesh_geometry_matches_reference_functions(tmp_path):
     assert torch.equal(mg.mesh_depth(zd, 1, False, False), torch.tensor([[4.0, 3.0]]))
     # the rescale uses the min / max from BEFORE the shift (reference quirk): 4 * ([0, 21] + 1) / 21 + 1
     assert torch.allclose(mg.mesh_depth(torch.tensor([[-1.0, 20.0]]), 0, False, False), torch.tensor([[1.0 + 4 / 21, 1.0 + 88 / 21]]))
+
+
+def test_funnel_group_plan():
+    """core._plan_groups: consecutive images of one size / mode / depth-source kind form a device batch, capped by the
+    pixel budget and at 64 images; Boost (batchable=False) goes image by image; order is preserved."""
+    from PIL import Image
+    import src.core as core
+    a, b = Image.new("RGB", (64, 48)), Image.new("RGB", (32, 48))
+    rgba = Image.new("RGBA", (64, 48))
+    ims = [a, a, a, b, b, a, rgba, a]
+    none = [None] * len(ims)
+    assert core._plan_groups(ims, none, True) == [[0, 1, 2], [3, 4], [5], [6], [7]]
+    assert core._plan_groups(ims, none, False) == [[i] for i in range(len(ims))]
+    deps = [None, object(), object(), None, None, None, None, None]
+    assert core._plan_groups(ims, deps, True) == [[0], [1, 2], [3, 4], [5], [6], [7]]
+    many = [a] * 150
+    g = core._plan_groups(many, [None] * 150, True)
+    assert [len(x) for x in g] == [64, 64, 22] and sum(g, []) == list(range(150))
+    old = core.FUNNEL_BATCH_PIXELS
+    try:
+        core.FUNNEL_BATCH_PIXELS = 64 * 48 * 2
+        assert [len(x) for x in core._plan_groups([a] * 5, [None] * 5, True)] == [2, 2, 1]
+        core.FUNNEL_BATCH_PIXELS = 1
+        assert [len(x) for x in core._plan_groups([a] * 3, [None] * 3, True)] == [1, 1, 1]
+    finally:
+        core.FUNNEL_BATCH_PIXELS = old

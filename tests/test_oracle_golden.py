@@ -105,3 +105,26 @@ def test_heatmap_oracle_matches_reference_colorize():
     for name in names:
         got = orc.colorize_u16(z[f'{name}__depth'], lut)
         assert got.dtype == np.uint8 and np.array_equal(got, z[f'{name}__rgba']), name
+
+
+def test_python_port_reproduces_reference_goldens(oracle):
+    """oracle/oracle_py.py (the pure-Python port bench.py times as cpu_baseline.python_fallback) against every small
+    reference-made polylines golden with a left-right output, and against the C port on a seeded case."""
+    from oracle import oracle_py
+    z, index = util.load_stereo_golden()
+    n = 0
+    for case in index:
+        if not case['fill'].startswith('polylines') or 'left-right' not in case['modes']:
+            continue
+        img, dep = util.golden_inputs(case)
+        if img.shape[0] * img.shape[1] > 8000:
+            continue
+        got = oracle_py.create_stereoimages_arrays(img, dep, case['div'], case['sep'], ['left-right'], case['bal'], case['exp'], case['fill'])[0]
+        assert np.array_equal(z[case['name'].replace('/', '__') + '__left-right'], got), case['name']
+        n += 1
+    assert n >= 10
+    img, dep = util.survey_inputs(40, 96, 3)
+    for fill in ('polylines_sharp', 'polylines_soft'):
+        a = oracle_py.create_stereoimages_arrays(img[0], dep[0], 4.0, 0.5, ['left-right'], 0.2, 1.0, fill)[0]
+        b = oracle.create_stereoimages_arrays(img[0], dep[0], 4.0, 0.5, ['left-right'], 0.2, 1.0, fill)[0]
+        assert np.array_equal(a, b), fill
