@@ -23,6 +23,8 @@
 // to 136 B (conflict-free ds_read_b64).  The next tile is fetched into registers (buffer loads through descriptors) while
 // the current one is computed and stashed into the other of two LDS buffers: one barrier per tile.  Workgroups are
 // ordered so that one XCD's L2 serves all query blocks of a (batch, head) and one head's bias (see the kernel).
+#include <type_traits>
+
 #include "ds_common.h"
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
@@ -296,6 +298,356 @@ __global__ __launch_bounds__(AT_THREADS, 3) void k_attention_fwd(AttnParams P)
     }
 }
 
+
+// =====================================================================================================================
+// Version 2 of the kernel (default; DS_ATT_V1=1 selects the first one above for A/B runs).
+//
+// What changed, and why (round-1 profile: MFMA busy 20-26 %, ~200 VALU instructions per 16 MFMA with the bias, 3 waves/SIMD):
+//   * 64 query rows per wave (two 32-row blocks), 256 per workgroup: every K / V^T fragment read from LDS feeds TWO MFMAs,
+//     and K / V^T / the staging traffic per query row halve.  Two fat waves per SIMD (<= 256 VGPRs).
+//   * the relative-position bias enters through the MATRIX pipe:  S^T = K.Q^T + Bias^T.I  with a constant identity B operand
+//     (2 extra MFMAs per 32 x 32 logits block, exact: an f16 value times 1.0 accumulated in float32).  The packed operand is
+//     stored as MFMA A fragments, in units of 1/scale (x8: exact), so the logits need NO per-element VALU work before the
+//     softmax: 64 v_fma_mix + unpacking per tile become 8 MFMAs on a pipe that was three quarters idle.
+//   * deferred running maximum: a query's maximum is only raised (and O rescaled) when it grows by more than 2^AT2_THR;
+//     probabilities are then bounded by 2^AT2_THR instead of 1, harmless in f16/bf16 with float32 accumulation.
+//   * K and V^T tiles use padded 144-byte rows (conflict-free ds_read_b128 for both; the XOR swizzle of version 1 left the
+//     K reads 2-way conflicted), and V^T is stored key-permuted so that a P.V fragment is ONE ds_read_b128: within every 16
+//     keys the order is [0-3, 8-11, 4-7, 12-15] -- the k-slot order the S^T accumulator hands to the P^T operand.
+// three-input maximum: IEEE-754 maximum (v_maximum3_f32 on gfx950) needs none of the canonicalising v_max instructions the
+// compiler puts in front of fmaxf() on MFMA results, and stays an ordinary VALU instruction for the scheduler
+__device__ __forceinline__ float at_max3(float a, float b, float c)
+{
+    return __builtin_elementwise_maximum(__builtin_elementwise_maximum(a, b), c);
+}
+
+#define AT2_ROW 144                     // bytes per LDS row: 64 halves + 16 pad
+#define AT2_TILE (64 * AT2_ROW)         // one K or V^T tile
+#define AT2_QW 64                       // query rows per wave
+#define AT2_QB 256                      // query rows per workgroup
+#define AT2_THR 6.0f                    // deferred-max threshold, log2 units
+
+template <int BF16, int HAS_BIAS, int SPLIT>
+__global__ __launch_bounds__(AT_THREADS, 2) void k_attention_fwd2(AttnParams P)
+{
+    typedef at_traits<BF16> TR;
+    typedef typename TR::T T;
+    typedef typename TR::V8 V8;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[4 * AT2_TILE];       // K[2], V^T[2]: 36,864 B
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, hi = lane >> 5, l31 = lane & 31;
+    int L = blockIdx.x;
+    if (P.chunk > 0) {                                          // XCD-aware order, as in version 1
+        L = (int)(blockIdx.x & 7) * P.chunk + (int)(blockIdx.x >> 3);
+        if (L >= P.total) return;
+    }
+    const int qblk = L % P.nq, b = (L / P.nq) % P.B, h = L / (P.nq * P.B);
+    const int q0 = qblk * AT2_QB + wave * AT2_QW;
+    const int Np = P.Np, H = P.H;
+    const size_t tok_stride = (size_t)2 * H * AT_D;
+    const T *qk = (const T *)P.qk + (size_t)b * Np * tok_stride;
+    const T *q_base = qk + (size_t)h * AT_D;
+    const T *k_base = qk + (size_t)(H + h) * AT_D;
+    const T *vt = (const T *)P.vt + ((size_t)b * H + h) * AT_D * (size_t)Np;
+    T *out_base = (T *)P.out + (size_t)b * Np * (size_t)(H * AT_D) + (size_t)h * AT_D;
+    // a wave whose rows are all padding only helps staging; its output rows are zeroed (they feed the next GEMM as ordinary
+    // rows and must stay finite), rows >= Np do not exist
+    const bool wave_live = q0 < P.n_valid;
+    if (!wave_live && q0 < Np) {
+        const int row = q0 + lane;
+        if (row < Np) {
+            uint4 z = make_uint4(0, 0, 0, 0);
+#pragma unroll
+            for (int c = 0; c < 8; c++) *reinterpret_cast<uint4 *>(out_base + (size_t)row * (H * AT_D) + 8 * c) = z;
+        }
+    }
+
+    V8 qf[2][4];
+#pragma unroll
+    for (int qb = 0; qb < 2; qb++) {
+        const int qrow = min(q0 + 32 * qb + l31, Np - 1);
+        const T *qp = q_base + (size_t)qrow * tok_stride + 8 * hi;
+#pragma unroll
+        for (int s = 0; s < 4; s++) qf[qb][s] = *reinterpret_cast<const V8 *>(qp + 16 * s);
+    }
+    // identity B operand of the bias MFMAs: element t of slice s is I[k = 16 s + 8 hi + t][column l31]
+    V8 ident[2];
+#pragma unroll
+    for (int s = 0; s < 2; s++)
+#pragma unroll
+        for (int t = 0; t < 8; t++) ident[s][t] = TR::from_f32((16 * s + 8 * hi + t) == l31 ? 1.0f : 0.0f);
+
+    f32x16 o_acc[2][2];
+#pragma unroll
+    for (int qb = 0; qb < 2; qb++)
+#pragma unroll
+        for (int d = 0; d < 2; d++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) o_acc[qb][d][r] = 0.f;
+    float m_run[2] = { -__builtin_inff(), -__builtin_inff() }, l_run[2] = { 0.f, 0.f };
+
+    const int st_row = tid >> 3, st_chunk = tid & 7;
+    u32x4 kreg0, kreg1, vreg0, vreg1;
+    const __amdgpu_buffer_rsrc_t rs_k = __builtin_amdgcn_make_buffer_rsrc(
+        (void *)k_base, 0, (int)(((size_t)Np * tok_stride - (size_t)(H + h) * AT_D) * sizeof(T)), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_v = __builtin_amdgcn_make_buffer_rsrc((void *)vt, 0, (int)((size_t)AT_D * Np * sizeof(T)), 0x00020000);
+    const int vo_k = (int)((st_row * tok_stride + 8 * st_chunk) * sizeof(T));
+    const int vo_v = (int)((st_row * Np + 8 * st_chunk) * sizeof(T));
+    const int so_k32 = (int)(32 * tok_stride * sizeof(T)), so_r32 = (int)(32 * Np * sizeof(T));
+#define A2_FETCH(kt_) do {                                                                                             \
+        const int key0_ = (kt_) * AT_KB;                                                                                \
+        const int sk_ = __builtin_amdgcn_readfirstlane(key0_ * (int)(tok_stride * sizeof(T)));                          \
+        const int sv_ = __builtin_amdgcn_readfirstlane(key0_ * (int)sizeof(T));                                         \
+        kreg0 = __builtin_amdgcn_raw_buffer_load_b128(rs_k, vo_k, sk_, 0);                                              \
+        kreg1 = __builtin_amdgcn_raw_buffer_load_b128(rs_k, vo_k, sk_ + so_k32, 0);                                     \
+        vreg0 = __builtin_amdgcn_raw_buffer_load_b128(rs_v, vo_v, sv_, 0);                                              \
+        vreg1 = __builtin_amdgcn_raw_buffer_load_b128(rs_v, vo_v, sv_ + so_r32, 0);                                     \
+    } while (0)
+    // K row r, chunk c -> r*144 + 16c.  V^T row d, chunk c (keys 8c .. 8c+7) -> the permuted order described above: the low
+    // four keys go to chunk (c & ~1), the high four to chunk (c | 1), each at byte offset 8 (c & 1)
+    const int vst_lo = ((st_chunk & ~1) << 4) + ((st_chunk & 1) << 3), vst_hi = vst_lo + 16;
+#define A2_STASH1(buf_, row_, kr_, vr_) do {                                                                            \
+        *reinterpret_cast<u32x4 *>(smem + (buf_) * AT2_TILE + (row_) * AT2_ROW + (st_chunk << 4)) = kr_;                \
+        unsigned char *vd_ = smem + (2 + (buf_)) * AT2_TILE + (row_) * AT2_ROW;                                         \
+        *reinterpret_cast<uint2 *>(vd_ + vst_lo) = make_uint2(vr_.x, vr_.y);                                            \
+        *reinterpret_cast<uint2 *>(vd_ + vst_hi) = make_uint2(vr_.z, vr_.w);                                            \
+    } while (0)
+    // Bias: [head][32-query block][64-key tile][chunk c = 2 kb + s][64 lanes][8]: lane (hi, l31) of chunk c holds
+    // bias[query 16 s + 8 hi + t][key 32 kb + l31] / scale, t = 0..7 -- the A fragment of the MFMA that adds it.
+    u32x4 breg[HAS_BIAS ? 2 : 1][HAS_BIAS ? 4 : 1];
+    const int n_kt = Np / AT_KB;
+    const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc(
+        (void *)(HAS_BIAS ? (const T *)P.bias + (size_t)h * Np * (size_t)Np : (const T *)P.qk), 0,
+        (int)((size_t)Np * Np * sizeof(T)), 0x00020000);
+    const int vo_b = (int)((((size_t)(q0 / 32) * n_kt) * 2048 + (size_t)lane * 8) * sizeof(T));
+    const int so_bq = (int)((size_t)n_kt * 2048 * sizeof(T));                               // next 32-query block
+#define A2_FETCH_BIAS(kt_) do {                                                                                        \
+        const int sb_ = __builtin_amdgcn_readfirstlane((kt_) * (int)(2048 * sizeof(T)));                                \
+        _Pragma("unroll") for (int qb_ = 0; qb_ < 2; qb_++)                                                             \
+        _Pragma("unroll") for (int c_i = 0; c_i < 4; c_i++)                                                             \
+            breg[qb_][c_i] = __builtin_amdgcn_raw_buffer_load_b128(rs_b, vo_b + qb_ * so_bq + c_i * 1024, sb_, 0);     \
+    } while (0)
+
+    const int ntiles = (P.n_valid + AT_KB - 1) / AT_KB;
+    const float c_ = P.c_exp;                                   // scale * log2(e): the bias is stored in units of 1/scale
+    const float thr_x = AT2_THR / c_;
+    A2_FETCH(0);
+    if (HAS_BIAS && wave_live) A2_FETCH_BIAS(0);
+    A2_STASH1(0, st_row, kreg0, vreg0);
+    A2_STASH1(0, st_row + 32, kreg1, vreg1);
+    __syncthreads();
+    // One 64-key tile.  MASKED is a compile-time flag: only the last tile can hold pad keys, so the steady-state body has no
+    // mask code and no control flow besides the (rare) rescale.
+    auto tile = [&](const int kt, auto masked_tag) __attribute__((always_inline)) {
+        constexpr bool MASKED = decltype(masked_tag)::value;
+        const int cur = kt & 1;
+        const unsigned char *s_k = smem + cur * AT2_TILE, *s_v = smem + (2 + cur) * AT2_TILE;
+        const bool more = kt + 1 < ntiles;
+        // next tile's K / V^T: in flight while this tile is computed.  The staggered variant requests them after its first
+        // mixed region, where the register pressure peaks (the remaining three regions still cover an L2 round trip)
+        if (more && (SPLIT == 0 || !wave_live)) A2_FETCH(kt + 1);
+        if (wave_live) {
+            const int key0 = kt * AT_KB;
+            f32x16 s_acc[2][2];
+            V8 pf[2][2][2];
+            float alpha[2];
+            bool grow[2];
+            // S^T = Bias^T.I (+) K.Q^T of query block qb_, key block kb_: the two bias MFMAs start the accumulation chain
+#define A2_S_BIAS(qb_, kb_) do {                                                                                       \
+                if (HAS_BIAS) {                                                                                         \
+                    f32x16 z_;                                                                                          \
+                    _Pragma("unroll") for (int r_ = 0; r_ < 16; r_++) z_[r_] = 0.f;                                     \
+                    union { u32x4 u; V8 v; } b0_, b1_;                                                                  \
+                    b0_.u = breg[qb_][2 * (kb_)]; b1_.u = breg[qb_][2 * (kb_) + 1];                                     \
+                    s_acc[qb_][kb_] = TR::mfma(b0_.v, ident[0], z_);                                                    \
+                    s_acc[qb_][kb_] = TR::mfma(b1_.v, ident[1], s_acc[qb_][kb_]);                                       \
+                } else {                                                                                                \
+                    _Pragma("unroll") for (int r_ = 0; r_ < 16; r_++) s_acc[qb_][kb_][r_] = 0.f;                        \
+                }                                                                                                       \
+            } while (0)
+#define A2_MASK(qb_) do {                                                                                              \
+                if (MASKED) {                                                                                           \
+                    _Pragma("unroll") for (int kb_ = 0; kb_ < 2; kb_++)                                                 \
+                    _Pragma("unroll") for (int r_ = 0; r_ < 16; r_++)                                                   \
+                        if (key0 + kb_ * 32 + at_crow(r_, hi) >= P.n_valid) s_acc[qb_][kb_][r_] = -__builtin_inff();    \
+                }                                                                                                       \
+            } while (0)
+            // online softmax of one 32-query block in the exp2 domain with a deferred maximum: the running maximum is only
+            // raised when it would grow by more than the threshold (first tile: from -inf); alpha = 1 when kept
+#define A2_SOFTMAX(qb_) do {                                                                                           \
+                float mx_ = at_max3(s_acc[qb_][0][0], s_acc[qb_][1][0], s_acc[qb_][0][1]);                              \
+                mx_ = at_max3(mx_, s_acc[qb_][1][1], s_acc[qb_][0][2]);                                                 \
+                mx_ = at_max3(mx_, s_acc[qb_][1][2], s_acc[qb_][0][3]);                                                 \
+                _Pragma("unroll") for (int r_ = 3; r_ < 15; r_ += 2) {                                                  \
+                    mx_ = at_max3(mx_, s_acc[qb_][1][r_], s_acc[qb_][0][r_ + 1]);                                       \
+                    mx_ = at_max3(mx_, s_acc[qb_][1][r_ + 1], s_acc[qb_][0][r_ + 2]);                                   \
+                }                                                                                                       \
+                mx_ = at_max3(mx_, s_acc[qb_][1][15], mx_);                                                             \
+                mx_ = at_max3(mx_, __shfl_xor(mx_, 32, 64), mx_);                                                       \
+                grow[qb_] = mx_ > m_run[qb_] + thr_x;                                                                   \
+                const float mn_ = grow[qb_] ? mx_ : m_run[qb_];                                                         \
+                alpha[qb_] = __builtin_amdgcn_exp2f((m_run[qb_] - mn_) * c_);                                           \
+                m_run[qb_] = mn_;                                                                                       \
+                const float mc_ = -mn_ * c_;                                                                            \
+                float l0_ = 0.f, l1_ = 0.f;                                                                             \
+                _Pragma("unroll") for (int kb_ = 0; kb_ < 2; kb_++)                                                     \
+                _Pragma("unroll") for (int j_ = 0; j_ < 2; j_++)                                                        \
+                _Pragma("unroll") for (int t_ = 0; t_ < 8; t_ += 2) {                                                   \
+                    const float p0_ = __builtin_amdgcn_exp2f(__builtin_fmaf(s_acc[qb_][kb_][8 * j_ + t_], c_, mc_));    \
+                    const float p1_ = __builtin_amdgcn_exp2f(__builtin_fmaf(s_acc[qb_][kb_][8 * j_ + t_ + 1], c_, mc_)); \
+                    l0_ += p0_; l1_ += p1_;                                                                             \
+                    pf[qb_][kb_][j_][t_] = TR::from_f32(p0_);                                                           \
+                    pf[qb_][kb_][j_][t_ + 1] = TR::from_f32(p1_);                                                       \
+                }                                                                                                       \
+                l_run[qb_] = l_run[qb_] * alpha[qb_] + (l0_ + l1_);                                                     \
+            } while (0)
+#define A2_RESCALE(qb_) do {                                                                                           \
+                if (__any(grow[qb_])) {                         /* some query of this block moved its maximum */        \
+                    _Pragma("unroll") for (int d_ = 0; d_ < 2; d_++)                                                    \
+                    _Pragma("unroll") for (int r_ = 0; r_ < 16; r_++) o_acc[qb_][d_][r_] *= alpha[qb_];                 \
+                }                                                                                                       \
+            } while (0)
+            if (SPLIT == 0) {
+                // ---- S^T for both query blocks (every K fragment feeds two MFMAs), softmax, P.V (every V^T fragment too) ----
+#pragma unroll
+                for (int qb = 0; qb < 2; qb++)
+#pragma unroll
+                    for (int kb = 0; kb < 2; kb++) A2_S_BIAS(qb, kb);
+#pragma unroll
+                for (int kb = 0; kb < 2; kb++) {
+                    const unsigned char *krow = s_k + (kb * 32 + l31) * AT2_ROW + (hi << 4);
+#pragma unroll
+                    for (int s = 0; s < 4; s++) {
+                        const V8 kf = *reinterpret_cast<const V8 *>(krow + (s << 5));
+                        s_acc[0][kb] = TR::mfma(kf, qf[0][s], s_acc[0][kb]);
+                        s_acc[1][kb] = TR::mfma(kf, qf[1][s], s_acc[1][kb]);
+                    }
+                }
+                // the bias registers are free: next tile's fragments land under the softmax / P.V of this one
+                if (HAS_BIAS && more) A2_FETCH_BIAS(kt + 1);
+                A2_MASK(0); A2_MASK(1);
+                A2_SOFTMAX(0); A2_RESCALE(0);
+                A2_SOFTMAX(1); A2_RESCALE(1);
+#pragma unroll
+                for (int d = 0; d < 2; d++) {
+                    const unsigned char *vrow = s_v + (d * 32 + l31) * AT2_ROW + (hi << 4);
+#pragma unroll
+                    for (int kb = 0; kb < 2; kb++)
+#pragma unroll
+                        for (int j = 0; j < 2; j++) {
+                            const V8 vf = *reinterpret_cast<const V8 *>(vrow + ((kb * 4 + j * 2) << 4));
+                            o_acc[0][d] = TR::mfma(vf, pf[0][kb][j], o_acc[0][d]);
+                            o_acc[1][d] = TR::mfma(vf, pf[1][kb][j], o_acc[1][d]);
+                        }
+                }
+            } else {
+                // ---- staggered: the VALU work of one query block sits in the same scheduling region as MFMAs of the other ----
+                //   S(0) | S(1) || softmax(0) | P.V(0) || softmax(1) | P.V(1)        (fragments are read once per block)
+#define A2_S_ONE(qb_) do {                                                                                             \
+                    A2_S_BIAS(qb_, 0); A2_S_BIAS(qb_, 1);                                                               \
+                    _Pragma("unroll") for (int kb_ = 0; kb_ < 2; kb_++) {                                               \
+                        const unsigned char *krow_ = s_k + (kb_ * 32 + l31) * AT2_ROW + (hi << 4);                      \
+                        _Pragma("unroll") for (int s_ = 0; s_ < 4; s_++) {                                              \
+                            const V8 kf_ = *reinterpret_cast<const V8 *>(krow_ + (s_ << 5));                            \
+                            s_acc[qb_][kb_] = TR::mfma(kf_, qf[qb_][s_], s_acc[qb_][kb_]);                              \
+                        }                                                                                               \
+                    }                                                                                                   \
+                } while (0)
+#define A2_PV_ONE(qb_) do {                                                                                            \
+                    _Pragma("unroll") for (int d_ = 0; d_ < 2; d_++) {                                                  \
+                        const unsigned char *vrow_ = s_v + (d_ * 32 + l31) * AT2_ROW + (hi << 4);                       \
+                        _Pragma("unroll") for (int kb_ = 0; kb_ < 2; kb_++)                                             \
+                        _Pragma("unroll") for (int j_ = 0; j_ < 2; j_++) {                                              \
+                            const V8 vf_ = *reinterpret_cast<const V8 *>(vrow_ + ((kb_ * 4 + j_ * 2) << 4));            \
+                            o_acc[qb_][d_] = TR::mfma(vf_, pf[qb_][kb_][j_], o_acc[qb_][d_]);                           \
+                        }                                                                                               \
+                    }                                                                                                   \
+                } while (0)
+                A2_S_ONE(0);
+                A2_MASK(0);
+                A2_S_ONE(1);
+                A2_SOFTMAX(0);
+                if (!MASKED) {                                 // one MFMA, then its share of the softmax VALU work
+#pragma unroll
+                    for (int i = 0; i < 12; i++) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x002, 12, 0);
+                    }
+                }
+                if (more) A2_FETCH(kt + 1);
+                A2_RESCALE(0);
+                A2_MASK(1);
+                A2_PV_ONE(0);
+                A2_SOFTMAX(1);
+                if (!MASKED) {
+#pragma unroll
+                    for (int i = 0; i < 8; i++) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 1);
+                        __builtin_amdgcn_sched_group_barrier(0x002, 18, 1);
+                    }
+                }
+                // register pressure peaks in the two mixed regions above: the next tile's bias fragments are requested only now
+                // and land under P.V(1), the stash and the barrier
+                if (HAS_BIAS && more) A2_FETCH_BIAS(kt + 1);
+                A2_RESCALE(1);
+                A2_PV_ONE(1);
+            }
+        }
+        if (more) {
+            A2_STASH1(cur ^ 1, st_row, kreg0, vreg0);
+            A2_STASH1(cur ^ 1, st_row + 32, kreg1, vreg1);
+        }
+        __syncthreads();
+    };
+    const bool pad_keys = (P.n_valid & (AT_KB - 1)) != 0;
+    for (int kt = 0; kt + 1 < ntiles; kt++) tile(kt, std::false_type());
+    if (pad_keys) tile(ntiles - 1, std::true_type());
+    else tile(ntiles - 1, std::false_type());
+    if (!wave_live) return;
+#pragma unroll
+    for (int qb = 0; qb < 2; qb++) {
+        const float l_tot = l_run[qb] + __shfl_xor(l_run[qb], 32, 64);
+        const float inv = 1.0f / l_tot;
+        const int qrow = q0 + 32 * qb + l31;
+        if (qrow < Np) {
+            T *op = out_base + (size_t)qrow * (size_t)(H * AT_D);
+#pragma unroll
+            for (int d = 0; d < 2; d++)
+#pragma unroll
+                for (int g = 0; g < 4; g++) {
+                    T v4[4];
+#pragma unroll
+                    for (int t = 0; t < 4; t++) v4[t] = TR::from_f32(o_acc[qb][d][4 * g + t] * inv);
+                    *reinterpret_cast<uint2 *>(op + d * 32 + 8 * g + 4 * hi) = *reinterpret_cast<const uint2 *>(v4);
+                }
+        }
+    }
+}
+
+// bias operand of version 2: [H][Np/32][Np/64][4 chunks][64 lanes][8], values bias / scale (scale = 1/8: exact)
+template <int BF16>
+__global__ void k_attention_bias_pack2(const float *__restrict__ bias, typename at_traits<BF16>::T *__restrict__ out,
+                                       int H, int n, int Np, float mul)
+{
+    typedef at_traits<BF16> TR;
+    const long long total = (long long)H * Np * Np;
+    const int n_kt = Np / AT_KB, nq32 = Np / 32;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+        const int t = (int)(idx & 7), lane = (int)((idx >> 3) & 63), c = (int)((idx >> 9) & 3);
+        const long long tile = idx >> 11;
+        const int kt = (int)(tile % n_kt), qb = (int)((tile / n_kt) % nq32), h = (int)(tile / ((long long)n_kt * nq32));
+        const int q = qb * 32 + 16 * (c & 1) + 8 * (lane >> 5) + t;
+        const int k = kt * AT_KB + 32 * (c >> 1) + (lane & 31);
+        const float v = (q < n && k < n) ? bias[((size_t)h * n + q) * n + k] * mul : 0.f;
+        out[idx] = TR::from_f32(v);
+    }
+}
+
+static int at_version()
+{
+    static const int v = (getenv("DS_ATT_V1") && atoi(getenv("DS_ATT_V1"))) ? 1 : 2;
+    return v;
+}
+
 // ---- bias operand: [H, n, n] float32 (natural units) -> packed register order, log2 units, zero padded to Np ----------
 template <int BF16>
 __global__ void k_attention_bias_pack(const float *__restrict__ bias, typename at_traits<BF16>::T *__restrict__ out,
@@ -325,7 +677,10 @@ DS_API int ds_attention_bias_pack(ds_ctx *ctx, const float *bias, int H, int n, 
     const int blocks = (int)std::min<long long>((total + 255) / 256, 65536);
     hipStream_t st = (hipStream_t)stream;
     const float log2e = 1.4426950408889634f;
-    if (dtype == DS_DTYPE_F16) hipLaunchKernelGGL((k_attention_bias_pack<0>), dim3(blocks), dim3(256), 0, st, bias, (_Float16 *)packed, H, n, Np, log2e);
+    if (at_version() == 2) {               // A fragments of the bias MFMA, in units of 1/scale (head_dim 64: x 8, exact)
+        if (dtype == DS_DTYPE_F16) hipLaunchKernelGGL((k_attention_bias_pack2<0>), dim3(blocks), dim3(256), 0, st, bias, (_Float16 *)packed, H, n, Np, 8.0f);
+        else hipLaunchKernelGGL((k_attention_bias_pack2<1>), dim3(blocks), dim3(256), 0, st, bias, (__bf16 *)packed, H, n, Np, 8.0f);
+    } else if (dtype == DS_DTYPE_F16) hipLaunchKernelGGL((k_attention_bias_pack<0>), dim3(blocks), dim3(256), 0, st, bias, (_Float16 *)packed, H, n, Np, log2e);
     else hipLaunchKernelGGL((k_attention_bias_pack<1>), dim3(blocks), dim3(256), 0, st, bias, (__bf16 *)packed, H, n, Np, log2e);
     DS_HIP_CHECK(hipGetLastError());
     return DS_OK;
@@ -347,6 +702,26 @@ DS_API int ds_attention_fwd(ds_ctx *ctx, const void *qk, const void *vt, const v
     P.qk = qk; P.vt = vt; P.bias = bias; P.out = out;
     P.B = B; P.Np = Np; P.H = H; P.n_valid = n_valid;
     const float log2e = 1.4426950408889634f;
+    if (at_version() == 2) {
+        DS_REQUIRE(!bias || scale == 0.125f, DS_EUNSUPPORTED, "ds_attention_fwd: the packed bias is stored in units of 1/scale for "
+                   "head_dim 64 (scale 0.125); got scale %g", (double)scale);
+        DS_REQUIRE(((uintptr_t)out & 15) == 0, DS_EINVAL, "ds_attention_fwd: out must be 16-byte aligned");
+        P.c_exp = scale * log2e; P.k_logit = 1.0f; P.flags = 0;
+        P.nq = (Np + AT2_QB - 1) / AT2_QB;
+        P.total = P.nq * H * B;
+        P.chunk = (P.total + 7) / 8;
+        dim3 grid2(8 * P.chunk);
+        hipStream_t st2 = (hipStream_t)stream;
+        static const int split = getenv("DS_ATT_SPLIT") ? atoi(getenv("DS_ATT_SPLIT")) : 0;      // A/B switch
+#define A2_LAUNCH(BF_, BI_) do {                                                                                       \
+            if (split) hipLaunchKernelGGL((k_attention_fwd2<BF_, BI_, 1>), grid2, dim3(AT_THREADS), 0, st2, P);         \
+            else hipLaunchKernelGGL((k_attention_fwd2<BF_, BI_, 0>), grid2, dim3(AT_THREADS), 0, st2, P);               \
+        } while (0)
+        if (dtype == DS_DTYPE_F16) { if (bias) A2_LAUNCH(0, 1); else A2_LAUNCH(0, 0); }
+        else { if (bias) A2_LAUNCH(1, 1); else A2_LAUNCH(1, 0); }
+        DS_HIP_CHECK(hipGetLastError());
+        return DS_OK;
+    }
     P.c_exp = bias ? 1.0f : scale * log2e;                  // the packed bias is in log2 units
     P.k_logit = scale * log2e;
     static const int att_flags = getenv("DS_ATT_FLAGS") ? atoi(getenv("DS_ATT_FLAGS")) : 1;   // setprio around the MFMA clusters: +2.5 % with bias

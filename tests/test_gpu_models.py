@@ -37,19 +37,26 @@ def test_attention_kernel_matches_definition(gpu, dtype, with_bias):
             packed = _native.attention_bias_pack(bias, npad, dtype)
             padded = torch.zeros((h, npad, npad), device='cuda')
             padded[:, :n_valid, :n_valid] = bias
-            # the pack kernel against its layout definition (include/depthstereo.h): [H][Np/32][Np/64][4][64 lanes][8]
+            # the pack kernel against its layout definition (include/depthstereo.h): [H][Np/32][Np/64][4][64 lanes][8];
+            # chunk c = 2 kb + s holds, for lane (hi, l31), bias[query 16 s + 8 hi + t][key 32 kb + l31] / scale (t = 0..7):
+            # the A fragments of the MFMAs that add the bias to the logits
             t = packed.data.float().view(h, npad // 32, npad // 64, 4, 64, 8)
             lane = torch.arange(64, device='cuda')
             c = torch.arange(4, device='cuda')
             j = torch.arange(8, device='cuda')
-            r = 8 * (c[:, None, None] & 1) + j[None, None, :]                                   # accumulator register
-            key = (c[:, None, None] >> 1) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane[None, :, None] >> 5)
-            qq = (lane & 31)[None, :, None].expand(4, 64, 8)
+            if os.environ.get("DS_ATT_V1"):       # first kernel generation: register order of the logits tile, log2 units
+                r = 8 * (c[:, None, None] & 1) + j[None, None, :]
+                key = ((c[:, None, None] >> 1) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane[None, :, None] >> 5)).expand(4, 64, 8)
+                qq = (lane & 31)[None, :, None].expand(4, 64, 8)
+                mul = vm.LOG2E
+            else:
+                qq = (16 * (c[:, None, None] & 1) + 8 * (lane[None, :, None] >> 5) + j[None, None, :]).expand(4, 64, 8)
+                key = (32 * (c[:, None, None] >> 1) + (lane & 31)[None, :, None]).expand(4, 64, 8)
+                mul = 8.0
             for qb in (0, npad // 32 - 1):
                 for kt in (0, npad // 64 - 1):
-                    exact = (padded[:, qb * 32:(qb + 1) * 32, kt * 64:(kt + 1) * 64] * vm.LOG2E)[:, qq, key.expand(4, 64, 8)]
-                    # correctly rounded to the operand type (the kernel rounds the product once; float32 -> half of
-                    # a float32 product rounds twice and differs by one ulp in ~1e-4 of the cases)
+                    exact = (padded[:, qb * 32:(qb + 1) * 32, kt * 64:(kt + 1) * 64] * mul)[:, qq, key]
+                    # correctly rounded to the operand type (the kernel rounds the product once)
                     ulp = 2.0 ** (-10 if dtype == torch.float16 else -7)
                     assert ((t[:, qb, kt] - exact).abs() <= 0.5 * ulp * exact.abs() * 1.001 + 1e-30).all()
         got = _native.attention_fwd(qk, vt, n_valid, 0.125, packed)
@@ -345,7 +352,9 @@ def test_attention_kernel_at_benchmark_shapes(gpu, b, n_valid, h, with_bias, dty
         padded = torch.zeros((h, npad, npad), device='cuda')
         padded[:, :n_valid, :n_valid] = bias
     got = _native.attention_fwd(qk, vt, n_valid, 0.125, packed)
-    tol = (2e-3 if dtype == torch.float16 else 1.6e-2) if bias is None else (5e-3 if dtype == torch.float16 else 8e-2)
+    # with a bias: its values (a few units) are rounded to the 11 / 8 bit operand type -- 4e-3 / 3e-2 of absolute error on a
+    # logit, i.e. that relative error on a probability, times |V| ~ 3 at the 4 sigma tail of 5 * 10^8 outputs
+    tol = (2e-3 if dtype == torch.float16 else 1.6e-2) if bias is None else (1e-2 if dtype == torch.float16 else 8e-2)
     worst = 0.0
     for b0 in range(0, b, 4):                       # the definition in float32, four batch elements at a time
         want = vm.attention_reference(qk[b0:b0 + 4].float(), vt[b0:b0 + 4].float(), n_valid, 0.125, padded)

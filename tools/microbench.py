@@ -35,13 +35,27 @@ def main():
     B = 32
     dev = torch.device("cuda")
     if "attention" in which:
-        for name, n, bias in (("beit-l 1025 +bias", 1025, True), ("dinov2-l 1370", 1370, False)):
+        from src import vit_mi355x as vm
+        tag = "v1" if os.environ.get("DS_ATT_V1") else ("v2 split" if os.environ.get("DS_ATT_SPLIT") else "v2")
+        for name, n, bias, bb in (("beit-l 1025 +bias", 1025, True, B), ("dinov2-l 1370", 1370, False, B),
+                                  ("dinov2-l 2443 (1080p)", 2443, False, 8), ("beit-l 4097 +bias (net 1024)", 4097, True, 8),
+                                  ("vit-b 577", 577, False, B)):
             npad = (n + 63) // 64 * 64
-            qk = torch.randn(B, npad, 2, 16, 64, device=dev, dtype=torch.float16)
-            vt = torch.randn(B, 1024, npad, device=dev, dtype=torch.float16)
-            bt = nat.attention_bias_pack(torch.randn(16, n, n, device=dev), npad, torch.float16) if bias else None
+            hh = 12 if n == 577 else 16
+            qk = torch.randn(bb, npad, 2, hh, 64, device=dev, dtype=torch.float16)
+            vt = torch.randn(bb, hh * 64, npad, device=dev, dtype=torch.float16)
+            braw = torch.randn(hh, n, n, device=dev) if bias else None
+            bt = nat.attention_bias_pack(braw, npad, torch.float16) if bias else None
             ms = timeit(lambda: nat.attention_fwd(qk, vt, n, 0.125, bt))
-            print(f"attention {name}: {ms:.3f} ms  {4.0 * n * n * 1024 * B / ms / 1e9:.1f} TF/s")
+            # value check of the timed configuration on its first two batch elements (float32 definition)
+            padded = None
+            if bias:
+                padded = torch.zeros((hh, npad, npad), device=dev)
+                padded[:, :n, :n] = braw
+            got = nat.attention_fwd(qk[:2], vt[:2], n, 0.125, bt)
+            want = vm.attention_reference(qk[:2].float(), vt[:2].float(), n, 0.125, padded)
+            err = (got.float()[:, :n] - want[:, :n]).abs().max().item()
+            print(f"attention [{tag}] {name} x{bb}: {ms:.3f} ms  {4.0 * n * n * hh * 64 * bb / ms / 1e9:.1f} TF/s  max|err| {err:.2e}")
     if "head" in which:
         conv3 = nn.Conv2d(128, 32, 3, padding=1).to(dev).half()
         conv1 = nn.Conv2d(32, 1, 1).to(dev).half()
