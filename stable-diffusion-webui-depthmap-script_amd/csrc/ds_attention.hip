@@ -327,7 +327,10 @@ __device__ __forceinline__ float at_max3(float a, float b, float c)
 #define AT2_QB 256                      // query rows per workgroup
 #define AT2_THR 6.0f                    // deferred-max threshold, log2 units
 
-template <int BF16, int HAS_BIAS, int SPLIT>
+// ABL != 0: the same kernel with parts compiled out (timing experiments only, DS_ATT_ABLATE; results are WRONG), a bit mask:
+//   1 softmax reduced to a conversion   2 no K / V^T / bias fetch, no stash after the first tile   4 no barrier in the loop
+//   8 no P.V MFMAs   16 no S MFMAs   32 fragments are not read from LDS (a register stands in)
+template <int BF16, int HAS_BIAS, int SPLIT, int ABL>
 __global__ __launch_bounds__(AT_THREADS, 2) void k_attention_fwd2(AttnParams P)
 {
     typedef at_traits<BF16> TR;
@@ -444,7 +447,8 @@ __global__ __launch_bounds__(AT_THREADS, 2) void k_attention_fwd2(AttnParams P)
         const bool more = kt + 1 < ntiles;
         // next tile's K / V^T: in flight while this tile is computed.  The staggered variant requests them after its first
         // mixed region, where the register pressure peaks (the remaining three regions still cover an L2 round trip)
-        if (more && (SPLIT == 0 || !wave_live)) A2_FETCH(kt + 1);
+        constexpr int abl = ABL;
+        if (more && (SPLIT == 0 || !wave_live) && !(abl & 2)) A2_FETCH(kt + 1);
         if (wave_live) {
             const int key0 = kt * AT_KB;
             f32x16 s_acc[2][2];
@@ -511,33 +515,62 @@ __global__ __launch_bounds__(AT_THREADS, 2) void k_attention_fwd2(AttnParams P)
 #pragma unroll
                 for (int qb = 0; qb < 2; qb++)
 #pragma unroll
-                    for (int kb = 0; kb < 2; kb++) A2_S_BIAS(qb, kb);
+                    for (int kb = 0; kb < 2; kb++) {
+                        if (ABL && (abl & 16)) {
 #pragma unroll
-                for (int kb = 0; kb < 2; kb++) {
-                    const unsigned char *krow = s_k + (kb * 32 + l31) * AT2_ROW + (hi << 4);
+                            for (int r = 0; r < 16; r++) s_acc[qb][kb][r] = (float)(r + kt);
+                        } else A2_S_BIAS(qb, kb);
+                    }
+                if (!(ABL && (abl & 16))) {
 #pragma unroll
-                    for (int s = 0; s < 4; s++) {
-                        const V8 kf = *reinterpret_cast<const V8 *>(krow + (s << 5));
-                        s_acc[0][kb] = TR::mfma(kf, qf[0][s], s_acc[0][kb]);
-                        s_acc[1][kb] = TR::mfma(kf, qf[1][s], s_acc[1][kb]);
+                    for (int kb = 0; kb < 2; kb++) {
+                        const unsigned char *krow = s_k + (kb * 32 + l31) * AT2_ROW + (hi << 4);
+#pragma unroll
+                        for (int s = 0; s < 4; s++) {
+                            const V8 kf = (ABL && (abl & 32)) ? qf[1][s] : *reinterpret_cast<const V8 *>(krow + (s << 5));
+                            s_acc[0][kb] = TR::mfma(kf, qf[0][s], s_acc[0][kb]);
+                            s_acc[1][kb] = TR::mfma(kf, qf[1][s], s_acc[1][kb]);
+                        }
                     }
                 }
                 // the bias registers are free: next tile's fragments land under the softmax / P.V of this one
-                if (HAS_BIAS && more) A2_FETCH_BIAS(kt + 1);
+                if (HAS_BIAS && more && !(abl & 2)) A2_FETCH_BIAS(kt + 1);
                 A2_MASK(0); A2_MASK(1);
-                A2_SOFTMAX(0); A2_RESCALE(0);
-                A2_SOFTMAX(1); A2_RESCALE(1);
+                if (ABL && (abl & 1)) {
 #pragma unroll
-                for (int d = 0; d < 2; d++) {
-                    const unsigned char *vrow = s_v + (d * 32 + l31) * AT2_ROW + (hi << 4);
+                    for (int qb = 0; qb < 2; qb++) {
 #pragma unroll
-                    for (int kb = 0; kb < 2; kb++)
+                        for (int kb = 0; kb < 2; kb++)
 #pragma unroll
-                        for (int j = 0; j < 2; j++) {
-                            const V8 vf = *reinterpret_cast<const V8 *>(vrow + ((kb * 4 + j * 2) << 4));
-                            o_acc[0][d] = TR::mfma(vf, pf[0][kb][j], o_acc[0][d]);
-                            o_acc[1][d] = TR::mfma(vf, pf[1][kb][j], o_acc[1][d]);
-                        }
+                            for (int j = 0; j < 2; j++)
+#pragma unroll
+                                for (int t = 0; t < 8; t++) pf[qb][kb][j][t] = TR::from_f32(s_acc[qb][kb][8 * j + t]);
+                        l_run[qb] += 1.0f; grow[qb] = false; alpha[qb] = 1.0f;
+                    }
+                } else {
+                    A2_SOFTMAX(0); A2_RESCALE(0);
+                    A2_SOFTMAX(1); A2_RESCALE(1);
+                }
+                if (!(ABL && (abl & 8))) {
+#pragma unroll
+                    for (int d = 0; d < 2; d++) {
+                        const unsigned char *vrow = s_v + (d * 32 + l31) * AT2_ROW + (hi << 4);
+#pragma unroll
+                        for (int kb = 0; kb < 2; kb++)
+#pragma unroll
+                            for (int j = 0; j < 2; j++) {
+                                const V8 vf = (ABL && (abl & 32)) ? qf[0][kb * 2 + j] : *reinterpret_cast<const V8 *>(vrow + ((kb * 4 + j * 2) << 4));
+                                o_acc[0][d] = TR::mfma(vf, pf[0][kb][j], o_acc[0][d]);
+                                o_acc[1][d] = TR::mfma(vf, pf[1][kb][j], o_acc[1][d]);
+                            }
+                    }
+                } else {
+#pragma unroll
+                    for (int qb = 0; qb < 2; qb++)
+#pragma unroll
+                        for (int kb = 0; kb < 2; kb++)
+#pragma unroll
+                            for (int j = 0; j < 2; j++) asm volatile("" :: "v"(pf[qb][kb][j]));
                 }
             } else {
                 // ---- staggered: the VALU work of one query block sits in the same scheduling region as MFMAs of the other ----
@@ -592,11 +625,11 @@ __global__ __launch_bounds__(AT_THREADS, 2) void k_attention_fwd2(AttnParams P)
                 A2_PV_ONE(1);
             }
         }
-        if (more) {
+        if (more && !(abl & 2)) {
             A2_STASH1(cur ^ 1, st_row, kreg0, vreg0);
             A2_STASH1(cur ^ 1, st_row + 32, kreg1, vreg1);
         }
-        __syncthreads();
+        if (!(abl & 4)) __syncthreads();
     };
     const bool pad_keys = (P.n_valid & (AT_KB - 1)) != 0;
     for (int kt = 0; kt + 1 < ntiles; kt++) tile(kt, std::false_type());
@@ -713,9 +746,19 @@ DS_API int ds_attention_fwd(ds_ctx *ctx, const void *qk, const void *vt, const v
         dim3 grid2(8 * P.chunk);
         hipStream_t st2 = (hipStream_t)stream;
         static const int split = getenv("DS_ATT_SPLIT") ? atoi(getenv("DS_ATT_SPLIT")) : 0;      // A/B switch
+        static const int ablate = getenv("DS_ATT_ABLATE") ? atoi(getenv("DS_ATT_ABLATE")) : 0;   // timing experiments, wrong results
+        P.flags = ablate;
+#define A2_ABL(BI_, M_) case M_: hipLaunchKernelGGL((k_attention_fwd2<0, BI_, 0, M_>), grid2, dim3(AT_THREADS), 0, st2, P); break;
 #define A2_LAUNCH(BF_, BI_) do {                                                                                       \
-            if (split) hipLaunchKernelGGL((k_attention_fwd2<BF_, BI_, 1>), grid2, dim3(AT_THREADS), 0, st2, P);         \
-            else hipLaunchKernelGGL((k_attention_fwd2<BF_, BI_, 0>), grid2, dim3(AT_THREADS), 0, st2, P);               \
+            if (ablate && BF_ == 0) {                                                                                   \
+                switch (ablate) {                                                                                       \
+                A2_ABL(BI_, 1) A2_ABL(BI_, 2) A2_ABL(BI_, 4) A2_ABL(BI_, 6) A2_ABL(BI_, 7) A2_ABL(BI_, 8) A2_ABL(BI_, 16) A2_ABL(BI_, 32) \
+                A2_ABL(BI_, 38) A2_ABL(BI_, 39)                                                                         \
+                default: ds_set_error("ds_attention_fwd: DS_ATT_ABLATE=%d is not an instantiated mask", ablate); return DS_EINVAL; \
+                }                                                                                                       \
+            }                                                                                                           \
+            else if (split) hipLaunchKernelGGL((k_attention_fwd2<BF_, BI_, 1, 0>), grid2, dim3(AT_THREADS), 0, st2, P);  \
+            else hipLaunchKernelGGL((k_attention_fwd2<BF_, BI_, 0, 0>), grid2, dim3(AT_THREADS), 0, st2, P);            \
         } while (0)
         if (dtype == DS_DTYPE_F16) { if (bias) A2_LAUNCH(0, 1); else A2_LAUNCH(0, 0); }
         else { if (bias) A2_LAUNCH(1, 1); else A2_LAUNCH(1, 0); }

@@ -40,10 +40,11 @@
 //        12-byte pixel load, float64 normalisation (one division per column), both eyes' points written
 //        to LDS as aligned 16-byte pairs, entry table updated.                          -- barrier --
 //   P2   one lane per output pixel and eye: entry table -> 7 point coordinates + 4 packed RGBX words
-//        from LDS -> up to 6 predicated pieces -> bytes into an LDS output row.  General pixels go to an
-//        LDS queue.                                                                      -- barrier --
-//   P3   queued pixels, densely packed one per lane, evaluated from the same LDS staging. -- barrier --
-//        (skipped, with its barrier, when the queue is empty)
+//        from LDS -> up to 6 predicated pieces -> bytes into an LDS output row.  General pixels are APPENDED TO A
+//        QUEUE IN HBM (one private segment per persistent workgroup: no global atomics) and rendered afterwards by
+//        k_polylines_general, densely packed 8 per wave.  Round 1 rendered them inside this kernel (phase P3, one
+//        wave at work, three waiting at an extra barrier): with a network's noisy prediction almost every work item
+//        holds a few such pixels, and that serial phase cost 1 ms of the 2.4 ms launch.
 //   S0   (start of the next work item) the finished output rows leave LDS as 16-byte stores.
 // HBM sees each input byte once per supertile (+ the window halo) and each output byte once.
 #include <stdlib.h>
@@ -76,6 +77,9 @@ struct PolyParams {
     int *row_flags;            // one int per (image, eye, row)
     int *row_list;             // flagged rows, compacted
     int *counters;             // [0] = number of flagged rows, [1] = number of general pixels (statistics)
+    unsigned long long *gq;    // queue of general pixels: one segment of gq_cap entries per workgroup of k_polylines
+    int *gq_count;             // entries in each segment
+    int gq_cap, gq_segments;   // entry = (row id << 32) | column, row id = (image * n_eyes + eye) * h + row
     int dbg;                   // DS_PL_DEBUG ablation knob (0 = off); results are WRONG when set
     unsigned long long *prof;  // optional (DS_PL_PROF=1): 8 cycle accumulators, wave 0 of every workgroup
 };
@@ -497,7 +501,7 @@ __host__ __device__ inline PlLds pl_lds_layout(int S, int nwmax, int c, int np)
     L.off_out = L.off_g0 + 2 * S * 4;
     L.outstride = (S * c + 15) & ~15;
     L.off_queue = L.off_out + 2 * L.outstride;
-    L.off_misc = L.off_queue + 2 * S * 2;
+    L.off_misc = L.off_queue;                              // (the round-1 in-LDS queue of general pixels is gone)
     L.total = L.off_misc + 8 * 4;
     return L;
 }
@@ -515,8 +519,7 @@ __global__ __launch_bounds__(PL_THREADS, 4) void k_polylines(PolyParams P)
     uint32_t *s_rgbx = reinterpret_cast<uint32_t *>(smem + L.off_rgbx) + 4;
     uint32_t *s_g0 = reinterpret_cast<uint32_t *>(smem + L.off_g0);          // [eye][S]
     uint8_t *s_out = smem + L.off_out;                                       // [eye][outstride]
-    uint16_t *s_queue = reinterpret_cast<uint16_t *>(smem + L.off_queue);    // (eye << 15) | pixel
-    int *s_misc = reinterpret_cast<int *>(smem + L.off_misc);                // [0],[1]: queue counts (alternating), [2],[3]: row flag per eye
+    int *s_misc = reinterpret_cast<int *>(smem + L.off_misc);                // [0]: entries in this workgroup's queue segment, [2],[3]: row flag per eye
 
     // per-eye constants pinned in scalar registers: without this the compiler re-reads them from the kernel-argument
     // segment inside the per-column code (s_load + s_waitcnt lgkmcnt(0) in the hot path)
@@ -539,7 +542,6 @@ __global__ __launch_bounds__(PL_THREADS, 4) void k_polylines(PolyParams P)
     __syncthreads();
 
     int prev = -1, prev_img = 0, prev_row = 0, prev_c0 = 0;
-    int iter = 0;
 #ifdef DS_PL_PROFILE        // build with -DDS_PL_PROFILE to get per-phase cycle counts (DS_PL_PROF=1 at run time)
     unsigned long long tacc[12] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 }, tl = P.prof ? __builtin_readcyclecounter() : 0ull;
 #define PL_TICK(i) do { if (P.prof) { const unsigned long long t_ = __builtin_readcyclecounter(); tacc[i] += t_ - tl; tl = t_; } } while (0)
@@ -616,7 +618,6 @@ __global__ __launch_bounds__(PL_THREADS, 4) void k_polylines(PolyParams P)
         const int ncols = j1 - j0 + 1;
         const bool head = j0 == 0, tail = j1 == w - 1;
         const double *lut = (P.lut != nullptr && P.depth_dtype == DS_DEPTH_U16) ? P.lut + (size_t)img * 65536 : nullptr;
-        const int qi = iter & 1;
         int bad = 0;                                        // non-finite / absurd coordinates seen by this thread
         for (int i4 = tid * 4; i4 < ncols; i4 += 4 * PL_THREADS) {
             const int j = j0 + i4;
@@ -705,7 +706,6 @@ __global__ __launch_bounds__(PL_THREADS, 4) void k_polylines(PolyParams P)
         PL_TICK(1);
         __syncthreads();                                                                        // ---- A ----
         PL_TICK(2);
-        if (tid == 0) s_misc[qi ^ 1] = 0;
         if (bad) { atomicOr(&s_misc[2], 1); atomicOr(&s_misc[3], 1); }
 
         // ---- P2: one lane per output pixel, both eyes in one straight line -----------------------------------
@@ -753,163 +753,35 @@ __global__ __launch_bounds__(PL_THREADS, 4) void k_polylines(PolyParams P)
                 if (flag[e]) atomicOr(&s_misc[2 + e], 1);
                 const unsigned long long qmask = __ballot(queued[e]);
                 if (qmask != 0ull) {
-                    const int lane = tid & 63;
-                    int base = 0;
-                    if (lane == 0) base = atomicAdd(&s_misc[qi], __popcll(qmask));
-                    base = __shfl(base, 0, 64);
-                    if (queued[e]) s_queue[base + __popcll(qmask & ((1ull << lane) - 1ull))] = (uint16_t)((e << 15) | p);
+                    if (P.K > PL_KMAX) {                     // candidate window too wide for the bit masks: exact sweep
+                        if (queued[e]) atomicOr(&s_misc[2 + e], 1);
+                    } else {
+                        const int lane = tid & 63;
+                        int base = 0;
+                        if (lane == 0) base = atomicAdd(&s_misc[0], __popcll(qmask));
+                        base = __shfl(base, 0, 64);
+                        if (queued[e]) {
+                            const int slot = base + __popcll(qmask & ((1ull << lane) - 1ull));
+                            if (slot < P.gq_cap) {
+                                const unsigned rowid = (unsigned)((img * P.n_eyes + e) * P.h + row);
+                                P.gq[(size_t)blockIdx.x * P.gq_cap + slot] = ((unsigned long long)rowid << 32) | (unsigned)(c0 + p);
+                            } else {
+                                atomicOr(&s_misc[2 + e], 1);     // segment full: the row goes to the exact sweep instead
+                            }
+                        }
+                    }
                 }
             }
         }
         PL_TICK(3);
         __syncthreads();                                                                        // ---- B ----
         PL_TICK(4);
-
-        // ---- P3: queued pixels from the same staging, EIGHT LANES PER PIXEL ---------------------------------
-        // The 8 lanes of a group first test the pixel's candidate window together (8 segments per step) and share two
-        // bit masks (forward segments overlapping the strip, points inside the pixel); lane u then takes the u-th point,
-        // the group ranks its points (the reference's stable sort, :214-219), and lane t evaluates sub-interval t.  The
-        // terms are finally added in order (float64 addition is not associative) by every lane of the group.
-        const int nq = P.dbg == 2 ? 0 : s_misc[qi];
-        if (nq > 0) {
-            if (tid == 0) atomicAdd(&P.counters[1], nq);
-            const int wave = tid >> 6, lane = tid & 63, grp = lane >> 3, u = lane & 7;
-            for (int r = wave; r * 8 < nq; r += PL_THREADS / 64) {
-                const int idx = r * 8 + grp;
-                const bool have = idx < nq;
-                const uint32_t ent = have ? s_queue[idx] : 0u;
-                const int e = ent >> 15, p = ent & 0x7fff;
-                const int col = c0 + p;
-                // candidate window of the pixel: segments qlo .. qhi
-                const int iL = min(max(col + P.offL[e] - 1 - j0, 0), ncols - 1);
-                const int iU = min(max(col + P.offU[e] - j0, 0), ncols - 1);
-                const int qlo = NP * iL + 1;
-                const int qhi = !have ? 0 : ((iU == ncols - 1 && tail) ? NP * ncols + 1 : NP * (iU + 1));
-                PlWin V;
-                V.pt = s_pt + e * L.npt; V.nd = s_nd; V.rgbx = s_rgbx; V.ncols = ncols; V.head = head; V.tail = tail; V.div_px = k_div[e];
-                const double fq = (double)col, fq1 = (double)(col + 1);
-                unsigned long long fm[PL_KMAX], bm[PL_KMAX];
-#pragma unroll
-                for (int k = 0; k < PL_KMAX; k++) { fm[k] = 0ull; bm[k] = 0ull; }
-                const bool wide = P.K > PL_KMAX;                     // window too wide for the masks: exact sweep
-                if (!wide) {
-#pragma unroll
-                    for (int k = 0; k < PL_KMAX; k++) {
-                        if (k < P.K) {
-                            for (int st = 0; st < 8 && 64 * k + 8 * st < P.nseg; st++) {
-                                const int q = qlo + 64 * k + 8 * st + u;
-                                const bool valid = q <= qhi;
-                                const double x0 = V.pt[valid ? q - 1 : 0], x1 = V.pt[valid ? q : 0];
-                                const unsigned long long mf = __ballot(valid && x0 < x1 && x0 < fq1 && !(x1 < fq));
-                                const unsigned long long mb = __ballot(valid && !(x1 < fq) && x1 < fq1);
-                                fm[k] |= ((mf >> (8 * grp)) & 0xffull) << (8 * st);
-                                bm[k] |= ((mb >> (8 * grp)) & 0xffull) << (8 * st);
-                            }
-                        }
-                    }
-                }
-                int nb = 0;
-#pragma unroll
-                for (int k = 0; k < PL_KMAX; k++) nb += __popcll(bm[k]);
-                const bool ovf = wide || nb > 7;                     // more than 8 sub-intervals: one lane walks them all
-                const bool par = have && !ovf;
-                // lane u's point, its rank among the group's points, the sorted sequence
-                const double BIG = 1.0e300;
-                double bx = BIG;
-                {
-                    int n = u, qb = -1;
-#pragma unroll
-                    for (int k = 0; k < PL_KMAX; k++) {
-                        const int c = __popcll(bm[k]);
-                        if (qb < 0 && n < c) {
-                            unsigned long long mm = bm[k];
-#pragma unroll
-                            for (int i = 0; i < 7; i++) if (i < n) mm &= mm - 1ull;
-                            qb = 64 * k + __ffsll((long long)mm) - 1;
-                        }
-                        n -= c;
-                    }
-                    if (par && qb >= 0) bx = V.pt[qlo + qb];
-                }
-                int rank = 0;
-#pragma unroll
-                for (int i = 1; i < 8; i++) {
-                    const int ou = (u + i) & 7;
-                    const double ox = __shfl(bx, (lane & ~7) | ou, 64);
-                    rank += (ox < bx || (ox == bx && ou < u)) ? 1 : 0;
-                }
-                double sx;
-                {
-                    const int tgt = ((lane & ~7) | rank) << 2;
-                    const int lo = __builtin_amdgcn_ds_permute(tgt, __double2loint(bx));
-                    const int hi = __builtin_amdgcn_ds_permute(tgt, __double2hiint(bx));
-                    sx = __hiloint2double(hi, lo);
-                }
-                const double sprev = __shfl(sx, (lane & ~7) | ((u + 7) & 7), 64);
-                const double a = u == 0 ? fq : sprev;
-                const double b = u < nb ? sx : fq1;
-                double term[C];
-#pragma unroll
-                for (int k = 0; k < C; k++) term[k] = 0.0;
-                int flag = 0;
-                if (par && u <= nb) {
-                    // sub-interval u of the pixel: active set, winner, colour term (:235-279)
-                    const PlSub sb = pl_sub(a, b);
-                    if (!(sb.significance > 0.0)) flag = 1;          // centres may stop being monotone: history dependent
-                    int count = 0, first = -1, win = -1;
-                    double best = -PL_EPS;                                                       // :261
-                    bool hv = false;
-#pragma nounroll
-                    for (;;) {
-                        int q = -1;                                  // next forward candidate: lowest set bit of the multi-word mask
-#pragma unroll
-                        for (int k = 0; k < PL_KMAX; k++) {
-                            if (q < 0 && fm[k] != 0ull) {
-                                q = qlo + 64 * k + __ffsll((long long)fm[k]) - 1;
-                                fm[k] &= fm[k] - 1ull;
-                            }
-                        }
-                        if (q < 0) break;
-                        const double x0 = V.pt[q - 1], x1 = V.pt[q];
-                        if (x0 < sb.coord_center && !(x1 < sb.coord_center)) {                  // :242-253
-                            if (count == 0) first = q;
-                            count++;
-                            const double d0 = pl_dd_of<NP>(V, q - 1), d1 = pl_dd_of<NP>(V, q);
-                            const double ip_k = (sb.coord_center - x0) / (x1 - x0);             // :263
-                            const double closeness = (1.0 - ip_k) * d0 + ip_k * d1;             // :265
-                            const bool valid = 0.0 < ip_k && ip_k < 1.0;
-                            if (valid && hv && closeness == best) flag = 1;                     // exact tie: csg order decides
-                            if (best < closeness && valid) { best = closeness; win = q; hv = true; }   // :266
-                        }
-                    }
-                    if (count == 1) win = first;                                                 // :259
-                    if (count == 0 || (count > 1 && !hv)) flag = 1;  // reference reads a stale / falls back to csg[0]
-                    else pl_add_segment<C, NP>(V, win, V.pt[win - 1], V.pt[win], sb, term);
-                }
-                double color[C];
-#pragma unroll
-                for (int k = 0; k < C; k++) color[k] = 0.5;                                      // :229
-                for (int t = 0; __any(par && t <= nb); t++) {
-#pragma unroll
-                    for (int k = 0; k < C; k++) color[k] += __shfl(term[k], (lane & ~7) | (t & 7), 64);   // lanes past nb hold 0.0
-                }
-                if (have && ovf && u == 0) {
-                    if (wide) flag = 1;
-                    else pl_general_pixel_lds<C, NP>(V, qlo, P.K, fm, bm, fq, fq1, color, flag);
-                }
-                if (have && u == 0) {
-                    uint8_t *o = s_out + e * L.outstride + p * C;
-#pragma unroll
-                    for (int k = 0; k < C; k++) o[k] = ds_f64_to_u8(color[k]);
-                }
-                if (flag) atomicOr(&s_misc[2 + e], 1);
-            }
-            PL_TICK(5);
-            __syncthreads();                                                                    // ---- C ----
-            PL_TICK(6);
-        }
         prev = work; prev_img = img; prev_row = row; prev_c0 = c0;
-        iter++;
+    }
+    if (tid == 0) {                                        // s_misc[0] was last written before the final barrier B
+        const int nq = s_misc[0];
+        P.gq_count[blockIdx.x] = min(nq, P.gq_cap);
+        if (nq > 0) atomicAdd(&P.counters[1], nq);
     }
 #ifdef DS_PL_PROFILE
     if (P.prof && tid == 0) {
@@ -920,6 +792,229 @@ __global__ __launch_bounds__(PL_THREADS, 4) void k_polylines(PolyParams P)
 #endif
 #undef PL_TICK
 #undef PL_TICKW
+}
+
+// ------------------------------------------------------------------------------------------------
+// GENERAL pixels, second pass.  k_polylines queued them (row id, column) in HBM; here they are rendered densely packed,
+// EIGHT LANES PER PIXEL, 8 pixels per wave, one wave per workgroup (no workgroup barrier is ever shared with idle waves).
+// A group first rebuilds the pixel's own source window in LDS -- the <= offU - offL + 2 columns that can reach it: normalised
+// depth, points, packed colours, with the arithmetic of phase P01, so every value is bit-identical to what the main kernel
+// staged -- then the 8 lanes test the candidate segments together (8 per step) and share two bit masks (forward segments
+// overlapping the strip, points inside the pixel); lane u takes the u-th point, the group ranks its points (the reference's
+// stable sort, :214-219), lane t evaluates sub-interval t, and the terms are added in order (float64 addition is not
+// associative).  More than 8 sub-intervals: one lane walks them all (pl_general_pixel_lds).  History-dependent corners flag
+// the row for the exact sweep, exactly as in the main kernel.
+struct PlGenLds { int ptn, ndn, stride; };
+__host__ __device__ inline PlGenLds pl_gen_layout(int ncmax, int np)
+{
+    PlGenLds G;
+    G.ptn = (np * ncmax + PL_PT_PAD + 2 + 1) & ~1;         // doubles
+    G.ndn = (ncmax + 2 + 1) & ~1;                          // doubles (nd[-1] exists)
+    G.stride = (G.ptn + G.ndn) * 8 + ((ncmax + 2 + 3) & ~3) * 4;   // + rgbx words; multiple of 16 bytes
+    return G;
+}
+
+// normalised depth of ONE column, same expressions as pl_load_nd
+__device__ __forceinline__ double pl_nd_one(const PolyParams &P, const void *depth_row, int j, double mn, double mx, const double *lut)
+{
+    if (P.depth_dtype == DS_DEPTH_U16) {
+        const uint32_t v = ((const uint16_t *)depth_row)[j];
+        if (lut != nullptr) return lut[v];
+        const uint32_t mn16 = (uint32_t)mn & 0xffffu;
+        const double b = (double)(((uint32_t)mx - mn16) & 0xffffu);
+        const double y = 1.0 / b;
+        const double a = (double)((v - mn16) & 0xffffu);
+        const double q0 = a * y;
+        return fma(fma(-b, q0, a), y, q0);
+    }
+    if (P.depth_dtype == DS_DEPTH_F32) {
+        const float v = ((const float *)depth_row)[j];
+        const float mnf = (float)mn, den = (float)mx - (float)mn;
+        return (double)((v - mnf) / den);
+    }
+    const double v = ((const double *)depth_row)[j];
+    return (v - mn) / (mx - mn);
+}
+
+template <int C, int SHARP>
+__global__ __launch_bounds__(64) void k_polylines_general(PolyParams P, int ncmax, int per_seg)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int NP = SHARP ? 2 : 1;
+    const int lane = threadIdx.x, grp = lane >> 3, u = lane & 7;
+    const PlGenLds G = pl_gen_layout(ncmax, NP);
+    unsigned char *gbase = smem + grp * G.stride;
+    double *g_pt = reinterpret_cast<double *>(gbase);
+    double *g_nd = reinterpret_cast<double *>(gbase) + G.ptn + 1;            // g_nd[-1] exists
+    uint32_t *g_rgbx = reinterpret_cast<uint32_t *>(gbase + (G.ptn + G.ndn) * 8) + 1;   // g_rgbx[-1] exists
+    const int w = P.w;
+    // workgroup (seg, part): entries part*8, part*8 + 8*per_seg, ... of queue segment seg
+    const int seg = blockIdx.x / per_seg, part = blockIdx.x - seg * per_seg;
+    const int count = P.gq_count[seg];
+    const unsigned long long *q = P.gq + (size_t)seg * P.gq_cap;
+    for (int base = part * 8; base < count; base += 8 * per_seg) {
+        const int idx = base + grp;
+        const bool have = idx < count;
+        const unsigned long long ent = have ? q[idx] : 0ull;
+        const int rowid = (int)(ent >> 32), col = (int)(ent & 0xffffffffull);
+        const int row = rowid % P.h, ie = rowid / P.h;
+        const int e = ie % P.n_eyes, img = ie / P.n_eyes;
+        const double div_px = P.div_px[e], sep_px = P.sep_px[e];
+        const double mn = P.minmax[img * 2], mx = P.minmax[img * 2 + 1];
+        const uint8_t *src_row = P.img + ((size_t)img * P.h + row) * (size_t)w * C;
+        const size_t esz = P.depth_dtype == DS_DEPTH_U16 ? 2 : (P.depth_dtype == DS_DEPTH_F32 ? 4 : 8);
+        const void *depth_row = (const char *)P.depth + ((size_t)img * P.h + row) * (size_t)w * esz;
+        const double *lut = (P.lut != nullptr && P.depth_dtype == DS_DEPTH_U16) ? P.lut + (size_t)img * 65536 : nullptr;
+        // the pixel's source window: columns j0 .. j1 (what phase P3 of round 1 selected out of the supertile's staging)
+        const int j0 = max(0, col + P.offL[e] - 1);
+        const int j1 = max(j0, min(w - 1, col + P.offU[e]));
+        const int ncols = have ? j1 - j0 + 1 : 1;
+        const bool head = j0 == 0, tail = j1 == w - 1;
+        __syncthreads();                                    // the previous pixel's window is no longer read
+        if (have) {
+            for (int i = u - 1; i < ncols; i += 8) {        // i = -1: the column before the window (point 0, colour -1)
+                const int j = j0 + i;
+                double nd = 0.0;
+                uint32_t px = 0;
+                if (j >= 0) {
+                    nd = pl_nd_one(P, depth_row, j, mn, mx, lut);
+#pragma unroll
+                    for (int k = 0; k < C; k++) px |= (uint32_t)src_row[(size_t)j * C + k] << (8 * k);
+                }
+                g_nd[i] = nd;
+                g_rgbx[i] = px;
+                const double coord_d = nd * div_px;                                             // :182
+                const double coord_x = ((double)j + 0.5) + coord_d + sep_px;                    // :183
+                if (i < 0) {
+                    g_pt[0] = head ? -1.0 * (double)w : (SHARP ? coord_x + 0.45 : coord_x);   // :179 / the previous point
+                } else if (SHARP) {
+                    g_pt[2 * i + 1] = coord_x - 0.45;                                           // :188
+                    g_pt[2 * i + 2] = coord_x + 0.45;                                           // :189
+                } else {
+                    g_pt[i + 1] = coord_x;                                                      // :185
+                }
+            }
+            if (u == 0) {
+                const int qT = NP * ncols + 1;
+                for (int k = 0; k < PL_PT_PAD - 1; k++) g_pt[qT + k] = 2.0 * (double)w;         // :191 (or harmless padding)
+            }
+        }
+        __syncthreads();
+        PlWin V;
+        V.pt = g_pt; V.nd = g_nd; V.rgbx = g_rgbx; V.ncols = ncols; V.head = head; V.tail = tail; V.div_px = div_px;
+        const int qlo = 1;
+        const int qhi = !have ? 0 : (tail ? NP * ncols + 1 : NP * ncols);
+        const double fq = (double)col, fq1 = (double)(col + 1);
+        unsigned long long fm[PL_KMAX], bm[PL_KMAX];
+#pragma unroll
+        for (int k = 0; k < PL_KMAX; k++) { fm[k] = 0ull; bm[k] = 0ull; }
+#pragma unroll
+        for (int k = 0; k < PL_KMAX; k++) {
+            if (k < P.K) {
+                for (int st = 0; st < 8 && 64 * k + 8 * st < P.nseg; st++) {
+                    const int qq = qlo + 64 * k + 8 * st + u;
+                    const bool valid = qq <= qhi;
+                    const double x0 = V.pt[valid ? qq - 1 : 0], x1 = V.pt[valid ? qq : 0];
+                    const unsigned long long mf = __ballot(valid && x0 < x1 && x0 < fq1 && !(x1 < fq));
+                    const unsigned long long mb = __ballot(valid && !(x1 < fq) && x1 < fq1);
+                    fm[k] |= ((mf >> (8 * grp)) & 0xffull) << (8 * st);
+                    bm[k] |= ((mb >> (8 * grp)) & 0xffull) << (8 * st);
+                }
+            }
+        }
+        int nb = 0;
+#pragma unroll
+        for (int k = 0; k < PL_KMAX; k++) nb += __popcll(bm[k]);
+        const bool ovf = nb > 7;                             // more than 8 sub-intervals: one lane walks them all
+        const bool par = have && !ovf;
+        // lane u's point, its rank among the group's points, the sorted sequence
+        const double BIG = 1.0e300;
+        double bx = BIG;
+        {
+            int n = u, qb = -1;
+#pragma unroll
+            for (int k = 0; k < PL_KMAX; k++) {
+                const int c = __popcll(bm[k]);
+                if (qb < 0 && n < c) {
+                    unsigned long long mm = bm[k];
+#pragma unroll
+                    for (int i = 0; i < 7; i++) if (i < n) mm &= mm - 1ull;
+                    qb = 64 * k + __ffsll((long long)mm) - 1;
+                }
+                n -= c;
+            }
+            if (par && qb >= 0) bx = V.pt[qlo + qb];
+        }
+        int rank = 0;
+#pragma unroll
+        for (int i = 1; i < 8; i++) {
+            const int ou = (u + i) & 7;
+            const double ox = __shfl(bx, (lane & ~7) | ou, 64);
+            rank += (ox < bx || (ox == bx && ou < u)) ? 1 : 0;
+        }
+        double sx;
+        {
+            const int tgt = ((lane & ~7) | rank) << 2;
+            const int lo = __builtin_amdgcn_ds_permute(tgt, __double2loint(bx));
+            const int hi = __builtin_amdgcn_ds_permute(tgt, __double2hiint(bx));
+            sx = __hiloint2double(hi, lo);
+        }
+        const double sprev = __shfl(sx, (lane & ~7) | ((u + 7) & 7), 64);
+        const double a = u == 0 ? fq : sprev;
+        const double b = u < nb ? sx : fq1;
+        double term[C];
+#pragma unroll
+        for (int k = 0; k < C; k++) term[k] = 0.0;
+        int flag = 0;
+        if (par && u <= nb) {
+            // sub-interval u of the pixel: active set, winner, colour term (:235-279)
+            const PlSub sb = pl_sub(a, b);
+            if (!(sb.significance > 0.0)) flag = 1;          // centres may stop being monotone: history dependent
+            int count_a = 0, first = -1, win = -1;
+            double best = -PL_EPS;                                                       // :261
+            bool hv = false;
+#pragma nounroll
+            for (;;) {
+                int qq = -1;                                 // next forward candidate: lowest set bit of the multi-word mask
+#pragma unroll
+                for (int k = 0; k < PL_KMAX; k++) {
+                    if (qq < 0 && fm[k] != 0ull) {
+                        qq = qlo + 64 * k + __ffsll((long long)fm[k]) - 1;
+                        fm[k] &= fm[k] - 1ull;
+                    }
+                }
+                if (qq < 0) break;
+                const double x0 = V.pt[qq - 1], x1 = V.pt[qq];
+                if (x0 < sb.coord_center && !(x1 < sb.coord_center)) {                  // :242-253
+                    if (count_a == 0) first = qq;
+                    count_a++;
+                    const double d0 = pl_dd_of<NP>(V, qq - 1), d1 = pl_dd_of<NP>(V, qq);
+                    const double ip_k = (sb.coord_center - x0) / (x1 - x0);             // :263
+                    const double closeness = (1.0 - ip_k) * d0 + ip_k * d1;             // :265
+                    const bool valid = 0.0 < ip_k && ip_k < 1.0;
+                    if (valid && hv && closeness == best) flag = 1;                     // exact tie: csg order decides
+                    if (best < closeness && valid) { best = closeness; win = qq; hv = true; }   // :266
+                }
+            }
+            if (count_a == 1) win = first;                                               // :259
+            if (count_a == 0 || (count_a > 1 && !hv)) flag = 1;  // reference reads a stale / falls back to csg[0]
+            else pl_add_segment<C, NP>(V, win, V.pt[win - 1], V.pt[win], sb, term);
+        }
+        double color[C];
+#pragma unroll
+        for (int k = 0; k < C; k++) color[k] = 0.5;                                      // :229
+        for (int t = 0; __any(par && t <= nb); t++) {
+#pragma unroll
+            for (int k = 0; k < C; k++) color[k] += __shfl(term[k], (lane & ~7) | (t & 7), 64);   // lanes past nb hold 0.0
+        }
+        if (have && ovf && u == 0) pl_general_pixel_lds<C, NP>(V, qlo, P.K, fm, bm, fq, fq1, color, flag);
+        if (have && u == 0) {
+            uint8_t *o = P.out[e] + (int64_t)img * P.ois[e] + (int64_t)row * P.ors[e] + (size_t)col * C;
+#pragma unroll
+            for (int k = 0; k < C; k++) o[k] = ds_f64_to_u8(color[k]);
+        }
+        if (have && flag) pl_flag_row(P, img, e, row);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1043,7 +1138,7 @@ __global__ __launch_bounds__(64) void k_polylines_exact(PolyParams P, ExactScrat
 
 
 template <int C, int SHARP, int NE>
-static int pl_launch_main(const PolyParams &P, int ncu, long long nwork, size_t lds, hipStream_t st)
+static int pl_main_blocks(int ncu, long long nwork, size_t lds, long long *nblocks_out)
 {
     auto kfn = k_polylines<C, SHARP, NE>;
     DS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -1053,28 +1148,47 @@ static int pl_launch_main(const PolyParams &P, int ncu, long long nwork, size_t 
     long long nblocks = (long long)per_cu * ncu;
     { const char *e = getenv("DS_PL_BLOCKS"); if (e && atoi(e) > 0) nblocks = atoi(e); }
     if (nblocks > nwork) nblocks = nwork;
-    if (getenv("DS_PL_VERBOSE")) fprintf(stderr, "k_polylines<%d,%d>: S=%d nwmax=%d K=%d lds=%zu per_cu=%d ncu=%d grid=%lld nwork=%lld\n", C, SHARP, P.S, P.nwmax, P.K, lds, per_cu, ncu, nblocks, nwork);
-    hipLaunchKernelGGL(kfn, dim3((unsigned)nblocks), dim3(PL_THREADS), lds, st, P);
+    *nblocks_out = nblocks;
     return DS_OK;
 }
 
-template <int SHARP>
-static int pl_launch_c(const PolyParams &P, int c, int ncu, long long nwork, size_t lds, hipStream_t st)
+template <int C, int SHARP, int NE>
+static int pl_launch_main(const PolyParams &P, long long nblocks, size_t lds, hipStream_t st)
 {
+    if (getenv("DS_PL_VERBOSE")) fprintf(stderr, "k_polylines<%d,%d>: S=%d nwmax=%d K=%d lds=%zu grid=%lld queue segment %d entries\n", C, SHARP, P.S, P.nwmax, P.K, lds, nblocks, P.gq_cap);
+    hipLaunchKernelGGL((k_polylines<C, SHARP, NE>), dim3((unsigned)nblocks), dim3(PL_THREADS), lds, st, P);
+    return DS_OK;
+}
+
+// dispatch on (channels, eyes): op 0 sizes the grid of the main kernel, 1 launches it, 2 launches the general-pixel pass
+template <int SHARP>
+static int pl_dispatch(int op, const PolyParams &P, int c, int ncu, long long nwork, size_t lds, long long *nblocks, int ncmax,
+                       int per_seg, size_t glds, hipStream_t st)
+{
+#define PL_CASE(C_, NE_)                                                                                                \
+    do {                                                                                                                \
+        if (op == 0) return pl_main_blocks<C_, SHARP, NE_>(ncu, nwork, lds, nblocks);                                   \
+        if (op == 1) return pl_launch_main<C_, SHARP, NE_>(P, *nblocks, lds, st);                                       \
+        DS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_polylines_general<C_, SHARP>),                \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)glds));                       \
+        hipLaunchKernelGGL((k_polylines_general<C_, SHARP>), dim3((unsigned)(P.gq_segments * per_seg)), dim3(64), glds, st, P, ncmax, per_seg); \
+        return DS_OK;                                                                                                   \
+    } while (0)
     if (P.n_eyes == 2) {
         switch (c) {
-        case 1: return pl_launch_main<1, SHARP, 2>(P, ncu, nwork, lds, st);
-        case 2: return pl_launch_main<2, SHARP, 2>(P, ncu, nwork, lds, st);
-        case 3: return pl_launch_main<3, SHARP, 2>(P, ncu, nwork, lds, st);
-        default: return pl_launch_main<4, SHARP, 2>(P, ncu, nwork, lds, st);
+        case 1: PL_CASE(1, 2);
+        case 2: PL_CASE(2, 2);
+        case 3: PL_CASE(3, 2);
+        default: PL_CASE(4, 2);
         }
     }
     switch (c) {
-    case 1: return pl_launch_main<1, SHARP, 1>(P, ncu, nwork, lds, st);
-    case 2: return pl_launch_main<2, SHARP, 1>(P, ncu, nwork, lds, st);
-    case 3: return pl_launch_main<3, SHARP, 1>(P, ncu, nwork, lds, st);
-    default: return pl_launch_main<4, SHARP, 1>(P, ncu, nwork, lds, st);
+    case 1: PL_CASE(1, 1);
+    case 2: PL_CASE(2, 1);
+    case 3: PL_CASE(3, 1);
+    default: PL_CASE(4, 1);
     }
+#undef PL_CASE
 }
 
 template <int DT>
@@ -1181,10 +1295,44 @@ int ds_polylines_launch(ds_ctx *ctx, const uint8_t *image, const void *depth, in
     const long long nwork = (long long)n * h * tiles;
     DS_REQUIRE(nwork < (1ll << 31) - (1 << 20), DS_EUNSUPPORTED, "ds_stereo_warp: too many row tiles in one call");
 
-    if (ctx->profile) (void)hipEventRecord(ctx->ev[0], st);
-    rc = sharp ? pl_launch_c<1>(P, c, s_ncu[ctx->device], nwork, (size_t)L.total, st)
-               : pl_launch_c<0>(P, c, s_ncu[ctx->device], nwork, (size_t)L.total, st);
+    // grid of the main kernel first: the queue of general pixels has one segment per workgroup
+    long long nblocks = 0;
+    rc = sharp ? pl_dispatch<1>(0, P, c, s_ncu[ctx->device], nwork, (size_t)L.total, &nblocks, 0, 0, 0, st)
+               : pl_dispatch<0>(0, P, c, s_ncu[ctx->device], nwork, (size_t)L.total, &nblocks, 0, 0, 0, st);
     if (rc) return rc;
+    // capacity: half of the pixel-eyes of the call, at least 64 K and at most 32 M entries in total (a full segment sends
+    // the row to the exact sweep: only speed is at stake)
+    {
+        long long total = (long long)n * n_eyes * h * (long long)w / 2;
+        if (total < 65536) total = 65536;
+        if (total > (32ll << 20)) total = 32ll << 20;
+        { const char *e = getenv("DS_PL_QUEUE"); if (e && atoll(e) > 0) total = atoll(e); }
+        long long per = (total + nblocks - 1) / nblocks;
+        per = (per + 7) & ~7ll;
+        P.gq_cap = (int)per; P.gq_segments = (int)nblocks;
+        rc = ds_ctx_reserve(ctx, &ctx->tmp_b, &ctx->tmp_b_bytes, (size_t)nblocks * (size_t)per * 8 + (size_t)nblocks * sizeof(int) + 64);
+        if (rc) return rc;
+        P.gq = (unsigned long long *)ctx->tmp_b;
+        P.gq_count = (int *)(P.gq + (size_t)nblocks * (size_t)per);
+    }
+    // the per-pixel source window of the second pass
+    const int ncmax = (uU - uL) + 4;
+    const PlGenLds G = pl_gen_layout(ncmax, np);
+    const size_t glds = (size_t)G.stride * 8;
+    if (glds > 160 * 1024) P.K = PL_KMAX + 1;             // window too large for the second pass too: rows go to the exact sweep
+    const bool wide = P.K > PL_KMAX;                       // the main kernel then queues nothing
+    int per_seg = 4;
+    { const char *e = getenv("DS_PL_PER_SEG"); if (e && atoi(e) > 0) per_seg = atoi(e); }
+
+    if (ctx->profile) (void)hipEventRecord(ctx->ev[0], st);
+    rc = sharp ? pl_dispatch<1>(1, P, c, 0, 0, (size_t)L.total, &nblocks, 0, 0, 0, st)
+               : pl_dispatch<0>(1, P, c, 0, 0, (size_t)L.total, &nblocks, 0, 0, 0, st);
+    if (rc) return rc;
+    if (!wide) {
+        rc = sharp ? pl_dispatch<1>(2, P, c, 0, 0, 0, &nblocks, ncmax, per_seg, glds, st)
+                   : pl_dispatch<0>(2, P, c, 0, 0, 0, &nblocks, ncmax, per_seg, glds, st);
+        if (rc) return rc;
+    }
     if (ctx->profile) { (void)hipEventRecord(ctx->ev[1], st); (void)hipEventRecord(ctx->ev[2], st); }
     switch (depth_dtype) {
     case DS_DEPTH_U16: pl_launch_exact<DS_DEPTH_U16>(P, sharp, X, nworkers / 64, st); break;
