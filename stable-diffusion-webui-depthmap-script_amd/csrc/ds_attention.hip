@@ -416,7 +416,7 @@ __global__ __launch_bounds__(AT_THREADS, 2) void k_attention_fwd2(AttnParams P)
     } while (0)
     // Bias: [head][32-query block][64-key tile][chunk c = 2 kb + s][64 lanes][8]: lane (hi, l31) of chunk c holds
     // bias[query 16 s + 8 hi + t][key 32 kb + l31] / scale, t = 0..7 -- the A fragment of the MFMA that adds it.
-    u32x4 breg[HAS_BIAS ? 2 : 1][HAS_BIAS ? 4 : 1];
+    u32x4 breg[2][4];                                           // (unused, and eliminated, without a bias)
     const int n_kt = Np / AT_KB;
     const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc(
         (void *)(HAS_BIAS ? (const T *)P.bias + (size_t)h * Np * (size_t)Np : (const T *)P.qk), 0,
