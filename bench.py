@@ -196,7 +196,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--config", default="c3", choices=["c2", "c3", "c3match", "c5"], help="BASELINE.json config preset (see the header)")
+    ap.add_argument("--config", default="c3", choices=["c2", "c3", "c3match", "c4", "c5"], help="BASELINE.json config preset (see the header)")
     ap.add_argument("--batch", type=int, default=None, help="units per GPU per step")
     ap.add_argument("--model", default=None, choices=["dav2_vitl", "dpt_beit_large_512", "dpt_hybrid_384", "none"])
     ap.add_argument("--height", type=int, default=None)
@@ -215,7 +215,10 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=4, help="distinct units of the CPU baseline sample")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="minimum wall time of the CPU baseline leg")
     ap.add_argument("--cpu-python-unit", type=int, default=512, help="side of the one unit timed through the pure-Python port (0 = skip)")
+    ap.add_argument("--boost-rmax", type=int, default=1600, help="c4: Boost's whole-image size limit (standalone default 1600, paper 3000)")
     args = ap.parse_args()
+    if args.config == "c4":
+        return run_c4(args)
     preset = {"c2": ("dpt_hybrid_384", 1, 512, 512, None), "c3": ("dpt_beit_large_512", 32, 1024, 1024, None),
               "c3match": ("dpt_beit_large_512", 8, 1024, 1024, 0), "c5": ("dav2_vitl", 8, 1080, 1920, None)}[args.config]
     model_name = args.model or preset[0]
@@ -432,6 +435,85 @@ def main():
                                                normalmap=normalmap, python_unit=args.cpu_python_unit,
                                                init_seed=minfo["init_seed"] if minfo else 0)
         print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def run_c4(args):
+    """BASELINE config 4: Boost (LeReS res101 + the pix2pix merge network, random init) on ONE 3840x2160 image, the patches
+    sharded over the ranks (src/boost.estimateboost: rank 0 runs the whole-image passes and the selection, every rank a
+    contiguous run of patch chunks, ONE gather, the blend on rank 0), then depth -> uint16 -> stereo pair + normal map on
+    rank 0.  One step = one image; strong scaling (the image is the fixed total work)."""
+    global H, W
+    import torch
+    import torch.distributed as dist
+    H, W = args.height or 2160, args.width or 3840
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU path exists)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+    import src._native as nat
+    import src.normalmap_generation as nmg
+    import src.stereoimage_generation as sg
+    from src import boost
+    from lib.multi_depth_model_woauxi import RelDepthModel
+    from pix2pix.models.pix2pix4depth_model import Pix2Pix4DepthModel
+    torch.manual_seed(0)
+    net = RelDepthModel('resnext101').eval().to(dev)                 # float32: Boost never runs LeReS in half (reference :271)
+    p2p = Pix2Pix4DepthModel().eval().to(dev)
+    rng = np.random.default_rng(1000)
+    yy, xx = np.mgrid[0:H, 0:W]
+    img_np = (127 + 60 * np.sin(xx / 37.0)[..., None] * np.cos(yy / 23.0)[..., None] + 40 * (((xx // 240 + yy // 180) % 2)[..., None] - 0.5)
+              + rng.normal(0, 25, (H, W, 3))).clip(0, 255).astype(np.uint8)
+    img = torch.from_numpy(img_np).to(dev)
+    grp = dist.group.WORLD if world > 1 else None
+    stats = {}
+
+    def step():
+        pred = boost.estimateboost(img, net, 0, p2p, whole_size_threshold=args.boost_rmax, stats=stats, group=grp)
+        if pred is None:
+            return None
+        d16 = nat.depth_to_u16(pred.unsqueeze(0), True)                # LeReS is a near-is-dark model (inverted)
+        sbs = sg.create_stereoimages_batch(img.unsqueeze(0), d16, 2.5, 0.0, ['left-right'], 0.0, 1.0, args.fill)[0]
+        nm = nmg.create_normalmap_batch(d16) if not args.no_normalmap else None
+        return sbs, nm
+
+    step()
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+        torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+        torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+    if rank == 0:
+        print(json.dumps({
+            "metric": f"Boost depth+stereo images/sec @{W}x{H}", "value": args.steps / elapsed, "unit": "images/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32 (networks) / f64 (stereo, normal map)",
+            "data": "synthetic",
+            "config": {"workload": f"BASELINE config c4: Boost multi-resolution merge (LeReS res101 + pix2pix, random init, float32) on one "
+                                   f"{W}x{H} image, r_max {args.boost_rmax}: {stats.get('patches')} patches at 896^2 + 448^2, whole image at "
+                                   f"{stats.get('whole_image_optimal_size')}, then depth->u16 + create_stereoimages({args.fill}) + normal map",
+                       "parallelism": f"patches sharded over {world} GPU(s) in whole chunks of 8, one RCCL gather of the merged patches, "
+                                      "blend on rank 0", "boost": stats}}))
     if world > 1:
         dist.destroy_process_group()
 

@@ -46,12 +46,19 @@ template <> struct at_traits<0> {
     static __device__ __forceinline__ f32x16 mfma(V8 a, V8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
     static __device__ __forceinline__ T from_f32(float x) { return (_Float16)x; }
     static __device__ __forceinline__ float to_f32(T x) { return (float)x; }
+    // acc + a[i] + a[i+1]: v_dot2_f32_f16 against (1, 1)
+    static __device__ __forceinline__ float add2(V8 a, int i, float acc) {
+        typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+        const h2 v = { a[i], a[i + 1] }, one = { (_Float16)1.0f, (_Float16)1.0f };
+        return __builtin_amdgcn_fdot2(v, one, acc, false);
+    }
 };
 template <> struct at_traits<1> {
     typedef __bf16 T; typedef bf16x8 V8;
     static __device__ __forceinline__ f32x16 mfma(V8 a, V8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
     static __device__ __forceinline__ T from_f32(float x) { return (__bf16)x; }
     static __device__ __forceinline__ float to_f32(T x) { return (float)x; }
+    static __device__ __forceinline__ float add2(V8 a, int i, float acc) { return acc + ((float)a[i] + (float)a[i + 1]); }
 };
 
 // row of the 32x32 accumulator held in register r of a lane with hi = lane >> 5 (cdna_hip_programming.md, 3. MFMA)
@@ -330,6 +337,10 @@ __device__ __forceinline__ float at_max3(float a, float b, float c)
 // ABL != 0: the same kernel with parts compiled out (timing experiments only, DS_ATT_ABLATE; results are WRONG), a bit mask:
 //   1 softmax reduced to a conversion   2 no K / V^T / bias fetch, no stash after the first tile   4 no barrier in the loop
 //   8 no P.V MFMAs   16 no S MFMAs   32 fragments are not read from LDS (a register stands in)
+// Bits 256 and up are OPTIONS with correct results (DS_ATT_OPT, A/B experiments):
+//   256 s_setprio around the MFMA clusters   512 the bias MFMAs interleaved over the four accumulators (no back-to-back
+//   dependent pair)   1024 row sums from the ROUNDED probabilities, two per v_dot2 (f16)   2048 every other workgroup starts
+//   half a tile late (two waves of one SIMD otherwise run the same phase at the same time)
 template <int BF16, int HAS_BIAS, int SPLIT, int ABL>
 __global__ __launch_bounds__(AT_THREADS, 2) void k_attention_fwd2(AttnParams P)
 {
@@ -498,9 +509,10 @@ __global__ __launch_bounds__(AT_THREADS, 2) void k_attention_fwd2(AttnParams P)
                 _Pragma("unroll") for (int t_ = 0; t_ < 8; t_ += 2) {                                                   \
                     const float p0_ = __builtin_amdgcn_exp2f(__builtin_fmaf(s_acc[qb_][kb_][8 * j_ + t_], c_, mc_));    \
                     const float p1_ = __builtin_amdgcn_exp2f(__builtin_fmaf(s_acc[qb_][kb_][8 * j_ + t_ + 1], c_, mc_)); \
-                    l0_ += p0_; l1_ += p1_;                                                                             \
                     pf[qb_][kb_][j_][t_] = TR::from_f32(p0_);                                                           \
                     pf[qb_][kb_][j_][t_ + 1] = TR::from_f32(p1_);                                                       \
+                    if (ABL & 1024) { if (t_ & 2) l1_ = TR::add2(pf[qb_][kb_][j_], t_, l1_); else l0_ = TR::add2(pf[qb_][kb_][j_], t_, l0_); } \
+                    else { l0_ += p0_; l1_ += p1_; }                                                                    \
                 }                                                                                                       \
                 l_run[qb_] = l_run[qb_] * alpha[qb_] + (l0_ + l1_);                                                     \
             } while (0)
@@ -516,27 +528,46 @@ __global__ __launch_bounds__(AT_THREADS, 2) void k_attention_fwd2(AttnParams P)
                 for (int qb = 0; qb < 2; qb++)
 #pragma unroll
                     for (int kb = 0; kb < 2; kb++) {
-                        if (ABL && (abl & 16)) {
+                        if (abl & 16) {
 #pragma unroll
                             for (int r = 0; r < 16; r++) s_acc[qb][kb][r] = (float)(r + kt);
+                        } else if (HAS_BIAS && (abl & 512)) {
+                            f32x16 z_;
+#pragma unroll
+                            for (int r = 0; r < 16; r++) z_[r] = 0.f;
+                            union { u32x4 u; V8 v; } b0_;
+                            b0_.u = breg[qb][2 * kb];
+                            s_acc[qb][kb] = TR::mfma(b0_.v, ident[0], z_);
                         } else A2_S_BIAS(qb, kb);
                     }
+                if (HAS_BIAS && (abl & 512) && !(abl & 16)) {
+#pragma unroll
+                    for (int qb = 0; qb < 2; qb++)
+#pragma unroll
+                        for (int kb = 0; kb < 2; kb++) {
+                            union { u32x4 u; V8 v; } b1_;
+                            b1_.u = breg[qb][2 * kb + 1];
+                            s_acc[qb][kb] = TR::mfma(b1_.v, ident[1], s_acc[qb][kb]);
+                        }
+                }
+                if (abl & 256) __builtin_amdgcn_s_setprio(1);
                 if (!(ABL && (abl & 16))) {
 #pragma unroll
                     for (int kb = 0; kb < 2; kb++) {
                         const unsigned char *krow = s_k + (kb * 32 + l31) * AT2_ROW + (hi << 4);
 #pragma unroll
                         for (int s = 0; s < 4; s++) {
-                            const V8 kf = (ABL && (abl & 32)) ? qf[1][s] : *reinterpret_cast<const V8 *>(krow + (s << 5));
+                            const V8 kf = (abl & 32) ? qf[1][s] : *reinterpret_cast<const V8 *>(krow + (s << 5));
                             s_acc[0][kb] = TR::mfma(kf, qf[0][s], s_acc[0][kb]);
                             s_acc[1][kb] = TR::mfma(kf, qf[1][s], s_acc[1][kb]);
                         }
                     }
                 }
+                if (abl & 256) __builtin_amdgcn_s_setprio(0);
                 // the bias registers are free: next tile's fragments land under the softmax / P.V of this one
                 if (HAS_BIAS && more && !(abl & 2)) A2_FETCH_BIAS(kt + 1);
                 A2_MASK(0); A2_MASK(1);
-                if (ABL && (abl & 1)) {
+                if (abl & 1) {
 #pragma unroll
                     for (int qb = 0; qb < 2; qb++) {
 #pragma unroll
@@ -551,7 +582,8 @@ __global__ __launch_bounds__(AT_THREADS, 2) void k_attention_fwd2(AttnParams P)
                     A2_SOFTMAX(0); A2_RESCALE(0);
                     A2_SOFTMAX(1); A2_RESCALE(1);
                 }
-                if (!(ABL && (abl & 8))) {
+                if (!(abl & 8)) {
+                    if (abl & 256) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
                     for (int d = 0; d < 2; d++) {
                         const unsigned char *vrow = s_v + (d * 32 + l31) * AT2_ROW + (hi << 4);
@@ -559,11 +591,12 @@ __global__ __launch_bounds__(AT_THREADS, 2) void k_attention_fwd2(AttnParams P)
                         for (int kb = 0; kb < 2; kb++)
 #pragma unroll
                             for (int j = 0; j < 2; j++) {
-                                const V8 vf = (ABL && (abl & 32)) ? qf[0][kb * 2 + j] : *reinterpret_cast<const V8 *>(vrow + ((kb * 4 + j * 2) << 4));
+                                const V8 vf = (abl & 32) ? qf[0][kb * 2 + j] : *reinterpret_cast<const V8 *>(vrow + ((kb * 4 + j * 2) << 4));
                                 o_acc[0][d] = TR::mfma(vf, pf[0][kb][j], o_acc[0][d]);
                                 o_acc[1][d] = TR::mfma(vf, pf[1][kb][j], o_acc[1][d]);
                             }
                     }
+                    if (abl & 256) __builtin_amdgcn_s_setprio(0);
                 } else {
 #pragma unroll
                     for (int qb = 0; qb < 2; qb++)
@@ -632,6 +665,7 @@ __global__ __launch_bounds__(AT_THREADS, 2) void k_attention_fwd2(AttnParams P)
         if (!(abl & 4)) __syncthreads();
     };
     const bool pad_keys = (P.n_valid & (AT_KB - 1)) != 0;
+    if ((ABL & 2048) && ((blockIdx.x >> 3) & 1)) __builtin_amdgcn_s_sleep(48);
     for (int kt = 0; kt + 1 < ntiles; kt++) tile(kt, std::false_type());
     if (pad_keys) tile(ntiles - 1, std::true_type());
     else tile(ntiles - 1, std::false_type());
@@ -746,14 +780,16 @@ DS_API int ds_attention_fwd(ds_ctx *ctx, const void *qk, const void *vt, const v
         dim3 grid2(8 * P.chunk);
         hipStream_t st2 = (hipStream_t)stream;
         static const int split = getenv("DS_ATT_SPLIT") ? atoi(getenv("DS_ATT_SPLIT")) : 0;      // A/B switch
-        static const int ablate = getenv("DS_ATT_ABLATE") ? atoi(getenv("DS_ATT_ABLATE")) : 0;   // timing experiments, wrong results
+        static const int ablate = (getenv("DS_ATT_ABLATE") ? atoi(getenv("DS_ATT_ABLATE")) : 0)    // timing experiments, wrong results
+                                  | (getenv("DS_ATT_OPT") ? atoi(getenv("DS_ATT_OPT")) : 0);        // options, correct results
         P.flags = ablate;
 #define A2_ABL(BI_, M_) case M_: hipLaunchKernelGGL((k_attention_fwd2<0, BI_, 0, M_>), grid2, dim3(AT_THREADS), 0, st2, P); break;
 #define A2_LAUNCH(BF_, BI_) do {                                                                                       \
             if (ablate && BF_ == 0) {                                                                                   \
                 switch (ablate) {                                                                                       \
                 A2_ABL(BI_, 1) A2_ABL(BI_, 2) A2_ABL(BI_, 4) A2_ABL(BI_, 6) A2_ABL(BI_, 7) A2_ABL(BI_, 8) A2_ABL(BI_, 16) A2_ABL(BI_, 32) \
-                A2_ABL(BI_, 38) A2_ABL(BI_, 39)                                                                         \
+                A2_ABL(BI_, 38) A2_ABL(BI_, 39) A2_ABL(BI_, 256) A2_ABL(BI_, 512) A2_ABL(BI_, 1024) A2_ABL(BI_, 2048) A2_ABL(BI_, 1536) \
+                A2_ABL(BI_, 1792) A2_ABL(BI_, 3584) A2_ABL(BI_, 3840)                                                    \
                 default: ds_set_error("ds_attention_fwd: DS_ATT_ABLATE=%d is not an instantiated mask", ablate); return DS_EINVAL; \
                 }                                                                                                       \
             }                                                                                                           \

@@ -1321,7 +1321,7 @@ int ds_polylines_launch(ds_ctx *ctx, const uint8_t *image, const void *depth, in
     const size_t glds = (size_t)G.stride * 8;
     if (glds > 160 * 1024) P.K = PL_KMAX + 1;             // window too large for the second pass too: rows go to the exact sweep
     const bool wide = P.K > PL_KMAX;                       // the main kernel then queues nothing
-    int per_seg = 4;
+    int per_seg = 8;                                        // measured: 1.97 / 1.53 / 1.49 / 1.46 ms per launch at 1 / 2 / 4 / 8
     { const char *e = getenv("DS_PL_PER_SEG"); if (e && atoi(e) > 0) per_seg = atoi(e); }
 
     if (ctx->profile) (void)hipEventRecord(ctx->ev[0], st);

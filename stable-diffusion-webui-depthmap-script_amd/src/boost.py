@@ -244,7 +244,9 @@ def _single_estimates(patches, msize, net, model_type, chunk):
 def doubleestimate(patches, size1, size2, net, model_type, pix2pix, chunk=8):
     """:1028-1049 for a list of patches: low-res + high-res estimate -> merge network -> min-max normalised
     float32 [P, 1024, 1024]."""
-    e1 = _single_estimates(patches, size1, net, model_type, chunk * 4)
+    # both estimates in batches of `chunk` CONSECUTIVE patches: the batch composition is then a function of the patch list
+    # alone, whatever the number of ranks the list is sharded over (estimateboost shards in whole chunks)
+    e1 = _single_estimates(patches, size1, net, model_type, chunk)
     e2 = _single_estimates(patches, size2, net, model_type, chunk)
     outs = []
     for s in range(0, len(patches), chunk):
@@ -271,40 +273,103 @@ def _polyfit1(x, y):
 
 
 # ---- the pipeline -----------------------------------------------------------------------------------------------------------------
+def _patch_merge(patches, base_patches, rf, patch_netsize, net, model_type, pix2pix, chunk):
+    """Per-patch half of estimateboost (:879-915) for a list of patches: double estimation, merge against the base patch,
+    degree-1 polyfit.  -> (merged [P, 1024, 1024] float32, coefficients [P, 2] float64).  Depends only on the patch and
+    on the base estimate, never on the running blend: this is what shards over GPUs."""
+    dev = patches[0].device
+    est = doubleestimate(patches, rf, patch_netsize, net, model_type, pix2pix, chunk)                          # :887-888
+    mapped_all, coefs = [], []
+    for s in range(0, len(patches), chunk):
+        b1024 = torch.stack([_resize(t, (PIX2PIX_SIZE, PIX2PIX_SIZE), 'bicubic') for t in base_patches[s:s + chunk]])
+        mapped = pix2pix.merge(b1024, est[s:s + chunk])                                                        # :896-909
+        p0, p1 = _polyfit1(mapped, b1024)                                                                      # :915
+        mapped_all.append(mapped)
+        coefs.append(torch.stack((p0, p1), dim=1))
+    return torch.cat(mapped_all).to(dev), torch.cat(coefs).to(dev)
+
+
+def _gather_ragged(local, counts, group, dst):
+    """One gather of per-rank blocks of different lengths (counts[r] rows on rank r), padded to the longest."""
+    import torch.distributed as dist
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    per = max(max(counts), 1)
+    send = local.new_zeros((per,) + tuple(local.shape[1:]))
+    send[:local.shape[0]] = local
+    if rank == dst:
+        bufs = [torch.empty_like(send) for _ in range(world)]
+        dist.gather(send, bufs, dst=dst, group=group)
+        return torch.cat([bufs[r][:counts[r]] for r in range(world)], dim=0)
+    dist.gather(send, None, dst=dst, group=group)
+    return None
+
+
 @torch.no_grad()
-def estimateboost(image_u8, net, model_type, pix2pix, whole_size_threshold=1600, chunk=8, stats=None):
+def estimateboost(image_u8, net, model_type, pix2pix, whole_size_threshold=1600, chunk=8, stats=None, group=None, dst=0,
+                  blend=None):
     """:774-941.  image_u8: uint8 [H, W, 3] on the device, channel order as the funnel hands it over (RGB).
-    Returns the boosted float32 [H, W] prediction (device)."""
-    _native.require_gpu()
+    Returns the boosted float32 [H, W] prediction (device).
+
+    group: a torch.distributed process group (one process per GPU) to shard the PATCHES over (BASELINE config 4,
+    SURVEY.md 8e).  Rank `dst` runs the whole-image passes and the patch selection and broadcasts the base estimate and
+    the patch rectangles; every rank then renders a contiguous run of whole chunks of the ordered patch list (double
+    estimation + merge network + polyfit: all that depends on the patch and the base only), ONE gather brings the merged
+    1024^2 patches and their coefficients to `dst`, and `dst` blends them in the original order (:1098, :936) with one
+    launch.  Chunk-aligned shards keep every network batch identical to the single-rank run, so the result does not
+    depend on the number of ranks.  Ranks other than `dst` return None.
+    blend: test hook replacing ds_boost_blend (CPU runs of the sharding logic); the product always uses the HIP kernel."""
+    import torch.distributed as dist
+    multi = group is not None and dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+    rank = dist.get_rank(group) if multi else 0
+    world = dist.get_world_size(group) if multi else 1
+    if blend is None:
+        _native.require_gpu()
+        blend = _native.boost_blend
     rf = {0: 448, 1: 512, 11: 518, 12: 518, 13: 518, 14: 518}.get(model_type, 384)          # :777-786
     patch_netsize = 2 * rf
     dev = image_u8.device
     img = image_u8.flip(-1).double() / 255.0                 # get_raw_prediction: cvtColor(BGR2RGB) / 255 (:381)
     H, W = img.shape[:2]
-    mask_org = generatemask(MASK_SIZE, dev)
 
-    whole_image_optimal_size, patch_scale = calculateprocessingres(img, rf, 0.2, 3, whole_size_threshold)
-    whole_estimate = doubleestimate([img], rf, whole_image_optimal_size, net, model_type, pix2pix, chunk)[0]
-
-    factor = max(min(1, 4 * patch_scale * whole_image_optimal_size / whole_size_threshold), 0.2)           # :819
-    if H > W:
-        a = 2 * whole_image_optimal_size
-        b = round(2 * whole_image_optimal_size * W / H)
-    else:
-        a = round(2 * whole_image_optimal_size * H / W)
-        b = 2 * whole_image_optimal_size
-    b, a = int(round(b / factor)), int(round(a / factor))
-    img_r = _resize_hwc(img, (a, b), 'bicubic')                                                               # :846
-    patchset = generatepatchs(img_r, rf * 2, factor)
+    head = torch.zeros(8, dtype=torch.int64, device=dev)
+    rect_t = None
+    if rank == dst:
+        whole_image_optimal_size, patch_scale = calculateprocessingres(img, rf, 0.2, 3, whole_size_threshold)
+        whole_estimate = doubleestimate([img], rf, whole_image_optimal_size, net, model_type, pix2pix, chunk)[0]
+        factor = max(min(1, 4 * patch_scale * whole_image_optimal_size / whole_size_threshold), 0.2)       # :819
+        if H > W:
+            a = 2 * whole_image_optimal_size
+            b = round(2 * whole_image_optimal_size * W / H)
+        else:
+            a = round(2 * whole_image_optimal_size * H / W)
+            b = 2 * whole_image_optimal_size
+        b, a = int(round(b / factor)), int(round(a / factor))
+        img_r = _resize_hwc(img, (a, b), 'bicubic')                                                           # :846
+        patchset = generatepatchs(img_r, rf * 2, factor)
+        rect_t = torch.tensor([list(info['rect']) for _, info in patchset], dtype=torch.int64, device=dev).reshape(-1, 4)
+        head[0], head[1], head[2] = a, b, rect_t.shape[0]
+    if multi:
+        dist.broadcast(head, src=dst, group=group)
+        a, b = int(head[0]), int(head[1])
+        if rank != dst:
+            rect_t = torch.zeros((int(head[2]), 4), dtype=torch.int64, device=dev)
+            img_r = _resize_hwc(img, (a, b), 'bicubic')
+        if rect_t.shape[0]:
+            dist.broadcast(rect_t, src=dst, group=group)
     mergein_scale = H / img_r.shape[0]                                                                         # :866
-    rgb_image = _resize_hwc(img_r, (round(img_r.shape[0] * mergein_scale), round(img_r.shape[1] * mergein_scale)), 'bicubic')
-    base = _resize(whole_estimate, (round(img_r.shape[0] * mergein_scale), round(img_r.shape[1] * mergein_scale)),
-                   'bicubic').float().contiguous()
-    dst = base.clone()
+    size_m = (round(img_r.shape[0] * mergein_scale), round(img_r.shape[1] * mergein_scale))
+    rgb_image = _resize_hwc(img_r, size_m, 'bicubic')
+    if rank == dst:
+        base = _resize(whole_estimate, size_m, 'bicubic').float().contiguous()
+    else:
+        base = torch.empty(size_m, dtype=torch.float32, device=dev)
+    if multi:
+        dist.broadcast(base, src=dst, group=group)           # every rank merges against the SAME base estimate
+    dst_img = base.clone() if rank == dst else None
 
     rects, patches, base_patches = [], [], []
-    for _, info in patchset:
-        r = np.round(np.array(info['rect']) * mergein_scale).astype('int')                                    # :595-597
+    for rect in rect_t.tolist():
+        r = np.round(np.array(rect) * mergein_scale).astype('int')                                            # :595-597
         w1, h1, w2, h2 = int(r[0]), int(r[1]), int(r[0] + r[2]), int(r[1] + r[3])
         prgb = rgb_image[max(h1, 0):h2, max(w1, 0):w2]
         pbase = base[max(h1, 0):h2, max(w1, 0):w2]
@@ -313,20 +378,32 @@ def estimateboost(image_u8, net, model_type, pix2pix, whole_size_threshold=1600,
         rects.append((max(w1, 0), max(h1, 0), pbase.shape[1], pbase.shape[0]))
         patches.append(prgb)
         base_patches.append(pbase)
-    if stats is not None:
+    if stats is not None and rank == dst:
         stats.update({"whole_image_optimal_size": whole_image_optimal_size, "patch_scale": patch_scale, "factor": factor,
-                      "target": (a, b), "patches": len(rects)})
+                      "target": (a, b), "patches": len(rects), "ranks": world})
     if rects:
-        est = doubleestimate(patches, rf, patch_netsize, net, model_type, pix2pix, chunk)                      # :887-888
-        mapped_all, p0s, p1s = [], [], []
-        for s in range(0, len(rects), chunk):
-            b1024 = torch.stack([_resize(t, (PIX2PIX_SIZE, PIX2PIX_SIZE), 'bicubic') for t in base_patches[s:s + chunk]])
-            mapped = pix2pix.merge(b1024, est[s:s + chunk])                                                    # :896-909
-            p0, p1 = _polyfit1(mapped, b1024)                                                                  # :915
-            mapped_all.append(mapped)
-            p0s.append(p0)
-            p1s.append(p1)
-        mapped_all = torch.cat(mapped_all)
-        coefs = list(zip(torch.cat(p0s).tolist(), torch.cat(p1s).tolist()))
-        _native.boost_blend(dst, rects, coefs, mapped_all, mask_org)                                           # :916-937
-    return _resize(dst, (H, W), 'bicubic')                                                                    # :940
+        # whole chunks of the ordered list, contiguous per rank
+        from .multigpu import shard_bounds
+        n_chunks = (len(rects) + chunk - 1) // chunk
+        bounds = [(min(s * chunk, len(rects)), min(e * chunk, len(rects))) for s, e in shard_bounds(n_chunks, world)]
+        s, e = bounds[rank]
+        if e > s:
+            mapped, coef = _patch_merge(patches[s:e], base_patches[s:e], rf, patch_netsize, net, model_type, pix2pix, chunk)
+        else:
+            mapped = torch.zeros((0, PIX2PIX_SIZE, PIX2PIX_SIZE), dtype=torch.float32, device=dev)
+            coef = torch.zeros((0, 2), dtype=torch.float64, device=dev)
+        if multi:
+            # ONE collective on the data path: a patch travels as its 1024^2 merged estimate followed by the two float64
+            # polyfit coefficients (four float32 words, bit patterns untouched)
+            counts = [b1 - b0 for b0, b1 in bounds]
+            payload = torch.cat((mapped.flatten(1), coef.contiguous().view(torch.float32).reshape(-1, 4)), dim=1)
+            payload = _gather_ragged(payload.contiguous(), counts, group, dst)
+            if rank == dst:
+                n_px = PIX2PIX_SIZE * PIX2PIX_SIZE
+                mapped = payload[:, :n_px].reshape(-1, PIX2PIX_SIZE, PIX2PIX_SIZE)
+                coef = payload[:, n_px:].contiguous().view(torch.float64).reshape(-1, 2)
+        if rank == dst:
+            blend(dst_img, rects, [tuple(c) for c in coef.tolist()], mapped, generatemask(MASK_SIZE, dev))     # :916-937
+    if rank != dst:
+        return None
+    return _resize(dst_img, (H, W), 'bicubic')                                                                # :940

@@ -220,6 +220,9 @@ def _launch_group(gen, idxs, inputimages, inputdepthmaps, inp, device):
         else:
             rgb_t = upload([np.asarray(im.convert("RGB"), dtype=np.uint8) for im in images], "rgb", torch.uint8)
         pred, invert = model_holder.get_raw_prediction_batch(images, rgb_t, net_width, net_height)
+        if pred is None:                 # Boost sharded over ranks (ModelHolder.boost_group): only the group's rank 0 renders
+            g["skip"] = True
+            return g
         pred = pred.to(device=device, dtype=torch.float32)
         mesh_source = pred
         if not inp[go.CLIPDEPTH] and not inp[go.DO_OUTPUT_DEPTH_PREDICTION]:
@@ -275,6 +278,8 @@ def _emit_group(g, outpath, inp, device):
     """Yield a finished group's results image by image in the reference's order (:208-306).  The pinned buffers are reused
     two groups later, so every result is copied out of them (PIL owns its pixels)."""
     torch = _native._torch()
+    if g.get("skip"):
+        return
     g["done"].synchronize()
     host = {k: v.numpy() for k, v in g["host"].items()}
     for j, count in enumerate(g["idxs"]):

@@ -220,7 +220,7 @@ class ModelHolder:
             from . import boost
             img = torch.from_numpy(np.array(input.convert("RGB"), dtype=np.uint8, order="C")).to(self.device)
             raw = boost.estimateboost(img, self.depth_model.net, self.depth_model_type, self.pix2pix_model,
-                                      int(getattr(self, "boost_rmax", 1600)))
+                                      int(getattr(self, "boost_rmax", 1600)), group=getattr(self, "boost_group", None))
         else:
             raw = self.depth_model(input, net_width, net_height, self.device)
         return raw, (self.depth_model_type in INVERTED_MODEL_IDS)
@@ -235,8 +235,13 @@ class ModelHolder:
         invert = self.depth_model_type in INVERTED_MODEL_IDS
         if self.pix2pix_model is not None:
             from . import boost
+            # boost_group (update_settings): a torch.distributed group to shard every image's PATCHES over (one process per
+            # GPU, all ranks call the funnel with the same images); only rank 0 of the group gets predictions back
+            grp = getattr(self, "boost_group", None)
             outs = [boost.estimateboost(rgb_u8[i], self.depth_model.net, self.depth_model_type, self.pix2pix_model,
-                                        int(getattr(self, "boost_rmax", 1600))) for i in range(rgb_u8.shape[0])]
+                                        int(getattr(self, "boost_rmax", 1600)), group=grp) for i in range(rgb_u8.shape[0])]
+            if any(o is None for o in outs):
+                return None, invert
             return torch.stack([torch.as_tensor(o) for o in outs]), invert
         if isinstance(self.depth_model, _NetPredictor):
             return self.depth_model.predict_batch(rgb_u8, net_width, net_height), invert

@@ -151,3 +151,86 @@ def test_percentiles_match_numpy_single_process():
             got = vm._global_percentiles(torch.from_numpy(a), qs, None)
             want = np.percentile(a, qs)
             assert np.array_equal(np.asarray(got), want), (n, kind, got, want)
+
+
+# ---- Boost: patches sharded over ranks (BASELINE config 4) ---------------------------------------------------------
+class _StubDepth(torch.nn.Module):
+    """Stand-in for the LeReS network of estimateboost's model_type 0 branch (net.depth_model(x) -> [B, 1, h, w]): the
+    sharding logic is under test, not the network."""
+
+    def __init__(self):
+        super().__init__()
+        g = torch.Generator().manual_seed(3)
+        self.w = torch.nn.Parameter(torch.randn((1, 3, 5, 5), generator=g) * 0.2)
+
+    def depth_model(self, x):
+        return torch.nn.functional.conv2d(x, self.w, padding=2).abs() + 0.1 * x.mean(1, keepdim=True)
+
+
+class _StubMerge:
+    def merge(self, a, b):
+        k = torch.tensor([[0.05, 0.1, 0.05], [0.1, 0.4, 0.1], [0.05, 0.1, 0.05]]).view(1, 1, 3, 3)
+        return torch.nn.functional.conv2d((0.4 * a + 0.6 * b)[:, None], k, padding=1)[:, 0].contiguous()
+
+
+def _boost_image():
+    rng = np.random.default_rng(5)
+    yy, xx = np.mgrid[0:360, 0:520]
+    img = 127 + 70 * np.sin(xx / 9.0)[..., None] * np.cos(yy / 7.0)[..., None] + rng.normal(0, 30, (360, 520, 3))
+    img[100:260, 150:400] += 60 * np.sign(np.sin(xx[100:260, 150:400] / 2.0))[..., None]
+    return torch.from_numpy(img.clip(0, 255).astype(np.uint8))
+
+
+def _oracle_blend(dst, rects, coefs, preds, mask):
+    from oracle import oracle as orc
+    out = orc.boost_blend(dst.numpy(), rects, coefs, preds.numpy(), mask.numpy())
+    dst.copy_(torch.from_numpy(np.asarray(out, dtype=np.float32)))
+
+
+def _boost_worker(rank, world, port, result_path):
+    for p in (conftest.ROOT, conftest.PKG):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(2)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from src import boost
+    boost.MASK_SIZE = 301                                        # a small Gaussian template keeps the CPU run short
+    stats = {}
+    out = boost.estimateboost(_boost_image(), _StubDepth(), 0, _StubMerge(), whole_size_threshold=1400, chunk=2, stats=stats,
+                              group=dist.group.WORLD, dst=0, blend=_oracle_blend)
+    if rank == 0:
+        assert out is not None and stats["ranks"] == world
+        np.save(result_path, out.numpy())
+        np.save(result_path + ".patches.npy", np.array([stats["patches"]]))
+    else:
+        assert out is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_boost_patch_sharding_is_rank_count_invariant(tmp_path):
+    """estimateboost with the patches sharded over 2 and 3 ranks (whole chunks of the size-ordered patch list, ONE gather
+    of merged patches + coefficients, blend on rank 0 in the original order, src/depthmap_generation.py:879-937,1098):
+    byte-identical to the single-process run.  CPU tensors, a stub depth / merge network, the oracle's blend through the
+    test hook (the product's blend is the HIP kernel, GPU-tested against the same oracle function)."""
+    for p in (conftest.ROOT, conftest.PKG):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    from src import boost
+    old = boost.MASK_SIZE
+    boost.MASK_SIZE = 301
+    try:
+        stats = {}
+        want = boost.estimateboost(_boost_image(), _StubDepth(), 0, _StubMerge(), whole_size_threshold=1400, chunk=2, stats=stats,
+                                   blend=_oracle_blend).numpy()
+    finally:
+        boost.MASK_SIZE = old
+    assert stats["patches"] >= 5, stats                           # at least three chunks of two: every rank gets work
+    for world in (2, 3):
+        path = str(tmp_path / f"boost{world}.npy")
+        mp.spawn(_boost_worker, args=(world, _free_port(), path), nprocs=world, join=True)
+        got = np.load(path)
+        assert int(np.load(path + ".patches.npy")[0]) == stats["patches"]
+        assert got.shape == want.shape and np.array_equal(got, want), (world, float(np.abs(got - want).max()))
