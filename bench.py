@@ -445,6 +445,8 @@ def run_c4(args):
     contiguous run of patch chunks, ONE gather, the blend on rank 0), then depth -> uint16 -> stereo pair + normal map on
     rank 0.  One step = one image; strong scaling (the image is the fixed total work)."""
     global H, W
+    # float32 ResNeXt / U-Net convolutions at a dozen shapes: MIOpen's exhaustive search costs minutes on a fresh box
+    os.environ.setdefault("MIOPEN_FIND_MODE", "FAST")
     import torch
     import torch.distributed as dist
     H, W = args.height or 2160, args.width or 3840

@@ -207,6 +207,28 @@ int ds_residual_layernorm(ds_ctx *ctx, const void *x, const void *branch, const 
                           void *stream);
 
 /*
+ * ds_reassemble_readout -- epilogue of the DPT reassemble read-out (ProjectReadout, dmidas/backbones/utils.py:28-39;
+ * forward_adapted_unflatten :83-124): the reference concatenates every token with the cls token, applies Linear(2C -> C)
+ * and GELU.  The host splits the linear map (W.[tok ; cls] + b = W_tok.tok + (W_cls.cls + b)) into the token GEMM and one
+ * vector per image; this entry point does the rest in one pass:
+ *     out[b, n-1, :] = gelu_erf(proj[b, n, :] + clsvec[b, :]),  n = 1 .. tokens-1
+ * proj [batch, tokens, channels] (the token GEMM's output, cls row included), clsvec [batch, channels],
+ * out [batch, tokens-1, channels] = the NHWC operand of the 1x1 convolution that follows.  f16/bf16, channels % 8 == 0.
+ */
+int ds_reassemble_readout(ds_ctx *ctx, const void *proj, const void *clsvec, void *out, int batch, int tokens, int channels,
+                          int dtype, void *stream);
+
+/*
+ * ds_bias_act_nhwc -- element-wise tail of a decoder convolution on a channels-last activation, one pass:
+ *     out = [relu]( x + bias[channel] [+ res1] [+ res2] )
+ * (ResidualConvUnit_custom, dmidas/blocks.py:352-377; ResidualConvUnit, ddepth_anything_v2/.../util/blocks.py:56-85; the
+ * skip add of the fusion blocks).  x, res1, res2, out: `elements` values, channel fastest; res1 / res2 may be NULL; out may
+ * alias x.  f16/bf16, channels % 8 == 0.
+ */
+int ds_bias_act_nhwc(ds_ctx *ctx, const void *x, const void *bias, const void *res1, const void *res2, void *out,
+                     int64_t elements, int channels, int relu, int dtype, void *stream);
+
+/*
  * ds_upsample_bilinear_nhwc -- torch.nn.functional.interpolate(x, size, mode="bilinear", align_corners) for channels_last
  * activations: the x2 upsamples of the DPT decoders (dmidas/blocks.py:429-431; ddepth_anything_v2/.../util/blocks.py:141-145;
  * the heads' Interpolate, dmidas/dpt_depth.py:151, dpt.py:146).  in [batch, in_h, in_w, channels], out [batch, out_h, out_w,

@@ -341,8 +341,9 @@ __device__ __forceinline__ float at_max3(float a, float b, float c)
 //   256 s_setprio around the MFMA clusters   512 the bias MFMAs interleaved over the four accumulators (no back-to-back
 //   dependent pair)   1024 row sums from the ROUNDED probabilities, two per v_dot2 (f16)   2048 every other workgroup starts
 //   half a tile late (two waves of one SIMD otherwise run the same phase at the same time)
-template <int BF16, int HAS_BIAS, int SPLIT, int ABL>
-__global__ __launch_bounds__(AT_THREADS, 2) void k_attention_fwd2(AttnParams P)
+// NQB = 32-row query blocks per wave: 2 (64 rows, <= 256 VGPRs, two waves per SIMD) or 1 (32 rows, four waves per SIMD).
+template <int BF16, int HAS_BIAS, int NQB, int ABL>
+__global__ __launch_bounds__(AT_THREADS, NQB == 2 ? 2 : 3) void k_attention_fwd2(AttnParams P)
 {
     typedef at_traits<BF16> TR;
     typedef typename TR::T T;
@@ -355,7 +356,7 @@ __global__ __launch_bounds__(AT_THREADS, 2) void k_attention_fwd2(AttnParams P)
         if (L >= P.total) return;
     }
     const int qblk = L % P.nq, b = (L / P.nq) % P.B, h = L / (P.nq * P.B);
-    const int q0 = qblk * AT2_QB + wave * AT2_QW;
+    const int q0 = qblk * (128 * NQB) + wave * (32 * NQB);
     const int Np = P.Np, H = P.H;
     const size_t tok_stride = (size_t)2 * H * AT_D;
     const T *qk = (const T *)P.qk + (size_t)b * Np * tok_stride;
@@ -368,7 +369,7 @@ __global__ __launch_bounds__(AT_THREADS, 2) void k_attention_fwd2(AttnParams P)
     const bool wave_live = q0 < P.n_valid;
     if (!wave_live && q0 < Np) {
         const int row = q0 + lane;
-        if (row < Np) {
+        if (row < Np && lane < 32 * NQB) {
             uint4 z = make_uint4(0, 0, 0, 0);
 #pragma unroll
             for (int c = 0; c < 8; c++) *reinterpret_cast<uint4 *>(out_base + (size_t)row * (H * AT_D) + 8 * c) = z;
@@ -377,7 +378,7 @@ __global__ __launch_bounds__(AT_THREADS, 2) void k_attention_fwd2(AttnParams P)
 
     V8 qf[2][4];
 #pragma unroll
-    for (int qb = 0; qb < 2; qb++) {
+    for (int qb = 0; qb < NQB; qb++) {
         const int qrow = min(q0 + 32 * qb + l31, Np - 1);
         const T *qp = q_base + (size_t)qrow * tok_stride + 8 * hi;
 #pragma unroll
@@ -436,7 +437,7 @@ __global__ __launch_bounds__(AT_THREADS, 2) void k_attention_fwd2(AttnParams P)
     const int so_bq = (int)((size_t)n_kt * 2048 * sizeof(T));                               // next 32-query block
 #define A2_FETCH_BIAS(kt_) do {                                                                                        \
         const int sb_ = __builtin_amdgcn_readfirstlane((kt_) * (int)(2048 * sizeof(T)));                                \
-        _Pragma("unroll") for (int qb_ = 0; qb_ < 2; qb_++)                                                             \
+        _Pragma("unroll") for (int qb_ = 0; qb_ < NQB; qb_++)                                                           \
         _Pragma("unroll") for (int c_i = 0; c_i < 4; c_i++)                                                             \
             breg[qb_][c_i] = __builtin_amdgcn_raw_buffer_load_b128(rs_b, vo_b + qb_ * so_bq + c_i * 1024, sb_, 0);     \
     } while (0)
@@ -459,7 +460,7 @@ __global__ __launch_bounds__(AT_THREADS, 2) void k_attention_fwd2(AttnParams P)
         // next tile's K / V^T: in flight while this tile is computed.  The staggered variant requests them after its first
         // mixed region, where the register pressure peaks (the remaining three regions still cover an L2 round trip)
         constexpr int abl = ABL;
-        if (more && (SPLIT == 0 || !wave_live) && !(abl & 2)) A2_FETCH(kt + 1);
+        if (more && !(abl & 2)) A2_FETCH(kt + 1);
         if (wave_live) {
             const int key0 = kt * AT_KB;
             f32x16 s_acc[2][2];
@@ -522,10 +523,10 @@ __global__ __launch_bounds__(AT_THREADS, 2) void k_attention_fwd2(AttnParams P)
                     _Pragma("unroll") for (int r_ = 0; r_ < 16; r_++) o_acc[qb_][d_][r_] *= alpha[qb_];                 \
                 }                                                                                                       \
             } while (0)
-            if (SPLIT == 0) {
+            {
                 // ---- S^T for both query blocks (every K fragment feeds two MFMAs), softmax, P.V (every V^T fragment too) ----
 #pragma unroll
-                for (int qb = 0; qb < 2; qb++)
+                for (int qb = 0; qb < NQB; qb++)
 #pragma unroll
                     for (int kb = 0; kb < 2; kb++) {
                         if (abl & 16) {
@@ -542,7 +543,7 @@ __global__ __launch_bounds__(AT_THREADS, 2) void k_attention_fwd2(AttnParams P)
                     }
                 if (HAS_BIAS && (abl & 512) && !(abl & 16)) {
 #pragma unroll
-                    for (int qb = 0; qb < 2; qb++)
+                    for (int qb = 0; qb < NQB; qb++)
 #pragma unroll
                         for (int kb = 0; kb < 2; kb++) {
                             union { u32x4 u; V8 v; } b1_;
@@ -557,19 +558,20 @@ __global__ __launch_bounds__(AT_THREADS, 2) void k_attention_fwd2(AttnParams P)
                         const unsigned char *krow = s_k + (kb * 32 + l31) * AT2_ROW + (hi << 4);
 #pragma unroll
                         for (int s = 0; s < 4; s++) {
-                            const V8 kf = (abl & 32) ? qf[1][s] : *reinterpret_cast<const V8 *>(krow + (s << 5));
+                            const V8 kf = (abl & 32) ? qf[NQB - 1][s] : *reinterpret_cast<const V8 *>(krow + (s << 5));
                             s_acc[0][kb] = TR::mfma(kf, qf[0][s], s_acc[0][kb]);
-                            s_acc[1][kb] = TR::mfma(kf, qf[1][s], s_acc[1][kb]);
+                            if (NQB == 2) s_acc[1][kb] = TR::mfma(kf, qf[1][s], s_acc[1][kb]);
                         }
                     }
                 }
                 if (abl & 256) __builtin_amdgcn_s_setprio(0);
                 // the bias registers are free: next tile's fragments land under the softmax / P.V of this one
                 if (HAS_BIAS && more && !(abl & 2)) A2_FETCH_BIAS(kt + 1);
-                A2_MASK(0); A2_MASK(1);
+                A2_MASK(0);
+                if (NQB == 2) A2_MASK(1);
                 if (abl & 1) {
 #pragma unroll
-                    for (int qb = 0; qb < 2; qb++) {
+                    for (int qb = 0; qb < NQB; qb++) {
 #pragma unroll
                         for (int kb = 0; kb < 2; kb++)
 #pragma unroll
@@ -580,7 +582,7 @@ __global__ __launch_bounds__(AT_THREADS, 2) void k_attention_fwd2(AttnParams P)
                     }
                 } else {
                     A2_SOFTMAX(0); A2_RESCALE(0);
-                    A2_SOFTMAX(1); A2_RESCALE(1);
+                    if (NQB == 2) { A2_SOFTMAX(1); A2_RESCALE(1); }
                 }
                 if (!(abl & 8)) {
                     if (abl & 256) __builtin_amdgcn_s_setprio(1);
@@ -593,69 +595,18 @@ __global__ __launch_bounds__(AT_THREADS, 2) void k_attention_fwd2(AttnParams P)
                             for (int j = 0; j < 2; j++) {
                                 const V8 vf = (abl & 32) ? qf[0][kb * 2 + j] : *reinterpret_cast<const V8 *>(vrow + ((kb * 4 + j * 2) << 4));
                                 o_acc[0][d] = TR::mfma(vf, pf[0][kb][j], o_acc[0][d]);
-                                o_acc[1][d] = TR::mfma(vf, pf[1][kb][j], o_acc[1][d]);
+                                if (NQB == 2) o_acc[1][d] = TR::mfma(vf, pf[1][kb][j], o_acc[1][d]);
                             }
                     }
                     if (abl & 256) __builtin_amdgcn_s_setprio(0);
                 } else {
 #pragma unroll
-                    for (int qb = 0; qb < 2; qb++)
+                    for (int qb = 0; qb < NQB; qb++)
 #pragma unroll
                         for (int kb = 0; kb < 2; kb++)
 #pragma unroll
                             for (int j = 0; j < 2; j++) asm volatile("" :: "v"(pf[qb][kb][j]));
                 }
-            } else {
-                // ---- staggered: the VALU work of one query block sits in the same scheduling region as MFMAs of the other ----
-                //   S(0) | S(1) || softmax(0) | P.V(0) || softmax(1) | P.V(1)        (fragments are read once per block)
-#define A2_S_ONE(qb_) do {                                                                                             \
-                    A2_S_BIAS(qb_, 0); A2_S_BIAS(qb_, 1);                                                               \
-                    _Pragma("unroll") for (int kb_ = 0; kb_ < 2; kb_++) {                                               \
-                        const unsigned char *krow_ = s_k + (kb_ * 32 + l31) * AT2_ROW + (hi << 4);                      \
-                        _Pragma("unroll") for (int s_ = 0; s_ < 4; s_++) {                                              \
-                            const V8 kf_ = *reinterpret_cast<const V8 *>(krow_ + (s_ << 5));                            \
-                            s_acc[qb_][kb_] = TR::mfma(kf_, qf[qb_][s_], s_acc[qb_][kb_]);                              \
-                        }                                                                                               \
-                    }                                                                                                   \
-                } while (0)
-#define A2_PV_ONE(qb_) do {                                                                                            \
-                    _Pragma("unroll") for (int d_ = 0; d_ < 2; d_++) {                                                  \
-                        const unsigned char *vrow_ = s_v + (d_ * 32 + l31) * AT2_ROW + (hi << 4);                       \
-                        _Pragma("unroll") for (int kb_ = 0; kb_ < 2; kb_++)                                             \
-                        _Pragma("unroll") for (int j_ = 0; j_ < 2; j_++) {                                              \
-                            const V8 vf_ = *reinterpret_cast<const V8 *>(vrow_ + ((kb_ * 4 + j_ * 2) << 4));            \
-                            o_acc[qb_][d_] = TR::mfma(vf_, pf[qb_][kb_][j_], o_acc[qb_][d_]);                           \
-                        }                                                                                               \
-                    }                                                                                                   \
-                } while (0)
-                A2_S_ONE(0);
-                A2_MASK(0);
-                A2_S_ONE(1);
-                A2_SOFTMAX(0);
-                if (!MASKED) {                                 // one MFMA, then its share of the softmax VALU work
-#pragma unroll
-                    for (int i = 0; i < 12; i++) {
-                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                        __builtin_amdgcn_sched_group_barrier(0x002, 12, 0);
-                    }
-                }
-                if (more) A2_FETCH(kt + 1);
-                A2_RESCALE(0);
-                A2_MASK(1);
-                A2_PV_ONE(0);
-                A2_SOFTMAX(1);
-                if (!MASKED) {
-#pragma unroll
-                    for (int i = 0; i < 8; i++) {
-                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 1);
-                        __builtin_amdgcn_sched_group_barrier(0x002, 18, 1);
-                    }
-                }
-                // register pressure peaks in the two mixed regions above: the next tile's bias fragments are requested only now
-                // and land under P.V(1), the stash and the barrier
-                if (HAS_BIAS && more) A2_FETCH_BIAS(kt + 1);
-                A2_RESCALE(1);
-                A2_PV_ONE(1);
             }
         }
         if (more && !(abl & 2)) {
@@ -671,7 +622,7 @@ __global__ __launch_bounds__(AT_THREADS, 2) void k_attention_fwd2(AttnParams P)
     else tile(ntiles - 1, std::false_type());
     if (!wave_live) return;
 #pragma unroll
-    for (int qb = 0; qb < 2; qb++) {
+    for (int qb = 0; qb < NQB; qb++) {
         const float l_tot = l_run[qb] + __shfl_xor(l_run[qb], 32, 64);
         const float inv = 1.0f / l_tot;
         const int qrow = q0 + 32 * qb + l31;
@@ -774,27 +725,26 @@ DS_API int ds_attention_fwd(ds_ctx *ctx, const void *qk, const void *vt, const v
                    "head_dim 64 (scale 0.125); got scale %g", (double)scale);
         DS_REQUIRE(((uintptr_t)out & 15) == 0, DS_EINVAL, "ds_attention_fwd: out must be 16-byte aligned");
         P.c_exp = scale * log2e; P.k_logit = 1.0f; P.flags = 0;
-        P.nq = (Np + AT2_QB - 1) / AT2_QB;
+        static const int nqb = (getenv("DS_ATT_NQB") && atoi(getenv("DS_ATT_NQB")) == 1) ? 1 : 2;   // A/B switch: rows per wave / 32
+        P.nq = (Np + 128 * nqb - 1) / (128 * nqb);
         P.total = P.nq * H * B;
         P.chunk = (P.total + 7) / 8;
         dim3 grid2(8 * P.chunk);
         hipStream_t st2 = (hipStream_t)stream;
-        static const int split = getenv("DS_ATT_SPLIT") ? atoi(getenv("DS_ATT_SPLIT")) : 0;      // A/B switch
         static const int ablate = (getenv("DS_ATT_ABLATE") ? atoi(getenv("DS_ATT_ABLATE")) : 0)    // timing experiments, wrong results
                                   | (getenv("DS_ATT_OPT") ? atoi(getenv("DS_ATT_OPT")) : 0);        // options, correct results
         P.flags = ablate;
-#define A2_ABL(BI_, M_) case M_: hipLaunchKernelGGL((k_attention_fwd2<0, BI_, 0, M_>), grid2, dim3(AT_THREADS), 0, st2, P); break;
+#define A2_ABL(BI_, M_) case M_: hipLaunchKernelGGL((k_attention_fwd2<0, BI_, 2, M_>), grid2, dim3(AT_THREADS), 0, st2, P); break;
 #define A2_LAUNCH(BF_, BI_) do {                                                                                       \
-            if (ablate && BF_ == 0) {                                                                                   \
+            if (ablate && BF_ == 0 && nqb == 2) {                                                                       \
                 switch (ablate) {                                                                                       \
                 A2_ABL(BI_, 1) A2_ABL(BI_, 2) A2_ABL(BI_, 4) A2_ABL(BI_, 6) A2_ABL(BI_, 7) A2_ABL(BI_, 8) A2_ABL(BI_, 16) A2_ABL(BI_, 32) \
-                A2_ABL(BI_, 38) A2_ABL(BI_, 39) A2_ABL(BI_, 256) A2_ABL(BI_, 512) A2_ABL(BI_, 1024) A2_ABL(BI_, 2048) A2_ABL(BI_, 1536) \
-                A2_ABL(BI_, 1792) A2_ABL(BI_, 3584) A2_ABL(BI_, 3840)                                                    \
-                default: ds_set_error("ds_attention_fwd: DS_ATT_ABLATE=%d is not an instantiated mask", ablate); return DS_EINVAL; \
+                A2_ABL(BI_, 38) A2_ABL(BI_, 39) A2_ABL(BI_, 512) A2_ABL(BI_, 1024) A2_ABL(BI_, 2048)                     \
+                default: ds_set_error("ds_attention_fwd: DS_ATT_ABLATE/OPT=%d is not an instantiated mask", ablate); return DS_EINVAL; \
                 }                                                                                                       \
             }                                                                                                           \
-            else if (split) hipLaunchKernelGGL((k_attention_fwd2<BF_, BI_, 1, 0>), grid2, dim3(AT_THREADS), 0, st2, P);  \
-            else hipLaunchKernelGGL((k_attention_fwd2<BF_, BI_, 0, 0>), grid2, dim3(AT_THREADS), 0, st2, P);            \
+            else if (nqb == 1) hipLaunchKernelGGL((k_attention_fwd2<BF_, BI_, 1, 256>), grid2, dim3(AT_THREADS), 0, st2, P); \
+            else hipLaunchKernelGGL((k_attention_fwd2<BF_, BI_, 2, 256>), grid2, dim3(AT_THREADS), 0, st2, P);          \
         } while (0)
         if (dtype == DS_DTYPE_F16) { if (bias) A2_LAUNCH(0, 1); else A2_LAUNCH(0, 0); }
         else { if (bias) A2_LAUNCH(1, 1); else A2_LAUNCH(1, 0); }

@@ -6,6 +6,8 @@
 // stream (so h is exactly LayerNorm of the x that is stored), two-pass variance in registers.
 #include <stdlib.h>
 
+#include <algorithm>
+
 #include "ds_common.h"
 
 template <int BF16> struct eo_traits;
@@ -317,6 +319,105 @@ DS_API int ds_dpt_head_tail(ds_ctx *ctx, const void *x, int batch, int in_h, int
     if (dtype == DS_DTYPE_F16) { if (s_rpw == 2) HT_LAUNCH(0, 2); else HT_LAUNCH(0, 1); }
     else { if (s_rpw == 2) HT_LAUNCH(1, 2); else HT_LAUNCH(1, 1); }
 #undef HT_LAUNCH
+    DS_HIP_CHECK(hipGetLastError());
+    return DS_OK;
+}
+
+
+// ---- ds_reassemble_readout: the read-out of the DPT reassemble stage (dmidas/backbones/utils.py:28-39) --------------------
+// The reference builds cat(tokens[:, 1:], cls expanded) [B, N-1, 2C], runs Linear(2C -> C) and GELU.  The linear map of a
+// concatenation splits:  W.[tok ; cls] + b = W_tok.tok + (W_cls.cls + b), and the second term is ONE vector per image.  The
+// host runs the token GEMM on the tap as it is (K = C instead of 2C, no concatenated copy) and the tiny cls GEMM; this
+// kernel is the epilogue: out[b, n-1, :] = gelu_erf(proj[b, n, :] + clsvec[b, :]) for n = 1 .. N-1, written densely as the
+// [B, N-1, C] = [B, h, w, C] (NHWC) operand of the 1x1 convolution that follows -- bias add, exact (erf) GELU, the drop of
+// the cls row and the token -> image reshape in one pass at HBM speed.
+template <int BF16>
+__global__ __launch_bounds__(256) void k_reassemble_readout(const void *proj_, const void *cls_, void *out_, int N, int C8, long long total8)
+{
+    typedef typename eo_traits<BF16>::T T;
+    const T *proj = (const T *)proj_, *cls = (const T *)cls_;
+    T *out = (T *)out_;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total8; i += (long long)gridDim.x * 256) {
+        const int c8 = (int)(i % C8);
+        const long long row = i / C8;                      // output row = b * (N - 1) + (n - 1)
+        const int b = (int)(row / (N - 1)), n1 = (int)(row - (long long)b * (N - 1));
+        T pv[8], cv[8], ov[8];
+        __builtin_memcpy(pv, proj + (((size_t)b * N + n1 + 1) * C8 + c8) * 8, 16);
+        __builtin_memcpy(cv, cls + ((size_t)b * C8 + c8) * 8, 16);
+#pragma unroll
+        for (int t = 0; t < 8; t++) {
+            const float x = (float)(T)((float)pv[t] + (float)cv[t]);      // the Linear's output rounded to the storage type, like torch
+            ov[t] = (T)(0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)));
+        }
+        __builtin_memcpy(out + (size_t)i * 8, ov, 16);
+    }
+}
+
+DS_API int ds_reassemble_readout(ds_ctx *ctx, const void *proj, const void *clsvec, void *out, int batch, int tokens, int channels,
+                                 int dtype, void *stream)
+{
+    DS_REQUIRE(ctx && proj && clsvec && out, DS_EINVAL, "ds_reassemble_readout: null argument");
+    DS_REQUIRE(batch > 0 && tokens > 1 && channels > 0 && (channels % 8) == 0, DS_EINVAL,
+               "ds_reassemble_readout: need batch > 0, tokens > 1, channels a multiple of 8 (got %d, %d, %d)", batch, tokens, channels);
+    DS_REQUIRE(dtype == DS_DTYPE_F16 || dtype == DS_DTYPE_BF16, DS_EINVAL, "ds_reassemble_readout: dtype must be f16 or bf16");
+    DS_REQUIRE((((uintptr_t)proj | (uintptr_t)clsvec | (uintptr_t)out) & 15) == 0, DS_EINVAL, "ds_reassemble_readout: operands must be 16-byte aligned");
+    DS_HIP_CHECK(hipSetDevice(ctx->device));
+    const long long total8 = (long long)batch * (tokens - 1) * (channels / 8);
+    const int blocks = (int)std::min<long long>((total8 + 255) / 256, 256 * 32);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == DS_DTYPE_F16) hipLaunchKernelGGL((k_reassemble_readout<0>), dim3(blocks), dim3(256), 0, st, proj, clsvec, out, tokens, channels / 8, total8);
+    else hipLaunchKernelGGL((k_reassemble_readout<1>), dim3(blocks), dim3(256), 0, st, proj, clsvec, out, tokens, channels / 8, total8);
+    DS_HIP_CHECK(hipGetLastError());
+    return DS_OK;
+}
+
+
+// ---- ds_bias_act_nhwc: the element-wise tail of a decoder convolution ------------------------------------------------------
+// out = [relu]( conv_out + bias[c] [+ res1] [+ res2] ) over a channels-last activation, one pass.  The residual convolution
+// units of the DPT decoders (dmidas/blocks.py:352-377, ddepth_anything_v2/.../util/blocks.py:56-85, and the skip add of
+// the fusion blocks :427 / :135) are  conv -> +bias -> ReLU -> conv -> +bias -> +x [-> +skip]: the library convolution is
+// called WITHOUT its bias and this kernel does the rest, so a unit makes 3 element-wise passes instead of 5-6.
+template <int BF16>
+__global__ __launch_bounds__(256) void k_bias_act_nhwc(const void *x_, const void *bias_, const void *r1_, const void *r2_, void *out_,
+                                                       long long total8, int C8, int relu)
+{
+    typedef typename eo_traits<BF16>::T T;
+    const T *x = (const T *)x_, *bias = (const T *)bias_, *r1 = (const T *)r1_, *r2 = (const T *)r2_;
+    T *out = (T *)out_;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total8; i += (long long)gridDim.x * 256) {
+        const int c8 = (int)(i % C8);
+        T xv[8], bv[8], av[8], cv[8], ov[8];
+        __builtin_memcpy(xv, x + (size_t)i * 8, 16);
+        __builtin_memcpy(bv, bias + (size_t)c8 * 8, 16);
+        if (r1) __builtin_memcpy(av, r1 + (size_t)i * 8, 16);
+        if (r2) __builtin_memcpy(cv, r2 + (size_t)i * 8, 16);
+#pragma unroll
+        for (int t = 0; t < 8; t++) {
+            float f = (float)xv[t] + (float)bv[t];
+            if (r1) f += (float)av[t];
+            if (r2) f += (float)cv[t];
+            if (relu) f = f > 0.f ? f : 0.f;
+            ov[t] = (T)f;
+        }
+        __builtin_memcpy(out + (size_t)i * 8, ov, 16);
+    }
+}
+
+DS_API int ds_bias_act_nhwc(ds_ctx *ctx, const void *x, const void *bias, const void *res1, const void *res2, void *out,
+                            int64_t elements, int channels, int relu, int dtype, void *stream)
+{
+    DS_REQUIRE(ctx && x && bias && out, DS_EINVAL, "ds_bias_act_nhwc: null argument");
+    DS_REQUIRE(elements > 0 && channels > 0 && (channels % 8) == 0 && (elements % channels) == 0, DS_EINVAL,
+               "ds_bias_act_nhwc: elements must be a positive multiple of channels, channels a multiple of 8");
+    DS_REQUIRE(dtype == DS_DTYPE_F16 || dtype == DS_DTYPE_BF16, DS_EINVAL, "ds_bias_act_nhwc: dtype must be f16 or bf16");
+    DS_REQUIRE((((uintptr_t)x | (uintptr_t)bias | (uintptr_t)res1 | (uintptr_t)res2 | (uintptr_t)out) & 15) == 0, DS_EINVAL,
+               "ds_bias_act_nhwc: operands must be 16-byte aligned");
+    DS_HIP_CHECK(hipSetDevice(ctx->device));
+    const long long total8 = elements / 8;
+    const int blocks = (int)std::min<long long>((total8 + 255) / 256, 256 * 32);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == DS_DTYPE_F16) hipLaunchKernelGGL((k_bias_act_nhwc<0>), dim3(blocks), dim3(256), 0, st, x, bias, res1, res2, out, total8, channels / 8, relu);
+    else hipLaunchKernelGGL((k_bias_act_nhwc<1>), dim3(blocks), dim3(256), 0, st, x, bias, res1, res2, out, total8, channels / 8, relu);
     DS_HIP_CHECK(hipGetLastError());
     return DS_OK;
 }

@@ -22,9 +22,7 @@ class ResidualConvUnit(nn.Module):
         self.conv2 = nn.Conv2d(features, features, kernel_size=3, stride=1, padding=1, bias=True)
 
     def forward(self, x):               # blocks.py:56-85 (bn=False, activation ReLU(False))
-        out = self.conv1(F.relu(x))
-        out = self.conv2(F.relu(out))
-        return out + x
+        return vm.residual_conv_unit(self.conv1, self.conv2, x)
 
 
 class FeatureFusionBlock(nn.Module):
@@ -36,8 +34,8 @@ class FeatureFusionBlock(nn.Module):
 
     def forward(self, *xs, size=None):  # blocks.py:121-148 (align_corners=True)
         output = xs[0]
-        if len(xs) == 2:
-            output = output + self.resConfUnit1(xs[1])
+        if len(xs) == 2:                # skip add fused into the unit's last element-wise pass
+            output = vm.residual_conv_unit(self.resConfUnit1.conv1, self.resConfUnit1.conv2, xs[1], skip=output)
         output = self.resConfUnit2(output)
         # the reference interpolates, then applies the 1x1 out_conv; both are linear and the bilinear weights sum to one,
         # so they commute (bias included): the conv runs on 4x fewer pixels and the upsample writes the final tensor

@@ -212,14 +212,39 @@ class Beit(nn.Module):
 
 
 class ProjectReadout(nn.Module):       # utils.py:28-39
+    """cat(tokens[:, 1:], cls expanded) -> Linear(2C -> C) -> GELU, without the concatenation: the linear map splits into
+    the token part (a GEMM with K = C on the tap as it is) and the cls part (one vector per image),
+        W.[tok ; cls] + b = W_tok.tok + (W_cls.cls + b),
+    which halves the read-out GEMM and removes the [B, N-1, 2C] copy; on the GPU in half precision the bias add, the exact
+    (erf) GELU, the drop of the cls row and the token -> NHWC reshape are one HIP pass (ds_reassemble_readout)."""
+
     def __init__(self, in_features, start_index=1):
         super().__init__()
         self.start_index = start_index
         self.project = nn.Sequential(nn.Linear(2 * in_features, in_features), nn.GELU())
 
+    def _split(self):
+        lin = self.project[0]
+        key = (lin.weight._version, lin.weight.data_ptr(), lin.weight.dtype)
+        hit = getattr(self, "_w_split", None)
+        if hit is None or hit[0] != key:
+            c = lin.in_features // 2
+            hit = (key, lin.weight[:, :c].contiguous(), lin.weight[:, c:].contiguous())
+            if not torch.is_grad_enabled():
+                self._w_split = hit
+        return hit[1], hit[2]
+
     def forward(self, x):
-        readout = x[:, 0].unsqueeze(1).expand_as(x[:, self.start_index:])
-        return self.project(torch.cat((x[:, self.start_index:], readout), -1))
+        if self.start_index != 1:
+            readout = x[:, 0].unsqueeze(1).expand_as(x[:, self.start_index:])
+            return self.project(torch.cat((x[:, self.start_index:], readout), -1))
+        w_tok, w_cls = self._split()
+        clsvec = F.linear(x[:, 0], w_cls, self.project[0].bias)               # [B, C]
+        proj = F.linear(x, w_tok)                                             # [B, N, C] (row 0 is not used)
+        if x.is_cuda and x.dtype in (torch.float16, torch.bfloat16) and x.shape[-1] % 8 == 0:
+            from src import _native
+            return _native.reassemble_readout(proj, clsvec)
+        return F.gelu(proj[:, 1:] + clsvec[:, None])
 
 
 class _Skip(nn.Module):                 # placeholder for Transpose / Unflatten slots (no parameters) so indices match

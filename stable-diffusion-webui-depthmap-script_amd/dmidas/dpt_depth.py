@@ -26,9 +26,7 @@ class ResidualConvUnit_custom(nn.Module):
         self.conv2 = nn.Conv2d(features, features, kernel_size=3, stride=1, padding=1, bias=True)
 
     def forward(self, x):               # blocks.py:352-377, activation ReLU(False), bn False
-        out = self.conv1(F.relu(x))
-        out = self.conv2(F.relu(out))
-        return out + x
+        return vm.residual_conv_unit(self.conv1, self.conv2, x)
 
 
 class FeatureFusionBlock_custom(nn.Module):
@@ -40,8 +38,8 @@ class FeatureFusionBlock_custom(nn.Module):
 
     def forward(self, *xs, size=None):  # blocks.py:412-441, align_corners=True
         output = xs[0]
-        if len(xs) == 2:
-            output = output + self.resConfUnit1(xs[1])
+        if len(xs) == 2:                # skip add fused into the unit's last element-wise pass
+            output = vm.residual_conv_unit(self.resConfUnit1.conv1, self.resConfUnit1.conv2, xs[1], skip=output)
         output = self.resConfUnit2(output)
         # 1x1 out_conv and bilinear interpolation commute (linear, weights sum to one): conv first, on 4x fewer pixels
         output = self.out_conv(output)

@@ -18,7 +18,7 @@ DS_DEPTH_U16, DS_DEPTH_F32, DS_DEPTH_F64 = 0, 1, 2
 FILL_IDS = {"none": 0, "naive": 1, "naive_interpolating": 2, "polylines_soft": 3, "polylines_sharp": 4}
 
 EXPORTS = [
-    "ds_version", "ds_last_error", "ds_normalmap_f64", "ds_ctx_create", "ds_ctx_destroy", "ds_stereo_warp", "ds_depth_minmax",
+    "ds_version", "ds_last_error", "ds_normalmap_f64", "ds_reassemble_readout", "ds_bias_act_nhwc", "ds_ctx_create", "ds_ctx_destroy", "ds_stereo_warp", "ds_depth_minmax",
     "ds_stereo_last_exact_rows", "ds_copy_view", "ds_overlap_red_cyan", "ds_normalmap", "ds_depth_to_u16",
     "ds_convert_to_i16", "ds_profile_enable", "ds_profile_last_ms", "ds_stereo_last_stats", "ds_attention_fwd", "ds_attention_bias_pack", "ds_colorize_u16", "ds_residual_layernorm", "ds_boost_blend", "ds_upsample_bilinear_nhwc", "ds_dpt_head_tail",
 ]
@@ -69,6 +69,8 @@ def lib():
             L.ds_boost_blend.argtypes = [vp, vp, i64, ci, ci, vp, ci, vp, ci, vp, ci, vp]
             L.ds_upsample_bilinear_nhwc.argtypes = [vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, vp]
             L.ds_dpt_head_tail.argtypes = [vp, vp, ci, ci, ci, ci, ci, vp, vp, vp, ctypes.c_float, ci, vp, ci, vp]
+            L.ds_reassemble_readout.argtypes = [vp, vp, vp, vp, ci, ci, ci, ci, vp]
+            L.ds_bias_act_nhwc.argtypes = [vp, vp, vp, vp, vp, vp, i64, ci, ci, ci, vp]
             L.ds_profile_enable.argtypes = [vp, ci]
             L.ds_profile_last_ms.argtypes = [vp, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float)]
             for name in EXPORTS:          # fail at load time, not at first use, if a symbol is missing
@@ -327,6 +329,36 @@ def residual_layernorm(x, branch, gamma, ln_weight, ln_bias, eps=1e-6):
                                        w.data_ptr(), b.data_ptr(), None if branch is None else x_out.data_ptr(), h.data_ptr(),
                                        rows, c, float(eps), dt, _stream(x)))
     return x_out, h
+
+
+def reassemble_readout(proj, clsvec):
+    """gelu(proj[:, 1:] + clsvec[:, None]) -> [B, N-1, C] (include/depthstereo.h: ds_reassemble_readout).
+    proj [B, N, C], clsvec [B, C]: float16 / bfloat16 CUDA tensors."""
+    torch = require_gpu()
+    assert proj.is_cuda and proj.dtype in (torch.float16, torch.bfloat16) and proj.dim() == 3 and clsvec.dtype == proj.dtype
+    b, n, c = proj.shape
+    proj, clsvec = proj.contiguous(), clsvec.contiguous()
+    assert tuple(clsvec.shape) == (b, c)
+    out = torch.empty((b, n - 1, c), dtype=proj.dtype, device=proj.device)
+    _check(lib().ds_reassemble_readout(ctx_for(_dev_index(proj)), proj.data_ptr(), clsvec.data_ptr(), out.data_ptr(), b, n, c,
+                                       1 if proj.dtype == torch.float16 else 2, _stream(proj)))
+    return out
+
+
+def bias_act(x, bias, relu=False, res1=None, res2=None, inplace=True):
+    """[relu](x + bias[c] [+ res1] [+ res2]) for an NCHW-shaped float16/bfloat16 CUDA tensor in channels_last memory format
+    (include/depthstereo.h: ds_bias_act_nhwc); res1 / res2 must have x's shape and memory format.  In place by default."""
+    torch = require_gpu()
+    assert x.is_cuda and x.dtype in (torch.float16, torch.bfloat16) and x.dim() == 4 and x.shape[1] % 8 == 0
+    assert x.is_contiguous(memory_format=torch.channels_last)
+    for r in (res1, res2):
+        assert r is None or (r.shape == x.shape and r.dtype == x.dtype and r.is_contiguous(memory_format=torch.channels_last))
+    out = x if inplace else torch.empty_like(x)
+    b = bias.detach().to(x.dtype).contiguous()
+    _check(lib().ds_bias_act_nhwc(ctx_for(_dev_index(x)), x.data_ptr(), b.data_ptr(), None if res1 is None else res1.data_ptr(),
+                                  None if res2 is None else res2.data_ptr(), out.data_ptr(), x.numel(), x.shape[1], 1 if relu else 0,
+                                  1 if x.dtype == torch.float16 else 2, _stream(x)))
+    return out
 
 
 def boost_blend(dst, rects, coefs, preds, mask_template):

@@ -198,12 +198,21 @@ def _launch_group(gen, idxs, inputimages, inputdepthmaps, inp, device):
             np.copyto(stn[j], a)
         return st.to(device, non_blocking=True)
 
+    def upload_pixels(tag, to_array):
+        """PIL -> uint8 array -> pinned staging (decoded and copied on the host thread pool) -> device."""
+        first = to_array(images[0])
+        st = _staging.get(gen, tag, (b,) + first.shape, torch.uint8)
+        stn = st.numpy()
+        np.copyto(stn[0], first)
+        if b > 1:
+            list(_host_pool().map(lambda j: np.copyto(stn[j], to_array(images[j])), range(1, b)))
+        return st.to(device, non_blocking=True)
+
     img_t = None
     if want_stereo:
-        arrs = [np.asarray(im, dtype=np.uint8) for im in images]                                 # :252 np.array(image)
-        if arrs[0].ndim != 3:
-            raise ValueError('not enough values to unpack (expected 3, got %d)' % arrs[0].ndim)
-        img_t = upload(arrs, "img", torch.uint8)
+        if np.asarray(images[0]).ndim != 3:                                                      # :252 np.array(image)
+            raise ValueError('not enough values to unpack (expected 3, got %d)' % np.asarray(images[0]).ndim)
+        img_t = upload_pixels("img", lambda im: np.asarray(im, dtype=np.uint8))
     mesh_source = None
     if custom:
         outs = [_custom_depth_to_float(inputdepthmaps[i], inputimages[i]) for i in idxs]         # :145-174 (host: PIL)
@@ -218,7 +227,7 @@ def _launch_group(gen, idxs, inputimages, inputdepthmaps, inp, device):
         if images[0].mode == "RGB" and img_t is not None:
             rgb_t = img_t
         else:
-            rgb_t = upload([np.asarray(im.convert("RGB"), dtype=np.uint8) for im in images], "rgb", torch.uint8)
+            rgb_t = upload_pixels("rgb", lambda im: np.asarray(im.convert("RGB"), dtype=np.uint8))
         pred, invert = model_holder.get_raw_prediction_batch(images, rgb_t, net_width, net_height)
         if pred is None:                 # Boost sharded over ranks (ModelHolder.boost_group): only the group's rank 0 renders
             g["skip"] = True
@@ -274,43 +283,72 @@ def _launch_group(gen, idxs, inputimages, inputdepthmaps, inp, device):
     return g
 
 
+_pool = None
+
+
+def _host_pool():
+    """Threads that turn pinned result buffers into PIL images (numpy copies release the GIL)."""
+    global _pool
+    if _pool is None:
+        from concurrent.futures import ThreadPoolExecutor
+        _pool = ThreadPoolExecutor(max_workers=min(16, (_os.cpu_count() or 4)), thread_name_prefix="ds-funnel")
+    return _pool
+
+
 def _emit_group(g, outpath, inp, device):
     """Yield a finished group's results image by image in the reference's order (:208-306).  The pinned buffers are reused
-    two groups later, so every result is copied out of them (PIL owns its pixels)."""
+    two groups later, so every result is copied out of them (PIL owns its pixels); the copies of a group run on a small
+    thread pool while the generator hands out what is already done."""
     torch = _native._torch()
     if g.get("skip"):
         return
     g["done"].synchronize()
     host = {k: v.numpy() for k, v in g["host"].items()}
-    for j, count in enumerate(g["idxs"]):
+    pred_host = None if g["pred_host"] is None else g["pred_host"].numpy()
+
+    def render(j):
         image = g["images"][j]
-        if g["pred_host"] is not None and not g["broken"][j]:
-            yield count, 'depth_prediction', g["pred_host"][j].numpy().copy()
+        out = []
+        if pred_host is not None and not g["broken"][j]:
+            out.append(('depth_prediction', pred_host[j].copy()))
         if inp[go.DO_OUTPUT_DEPTH]:                                                              # :240-249
             img_output = host["depth"][j]
             img_depth = np.bitwise_not(img_output) if inp[go.OUTPUT_DEPTH_INVERT] else img_output   # cv2.bitwise_not
             if inp[go.OUTPUT_DEPTH_COMBINE]:
                 axis = 1 if inp[go.OUTPUT_DEPTH_COMBINE_AXIS] == 'Horizontal' else 0
-                yield count, 'concat_depth', Image.fromarray(np.concatenate(
-                    (image, convert_i16_to_rgb(img_depth, np.asarray(image))), axis=axis))
+                out.append(('concat_depth', Image.fromarray(np.concatenate(
+                    (image, convert_i16_to_rgb(img_depth, np.asarray(image))), axis=axis))))
             else:
-                yield count, 'depth', Image.fromarray(img_depth.copy())
+                out.append(('depth', Image.fromarray(img_depth.copy())))
         if inp[go.GEN_STEREO]:
             for c in range(g["n_stereo"]):
-                yield count, inp[go.STEREO_MODES][c], Image.fromarray(host["stereo%d" % c][j].copy())
+                out.append((inp[go.STEREO_MODES][c], Image.fromarray(host["stereo%d" % c][j].copy())))
         if inp[go.GEN_NORMALMAP]:
-            yield count, 'normalmap', Image.fromarray(host["normalmap"][j].copy())
+            out.append(('normalmap', Image.fromarray(host["normalmap"][j].copy())))
         if inp[go.GEN_HEATMAP]:
-            yield count, 'heatmap', Image.fromarray(host["heatmap"][j].copy())
-        if inp[go.GEN_SIMPLE_MESH]:                                                              # :277-306
-            from . import mesh_generation as mg
-            mt = inp[go.MODEL_TYPE]              # callers pass the numeric id; the option's default is a display name
-            depthi = mg.mesh_depth(g["mesh_source"][j], mt if isinstance(mt, int) else -1, bool(inp[go.BOOST]), g["custom"])
-            rgb_t = torch.from_numpy(np.array(image.convert('RGB'), dtype=np.uint8, order='C')).to(device)
-            verts, faces, colors = mg.create_mesh_arrays(rgb_t, depthi, keep_edges=not inp[go.SIMPLE_MESH_OCCLUDE],
-                                                         spherical=bool(inp[go.SIMPLE_MESH_SPHERICAL]))
-            fn = mg.unique_filename(outpath, 'depthmap', 'obj', 'simple')
-            yield count, 'simple_mesh', mg.write_obj(fn, verts.cpu().numpy(), faces.cpu().numpy(), colors.cpu().numpy())
+            out.append(('heatmap', Image.fromarray(host["heatmap"][j].copy())))
+        return out
+
+    n = len(g["idxs"])
+    futures = [_host_pool().submit(render, j) for j in range(n)] if n > 1 else None
+    try:
+        for j, count in enumerate(g["idxs"]):
+            image = g["images"][j]
+            for kind, res in (futures[j].result() if futures is not None else render(j)):
+                yield count, kind, res
+            if inp[go.GEN_SIMPLE_MESH]:                                                              # :277-306
+                from . import mesh_generation as mg
+                mt = inp[go.MODEL_TYPE]              # callers pass the numeric id; the option's default is a display name
+                depthi = mg.mesh_depth(g["mesh_source"][j], mt if isinstance(mt, int) else -1, bool(inp[go.BOOST]), g["custom"])
+                rgb_t = torch.from_numpy(np.array(image.convert('RGB'), dtype=np.uint8, order='C')).to(device)
+                verts, faces, colors = mg.create_mesh_arrays(rgb_t, depthi, keep_edges=not inp[go.SIMPLE_MESH_OCCLUDE],
+                                                             spherical=bool(inp[go.SIMPLE_MESH_SPHERICAL]))
+                fn = mg.unique_filename(outpath, 'depthmap', 'obj', 'simple')
+                yield count, 'simple_mesh', mg.write_obj(fn, verts.cpu().numpy(), faces.cpu().numpy(), colors.cpu().numpy())
+    finally:
+        if futures is not None:
+            for f in futures:                                # (also when the consumer stops early) the buffers must be
+                f.result()                                   # free before the next group reuses them
 
 
 def core_generation_funnel(outpath, inputimages, inputdepthmaps, inputnames, inp, ops=None):
@@ -371,7 +409,7 @@ def core_generation_funnel(outpath, inputimages, inputdepthmaps, inputnames, inp
             model_holder.offload()
         else:
             model_holder.unload_models()
-        gc.collect()
+            gc.collect()         # (the reference collects after every run; with resident models there is nothing to free)
 
 
 # the name BASELINE.json's north_star uses (a pre-0.4.0 name of the same function, see SURVEY.md naming note)

@@ -184,6 +184,32 @@ def interpolate_bilinear(x, size=None, scale_factor=None, align_corners=True):
     return F.interpolate(x, scale_factor=scale_factor, mode="bilinear", align_corners=align_corners)
 
 
+def residual_conv_unit(conv1, conv2, x, skip=None):
+    """[skip +] ( conv2(relu(conv1(relu(x)))) + x ): ResidualConvUnit_custom (dmidas/blocks.py:352-377) / ResidualConvUnit
+    (ddepth_anything_v2/.../util/blocks.py:56-85) and, with `skip`, the add of the fusion block around it (:427 / :135).
+    Half precision on the GPU: the library convolutions run WITHOUT their bias and ds_bias_act_nhwc does bias + ReLU and
+    bias + residual (+ skip) in one pass each.  Everything else: the plain torch sequence."""
+    if (x.is_cuda and x.dtype in (torch.float16, torch.bfloat16) and x.shape[1] % 8 == 0 and conv1.bias is not None
+            and conv2.bias is not None and conv1.out_channels % 8 == 0):
+        from . import _native
+        xc = x.contiguous(memory_format=torch.channels_last)
+        c1 = conv1._conv_forward(F.relu(xc), conv1.weight, None)          # honours padding_mode (TILING_MODE: circular)
+        if c1.is_contiguous(memory_format=torch.channels_last):
+            a = _native.bias_act(c1, conv1.bias, relu=True)
+            c2 = conv2._conv_forward(a, conv2.weight, None)
+            if c2.is_contiguous(memory_format=torch.channels_last) and c2.shape == xc.shape:
+                sk = None if skip is None else skip.contiguous(memory_format=torch.channels_last)
+                return _native.bias_act(c2, conv2.bias, relu=False, res1=xc, res2=sk)
+            out = c2 + conv2.bias.view(1, -1, 1, 1) + x
+            return out if skip is None else skip + out
+        out = conv2(F.relu(c1 + conv1.bias.view(1, -1, 1, 1))) + x
+        return out if skip is None else skip + out
+    out = conv1(F.relu(x))
+    out = conv2(F.relu(out))
+    out = out + x
+    return out if skip is None else skip + out
+
+
 class Mlp(nn.Module):
     """fc1 -> GELU -> fc2 (dinov2_layers/mlp.py:20-41; timm Mlp has the same parameter names)."""
 

@@ -455,3 +455,72 @@ def test_leres_and_hybrid_gpu_fp32_vs_reference(gpu):
         y16 = m.half()(x4.half().contiguous(memory_format=torch.channels_last)).float().cpu().numpy()
     # the ResNetV2 stem (weight-standardised convolutions, GroupNorm) in half precision with synthetic weights: 3.7e-2 measured
     assert np.abs(y16 - ref).max() / np.abs(ref).max() < 6e-2
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float16, 2e-3), (torch.bfloat16, 1.6e-2)])
+def test_reassemble_readout_kernel(gpu, dtype, tol):
+    """ds_reassemble_readout against its definition, and ProjectReadout (split GEMM + fused epilogue) against the
+    reference's formulation cat(tokens, cls) -> Linear(2C -> C) -> GELU (dmidas/backbones/utils.py:28-39)."""
+    from src import _native
+    from dmidas.backbones.beit import ProjectReadout
+    g = torch.Generator().manual_seed(12)
+    for (b, n, c) in [(2, 5, 64), (3, 1025, 1024), (1, 577, 768)]:
+        proj = torch.randn((b, n, c), generator=g).to(dtype).cuda()
+        cls = torch.randn((b, c), generator=g).to(dtype).cuda()
+        got = _native.reassemble_readout(proj, cls)
+        want = torch.nn.functional.gelu((proj[:, 1:].float() + cls[:, None].float()).to(dtype).float())
+        assert tuple(got.shape) == (b, n - 1, c)
+        assert (got.float() - want).abs().max().item() < tol * (1 + want.abs().max().item())
+    torch.manual_seed(5)
+    ro = ProjectReadout(256).cuda()
+    x = torch.randn((2, 101, 256), device='cuda')
+    with torch.no_grad():
+        ref = ro.project(torch.cat((x[:, 1:], x[:, 0].unsqueeze(1).expand_as(x[:, 1:])), -1))     # the reference's forward
+        y32 = ro(x)
+        y16 = ro.to(dtype)(x.to(dtype)).float()
+    assert (y32 - ref).abs().max().item() < 1e-5 * (1 + ref.abs().max().item())
+    assert (y16 - ref).abs().max().item() < 4 * tol * (1 + ref.abs().max().item())
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float16, 2e-3), (torch.bfloat16, 1.6e-2)])
+def test_bias_act_kernel_and_residual_conv_unit(gpu, dtype, tol):
+    """ds_bias_act_nhwc against its definition (all optional operands, in place and out of place), and the fused residual
+    convolution unit against the reference's sequence conv(relu) -> conv(relu) -> + x (dmidas/blocks.py:352-377) in float32."""
+    import torch.nn as nn
+    import torch.nn.functional as F
+    from src import _native
+    from src import vit_mi355x as vm
+    g = torch.Generator().manual_seed(21)
+    for (b, c, h, w) in [(2, 64, 5, 7), (1, 256, 33, 17), (3, 8, 4, 4)]:
+        mk = lambda: torch.randn((b, c, h, w), generator=g).to(dtype).cuda().contiguous(memory_format=torch.channels_last)  # noqa: E731
+        x, r1, r2 = mk(), mk(), mk()
+        bias = torch.randn(c, generator=g).to(dtype).cuda()
+        for relu in (False, True):
+            for a, bb in ((None, None), (r1, None), (r1, r2)):
+                want = x.float() + bias.float().view(1, -1, 1, 1)
+                if a is not None:
+                    want = want + a.float()
+                if bb is not None:
+                    want = want + bb.float()
+                if relu:
+                    want = F.relu(want)
+                got = _native.bias_act(x, bias, relu=relu, res1=a, res2=bb, inplace=False)
+                assert got.is_contiguous(memory_format=torch.channels_last)
+                assert (got.float() - want).abs().max().item() < tol * (1 + want.abs().max().item())
+        y = x.clone(memory_format=torch.channels_last)
+        assert _native.bias_act(y, bias, relu=True).data_ptr() == y.data_ptr()
+        assert torch.equal(y, _native.bias_act(x, bias, relu=True, inplace=False))
+    torch.manual_seed(3)
+    c1, c2 = nn.Conv2d(64, 64, 3, padding=1).cuda(), nn.Conv2d(64, 64, 3, padding=1).cuda()
+    x = torch.randn((2, 64, 19, 23), device='cuda')
+    skip = torch.randn((2, 64, 19, 23), device='cuda')
+    with torch.no_grad():
+        ref = c2(F.relu(c1(F.relu(x)))) + x
+        got32 = vm.residual_conv_unit(c1, c2, x)
+        assert (got32 - ref).abs().max().item() < 1e-5 * (1 + ref.abs().max().item())
+        c1h, c2h = c1.to(dtype), c2.to(dtype)
+        xh = x.to(dtype).contiguous(memory_format=torch.channels_last)
+        got = vm.residual_conv_unit(c1h, c2h, xh).float()
+        got_s = vm.residual_conv_unit(c1h, c2h, xh, skip=skip.to(dtype)).float()
+    assert (got - ref).abs().max().item() < 6 * tol * (1 + ref.abs().max().item())
+    assert (got_s - (ref + skip)).abs().max().item() < 6 * tol * (1 + ref.abs().max().item())
