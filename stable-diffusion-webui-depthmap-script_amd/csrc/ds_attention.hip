@@ -725,7 +725,11 @@ DS_API int ds_attention_fwd(ds_ctx *ctx, const void *qk, const void *vt, const v
                    "head_dim 64 (scale 0.125); got scale %g", (double)scale);
         DS_REQUIRE(((uintptr_t)out & 15) == 0, DS_EINVAL, "ds_attention_fwd: out must be 16-byte aligned");
         P.c_exp = scale * log2e; P.k_logit = 1.0f; P.flags = 0;
-        static const int nqb = (getenv("DS_ATT_NQB") && atoi(getenv("DS_ATT_NQB")) == 1) ? 1 : 2;   // A/B switch: rows per wave / 32
+        // rows per wave / 32.  Measured (f16, MI355X): 32 rows x 3 waves per SIMD wins on short sequences (N = 1025 + bias:
+        // 0.286 vs 0.310 ms at batch 32; N = 577: 0.060 vs 0.076), 64 rows x 2 waves on long ones (N = 4097 + bias: 0.903 vs
+        // 0.944; N = 2443: 0.255 vs 0.263); N = 1370 is a tie.  DS_ATT_NQB overrides (A/B runs).
+        static const int nqb_env = getenv("DS_ATT_NQB") ? atoi(getenv("DS_ATT_NQB")) : 0;
+        const int nqb = (nqb_env == 1 || nqb_env == 2) ? nqb_env : (Np <= 1280 ? 1 : 2);
         P.nq = (Np + 128 * nqb - 1) / (128 * nqb);
         P.total = P.nq * H * B;
         P.chunk = (P.total + 7) / 8;

@@ -8,6 +8,7 @@
 // General path (Gaussian pre/post blur, other Sobel sizes): separable float64 passes over planes in
 // the context's scratch, rows first then columns, taps accumulated in order (BORDER_REFLECT_101).
 #include <math.h>
+#include <stdlib.h>
 
 #include "ds_common.h"
 
@@ -70,6 +71,62 @@ __global__ __launch_bounds__(NM_BX * NM_BY) void k_normalmap_fused(const uint16_
     }
 #undef NMV
     nm_store(zx, zy, out + ((size_t)img * h * w + (size_t)y * w + x) * 3);
+}
+
+// Four pixels per lane (w % 4 == 0): the three input rows arrive as one aligned 8-byte load each plus the two edge columns,
+// the 12 output bytes leave as three aligned 32-bit stores (round 1: one pixel per lane, three single-byte stores -- 0.20 ms
+// per 32 x 1024^2 = 10 % of the HBM roofline).  Same float64 arithmetic per pixel as k_normalmap_fused.
+template <int SOBEL3>
+__global__ __launch_bounds__(NM_BX * NM_BY) void k_normalmap_fused4(const uint16_t *__restrict__ depth, int h, int w, int invert,
+                                                                    uint8_t *__restrict__ out)
+{
+    const int img = blockIdx.z;
+    const int x0 = (blockIdx.x * NM_BX + threadIdx.x) * 4;
+    const int y = blockIdx.y * NM_BY + threadIdx.y;
+    if (x0 >= w || y >= h) return;
+    const uint16_t *d = depth + (size_t)img * h * w;
+    const double sgn = invert ? 1.0 : -1.0;
+    // rows y-1, y, y+1 and columns x0-1 .. x0+4; outside the image: BORDER_REFLECT_101 for Sobel, clamped (unused) for gradient
+    int ry[3], cl, cr;
+    if (SOBEL3) {
+        ry[0] = nm_reflect101(y - 1, h); ry[2] = nm_reflect101(y + 1, h);
+        cl = nm_reflect101(x0 - 1, w); cr = nm_reflect101(x0 + 4, w);
+    } else {
+        ry[0] = y > 0 ? y - 1 : 0; ry[2] = y < h - 1 ? y + 1 : h - 1;
+        cl = x0 > 0 ? x0 - 1 : 0; cr = x0 + 4 < w ? x0 + 4 : w - 1;
+    }
+    ry[1] = y;
+    double v[3][6];
+#pragma unroll
+    for (int r = 0; r < 3; r++) {
+        const uint16_t *row = d + (size_t)ry[r] * w;
+        const uint2 q = *reinterpret_cast<const uint2 *>(row + x0);
+        const uint32_t e[6] = { row[cl], q.x & 0xffffu, q.x >> 16, q.y & 0xffffu, q.y >> 16, row[cr] };
+#pragma unroll
+        for (int c = 0; c < 6; c++) v[r][c] = ((double)e[c] * sgn) / 256.0;                 /* :20-21 */
+    }
+    uint8_t o[12];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int x = x0 + i;
+        double zx, zy;
+        if (SOBEL3) {
+            zx = (v[0][i + 2] - v[0][i]) + 2.0 * (v[1][i + 2] - v[1][i]) + (v[2][i + 2] - v[2][i]);      /* cv2.Sobel dx, ksize 3 */
+            zy = (v[2][i] - v[0][i]) + 2.0 * (v[2][i + 1] - v[0][i + 1]) + (v[2][i + 2] - v[0][i + 2]);  /* cv2.Sobel dy, ksize 3 */
+        } else {                                                                                         /* np.gradient, :31 */
+            if (x == 0) zx = v[1][i + 2] - v[1][i + 1];
+            else if (x == w - 1) zx = v[1][i + 1] - v[1][i];
+            else zx = (v[1][i + 2] - v[1][i]) / 2.0;
+            if (y == 0) zy = v[2][i + 1] - v[1][i + 1];
+            else if (y == h - 1) zy = v[1][i + 1] - v[0][i + 1];
+            else zy = (v[2][i + 1] - v[0][i + 1]) / 2.0;
+        }
+        nm_store(zx, zy, o + 3 * i);
+    }
+    uint32_t *dst = reinterpret_cast<uint32_t *>(out + ((size_t)img * h * w + (size_t)y * w + x0) * 3);
+#pragma unroll
+    for (int k = 0; k < 3; k++)
+        dst[k] = (uint32_t)o[4 * k] | ((uint32_t)o[4 * k + 1] << 8) | ((uint32_t)o[4 * k + 2] << 16) | ((uint32_t)o[4 * k + 3] << 24);
 }
 
 // ---- general path ---------------------------------------------------------------------------------
@@ -225,6 +282,13 @@ static int nm_run(ds_ctx *ctx, const void *depth_any, int is_f64, int n, int h, 
     if (!is_f64 && pre_blur == 0 && post_blur == 0 && (sobel_ksize == 3 || sobel_ksize == 0)) {
         dim3 grid((w + NM_BX - 1) / NM_BX, (h + NM_BY - 1) / NM_BY, n), block(NM_BX, NM_BY);
         DS_REQUIRE(grid.y <= 65535, DS_EUNSUPPORTED, "ds_normalmap: image too tall");
+        if ((w & 3) == 0 && w >= 4 && h >= 2 && (((uintptr_t)depth) & 7) == 0 && (((uintptr_t)out) & 3) == 0 && !getenv("DS_NM_SCALAR")) {
+            dim3 grid4((w / 4 + NM_BX - 1) / NM_BX, grid.y, n);
+            if (sobel_ksize == 3) hipLaunchKernelGGL(k_normalmap_fused4<1>, grid4, block, 0, st, depth, h, w, invert ? 1 : 0, out);
+            else hipLaunchKernelGGL(k_normalmap_fused4<0>, grid4, block, 0, st, depth, h, w, invert ? 1 : 0, out);
+            DS_HIP_CHECK(hipGetLastError());
+            return DS_OK;
+        }
         if (sobel_ksize == 3) hipLaunchKernelGGL(k_normalmap_fused<1>, grid, block, 0, st, depth, h, w, invert ? 1 : 0, out);
         else hipLaunchKernelGGL(k_normalmap_fused<0>, grid, block, 0, st, depth, h, w, invert ? 1 : 0, out);
         DS_HIP_CHECK(hipGetLastError());

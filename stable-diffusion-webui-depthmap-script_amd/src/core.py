@@ -107,8 +107,10 @@ def _custom_depth_to_float(dp, image):
 
 import os as _os
 
-# device batch of the funnel: up to this many pixels (36 x 1024^2 by default), at most 64 images
-FUNNEL_BATCH_PIXELS = int(_os.environ.get("DS_FUNNEL_BATCH_PIXELS", 36 << 20))
+# device batch of the funnel: up to this many pixels (16 x 1024^2 by default), at most 64 images.  Measured on 32 x 1024^2
+# through dpt_beit_large_512: one group of 32 -> 176 pairs/s, two pipelined groups of 16 -> 289 pairs/s (the PIL conversion
+# of a group overlaps the next group's device work)
+FUNNEL_BATCH_PIXELS = int(_os.environ.get("DS_FUNNEL_BATCH_PIXELS", 16 << 20))
 
 
 def _postprocess_batch(pred, invert, inp):

@@ -167,6 +167,8 @@ def test_normalmap_vs_oracle(gpu, oracle):
     import src.normalmap_generation as nm
     rng = np.random.default_rng(11)
     deps = [rng.integers(0, 65536, (33, 70), dtype=np.uint16),
+            rng.integers(0, 65536, (37, 72), dtype=np.uint16),          # width % 4 == 0: the four-pixels-per-lane kernel
+            rng.integers(0, 65536, (2, 4), dtype=np.uint16),
             (util.smooth_depth(50, 41, 2) * 20000 + 20000).clip(0, 65535).astype(np.uint16),
             util.survey_inputs(48, 64, 1)[1][0]]
     for dep in deps:

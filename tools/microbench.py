@@ -31,7 +31,7 @@ def timeit(fn, reps=20, warm=3):
 
 
 def main():
-    which = set(sys.argv[1:]) or {"attention", "head", "rln", "upsample", "stereo"}
+    which = set(sys.argv[1:]) or {"attention", "head", "rln", "upsample", "stereo", "normalmap", "readout"}
     B = 32
     dev = torch.device("cuda")
     if "attention" in which:
@@ -84,5 +84,26 @@ def main():
         print(f"create_stereoimages_batch polylines_sharp x{B} (1024^2): {ms:.3f} ms  {B / ms * 1e3:.0f} pairs/s")
 
 
+def extra(which):
+    B = 32
+    dev = torch.device("cuda")
+    if "normalmap" in which:
+        import numpy as np
+        import src.normalmap_generation as nmg
+        d16 = torch.from_numpy(np.random.default_rng(0).integers(0, 65536, (B, 1024, 1024), dtype=np.uint16)).to(dev)
+        ms = timeit(lambda: nmg.create_normalmap_batch(d16))
+        print(f"create_normalmap_batch x{B} (1024^2): {ms * 1e3:.1f} us  {5 * d16.numel() / ms / 1e6:.0f} GB/s")
+    if "readout" in which:
+        proj = torch.randn(B, 1025, 1024, device=dev, dtype=torch.float16)
+        cls = torch.randn(B, 1024, device=dev, dtype=torch.float16)
+        ms = timeit(lambda: nat.reassemble_readout(proj, cls))
+        print(f"reassemble_readout {B}x1025x1024: {ms * 1e3:.1f} us  {2 * proj.numel() * 2 / ms / 1e6:.0f} GB/s")
+        x = torch.randn(B, 256, 128, 128, device=dev, dtype=torch.float16).contiguous(memory_format=torch.channels_last)
+        bias = torch.randn(256, device=dev, dtype=torch.float16)
+        ms = timeit(lambda: nat.bias_act(x, bias, relu=True, res1=x, inplace=False))
+        print(f"bias_act {B}x256x128x128 (+residual, relu): {ms * 1e3:.1f} us  {3 * x.numel() * 2 / ms / 1e6:.0f} GB/s")
+
+
 if __name__ == "__main__":
     main()
+    extra(set(sys.argv[1:]) or {"normalmap", "readout"})
