@@ -445,8 +445,8 @@ def run_c4(args):
     contiguous run of patch chunks, ONE gather, the blend on rank 0), then depth -> uint16 -> stereo pair + normal map on
     rank 0.  One step = one image; strong scaling (the image is the fixed total work)."""
     global H, W
-    # float32 ResNeXt / U-Net convolutions at a dozen shapes: MIOpen's exhaustive search costs minutes on a fresh box
-    os.environ.setdefault("MIOPEN_FIND_MODE", "FAST")
+    # (float32 ResNeXt / U-Net convolutions at a dozen shapes: on a fresh box MIOpen's search makes the priming pass take
+    # minutes; MIOPEN_FIND_MODE=FAST shortens it but picks slower kernels -- 4.5 s instead of 2.4 s per image at r_max 3000)
     import torch
     import torch.distributed as dist
     H, W = args.height or 2160, args.width or 3840
