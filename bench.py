@@ -30,6 +30,7 @@ collective) and the collated stereo pairs are gathered to rank 0 with ONE RCCL g
 step's kernels (--no-gather to leave it out).  Rank 0 prints ONE JSON line.
 """
 import argparse
+import contextlib
 import json
 import os
 import sys
@@ -204,6 +205,7 @@ def main():
     ap.add_argument("--net-size", type=int, default=None, help="network input size (default: the model's; 0 = NET_SIZE_MATCH)")
     ap.add_argument("--fill", default="polylines_sharp")
     ap.add_argument("--no-normalmap", action="store_true", help="leave the normal map out of the step (round-1 workload)")
+    ap.add_argument("--no-overlap", action="store_true", help="run the per-pixel kernels on the network's stream (no cross-step overlap)")
     ap.add_argument("--no-gather", action="store_true", help="N > 1: do not gather the collated outputs to rank 0")
     ap.add_argument("--funnel", action="store_true", help="also time the drop-in funnel (PIL in -> PIL out) on the same batch")
     ap.add_argument("--depth", default="steps", choices=["steps", "smooth"],
@@ -236,6 +238,8 @@ def main():
 
     import torch
     import torch.distributed as dist
+    if os.environ.get("DS_CUDNN_BENCHMARK"):                  # A/B switch: let MIOpen time its solvers per convolution shape
+        torch.backends.cudnn.benchmark = True
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -287,6 +291,11 @@ def main():
     if gather_ok and rank == 0:
         gathered = [torch.empty((batch, H, 2 * W, 3), dtype=torch.uint8, device=dev) for _ in range(world)]
 
+    # The per-pixel kernels (float64 VALU / LDS bound) of step k run on their own stream beside the network forward of step
+    # k+1 (MFMA bound): the units of every step are complete inside the timed region, the two halves of the path just overlap
+    # across steps like the funnel overlaps its groups.  --no-overlap keeps everything on one stream.
+    post = torch.cuda.Stream(device=dev) if (model is not None and not args.no_overlap) else None
+
     def step(check=False):
         if model is not None:
             pred = run_forward(model, model_name, img, net_size, net_h)
@@ -295,16 +304,22 @@ def main():
         if check:                                            # outside the timed region: every unit's prediction varies
             lo, hi = pred.flatten(1).min(1).values, pred.flatten(1).max(1).values
             assert bool((hi > lo).all()), "degenerate (constant) depth prediction: the stereo leg would be meaningless"
-        d16 = nat.depth_to_u16(pred, False)
-        sbs = sg.create_stereoimages_batch(img, d16, 2.5, 0.0, ['left-right'], 0.0, 1.0, args.fill)[0]
-        nmap = nmg.create_normalmap_batch(d16) if normalmap else None
-        if gather_ok:
-            ev = torch.cuda.Event()
-            ev.record()
-            with torch.cuda.stream(side):
-                side.wait_event(ev)
-                dist.gather(sbs, gathered if rank == 0 else None, dst=0)
-                sbs.record_stream(side)
+        if post is not None:
+            ready = torch.cuda.Event()
+            ready.record()
+            post.wait_event(ready)
+            pred.record_stream(post)
+        with torch.cuda.stream(post) if post is not None else contextlib.nullcontext():
+            d16 = nat.depth_to_u16(pred, False)
+            sbs = sg.create_stereoimages_batch(img, d16, 2.5, 0.0, ['left-right'], 0.0, 1.0, args.fill)[0]
+            nmap = nmg.create_normalmap_batch(d16) if normalmap else None
+            if gather_ok:
+                ev = torch.cuda.Event()
+                ev.record()
+                with torch.cuda.stream(side):
+                    side.wait_event(ev)
+                    dist.gather(sbs, gathered if rank == 0 else None, dst=0)
+                    sbs.record_stream(side)
         return sbs, nmap, d16
 
     step(check=True)            # priming pass, never timed: library kernel selection (MIOpen find), bias operands, allocator
@@ -329,6 +344,7 @@ def main():
     render_ms, exact_ms, nm_ms = [], [], []
     for _ in range(min(args.steps, 5)):
         _, _, d16 = step()
+        torch.cuda.synchronize()
         r, e = nat.profile_last_ms(local_rank)
         render_ms.append(r)
         exact_ms.append(e)
@@ -413,6 +429,7 @@ def main():
                        "depth_network": model_name, "units_per_step": batch * world, "height": H, "width": W,
                        "network_precision_vs_reference": "fp16 = the reference's GPU default; held to 2e-2 of its float32 output "
                                                          "(float32 path: 1e-4), tests/test_gpu_models.py",
+                       "overlap": "per-pixel kernels of step k on a second stream beside the forward of step k+1" if post is not None else "single stream",
                        "parallelism": f"units sharded over {world} GPU(s), no data-path collective"
                                       + (", ONE RCCL gather of the stereo pairs to rank 0 per step, overlapped" if gather_ok else "")},
             # the dominant hand-written kernel of the step: the fused attention when a network runs, else the stereo kernel

@@ -814,15 +814,15 @@ __host__ __device__ inline PlGenLds pl_gen_layout(int ncmax, int np)
     return G;
 }
 
-// normalised depth of ONE column, same expressions as pl_load_nd
-__device__ __forceinline__ double pl_nd_one(const PolyParams &P, const void *depth_row, int j, double mn, double mx, const double *lut)
+// normalised depth of ONE column, same expressions as pl_load_nd; y = 1 / (max - min) of the uint16 path is computed once
+// per pixel by the caller
+__device__ __forceinline__ double pl_nd_one(const PolyParams &P, const void *depth_row, int j, double mn, double mx, const double *lut,
+                                            double b, double y)
 {
     if (P.depth_dtype == DS_DEPTH_U16) {
         const uint32_t v = ((const uint16_t *)depth_row)[j];
         if (lut != nullptr) return lut[v];
         const uint32_t mn16 = (uint32_t)mn & 0xffffu;
-        const double b = (double)(((uint32_t)mx - mn16) & 0xffffu);
-        const double y = 1.0 / b;
         const double a = (double)((v - mn16) & 0xffffu);
         const double q0 = a * y;
         return fma(fma(-b, q0, a), y, q0);
@@ -871,13 +871,14 @@ __global__ __launch_bounds__(64) void k_polylines_general(PolyParams P, int ncma
         const int ncols = have ? j1 - j0 + 1 : 1;
         const bool head = j0 == 0, tail = j1 == w - 1;
         __syncthreads();                                    // the previous pixel's window is no longer read
+        const double b16 = (double)(((uint32_t)mx - ((uint32_t)mn & 0xffffu)) & 0xffffu), y16 = 1.0 / b16;   // uint16 path only
         if (have) {
             for (int i = u - 1; i < ncols; i += 8) {        // i = -1: the column before the window (point 0, colour -1)
                 const int j = j0 + i;
                 double nd = 0.0;
                 uint32_t px = 0;
                 if (j >= 0) {
-                    nd = pl_nd_one(P, depth_row, j, mn, mx, lut);
+                    nd = pl_nd_one(P, depth_row, j, mn, mx, lut, b16, y16);
 #pragma unroll
                     for (int k = 0; k < C; k++) px |= (uint32_t)src_row[(size_t)j * C + k] << (8 * k);
                 }
