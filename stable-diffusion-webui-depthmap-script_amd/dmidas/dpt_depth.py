@@ -164,6 +164,18 @@ class DPTDepthModel(DPT):
     def forward(self, x, features=None):
         return super().forward(x, features).squeeze(dim=1)
 
+    @staticmethod
+    def preprocess(images_u8, net_size=512, net_h=None, resize_mode="minimal", mean=0.5, std=0.5):
+        """The transform chain of estimatemidas (src/depthmap_generation.py:457-476: Resize(keep_aspect_ratio, multiple of 32,
+        INTER_CUBIC) -> NormalizeImage -> PrepareForNet) after get_raw_prediction's channel swap and /255 (:381), as tensor ops:
+        uint8 [B,H,W,3] (RGB) -> float32 [B,3,nh,nw].  Pinned against the reference's own transform classes run with a numpy
+        stand-in for cv2.resize (tests/golden/make_golden_transforms.py); cv2's arithmetic itself stays unpinned."""
+        b, h, w, _ = images_u8.shape
+        nw, nh = midas_net_size(w, h, int(net_size), int(net_size if net_h is None else net_h), resize_mode)
+        x = images_u8.flip(-1).permute(0, 3, 1, 2).float() / 255.0
+        x = F.interpolate(x, size=(nh, nw), mode="bicubic", align_corners=False)
+        return (x - mean) / std
+
     # ---- device-resident pre/post of estimatemidas (src/depthmap_generation.py:455-499; SURVEY.md 8f-1) ------------------
     @torch.no_grad()
     def infer_batch(self, images_u8, net_size=512, resize_mode="minimal", mean=0.5, std=0.5, net_h=None):
@@ -174,10 +186,7 @@ class DPTDepthModel(DPT):
         order -- reproduced.  cv2.INTER_CUBIC resize -> torch bicubic (same kernel a=-0.75, half-pixel centres; cv2 is
         not available here: unpinned); prediction upsampled with torch bicubic align_corners=False exactly as :484-489."""
         b, h, w, _ = images_u8.shape
-        nw, nh = midas_net_size(w, h, int(net_size), int(net_size if net_h is None else net_h), resize_mode)
-        x = images_u8.flip(-1).permute(0, 3, 1, 2).float() / 255.0
-        x = F.interpolate(x, size=(nh, nw), mode="bicubic", align_corners=False)
-        x = (x - mean) / std
+        x = self.preprocess(images_u8, net_size, net_h, resize_mode, mean, std)
         dtype = self.scratch.layer1_rn.weight.dtype
         x = x.to(dtype)
         if x.is_cuda:

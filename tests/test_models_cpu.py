@@ -370,3 +370,19 @@ def test_float32_attention_is_tiled_and_large_bias_is_not_kept_dense(monkeypatch
     monkeypatch.setattr(vm, "SCORE_BYTES_MAX", 2 * 2 * 64 * 4 * 7)            # 7 query rows per tile
     assert torch.equal(vm.attention_reference(qk, vt, 31, 0.125, lazy)[:, :31], want[:, :31])
     assert torch.equal(vm.attention_reference(qk, vt, 31, 0.125, dense)[:, :31], want[:, :31])
+
+
+def test_dpt_preprocess_matches_reference_transform_chain():
+    """DPTDepthModel.preprocess (device-side stand-in for estimatemidas' transform chain) against the reference's own
+    Resize / NormalizeImage / PrepareForNet classes run on the same pixels (tests/golden/make_golden_transforms.py: cv2.resize
+    replaced by the numpy restatement of its cubic kernel): size rule, channel order (BGR reaches the network), scaling,
+    normalisation, layout.  5e-5 (measured 1.3e-5): float32 torch bicubic against the float64 numpy kernel."""
+    import os
+    import make_golden_transforms as mgt
+    from dmidas.dpt_depth import DPTDepthModel
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "transform_cases.npz"))
+    for name, h, w, nw, nh, method, seed in mgt.CASES:
+        x = DPTDepthModel.preprocess(torch.from_numpy(mgt.image(h, w, seed))[None], nw, nh, method, 0.5, 0.5)[0].numpy()
+        want = z[name]
+        assert x.shape == want.shape and x.dtype == want.dtype, (name, x.shape, want.shape)
+        assert np.abs(x - want).max() < 5e-5, (name, float(np.abs(x - want).max()))
