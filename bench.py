@@ -207,6 +207,8 @@ def main():
     ap.add_argument("--no-normalmap", action="store_true", help="leave the normal map out of the step (round-1 workload)")
     ap.add_argument("--overlap", action="store_true", help="run the per-pixel kernels of step k on a second stream beside the forward of "
                                                          "step k+1 (measured: +0.5 %, inside the run-to-run noise; off by default)")
+    ap.add_argument("--graph", action="store_true", help="replay the network forward as a hipGraph (default for the batch-1 config c2)")
+    ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-gather", action="store_true", help="N > 1: do not gather the collated outputs to rank 0")
     ap.add_argument("--funnel", action="store_true", help="also time the drop-in funnel (PIL in -> PIL out) on the same batch")
     ap.add_argument("--depth", default="steps", choices=["steps", "smooth"],
@@ -296,9 +298,16 @@ def main():
     # of step k+1 (MFMA bound); the units of every step are still complete inside the timed region.  Default: one stream.
     post = torch.cuda.Stream(device=dev) if (model is not None and args.overlap) else None
 
+    # launch-bound shapes (batch 1): the forward's ~600 launches are captured once into a hipGraph and replayed
+    use_graph = model is not None and (args.graph or (args.config == "c2" and not args.no_graph))
+    fwd = None
+    if use_graph:
+        from src.hip_graph import GraphedForward
+        fwd = GraphedForward(lambda x: run_forward(model, model_name, x, net_size, net_h))
+
     def step(check=False):
         if model is not None:
-            pred = run_forward(model, model_name, img, net_size, net_h)
+            pred = fwd(img) if fwd is not None else run_forward(model, model_name, img, net_size, net_h)
         else:
             pred = pred_in
         if check:                                            # outside the timed region: every unit's prediction varies
@@ -429,6 +438,7 @@ def main():
                        "depth_network": model_name, "units_per_step": batch * world, "height": H, "width": W,
                        "network_precision_vs_reference": "fp16 = the reference's GPU default; held to 2e-2 of its float32 output "
                                                          "(float32 path: 1e-4), tests/test_gpu_models.py",
+                       "forward_launch": ("hipGraph replay" if (fwd is not None and fwd.graphs) else "eager"),
                        "overlap": "per-pixel kernels of step k on a second stream beside the forward of step k+1" if post is not None else "single stream",
                        "parallelism": f"units sharded over {world} GPU(s), no data-path collective"
                                       + (", ONE RCCL gather of the stereo pairs to rank 0 per step, overlapped" if gather_ok else "")},

@@ -524,3 +524,26 @@ def test_bias_act_kernel_and_residual_conv_unit(gpu, dtype, tol):
         got_s = vm.residual_conv_unit(c1h, c2h, xh, skip=skip.to(dtype)).float()
     assert (got - ref).abs().max().item() < 6 * tol * (1 + ref.abs().max().item())
     assert (got_s - (ref + skip)).abs().max().item() < 6 * tol * (1 + ref.abs().max().item())
+
+
+def test_hip_graph_replay_equals_eager_forward(gpu):
+    """src/hip_graph.GraphedForward: the captured-and-replayed forward (fused attention, residual+LN, read-out, decoder tails,
+    head tail and the library kernels inside one hipGraph) returns what the eager forward returns, for new inputs too, and a
+    second shape gets its own graph; through ModelHolder's `hip_graphs` setting as well."""
+    from ddepth_anything_v2 import DepthAnythingV2
+    from dmidas.dpt_depth import DPTDepthModel
+    from src.hip_graph import GraphedForward
+    torch.manual_seed(0)
+    g = torch.Generator().manual_seed(4)
+    for net, call in ((DepthAnythingV2('vits', features=64, out_channels=[48, 96, 192, 384]).eval().cuda().half(),
+                       lambda m, x: m.infer_batch(x, 70)),
+                      (DPTDepthModel(path=None, backbone="vitb_rn50_384", non_negative=True).eval().cuda().half(),
+                       lambda m, x: m.infer_batch(x, net_size=128, net_h=96))):
+        gf = GraphedForward(lambda x, net=net, call=call: call(net, x))
+        for shape in ((1, 96, 128, 3), (1, 96, 128, 3), (2, 64, 96, 3), (1, 96, 128, 3)):
+            x = torch.randint(0, 256, shape, generator=g, dtype=torch.uint8).cuda()
+            want = call(net, x)
+            got = gf(x)
+            assert got.shape == want.shape and torch.isfinite(got).all()
+            assert (got - want).abs().max().item() <= 1e-3 * (1 + want.abs().max().item()), shape
+        assert len(gf.graphs) == 2 and not gf.failed
