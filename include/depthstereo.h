@@ -229,6 +229,18 @@ int ds_bias_act_nhwc(ds_ctx *ctx, const void *x, const void *bias, const void *r
                      int64_t elements, int channels, int relu, int dtype, void *stream);
 
 /*
+ * ds_linear -- y = act(x . W^T + bias), the token GEMMs of the ViT encoders with the epilogue fused (csrc/ds_linear.hip):
+ * `fc1 -> nn.GELU` of the encoder MLP (timm Mlp as run by dmidas/backbones/beit.py:93-107; ddepth_anything_v2/
+ * depth_anything_v2/dinov2_layers/mlp.py:33-39) is ONE kernel (act = 1: erf-GELU evaluated on the fp32 accumulator, see
+ * ln_gelu for the error bound), and act = 0 is a plain Linear (fc2, proj, qkv).
+ * x [rows, in_features], W [out_features, in_features] (torch.nn.Linear layout), bias [out_features] or NULL,
+ * y [rows, ldy] (ldy >= out_features, in elements).  f16/bf16, fp32 accumulation.  out_features % 256 == 0,
+ * in_features % 128 == 0; rows is free (the ragged last row panel is masked).  256 x 256 tiles on the MFMA units.
+ */
+int ds_linear(ds_ctx *ctx, const void *x, const void *w, const void *bias, void *y, int64_t rows, int64_t out_features,
+              int64_t in_features, int64_t ldy, int act, int dtype, void *stream);
+
+/*
  * ds_upsample_bilinear_nhwc -- torch.nn.functional.interpolate(x, size, mode="bilinear", align_corners) for channels_last
  * activations: the x2 upsamples of the DPT decoders (dmidas/blocks.py:429-431; ddepth_anything_v2/.../util/blocks.py:141-145;
  * the heads' Interpolate, dmidas/dpt_depth.py:151, dpt.py:146).  in [batch, in_h, in_w, channels], out [batch, out_h, out_w,

@@ -14,7 +14,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libdepthstereo_hip.so")
-SOURCES = ["ds_api.hip", "ds_stereo.hip", "ds_stereo_polylines.hip", "ds_normalmap.hip", "ds_attention.hip", "ds_encoder_ops.hip", "ds_boost.hip", "ds_heatmap.hip"]
+SOURCES = ["ds_api.hip", "ds_stereo.hip", "ds_stereo_polylines.hip", "ds_normalmap.hip", "ds_attention.hip", "ds_encoder_ops.hip", "ds_boost.hip", "ds_heatmap.hip", "ds_linear.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-fPIC",
          "-fvisibility=hidden", "-Wall", "-Wno-unused-function",
          # MFMA results land in ordinary VGPRs (gfx950 has one unified file): no v_accvgpr_read/write around the softmax

@@ -340,10 +340,11 @@ __device__ __forceinline__ float at_max3(float a, float b, float c)
 // Bits 256 and up are OPTIONS with correct results (DS_ATT_OPT, A/B experiments):
 //   256 s_setprio around the MFMA clusters   512 the bias MFMAs interleaved over the four accumulators (no back-to-back
 //   dependent pair)   1024 row sums from the ROUNDED probabilities, two per v_dot2 (f16)   2048 every other workgroup starts
-//   half a tile late (two waves of one SIMD otherwise run the same phase at the same time)
+//   half a tile late (two waves of one SIMD otherwise run the same phase at the same time)   4096 (NQB = 1) late fetches --
+//   the bias of a tile is requested at the top of that tile, K / V^T of the next one after S -- to fit 128 VGPRs: 4 waves/SIMD
 // NQB = 32-row query blocks per wave: 2 (64 rows, <= 256 VGPRs, two waves per SIMD) or 1 (32 rows, four waves per SIMD).
 template <int BF16, int HAS_BIAS, int NQB, int ABL>
-__global__ __launch_bounds__(AT_THREADS, NQB == 2 ? 2 : 3) void k_attention_fwd2(AttnParams P)
+__global__ __launch_bounds__(AT_THREADS, NQB == 2 ? 2 : ((ABL & 4096) ? 4 : 3)) void k_attention_fwd2(AttnParams P)
 {
     typedef at_traits<BF16> TR;
     typedef typename TR::T T;
@@ -446,7 +447,7 @@ __global__ __launch_bounds__(AT_THREADS, NQB == 2 ? 2 : 3) void k_attention_fwd2
     const float c_ = P.c_exp;                                   // scale * log2(e): the bias is stored in units of 1/scale
     const float thr_x = AT2_THR / c_;
     A2_FETCH(0);
-    if (HAS_BIAS && wave_live) A2_FETCH_BIAS(0);
+    if (HAS_BIAS && wave_live && !(ABL & 4096)) A2_FETCH_BIAS(0);
     A2_STASH1(0, st_row, kreg0, vreg0);
     A2_STASH1(0, st_row + 32, kreg1, vreg1);
     __syncthreads();
@@ -460,7 +461,8 @@ __global__ __launch_bounds__(AT_THREADS, NQB == 2 ? 2 : 3) void k_attention_fwd2
         // next tile's K / V^T: in flight while this tile is computed.  The staggered variant requests them after its first
         // mixed region, where the register pressure peaks (the remaining three regions still cover an L2 round trip)
         constexpr int abl = ABL;
-        if (more && !(abl & 2)) A2_FETCH(kt + 1);
+        if (more && !(abl & 2) && (!(abl & 4096) || !wave_live)) A2_FETCH(kt + 1);
+        if (HAS_BIAS && (abl & 4096) && wave_live) A2_FETCH_BIAS(kt);
         if (wave_live) {
             const int key0 = kt * AT_KB;
             f32x16 s_acc[2][2];
@@ -566,7 +568,8 @@ __global__ __launch_bounds__(AT_THREADS, NQB == 2 ? 2 : 3) void k_attention_fwd2
                 }
                 if (abl & 256) __builtin_amdgcn_s_setprio(0);
                 // the bias registers are free: next tile's fragments land under the softmax / P.V of this one
-                if (HAS_BIAS && more && !(abl & 2)) A2_FETCH_BIAS(kt + 1);
+                if (HAS_BIAS && more && !(abl & 2) && !(abl & 4096)) A2_FETCH_BIAS(kt + 1);
+                if ((abl & 4096) && more) A2_FETCH(kt + 1);
                 A2_MASK(0);
                 if (NQB == 2) A2_MASK(1);
                 if (abl & 1) {
@@ -738,6 +741,7 @@ DS_API int ds_attention_fwd(ds_ctx *ctx, const void *qk, const void *vt, const v
         static const int ablate = (getenv("DS_ATT_ABLATE") ? atoi(getenv("DS_ATT_ABLATE")) : 0)    // timing experiments, wrong results
                                   | (getenv("DS_ATT_OPT") ? atoi(getenv("DS_ATT_OPT")) : 0);        // options, correct results
         P.flags = ablate;
+        static const int late = getenv("DS_ATT_LATE") ? atoi(getenv("DS_ATT_LATE")) : 0;             // A/B switch, see option 4096
 #define A2_ABL(BI_, M_) case M_: hipLaunchKernelGGL((k_attention_fwd2<0, BI_, 2, M_>), grid2, dim3(AT_THREADS), 0, st2, P); break;
 #define A2_LAUNCH(BF_, BI_) do {                                                                                       \
             if (ablate && BF_ == 0 && nqb == 2) {                                                                       \
@@ -747,6 +751,7 @@ DS_API int ds_attention_fwd(ds_ctx *ctx, const void *qk, const void *vt, const v
                 default: ds_set_error("ds_attention_fwd: DS_ATT_ABLATE/OPT=%d is not an instantiated mask", ablate); return DS_EINVAL; \
                 }                                                                                                       \
             }                                                                                                           \
+            else if (nqb == 1 && late) hipLaunchKernelGGL((k_attention_fwd2<BF_, BI_, 1, 256 + 4096>), grid2, dim3(AT_THREADS), 0, st2, P); \
             else if (nqb == 1) hipLaunchKernelGGL((k_attention_fwd2<BF_, BI_, 1, 256>), grid2, dim3(AT_THREADS), 0, st2, P); \
             else hipLaunchKernelGGL((k_attention_fwd2<BF_, BI_, 2, 256>), grid2, dim3(AT_THREADS), 0, st2, P);          \
         } while (0)

@@ -1,0 +1,327 @@
+// ds_linear: y = act(x . W^T + b) for the token GEMMs of the ViT encoders (fc1 + GELU, fc2, proj, qkv) as ONE in-tree
+// MFMA kernel with the epilogue fused, instead of a library GEMM followed by an element-wise pass.
+//
+// Replaces, per encoder block of the reference: `self.fc1 -> self.act (nn.GELU)` of timm's Mlp as called from
+// dmidas/backbones/beit.py:93-107 (block_forward) and ddepth_anything_v2/depth_anything_v2/dinov2_layers/mlp.py:33-39.
+//
+// Shape of the problem on an MI355X: x is [M, K] (M = batch x padded tokens, 34 816 at the benchmark), W is [N, K]
+// (torch Linear layout: both operands K-contiguous, i.e. the "NT" GEMM whose MFMA fragments are plain 16-byte reads).
+//
+// Structure (one workgroup = one 256 x 256 tile of y, 8 waves as 2 (rows) x 4 (columns), wave tile 128 x 64):
+//   * K is walked in tiles of 64.  A K-tile of x and of W is kept in LDS as FOUR half-tiles of 128 rows x 64 k (16 KB):
+//     A0/A1 = the first/second 64 rows of every wave-row's 128, B0/B1 = the first/second 32 columns of every
+//     wave-column's 64 -- the halves follow the QUADRANTS of the wave tile, so a half-tile is read in exactly one of the
+//     four phases of a K-tile and can be re-staged two phases later.  Two K-tiles are resident (128 KB of the 160 KB).
+//   * staging is LDS-DMA (`global_load_lds_dwordx4`): no staging registers, no ds_write pass.  The DMA writes
+//     lane-linear, so the bank swizzle is applied to the per-lane SOURCE address and undone by the same XOR on the
+//     fragment read (16-byte slot ^= (row >> 1) & 7 inside a 128-byte row: a 16-lane group of a ds_read_b128 then covers
+//     all 16 slots of the 256-byte bank row; the XOR stays inside one 128-byte line, so global coalescing is intact).
+//   * the K loop is 8 phases per two K-tiles.  Each phase = {fragment reads of ONE half-tile, DMA issue of ONE
+//     half-tile, counted vmcnt} barrier {8 MFMA 32x32x16 on one quadrant} barrier.  The two wave-rows run staggered
+//     by one barrier, so at any time one wave of a SIMD is in its MFMA part while the other one is in its memory part.
+//     A half-tile is staged 6 phases before it is read; `s_waitcnt vmcnt(10)` (5 half-tiles stay in flight) never
+//     drains the queue.  Hazards (both directions) are argued next to the schedule table below.
+//   * operands go into the MFMA swapped (W fragment as "A", x fragment as "B"), so an accumulator register holds 4
+//     consecutive output COLUMNS of one row: the epilogue adds the bias, applies the activation in fp32 on the
+//     accumulator (not on a rounded half) and stores 8 bytes per lane and register group.
+//
+// Workgroup -> tile mapping is XCD-aware: the eight XCDs take contiguous ranges of the tile list (column index
+// fastest), so the 32 workgroups resident on one XCD share two row panels of x and sweep W together through that L2.
+#include "ds_common.h"
+
+#include <type_traits>
+
+typedef _Float16 lf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 lbf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 lf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 lbf16x4 __attribute__((ext_vector_type(4)));
+typedef float lf32x16 __attribute__((ext_vector_type(16)));
+
+#define LN_THREADS 512
+#define LN_LDS_BYTES 131072
+#define LN_HALF 16384            // one half-tile: 128 rows x 64 k x 2 B
+#define LN_B_BASE 65536          // LDS map: A0[2] | A1[2] | B0[2] | B1[2], 16 KB each
+
+template <int BF16> struct ln_traits;
+template <> struct ln_traits<0> {
+    typedef _Float16 T; typedef lf16x8 V8; typedef lf16x4 V4;
+    static __device__ __forceinline__ lf32x16 mfma(V8 a, V8 b, lf32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
+};
+template <> struct ln_traits<1> {
+    typedef __bf16 T; typedef lbf16x8 V8; typedef lbf16x4 V4;
+    static __device__ __forceinline__ lf32x16 mfma(V8 a, V8 b, lf32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+};
+
+struct LinParams {
+    const void *x, *w, *bias;
+    void *y;
+    int M, N, K;
+    int nbm, nbn;
+    long long ldy;          // row stride of y in elements
+};
+
+// erf-GELU on the fp32 accumulator.  GELU(v) = v Phi(v) = max(v, 0) - |v| Phi(-|v|), and Phi(-u) = 2^-Q(u) with
+// Q(u) = -log2 Phi(-u), a smooth, nearly quadratic function: a degree-7 polynomial on [0, 6] (Chebyshev fit, float64,
+// tools/linear_model.py prints the error) gives |GELU - exact| <= 6.6e-7 absolute and <= 5.2e-6 relative for |v| < 5.5;
+// beyond u = 6 the argument is clamped (Phi(-6) = 1e-9: |error| < 7e-9).  One transcendental (v_exp_f32) and 10 plain
+// VALU operations per element instead of libm erff's ~40 with a divergent branch: the epilogue of a 256 x 256 tile is
+// 128 elements per lane and sits on the critical path of a workgroup that owns its CU alone.
+__device__ __forceinline__ float ln_gelu(float v)
+{
+    const float u = fminf(fabsf(v), 6.0f);
+    float q = 1.8896206483987044e-06f;
+    q = __builtin_fmaf(q, u, -6.268127617659047e-05f);
+    q = __builtin_fmaf(q, u, 0.000938866869546473f);
+    q = __builtin_fmaf(q, u, -0.008539456874132156f);
+    q = __builtin_fmaf(q, u, 0.054020676761865616f);
+    q = __builtin_fmaf(q, u, 0.45840978622436523f);
+    q = __builtin_fmaf(q, u, 1.1512691974639893f);
+    q = __builtin_fmaf(q, u, 0.9999943375587463f);
+    const float h = __builtin_amdgcn_exp2f(-q);
+    return __builtin_fmaf(-u, h, fmaxf(v, 0.0f));
+}
+
+#define LN_WAIT_VM(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
+#define LN_WAIT_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+#define LN_BARRIER()                              \
+    do {                                          \
+        __builtin_amdgcn_sched_barrier(0);        \
+        __builtin_amdgcn_s_barrier();             \
+        __builtin_amdgcn_sched_barrier(0);        \
+    } while (0)
+
+template <int BF16, int EPI>
+__global__ __launch_bounds__(LN_THREADS) void k_linear256(LinParams P)
+{
+    typedef ln_traits<BF16> TR;
+    typedef typename TR::T T;
+    typedef typename TR::V8 V8;
+    typedef typename TR::V4 V4;
+    extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wid >> 2, wc = wid & 3;
+
+    // ---- XCD-aware tile choice: XCD x takes tiles [start(x), start(x+1)) of the column-fastest tile list ------------
+    const int nwg = P.nbm * P.nbn;
+    const int orig = blockIdx.x;
+    const int xcd = orig & 7, q8 = nwg >> 3, r8 = nwg & 7;
+    const int tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (orig >> 3);
+    const int bm0 = (tile / P.nbn) * 256, bn0 = (tile % P.nbn) * 256;
+    const int K = P.K;
+    const unsigned char *xb = (const unsigned char *)P.x + (size_t)bm0 * K * sizeof(T);
+    const unsigned char *wb = (const unsigned char *)P.w + (size_t)bn0 * K * sizeof(T);
+
+    // ---- staging: this thread's two 16-byte pieces of a half-tile (chunk c = 2*wave + i = LDS rows 8c .. 8c+7) -------
+    // LDS row j = 8c + (lane >> 3), LDS slot = lane & 7 holds SOURCE slot (lane & 7) ^ ((j >> 1) & 7).
+    unsigned srcA[2][2], srcB[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int c = 2 * wid + i;
+        const int j = 8 * c + (lane >> 3);
+        const int slot = (lane & 7) ^ ((j >> 1) & 7);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            int row = (j >> 6) * 128 + h * 64 + (j & 63);                   // A half h: wave-row j>>6, row j&63 of its 64
+            row = min(row, P.M - 1 - bm0);                                  // ragged last row panel: re-read the last row
+            srcA[h][i] = (unsigned)row * (unsigned)K * (unsigned)sizeof(T) + slot * 16;
+        }
+        const int col = (j >> 5) * 64 + (j & 31);                           // B half h adds 32 columns (uniform)
+        srcB[i] = (unsigned)col * (unsigned)K * (unsigned)sizeof(T) + slot * 16;
+    }
+    const unsigned b_half = 32u * (unsigned)K * (unsigned)sizeof(T);
+    const unsigned lds_stage = (unsigned)(2 * wid) * 1024u;                 // wave-uniform LDS offset of chunk 2*wave
+
+    // kind: 0 A0, 1 A1, 2 B0, 3 B1; kt = K-tile; s = LDS buffer
+#define LN_STAGE(kind, kt, s)                                                                                            \
+    do {                                                                                                                 \
+        const unsigned koff_ = (unsigned)(kt) * 128u;                                                                    \
+        const unsigned dst_ = ((kind) >> 1) * LN_B_BASE + ((kind) & 1) * 2 * LN_HALF + (s) * LN_HALF + lds_stage;        \
+        _Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_) {                                                               \
+            const unsigned char *g_ = ((kind) < 2) ? xb + srcA[(kind) & 1][i_] + koff_                                   \
+                                                   : wb + srcB[i_] + ((kind) & 1) * b_half + koff_;                      \
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g_,                         \
+                                             (__attribute__((address_space(3))) void *)(lds + dst_ + i_ * 1024), 16, 0, 0); \
+        }                                                                                                                \
+    } while (0)
+
+    // ---- fragment reads: lane reads LDS row (lane & 31) of its 32-row block, slot 2*ks + (lane >> 5), swizzled -----------
+    unsigned offA[4], offB[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        const unsigned sl = (unsigned)((2 * ks + (lane >> 5)) ^ ((lane >> 1) & 7)) << 4;
+        offA[ks] = (unsigned)(wr * 64 + (lane & 31)) * 128u + sl;
+        offB[ks] = LN_B_BASE + (unsigned)(wc * 32 + (lane & 31)) * 128u + sl;
+    }
+    V8 fa[2][2][4];      // [half][row block][k step]   x fragments
+    V8 fb[2][4];         // [half][k step]              W fragments
+    lf32x16 acc[2][2][2];  // [x half][row block][W half]
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[a][b][c][r] = 0.f;
+
+#define LN_READ_A(h, s)                                                                                                  \
+    _Pragma("unroll") for (int rb_ = 0; rb_ < 2; ++rb_) _Pragma("unroll") for (int ks_ = 0; ks_ < 4; ++ks_)              \
+        fa[h][rb_][ks_] = *(const V8 *)(lds + offA[ks_] + ((h) * 2 * LN_HALF + (s) * LN_HALF + rb_ * 4096))
+#define LN_READ_B(h, s)                                                                                                  \
+    _Pragma("unroll") for (int ks_ = 0; ks_ < 4; ++ks_)                                                                  \
+        fb[h][ks_] = *(const V8 *)(lds + offB[ks_] + ((h) * 2 * LN_HALF + (s) * LN_HALF))
+#define LN_MMA(ha, hb)                                                                                                   \
+    do {                                                                                                                 \
+        __builtin_amdgcn_s_setprio(1);                                                                                   \
+        _Pragma("unroll") for (int ks_ = 0; ks_ < 4; ++ks_) _Pragma("unroll") for (int rb_ = 0; rb_ < 2; ++rb_)          \
+            acc[ha][rb_][hb] = TR::mfma(fb[hb][ks_], fa[ha][rb_][ks_], acc[ha][rb_][hb]);                                \
+        __builtin_amdgcn_s_setprio(0);                                                                                   \
+    } while (0)
+
+    // ---- schedule ------------------------------------------------------------------------------------------------------
+    // Iteration i covers K-tiles E = 2i (LDS buffer 0) and O = 2i+1 (buffer 1); phase j = 0..7, quadrant j & 3:
+    //   phase  fragment read (this phase's MFMAs need it)    DMA issued                    MFMA quadrant
+    //     0    B0(E)                                          A1(O)      -> buf 1           (A0,B0) of E
+    //     1    B1(E)                                          A0(E+2)    -> buf 0           (A0,B1)
+    //     2    A1(E)                                          B0(E+2)    -> buf 0           (A1,B1)
+    //     3    A0(O)   [one phase early: A0 regs are free]    B1(E+2)    -> buf 0           (A1,B0)
+    //     4    B0(O)                                          A1(E+2)    -> buf 0           (A0,B0) of O
+    //     5    B1(O)                                          A0(O+2)    -> buf 1           (A0,B1)
+    //     6    A1(O)                                          B0(O+2)    -> buf 1           (A1,B1)
+    //     7    A0(E+2)                                        B1(O+2)    -> buf 1           (A1,B0)
+    // Wave-row 1 runs one barrier behind wave-row 0: with barriers b0, b1, ... wave-row 0 has the memory part of
+    // phase p in (b[2p-1], b[2p]) and its MFMAs in (b[2p], b[2p+1]); wave-row 1 has them in (b[2p], b[2p+1]) and
+    // (b[2p+1], b[2p+2]).
+    //   write-after-read: every half-tile is re-staged exactly 2 phases after the phase that read it.  The reads of
+    //     phase p are retired (lgkmcnt(0)) by wave-row 0 before b[2p+1] and by wave-row 1 before b[2p+2]; the first DMA
+    //     of phase p+2 is issued after b[2p+3].
+    //   read-after-write: a half-tile staged in phase s is read in phase s+6.  Every wave ends the memory part of phase
+    //     w with vmcnt(10) after having issued phase w's two loads, i.e. its loads of phases <= w-5 have landed; both
+    //     wave-rows have done so before b[2w+1], and every read of phase w+1 is issued after b[2w+1].
+    const int nt = K >> 6, ni = nt >> 1;
+
+    LN_STAGE(0, 0, 0); LN_STAGE(2, 0, 0); LN_STAGE(3, 0, 0); LN_STAGE(1, 0, 0);
+    LN_STAGE(0, 1, 1); LN_STAGE(2, 1, 1); LN_STAGE(3, 1, 1);
+    LN_WAIT_VM(10);                       // 14 issued: A0, B0 of tile 0 have landed
+    LN_BARRIER();
+    LN_READ_A(0, 0);
+    LN_WAIT_LGKM0();                      // retired here: wave-row 0 re-stages A0 of buffer 0 in its phase 1
+    if (wr == 1) LN_BARRIER();            // the stagger
+
+    auto iteration = [&](const int i, auto last_c) {
+        constexpr bool LAST = decltype(last_c)::value;
+        const int e2 = 2 * i + 2, o2 = 2 * i + 3;
+        // phase 0
+        LN_READ_B(0, 0); LN_STAGE(1, 2 * i + 1, 1); LN_WAIT_VM(10);
+        LN_BARRIER(); LN_WAIT_LGKM0(); LN_MMA(0, 0); LN_BARRIER();
+        // phase 1
+        LN_READ_B(1, 0);
+        if constexpr (!LAST) { LN_STAGE(0, e2, 0); LN_WAIT_VM(10); } else { LN_WAIT_VM(8); }
+        LN_BARRIER(); LN_WAIT_LGKM0(); LN_MMA(0, 1); LN_BARRIER();
+        // phase 2
+        LN_READ_A(1, 0);
+        if constexpr (!LAST) { LN_STAGE(2, e2, 0); LN_WAIT_VM(10); } else { LN_WAIT_VM(6); }
+        LN_BARRIER(); LN_WAIT_LGKM0(); LN_MMA(1, 1); LN_BARRIER();
+        // phase 3
+        LN_READ_A(0, 1);
+        if constexpr (!LAST) { LN_STAGE(3, e2, 0); LN_WAIT_VM(10); } else { LN_WAIT_VM(4); }
+        LN_BARRIER(); LN_WAIT_LGKM0(); LN_MMA(1, 0); LN_BARRIER();
+        // phase 4
+        LN_READ_B(0, 1);
+        if constexpr (!LAST) { LN_STAGE(1, e2, 0); LN_WAIT_VM(10); } else { LN_WAIT_VM(2); }
+        LN_BARRIER(); LN_WAIT_LGKM0(); LN_MMA(0, 0); LN_BARRIER();
+        // phase 5
+        LN_READ_B(1, 1);
+        if constexpr (!LAST) { LN_STAGE(0, o2, 1); LN_WAIT_VM(10); } else { LN_WAIT_VM(0); }
+        LN_BARRIER(); LN_WAIT_LGKM0(); LN_MMA(0, 1); LN_BARRIER();
+        // phase 6
+        LN_READ_A(1, 1);
+        if constexpr (!LAST) { LN_STAGE(2, o2, 1); LN_WAIT_VM(10); }
+        LN_BARRIER(); LN_WAIT_LGKM0(); LN_MMA(1, 1); LN_BARRIER();
+        // phase 7
+        if constexpr (!LAST) { LN_READ_A(0, 0); LN_STAGE(3, o2, 1); LN_WAIT_VM(10); }
+        LN_BARRIER(); LN_WAIT_LGKM0(); LN_MMA(1, 0); LN_BARRIER();
+    };
+    for (int i = 0; i < ni - 1; ++i) iteration(i, std::false_type());
+    iteration(ni - 1, std::true_type());
+    if (wr == 0) LN_BARRIER();            // wave-row 0 arrives at wave-row 1's last barrier
+
+    // ---- epilogue: register r of a 32x32 block = column (r&3) + 8 (r>>2) + 4 (lane>>5), lane & 31 = row ------------------
+    T *yb = (T *)P.y;
+    const T *bias = (const T *)P.bias;
+#pragma unroll
+    for (int hb = 0; hb < 2; ++hb) {
+        const int n0 = bn0 + wc * 64 + hb * 32 + 4 * (lane >> 5);
+        float bv[4][4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            if (bias) {
+                const V4 b4 = *(const V4 *)(bias + n0 + 8 * g);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) bv[g][t] = (float)b4[t];
+            } else {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) bv[g][t] = 0.f;
+            }
+        }
+#pragma unroll
+        for (int ha = 0; ha < 2; ++ha)
+#pragma unroll
+            for (int rb = 0; rb < 2; ++rb) {
+                const int m = bm0 + wr * 128 + ha * 64 + rb * 32 + (lane & 31);
+                if (m < P.M) {
+                    T *yrow = yb + (size_t)m * P.ldy + n0;
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        V4 o;
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) {
+                            float v = acc[ha][rb][hb][4 * g + t] + bv[g][t];
+                            if (EPI == 1) v = ln_gelu(v);
+                            o[t] = (T)v;
+                        }
+                        *(V4 *)(yrow + 8 * g) = o;
+                    }
+                }
+            }
+    }
+}
+
+// ---- C ABI -------------------------------------------------------------------------------------------------------------
+template <int BF16, int EPI>
+static int ln_launch(const LinParams &P, hipStream_t stream)
+{
+    static bool attr_set = false;
+    auto fn = k_linear256<BF16, EPI>;
+    if (!attr_set) {
+        DS_HIP_CHECK(hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, LN_LDS_BYTES));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(fn, dim3(P.nbm * P.nbn), dim3(LN_THREADS), LN_LDS_BYTES, stream, P);
+    DS_HIP_CHECK(hipGetLastError());
+    return DS_OK;
+}
+
+DS_API int ds_linear(ds_ctx *ctx, const void *x, const void *w, const void *bias, void *y, int64_t rows, int64_t out_features,
+                     int64_t in_features, int64_t ldy, int act, int dtype, void *stream)
+{
+    DS_REQUIRE(ctx && x && w && y, DS_EINVAL, "ds_linear: null argument");
+    DS_REQUIRE(rows > 0 && rows < (1ll << 31) - 256, DS_EINVAL, "ds_linear: rows out of range");
+    DS_REQUIRE(out_features > 0 && out_features % 256 == 0, DS_EINVAL, "ds_linear: out_features must be a multiple of 256");
+    DS_REQUIRE(in_features >= 128 && in_features % 128 == 0 && in_features <= 16384, DS_EINVAL,
+               "ds_linear: in_features must be a multiple of 128 (<= 16384)");
+    DS_REQUIRE(ldy >= out_features && ldy % 4 == 0, DS_EINVAL, "ds_linear: ldy must be >= out_features and a multiple of 4");
+    DS_REQUIRE(act == 0 || act == 1, DS_EINVAL, "ds_linear: act must be 0 (none) or 1 (erf-GELU)");
+    DS_REQUIRE(dtype == DS_DTYPE_F16 || dtype == DS_DTYPE_BF16, DS_EINVAL, "ds_linear: dtype must be f16 or bf16");
+    LinParams P;
+    P.x = x; P.w = w; P.bias = bias; P.y = y;
+    P.M = (int)rows; P.N = (int)out_features; P.K = (int)in_features;
+    P.nbm = (int)((rows + 255) / 256); P.nbn = (int)(out_features / 256);
+    P.ldy = ldy;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == DS_DTYPE_F16) return act ? ln_launch<0, 1>(P, st) : ln_launch<0, 0>(P, st);
+    return act ? ln_launch<1, 1>(P, st) : ln_launch<1, 0>(P, st);
+}

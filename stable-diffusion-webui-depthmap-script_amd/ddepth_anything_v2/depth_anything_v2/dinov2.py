@@ -45,7 +45,7 @@ class Block(vm.EncoderBlock):
         return w[:2 * c], b[:2 * c], w[2 * c:], b[2 * c:]
 
     def proj(self, o, b_v=None):
-        return F.linear(o, self.attn.proj.weight, vm.folded_proj_bias(self.attn.proj, b_v))
+        return vm.linear(o, self.attn.proj.weight, vm.folded_proj_bias(self.attn.proj, b_v))
 
     def gammas(self):
         return self.ls1.gamma, self.ls2.gamma

@@ -141,8 +141,8 @@ class DepthAnythingV2(nn.Module):
         nw, nh = lower_bound_size(w, h, input_size)
         x = images_u8.flip(-1).permute(0, 3, 1, 2).float() / 255.0
         x = F.interpolate(x, size=(nh, nw), mode="bicubic", align_corners=False)
-        mean = torch.tensor([0.485, 0.456, 0.406], device=x.device).view(1, 3, 1, 1)
-        std = torch.tensor([0.229, 0.224, 0.225], device=x.device).view(1, 3, 1, 1)
+        mean = vm.device_constant(vm.IMAGENET_MEAN, x.device).view(1, 3, 1, 1)
+        std = vm.device_constant(vm.IMAGENET_STD, x.device).view(1, 3, 1, 1)
         return (x - mean) / std, (h, w)
 
     @torch.no_grad()

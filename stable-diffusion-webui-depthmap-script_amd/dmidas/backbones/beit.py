@@ -86,7 +86,7 @@ class Block(vm.EncoderBlock):
         return w[:2 * c], hit[1], w[2 * c:], self.attn.v_bias
 
     def proj(self, o, b_v=None):
-        return F.linear(o, self.attn.proj.weight, vm.folded_proj_bias(self.attn.proj, b_v))
+        return vm.linear(o, self.attn.proj.weight, vm.folded_proj_bias(self.attn.proj, b_v))
 
     def gammas(self):
         return self.gamma_1, self.gamma_2

@@ -14,6 +14,8 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from src import vit_mi355x as vm
+
 
 def _folded(conv, bn, cache_holder):
     w, b = conv.weight, conv.bias
@@ -212,8 +214,8 @@ class RelDepthModel(nn.Module):
         b, h, w, _ = images_u8.shape
         x = images_u8.permute(0, 3, 1, 2).float() / 255.0
         x = F.interpolate(x, size=(int(net_h), int(net_w)), mode="bilinear", align_corners=False)
-        mean = torch.tensor([0.485, 0.456, 0.406], device=x.device).view(1, 3, 1, 1)
-        std = torch.tensor([0.229, 0.224, 0.225], device=x.device).view(1, 3, 1, 1)
+        mean = vm.device_constant(vm.IMAGENET_MEAN, x.device).view(1, 3, 1, 1)
+        std = vm.device_constant(vm.IMAGENET_STD, x.device).view(1, 3, 1, 1)
         x = ((x - mean) / std).to(self.depth_model.decoder_modules.conv1.weight.dtype)
         pred = self.depth_model(x).float()
         return F.interpolate(pred, size=(h, w), mode="bicubic", align_corners=False)[:, 0]

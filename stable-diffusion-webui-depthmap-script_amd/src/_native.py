@@ -18,7 +18,7 @@ DS_DEPTH_U16, DS_DEPTH_F32, DS_DEPTH_F64 = 0, 1, 2
 FILL_IDS = {"none": 0, "naive": 1, "naive_interpolating": 2, "polylines_soft": 3, "polylines_sharp": 4}
 
 EXPORTS = [
-    "ds_version", "ds_last_error", "ds_normalmap_f64", "ds_reassemble_readout", "ds_bias_act_nhwc", "ds_ctx_create", "ds_ctx_destroy", "ds_stereo_warp", "ds_depth_minmax",
+    "ds_version", "ds_last_error", "ds_normalmap_f64", "ds_reassemble_readout", "ds_bias_act_nhwc", "ds_linear", "ds_ctx_create", "ds_ctx_destroy", "ds_stereo_warp", "ds_depth_minmax",
     "ds_stereo_last_exact_rows", "ds_copy_view", "ds_overlap_red_cyan", "ds_normalmap", "ds_depth_to_u16",
     "ds_convert_to_i16", "ds_profile_enable", "ds_profile_last_ms", "ds_stereo_last_stats", "ds_attention_fwd", "ds_attention_bias_pack", "ds_colorize_u16", "ds_residual_layernorm", "ds_boost_blend", "ds_upsample_bilinear_nhwc", "ds_dpt_head_tail",
 ]
@@ -71,6 +71,7 @@ def lib():
             L.ds_dpt_head_tail.argtypes = [vp, vp, ci, ci, ci, ci, ci, vp, vp, vp, ctypes.c_float, ci, vp, ci, vp]
             L.ds_reassemble_readout.argtypes = [vp, vp, vp, vp, ci, ci, ci, ci, vp]
             L.ds_bias_act_nhwc.argtypes = [vp, vp, vp, vp, vp, vp, i64, ci, ci, ci, vp]
+            L.ds_linear.argtypes = [vp, vp, vp, vp, vp, i64, i64, i64, i64, ci, ci, vp]
             L.ds_profile_enable.argtypes = [vp, ci]
             L.ds_profile_last_ms.argtypes = [vp, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float)]
             for name in EXPORTS:          # fail at load time, not at first use, if a symbol is missing
@@ -342,6 +343,35 @@ def reassemble_readout(proj, clsvec):
     out = torch.empty((b, n - 1, c), dtype=proj.dtype, device=proj.device)
     _check(lib().ds_reassemble_readout(ctx_for(_dev_index(proj)), proj.data_ptr(), clsvec.data_ptr(), out.data_ptr(), b, n, c,
                                        1 if proj.dtype == torch.float16 else 2, _stream(proj)))
+    return out
+
+
+def linear_supported(x, weight):
+    """Shapes ds_linear takes: out_features % 256 == 0, in_features % 128 == 0 (every ViT of the path qualifies)."""
+    return weight.shape[0] % 256 == 0 and weight.shape[1] % 128 == 0 and 128 <= weight.shape[1] <= 16384 and x.numel() > 0
+
+
+def linear(x, weight, bias=None, gelu=False):
+    """[gelu](x @ weight.T + bias) by the in-tree MFMA GEMM (include/depthstereo.h: ds_linear).
+    x [..., K] float16 / bfloat16 CUDA, weight [N, K], bias [N] or None -> [..., N]."""
+    torch = require_gpu()
+    assert x.is_cuda and x.dtype in (torch.float16, torch.bfloat16) and linear_supported(x, weight)
+    k = x.shape[-1]
+    n = weight.shape[0]
+    assert weight.shape[1] == k
+    x2 = x.reshape(-1, k)
+    if not x2.is_contiguous():
+        x2 = x2.contiguous()
+    w = weight.detach()
+    w = w if (w.dtype == x.dtype and w.is_contiguous()) else w.to(x.dtype).contiguous()
+    b = None
+    if bias is not None:
+        b = bias.detach()
+        b = b if (b.dtype == x.dtype and b.is_contiguous()) else b.to(x.dtype).contiguous()
+    out = torch.empty(x.shape[:-1] + (n,), dtype=x.dtype, device=x.device)
+    _check(lib().ds_linear(ctx_for(_dev_index(x)), x2.data_ptr(), w.data_ptr(), None if b is None else b.data_ptr(),
+                           out.data_ptr(), x2.shape[0], n, k, n, 1 if gelu else 0,
+                           1 if x.dtype == torch.float16 else 2, _stream(x)))
     return out
 
 

@@ -26,6 +26,7 @@ import torch
 import torch.nn.functional as F
 
 from . import _native
+from . import vit_mi355x as vm
 
 PIX2PIX_SIZE = 1024
 MASK_SIZE = 3000
@@ -54,7 +55,7 @@ def rgb2gray(rgb):
 def sobel_abs_sum(gray):
     """|Sobel dy| + |Sobel dx|, ksize 3, float64, BORDER_REFLECT_101 (:987, :1073-1074)."""
     g = F.pad(gray[None, None], (1, 1, 1, 1), mode='reflect')
-    kx = torch.tensor([[-1., 0., 1.], [-2., 0., 2.], [-1., 0., 1.]], dtype=gray.dtype, device=gray.device)
+    kx = vm.device_constant((-1., 0., 1., -2., 0., 2., -1., 0., 1.), gray.device, gray.dtype).view(3, 3)
     gx = F.conv2d(g, kx[None, None])[0, 0]
     gy = F.conv2d(g, kx.t().contiguous()[None, None])[0, 0]
     return gy.abs() + gx.abs()
@@ -202,8 +203,8 @@ def _single_estimates(patches, msize, net, model_type, chunk):
     outs = []
     dev = patches[0].device
     if model_type == 0:                                      # estimateleres (:406-421)
-        mean = torch.tensor([0.485, 0.456, 0.406], device=dev).view(1, 3, 1, 1)
-        std = torch.tensor([0.229, 0.224, 0.225], device=dev).view(1, 3, 1, 1)
+        mean = vm.device_constant(vm.IMAGENET_MEAN, dev).view(1, 3, 1, 1)
+        std = vm.device_constant(vm.IMAGENET_STD, dev).view(1, 3, 1, 1)
         for s in range(0, len(patches), chunk):
             part = patches[s:s + chunk]
             x = torch.stack([_resize(p.flip(-1).permute(2, 0, 1), (msize, msize), 'bilinear') for p in part]).float()
@@ -217,8 +218,8 @@ def _single_estimates(patches, msize, net, model_type, chunk):
         return outs
     if model_type in (1, 2, 3, 4):                           # estimatemidasBoost (:1180-1220)
         from dmidas.dpt_depth import midas_net_size
-        mean = torch.tensor([0.485, 0.456, 0.406], device=dev).view(1, 3, 1, 1)      # ImageNet statistics for EVERY MiDaS
-        std = torch.tensor([0.229, 0.224, 0.225], device=dev).view(1, 3, 1, 1)       # model here, unlike estimatemidas
+        mean = vm.device_constant(vm.IMAGENET_MEAN, dev).view(1, 3, 1, 1)      # ImageNet statistics for EVERY MiDaS
+        std = vm.device_constant(vm.IMAGENET_STD, dev).view(1, 3, 1, 1)       # model here, unlike estimatemidas
         for p in patches:
             h, w = p.shape[:2]
             nw, nh = midas_net_size(w, h, msize, msize, "upper_bound")              # keep aspect, multiple of 32 (:1184-1191)

@@ -21,6 +21,7 @@ and what the CPU parity tests against the reference's own modules run); float16 
 kernel and raise if the library is missing -- there is no silent fallback.
 """
 import math
+import os
 
 import torch
 import torch.nn as nn
@@ -28,6 +29,23 @@ import torch.nn.functional as F
 
 HEAD_DIM = 64
 SEQ_ALIGN = 64
+
+_CONSTANTS = {}
+
+
+def device_constant(values, device, dtype=torch.float32):
+    """Small constant tensor (ImageNet mean/std, filter taps ...) resident on ``device``, created ONCE per
+    (values, device, dtype).  ``torch.tensor(list, device=gpu)`` is a pageable host-to-device copy on every call: a
+    synchronising memcpy in the middle of the forward, and an operation a capturing stream refuses (hip_graph.py)."""
+    key = (tuple(values), str(device), dtype)
+    t = _CONSTANTS.get(key)
+    if t is None:
+        t = _CONSTANTS[key] = torch.tensor(list(values), dtype=dtype, device=device)
+    return t
+
+
+IMAGENET_MEAN = (0.485, 0.456, 0.406)
+IMAGENET_STD = (0.229, 0.224, 0.225)
 
 
 def pad_len(n):
@@ -100,6 +118,23 @@ def folded_proj_bias(proj, b_v):
 LOG2E = 1.4426950408889634
 
 
+# Which token GEMMs take the in-tree MFMA kernel (csrc/ds_linear.hip) on float16 / bfloat16 CUDA tensors:
+#   "gelu" (default) fc1 + GELU only -- the fused epilogue removes the stand-alone GELU pass;
+#   "all"            every Linear of the encoder blocks;        "0"  none (library GEMMs + aten GELU).
+LINEAR_HIP = os.environ.get("DS_LINEAR", "gelu")
+
+
+def linear(x, weight, bias=None, gelu=False):
+    """[gelu](x @ weight.T + bias).  float16 / bfloat16 on a GPU: ds_linear when the switch above selects it (erf-GELU
+    on the fp32 accumulator); everything else: the library GEMM and aten's exact GELU."""
+    if x.is_cuda and x.dtype in (torch.float16, torch.bfloat16) and (LINEAR_HIP == "all" or (gelu and LINEAR_HIP == "gelu")):
+        from . import _native
+        if _native.linear_supported(x, weight):
+            return _native.linear(x, weight, bias, gelu)
+    y = F.linear(x, weight, bias)
+    return F.gelu(y) if gelu else y
+
+
 def fused_attention(qk, vt, n_valid, scale, bias=None):
     """bias: None, or what the block's attention_bias() cached for this dtype: the packed operand of the HIP kernel
     (_native.attention_bias_pack) for float16 / bfloat16, a padded [H, Np(query), Np(key)] tensor for float32."""
@@ -129,7 +164,7 @@ class EncoderBlock(nn.Module):
         """LayerNorm-ed tokens -> projected attention output (before LayerScale / residual)."""
         b, npad, c = h.shape
         w_qk, b_qk, w_v, b_v = self.qkv_weights()
-        qk = F.linear(h, w_qk, b_qk).view(b, npad, 2, self.num_heads, HEAD_DIM)
+        qk = linear(h, w_qk, b_qk).view(b, npad, 2, self.num_heads, HEAD_DIM)
         vt = v_transposed(w_v, h)                               # [B, C, Np]: V transposed, straight out of the GEMM
         o = fused_attention(qk, vt, n_valid, self.scale, self.attention_bias(npad, grid_hw, h.dtype, h.device))
         return self.proj(o, b_v)                                # V bias folded into the projection bias
@@ -219,7 +254,7 @@ class Mlp(nn.Module):
         self.fc2 = nn.Linear(hidden, dim)
 
     def forward(self, x):
-        return self.fc2(F.gelu(self.fc1(x)))
+        return linear(linear(x, self.fc1.weight, self.fc1.bias, gelu=True), self.fc2.weight, self.fc2.bias)
 
 
 def count_encoder_flops(depth, n, dim, mlp_ratio=4.0):

@@ -547,3 +547,63 @@ def test_hip_graph_replay_equals_eager_forward(gpu):
             assert got.shape == want.shape and torch.isfinite(got).all()
             assert (got - want).abs().max().item() <= 1e-3 * (1 + want.abs().max().item()), shape
         assert len(gf.graphs) == 2 and not gf.failed
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float16, 1.5e-3), (torch.bfloat16, 1.2e-2)])
+def test_linear_kernel_matches_float32_and_is_race_free(gpu, dtype, tol):
+    """ds_linear (csrc/ds_linear.hip: 256x256 MFMA tiles, LDS-DMA staging, 8-phase K loop, fused bias / erf-GELU) against
+    x @ W.T + b [-> GELU] in float32 on the SAME rounded operands.  Shapes cover: one K iteration (K = 128), odd numbers
+    of iterations, a ragged last row panel, rows < 256, no bias, several column panels, and the encoder shapes of
+    dpt_beit_large_512 (fc1 at one image).  The kernel's synchronisation is counted waits + barriers: a race would show
+    as run-to-run differences, so every launch is repeated and must be bit-identical."""
+    import torch.nn.functional as F
+    from src import _native
+    g = torch.Generator().manual_seed(31)
+    cases = [(256, 256, 128, True, True), (300, 256, 384, True, False), (77, 512, 256, False, True),
+             (1088, 4096, 1024, True, True), (1088, 1024, 4096, True, False), (2443, 768, 640, False, False),
+             (4352, 2048, 1024, True, False)]
+    for (m, n, k, has_bias, gelu) in cases:
+        x = torch.randn((m, k), generator=g).to(dtype).cuda()
+        w = (torch.randn((n, k), generator=g) * k ** -0.5).to(dtype).cuda()
+        b = torch.randn(n, generator=g).to(dtype).cuda() if has_bias else None
+        want = x.double() @ w.double().T
+        if has_bias:
+            want = want + b.double()
+        if gelu:
+            want = F.gelu(want)
+        got = _native.linear(x, w, b, gelu)
+        assert got.shape == (m, n) and got.dtype == dtype
+        err = (got.double() - want).abs().max().item()
+        assert err < tol * (1 + want.abs().max().item()), (m, n, k, has_bias, gelu, err)
+        for _ in range(3):
+            assert torch.equal(_native.linear(x, w, b, gelu), got), "run-to-run difference: a race in the K loop"
+    # a 3-D input and a strided (sliced) weight go through the same entry point
+    x3 = torch.randn((2, 130, 256), generator=g).to(dtype).cuda()
+    wbig = torch.randn((768, 256), generator=g).to(dtype).cuda()
+    got = _native.linear(x3, wbig[:512], None, False)
+    want = x3.double() @ wbig[:512].double().T
+    assert got.shape == (2, 130, 512) and (got.double() - want).abs().max().item() < tol * (1 + want.abs().max().item())
+    # argument errors are reported, not launched
+    with pytest.raises(AssertionError):
+        _native.linear(x3, wbig[:300], None, False)
+
+
+def test_linear_gelu_polynomial_against_erf_everywhere(gpu):
+    """The fused GELU is a polynomial/exp2 evaluation of the erf form, not the tanh approximation: on a dense sweep of
+    pre-activations (identity weight, bias carries the value) it must stay within 1 float16 ulp of erf-GELU computed in
+    float64, and agree exactly on > 99.8 % of the sweep."""
+    import torch.nn.functional as F
+    from src import _native
+    n = 256
+    w = torch.eye(n, 128, dtype=torch.float16).cuda()                  # x = 0 -> the accumulator is exactly the bias
+    x = torch.zeros((256, 128), dtype=torch.float16).cuda()
+    vals = torch.cat([torch.linspace(-9, 9, 256 * 255), torch.tensor([0.0] * 256)]).view(256, n)
+    bad = 0
+    for r in range(vals.shape[0]):
+        b = vals[r].half().cuda()
+        got = _native.linear(x, w, b, True)[0]
+        want = F.gelu(b.double()).half()
+        ulp = (got.view(torch.int16).int() - want.view(torch.int16).int()).abs()
+        assert ulp.max().item() <= 1, (r, ulp.max().item())
+        bad += int((ulp != 0).sum().item())
+    assert bad / vals.numel() < 2e-3, bad

@@ -104,6 +104,48 @@ def extra(which):
         print(f"bias_act {B}x256x128x128 (+residual, relu): {ms * 1e3:.1f} us  {3 * x.numel() * 2 / ms / 1e6:.0f} GB/s")
 
 
+def linear_bench():
+    """ds_linear against the library GEMM (+ aten GELU) at the encoder's shapes: values vs float32, a race screen
+    (repeated launches must be bit-identical), interleaved timing rounds."""
+    import torch.nn.functional as F
+    dev = torch.device("cuda")
+    shapes = [(34816, 4096, 1024, True, "fc1+gelu L/512 b32"), (34816, 1024, 4096, False, "fc2"),
+              (34816, 2048, 1024, False, "qk"), (34816, 1024, 1024, False, "proj"),
+              (3264, 4096, 1024, True, "fc1+gelu ragged rows"), (9772, 4096, 1024, True, "fc1+gelu DA-V2 1080p b4"),
+              (1088, 1536, 384, True, "fc1+gelu vits b1")]
+    only = os.environ.get("DS_LIN_SHAPES")
+    for dt in (torch.float16, torch.bfloat16):
+        for (m, n, k, gelu, name) in shapes:
+            if only and name.split()[0] not in only.split(","):
+                continue
+            g = torch.Generator(device="cpu").manual_seed(m + n + k)
+            x = (torch.randn(m, k, generator=g)).to(dev, dt)
+            w = (torch.randn(n, k, generator=g) * k ** -0.5).to(dev, dt)
+            b = torch.randn(n, generator=g).to(dev, dt)
+            got = nat.linear(x, w, b, gelu)
+            rows = torch.randint(0, m, (512,), generator=g).to(dev)
+            rows[-1] = m - 1
+            ref = x[rows].float() @ w.float().T + b.float()
+            ref = F.gelu(ref) if gelu else ref
+            err = (got[rows].float() - ref).abs().max().item()
+            lib = F.linear(x, w, b)
+            lib = F.gelu(lib) if gelu else lib
+            err_lib = (lib[rows].float() - ref).abs().max().item()
+            same = all(torch.equal(nat.linear(x, w, b, gelu), got) for _ in range(4))
+            full = (got.float() - lib.float()).abs().max().item()
+            t_hip, t_lib = [], []
+            for _ in range(3):
+                t_hip.append(timeit(lambda: nat.linear(x, w, b, gelu), reps=10, warm=2))
+                t_lib.append(timeit((lambda: F.gelu(F.linear(x, w, b))) if gelu else (lambda: F.linear(x, w, b)), reps=10, warm=2))
+            fl = 2.0 * m * n * k
+            print(f"linear {name:26s} {str(dt)[6:]:8s} M{m} N{n} K{k}: hip {min(t_hip) * 1e3:7.1f} us {fl / min(t_hip) / 1e9:6.0f} TF | "
+                  f"library {min(t_lib) * 1e3:7.1f} us {fl / min(t_lib) / 1e9:6.0f} TF | err {err:.2e} (library {err_lib:.2e}) "
+                  f"max|hip-lib| {full:.2e} repeat-identical {same}", flush=True)
+
+
 if __name__ == "__main__":
+    if "linear" in sys.argv[1:]:
+        linear_bench()
+        sys.exit(0)
     main()
     extra(set(sys.argv[1:]) or {"normalmap", "readout"})
