@@ -232,13 +232,27 @@ int ds_bias_act_nhwc(ds_ctx *ctx, const void *x, const void *bias, const void *r
  * ds_linear -- y = act(x . W^T + bias), the token GEMMs of the ViT encoders with the epilogue fused (csrc/ds_linear.hip):
  * `fc1 -> nn.GELU` of the encoder MLP (timm Mlp as run by dmidas/backbones/beit.py:93-107; ddepth_anything_v2/
  * depth_anything_v2/dinov2_layers/mlp.py:33-39) is ONE kernel (act = 1: erf-GELU evaluated on the fp32 accumulator, see
- * ln_gelu for the error bound), and act = 0 is a plain Linear (fc2, proj, qkv).
+ * ln_gelu for the error bound), act = 0 is a plain Linear (fc2, proj, qkv), act = 2 applies ReLU.
  * x [rows, in_features], W [out_features, in_features] (torch.nn.Linear layout), bias [out_features] or NULL,
  * y [rows, ldy] (ldy >= out_features, in elements).  f16/bf16, fp32 accumulation.  out_features % 256 == 0,
  * in_features % 128 == 0; rows is free (the ragged last row panel is masked).  256 x 256 tiles on the MFMA units.
  */
 int ds_linear(ds_ctx *ctx, const void *x, const void *w, const void *bias, void *y, int64_t rows, int64_t out_features,
               int64_t in_features, int64_t ldy, int act, int dtype, void *stream);
+
+/*
+ * ds_conv3x3_nhwc -- y = act(conv3x3(x, W) + bias [+ res1] [+ res2]), stride 1, zero padding 1, as the implicit GEMM of
+ * csrc/ds_linear.hip (same 256 x 256 MFMA tiles; a K-tile is 64 channels of one tap, fetched by LDS-DMA from the shifted
+ * pixel or from a zero line for the padding ring): the 3x3 convolutions of the DPT decoders with their element-wise tails
+ * -- ResidualConvUnit_custom (dmidas/blocks.py:352-377: conv -> +bias -> ReLU, conv -> +bias -> +x [-> +skip]) and
+ * scratch.layerN_rn (dmidas/blocks.py:64-80, no bias); ddepth_anything_v2/depth_anything_v2/util/blocks.py:56-85.
+ * x [batch, height, width, in_channels] (channels_last), W [out_channels, 3, 3, in_channels] (the channels_last memory of
+ * torch's [out, in, 3, 3] weight), bias [out_channels] or NULL, res1 / res2 / y [batch, height, width, out_channels].
+ * act: 0 none, 2 ReLU (applied after the adds).  f16/bf16, fp32 accumulation.  in_channels % 128 == 0,
+ * out_channels % 256 == 0.
+ */
+int ds_conv3x3_nhwc(ds_ctx *ctx, const void *x, const void *w, const void *bias, const void *res1, const void *res2, void *y,
+                    int batch, int height, int width, int in_channels, int out_channels, int act, int dtype, void *stream);
 
 /*
  * ds_upsample_bilinear_nhwc -- torch.nn.functional.interpolate(x, size, mode="bilinear", align_corners) for channels_last

@@ -731,8 +731,11 @@ DS_API int ds_attention_fwd(ds_ctx *ctx, const void *qk, const void *vt, const v
         // rows per wave / 32.  Measured (f16, MI355X): 32 rows x 3 waves per SIMD wins on short sequences (N = 1025 + bias:
         // 0.286 vs 0.310 ms at batch 32; N = 577: 0.060 vs 0.076), 64 rows x 2 waves on long ones (N = 4097 + bias: 0.903 vs
         // 0.944; N = 2443: 0.255 vs 0.263); N = 1370 is a tie.  DS_ATT_NQB overrides (A/B runs).
+        // Late fetch (option 4096: K / V^T of the next tile requested after S, 4 waves per SIMD) A/B on one box, 32 rows per
+        // wave: N = 577: 0.064 -> 0.060, N = 1370: 0.404 -> 0.387, N = 2443: 0.272 -> 0.254 (vs 0.261 for 64 rows), no bias;
+        // with bias it loses (N = 1025: 0.291 -> 0.300) and at N = 4097 64 rows per wave stay ahead (0.911 vs 0.946).
         static const int nqb_env = getenv("DS_ATT_NQB") ? atoi(getenv("DS_ATT_NQB")) : 0;
-        const int nqb = (nqb_env == 1 || nqb_env == 2) ? nqb_env : (Np <= 1280 ? 1 : 2);
+        const int nqb = (nqb_env == 1 || nqb_env == 2) ? nqb_env : (Np <= (bias ? 1280 : 2560) ? 1 : 2);
         P.nq = (Np + 128 * nqb - 1) / (128 * nqb);
         P.total = P.nq * H * B;
         P.chunk = (P.total + 7) / 8;
@@ -741,7 +744,8 @@ DS_API int ds_attention_fwd(ds_ctx *ctx, const void *qk, const void *vt, const v
         static const int ablate = (getenv("DS_ATT_ABLATE") ? atoi(getenv("DS_ATT_ABLATE")) : 0)    // timing experiments, wrong results
                                   | (getenv("DS_ATT_OPT") ? atoi(getenv("DS_ATT_OPT")) : 0);        // options, correct results
         P.flags = ablate;
-        static const int late = getenv("DS_ATT_LATE") ? atoi(getenv("DS_ATT_LATE")) : 0;             // A/B switch, see option 4096
+        static const int late_env = getenv("DS_ATT_LATE") ? atoi(getenv("DS_ATT_LATE")) : -1;        // A/B switch, see option 4096
+        const int late = late_env >= 0 ? late_env : (bias ? 0 : 1);
 #define A2_ABL(BI_, M_) case M_: hipLaunchKernelGGL((k_attention_fwd2<0, BI_, 2, M_>), grid2, dim3(AT_THREADS), 0, st2, P); break;
 #define A2_LAUNCH(BF_, BI_) do {                                                                                       \
             if (ablate && BF_ == 0 && nqb == 2) {                                                                       \

@@ -40,6 +40,8 @@ struct ds_ctx {
     void *exact_ws;    size_t exact_ws_bytes;    // scratch of the exact sequential sweep
     void *tmp_a;       size_t tmp_a_bytes;       // generic temporaries (normal-map blur planes ...)
     void *tmp_b;       size_t tmp_b_bytes;
+    void *zero_line;   size_t zero_line_bytes;   // 256 zero bytes: the padding ring of ds_conv3x3_nhwc
+    int zero_line_cleared;
     int64_t last_exact_rows_valid;
     // optional kernel timing (ds_profile_enable)
     int profile;

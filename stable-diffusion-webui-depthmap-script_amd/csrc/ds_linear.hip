@@ -23,7 +23,8 @@
 //     drains the queue.  Hazards (both directions) are argued next to the schedule table below.
 //   * operands go into the MFMA swapped (W fragment as "A", x fragment as "B"), so an accumulator register holds 4
 //     consecutive output COLUMNS of one row: the epilogue adds the bias, applies the activation in fp32 on the
-//     accumulator (not on a rounded half) and stores 8 bytes per lane and register group.
+//     accumulator (not on a rounded half); a half-wave exchange (v_permlane32_swap) widens that to 8 columns = one 16-byte
+//     store per lane.
 //
 // Workgroup -> tile mapping is XCD-aware: the eight XCDs take contiguous ranges of the tile list (column index
 // fastest), so the 32 workgroups resident on one XCD share two row panels of x and sweep W together through that L2.
@@ -54,10 +55,13 @@ template <> struct ln_traits<1> {
 
 struct LinParams {
     const void *x, *w, *bias;
+    const void *res1, *res2;    // optional addends of the epilogue, laid out like y
+    const void *zeros;          // CONV: >= 128 zero bytes (the padding ring of the image)
     void *y;
-    int M, N, K;
+    int M, N, K;                // K = reduction length (CONV: 9 * C)
     int nbm, nbn;
-    long long ldy;          // row stride of y in elements
+    int H, W, C, cpt, magic;    // CONV: image height / width, input channels, K-tiles per tap (C / 64), 65536 / cpt + 1
+    long long ldy;              // row stride of y (and res1 / res2) in elements
 };
 
 // erf-GELU on the fp32 accumulator.  GELU(v) = v Phi(v) = max(v, 0) - |v| Phi(-|v|), and Phi(-u) = 2^-Q(u) with
@@ -90,13 +94,15 @@ __device__ __forceinline__ float ln_gelu(float v)
         __builtin_amdgcn_sched_barrier(0);        \
     } while (0)
 
-template <int BF16, int EPI>
+// EPI: 0 none, 1 erf-GELU, 2 ReLU.  RES: number of residual addends (res1, res2).  CONV: 0 = x is a dense [M, K] matrix; 1 = x is an NHWC image [batch, H, W, C] and the
+// GEMM is the implicit one of a 3 x 3, stride 1, zero-padded convolution: row m = output pixel, K-tile kt = 64 channels
+// (kt % cpt) of tap kt / cpt, whose source is the same 128 bytes of the pixel shifted by (dy, dx) -- or the zero line.
+template <int BF16, int EPI, int CONV, int RES>
 __global__ __launch_bounds__(LN_THREADS) void k_linear256(LinParams P)
 {
     typedef ln_traits<BF16> TR;
     typedef typename TR::T T;
     typedef typename TR::V8 V8;
-    typedef typename TR::V4 V4;
     extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
 
     const int tid = threadIdx.x;
@@ -111,12 +117,14 @@ __global__ __launch_bounds__(LN_THREADS) void k_linear256(LinParams P)
     const int tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (orig >> 3);
     const int bm0 = (tile / P.nbn) * 256, bn0 = (tile % P.nbn) * 256;
     const int K = P.K;
-    const unsigned char *xb = (const unsigned char *)P.x + (size_t)bm0 * K * sizeof(T);
+    const int rowbytes = (CONV ? P.C : K) * (int)sizeof(T);                 // bytes of one row of x (one pixel for CONV)
+    const unsigned char *xb = (const unsigned char *)P.x + (size_t)bm0 * rowbytes;
     const unsigned char *wb = (const unsigned char *)P.w + (size_t)bn0 * K * sizeof(T);
 
     // ---- staging: this thread's two 16-byte pieces of a half-tile (chunk c = 2*wave + i = LDS rows 8c .. 8c+7) -------
     // LDS row j = 8c + (lane >> 3), LDS slot = lane & 7 holds SOURCE slot (lane & 7) ^ ((j >> 1) & 7).
     unsigned srcA[2][2], srcB[2];
+    unsigned okA = 0;       // CONV: bit 6*(2h+i) + t (t = 0..2): row y-1+t of this piece's pixel is inside the image; + 3 + t: column x-1+t
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int c = 2 * wid + i;
@@ -126,7 +134,13 @@ __global__ __launch_bounds__(LN_THREADS) void k_linear256(LinParams P)
         for (int h = 0; h < 2; ++h) {
             int row = (j >> 6) * 128 + h * 64 + (j & 63);                   // A half h: wave-row j>>6, row j&63 of its 64
             row = min(row, P.M - 1 - bm0);                                  // ragged last row panel: re-read the last row
-            srcA[h][i] = (unsigned)row * (unsigned)K * (unsigned)sizeof(T) + slot * 16;
+            srcA[h][i] = (unsigned)row * (unsigned)rowbytes + slot * 16;
+            if (CONV) {
+                const unsigned pix = (unsigned)(bm0 + row) % (unsigned)(P.H * P.W);
+                const int py = (int)(pix / (unsigned)P.W), px = (int)(pix % (unsigned)P.W);
+                const unsigned bits = (py > 0 ? 1u : 0u) | 2u | (py < P.H - 1 ? 4u : 0u) | (px > 0 ? 8u : 0u) | 16u | (px < P.W - 1 ? 32u : 0u);
+                okA |= bits << (6 * (2 * h + i));
+            }
         }
         const int col = (j >> 5) * 64 + (j & 31);                           // B half h adds 32 columns (uniform)
         srcB[i] = (unsigned)col * (unsigned)K * (unsigned)sizeof(T) + slot * 16;
@@ -139,9 +153,24 @@ __global__ __launch_bounds__(LN_THREADS) void k_linear256(LinParams P)
     do {                                                                                                                 \
         const unsigned koff_ = (unsigned)(kt) * 128u;                                                                    \
         const unsigned dst_ = ((kind) >> 1) * LN_B_BASE + ((kind) & 1) * 2 * LN_HALF + (s) * LN_HALF + lds_stage;        \
+        int dy_ = 0, dx_ = 0, aoff_ = (int)koff_;                                                                        \
+        if (CONV && (kind) < 2) {                                                                                        \
+            const int tap_ = ((kt) * P.magic) >> 16, cc_ = (kt) - tap_ * P.cpt;                                          \
+            dy_ = ((tap_ * 11) >> 5) - 1; dx_ = tap_ - 3 * (dy_ + 1) - 1;                                                \
+            aoff_ = cc_ * 128 + (dy_ * P.W + dx_) * rowbytes;                                                            \
+        }                                                                                                                \
         _Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_) {                                                               \
-            const unsigned char *g_ = ((kind) < 2) ? xb + srcA[(kind) & 1][i_] + koff_                                   \
-                                                   : wb + srcB[i_] + ((kind) & 1) * b_half + koff_;                      \
+            unsigned long long g_;                                                                                       \
+            if ((kind) < 2) {                                                                                            \
+                g_ = (unsigned long long)xb + (unsigned long long)(long long)((int)srcA[(kind) & 1][i_] + aoff_);        \
+                if (CONV) {                                                                                              \
+                    const unsigned sh_ = 6 * (2 * ((kind) & 1) + i_);                                                    \
+                    const unsigned ok_ = (okA >> (sh_ + dy_ + 1)) & (okA >> (sh_ + 4 + dx_)) & 1u;                       \
+                    g_ = ok_ ? g_ : (unsigned long long)P.zeros;                                                         \
+                }                                                                                                        \
+            } else {                                                                                                     \
+                g_ = (unsigned long long)wb + (srcB[i_] + ((kind) & 1) * b_half + koff_);                                \
+            }                                                                                                            \
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g_,                         \
                                              (__attribute__((address_space(3))) void *)(lds + dst_ + i_ * 1024), 16, 0, 0); \
         }                                                                                                                \
@@ -249,53 +278,83 @@ __global__ __launch_bounds__(LN_THREADS) void k_linear256(LinParams P)
     iteration(ni - 1, std::true_type());
     if (wr == 0) LN_BARRIER();            // wave-row 0 arrives at wave-row 1's last barrier
 
-    // ---- epilogue: register r of a 32x32 block = column (r&3) + 8 (r>>2) + 4 (lane>>5), lane & 31 = row ------------------
+    // ---- epilogue ---------------------------------------------------------------------------------------------------------
+    // Register r of a 32 x 32 accumulator block = column (r & 3) + 8 (r >> 2) + 4 (lane >> 5) of row lane & 31: a lane holds
+    // 4-column groups g = r >> 2, the other half-wave holds the groups in between.  One v_permlane32_swap per register pair
+    // (g = 2k, 2k+1) exchanges them so that lanes 0-31 end up with columns 16k .. 16k+7 and lanes 32-63 with 16k+8 .. 16k+15
+    // of their row, in fp32: bias, residuals and the activation are then applied on 8 consecutive columns and the row
+    // segment leaves as ONE 16-byte store (residuals arrive as 16-byte loads, all issued before the arithmetic).
     T *yb = (T *)P.y;
     const T *bias = (const T *)P.bias;
+    const T *r1 = (const T *)P.res1, *r2 = (const T *)P.res2;
+    const int hi8 = 8 * (lane >> 5);
 #pragma unroll
     for (int hb = 0; hb < 2; ++hb) {
-        const int n0 = bn0 + wc * 64 + hb * 32 + 4 * (lane >> 5);
-        float bv[4][4];
+        const int n0 = bn0 + wc * 64 + hb * 32 + hi8;          // + 16 k
+        float bv[2][8];
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
+        for (int k = 0; k < 2; ++k) {
             if (bias) {
-                const V4 b4 = *(const V4 *)(bias + n0 + 8 * g);
+                const V8 b8 = *(const V8 *)(bias + n0 + 16 * k);
 #pragma unroll
-                for (int t = 0; t < 4; ++t) bv[g][t] = (float)b4[t];
+                for (int t = 0; t < 8; ++t) bv[k][t] = (float)b8[t];
             } else {
 #pragma unroll
-                for (int t = 0; t < 4; ++t) bv[g][t] = 0.f;
+                for (int t = 0; t < 8; ++t) bv[k][t] = 0.f;
             }
         }
 #pragma unroll
-        for (int ha = 0; ha < 2; ++ha)
+        for (int ha = 0; ha < 2; ++ha) {
+            V8 ra[2][2], rb2[2][2];                              // residual pieces [row block][k]
+            size_t o0[2];
+            bool live[2];
 #pragma unroll
             for (int rb = 0; rb < 2; ++rb) {
                 const int m = bm0 + wr * 128 + ha * 64 + rb * 32 + (lane & 31);
-                if (m < P.M) {
-                    T *yrow = yb + (size_t)m * P.ldy + n0;
+                live[rb] = m < P.M;
+                o0[rb] = (size_t)m * P.ldy + n0;
 #pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        V4 o;
-#pragma unroll
-                        for (int t = 0; t < 4; ++t) {
-                            float v = acc[ha][rb][hb][4 * g + t] + bv[g][t];
-                            if (EPI == 1) v = ln_gelu(v);
-                            o[t] = (T)v;
-                        }
-                        *(V4 *)(yrow + 8 * g) = o;
-                    }
+                for (int k = 0; k < 2; ++k) {
+                    if (RES >= 1 && live[rb]) ra[rb][k] = *(const V8 *)(r1 + o0[rb] + 16 * k);
+                    if (RES >= 2 && live[rb]) rb2[rb][k] = *(const V8 *)(r2 + o0[rb] + 16 * k);
                 }
             }
+#pragma unroll
+            for (int rb = 0; rb < 2; ++rb) {
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    float v[8];
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        const unsigned a = __builtin_bit_cast(unsigned, acc[ha][rb][hb][8 * k + t]);
+                        const unsigned b = __builtin_bit_cast(unsigned, acc[ha][rb][hb][8 * k + 4 + t]);
+                        const auto sw = __builtin_amdgcn_permlane32_swap(a, b, false, false);
+                        v[t] = __builtin_bit_cast(float, sw[0]);
+                        v[4 + t] = __builtin_bit_cast(float, sw[1]);
+                    }
+                    V8 o;
+#pragma unroll
+                    for (int t = 0; t < 8; ++t) {
+                        float u = v[t] + bv[k][t];
+                        if (RES >= 1) u += (float)ra[rb][k][t];
+                        if (RES >= 2) u += (float)rb2[rb][k][t];
+                        if (EPI == 1) u = ln_gelu(u);
+                        if (EPI == 2) u = fmaxf(u, 0.f);
+                        o[t] = (T)u;
+                    }
+                    if (live[rb]) *(V8 *)(yb + o0[rb] + 16 * k) = o;
+                }
+            }
+        }
     }
 }
 
 // ---- C ABI -------------------------------------------------------------------------------------------------------------
-template <int BF16, int EPI>
+template <int BF16, int EPI, int CONV, int RES>
 static int ln_launch(const LinParams &P, hipStream_t stream)
 {
     static bool attr_set = false;
-    auto fn = k_linear256<BF16, EPI>;
+    auto fn = k_linear256<BF16, EPI, CONV, RES>;
     if (!attr_set) {
         DS_HIP_CHECK(hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, LN_LDS_BYTES));
         attr_set = true;
@@ -303,6 +362,28 @@ static int ln_launch(const LinParams &P, hipStream_t stream)
     hipLaunchKernelGGL(fn, dim3(P.nbm * P.nbn), dim3(LN_THREADS), LN_LDS_BYTES, stream, P);
     DS_HIP_CHECK(hipGetLastError());
     return DS_OK;
+}
+
+template <int BF16>
+static int ln_dispatch_dense(const LinParams &P, int act, hipStream_t st)
+{
+    if (act == 1) return ln_launch<BF16, 1, 0, 0>(P, st);
+    if (act == 2) return ln_launch<BF16, 2, 0, 0>(P, st);
+    return ln_launch<BF16, 0, 0, 0>(P, st);
+}
+
+template <int BF16>
+static int ln_dispatch_conv(const LinParams &P, int act, hipStream_t st)
+{
+    const int res = P.res1 ? (P.res2 ? 2 : 1) : 0;
+    if (act == 2) {
+        if (res == 2) return ln_launch<BF16, 2, 1, 2>(P, st);
+        if (res == 1) return ln_launch<BF16, 2, 1, 1>(P, st);
+        return ln_launch<BF16, 2, 1, 0>(P, st);
+    }
+    if (res == 2) return ln_launch<BF16, 0, 1, 2>(P, st);
+    if (res == 1) return ln_launch<BF16, 0, 1, 1>(P, st);
+    return ln_launch<BF16, 0, 1, 0>(P, st);
 }
 
 DS_API int ds_linear(ds_ctx *ctx, const void *x, const void *w, const void *bias, void *y, int64_t rows, int64_t out_features,
@@ -313,15 +394,47 @@ DS_API int ds_linear(ds_ctx *ctx, const void *x, const void *w, const void *bias
     DS_REQUIRE(out_features > 0 && out_features % 256 == 0, DS_EINVAL, "ds_linear: out_features must be a multiple of 256");
     DS_REQUIRE(in_features >= 128 && in_features % 128 == 0 && in_features <= 16384, DS_EINVAL,
                "ds_linear: in_features must be a multiple of 128 (<= 16384)");
-    DS_REQUIRE(ldy >= out_features && ldy % 4 == 0, DS_EINVAL, "ds_linear: ldy must be >= out_features and a multiple of 4");
-    DS_REQUIRE(act == 0 || act == 1, DS_EINVAL, "ds_linear: act must be 0 (none) or 1 (erf-GELU)");
+    DS_REQUIRE(ldy >= out_features && ldy % 8 == 0, DS_EINVAL, "ds_linear: ldy must be >= out_features and a multiple of 8");
+    DS_REQUIRE(((uintptr_t)y & 15) == 0 && (!bias || ((uintptr_t)bias & 15) == 0), DS_EINVAL, "ds_linear: y and bias must be 16-byte aligned");
+    DS_REQUIRE(act >= 0 && act <= 2, DS_EINVAL, "ds_linear: act must be 0 (none), 1 (erf-GELU) or 2 (ReLU)");
     DS_REQUIRE(dtype == DS_DTYPE_F16 || dtype == DS_DTYPE_BF16, DS_EINVAL, "ds_linear: dtype must be f16 or bf16");
     LinParams P;
+    memset(&P, 0, sizeof(P));
     P.x = x; P.w = w; P.bias = bias; P.y = y;
     P.M = (int)rows; P.N = (int)out_features; P.K = (int)in_features;
     P.nbm = (int)((rows + 255) / 256); P.nbn = (int)(out_features / 256);
     P.ldy = ldy;
-    hipStream_t st = (hipStream_t)stream;
-    if (dtype == DS_DTYPE_F16) return act ? ln_launch<0, 1>(P, st) : ln_launch<0, 0>(P, st);
-    return act ? ln_launch<1, 1>(P, st) : ln_launch<1, 0>(P, st);
+    return dtype == DS_DTYPE_F16 ? ln_dispatch_dense<0>(P, act, (hipStream_t)stream) : ln_dispatch_dense<1>(P, act, (hipStream_t)stream);
+}
+
+DS_API int ds_conv3x3_nhwc(ds_ctx *ctx, const void *x, const void *w, const void *bias, const void *res1, const void *res2, void *y,
+                           int batch, int height, int width, int in_channels, int out_channels, int act, int dtype, void *stream)
+{
+    DS_REQUIRE(ctx && x && w && y, DS_EINVAL, "ds_conv3x3_nhwc: null argument");
+    DS_REQUIRE(batch > 0 && height > 0 && width > 0 && height < 32768 && width < 32768, DS_EINVAL, "ds_conv3x3_nhwc: bad image shape");
+    DS_REQUIRE((int64_t)batch * height * width < (1ll << 31) - 256, DS_EINVAL, "ds_conv3x3_nhwc: too many pixels for one launch");
+    DS_REQUIRE(in_channels >= 64 && in_channels % 64 == 0 && (9 * in_channels / 64) % 2 == 0 && in_channels <= 4096, DS_EINVAL,
+               "ds_conv3x3_nhwc: in_channels must be a multiple of 128 (<= 4096)");
+    DS_REQUIRE(out_channels > 0 && out_channels % 256 == 0, DS_EINVAL, "ds_conv3x3_nhwc: out_channels must be a multiple of 256");
+    DS_REQUIRE(act == 0 || act == 2, DS_EINVAL, "ds_conv3x3_nhwc: act must be 0 (none) or 2 (ReLU)");
+    DS_REQUIRE(dtype == DS_DTYPE_F16 || dtype == DS_DTYPE_BF16, DS_EINVAL, "ds_conv3x3_nhwc: dtype must be f16 or bf16");
+    DS_REQUIRE(((uintptr_t)y & 15) == 0 && (!bias || ((uintptr_t)bias & 15) == 0) && ((uintptr_t)res1 & 15) == 0 && ((uintptr_t)res2 & 15) == 0,
+               DS_EINVAL, "ds_conv3x3_nhwc: y, bias, res1 and res2 must be 16-byte aligned");
+    int rc = ds_ctx_reserve(ctx, &ctx->zero_line, &ctx->zero_line_bytes, 256);
+    if (rc != DS_OK) return rc;
+    if (!ctx->zero_line_cleared) {
+        DS_HIP_CHECK(hipMemsetAsync(ctx->zero_line, 0, 256, (hipStream_t)stream));
+        ctx->zero_line_cleared = 1;
+    }
+    LinParams P;
+    memset(&P, 0, sizeof(P));
+    if (!res1 && res2) { res1 = res2; res2 = nullptr; }
+    P.x = x; P.w = w; P.bias = bias; P.res1 = res1; P.res2 = res2; P.y = y; P.zeros = ctx->zero_line;
+    P.M = batch * height * width; P.N = out_channels; P.K = 9 * in_channels;
+    P.nbm = (P.M + 255) / 256; P.nbn = out_channels / 256;
+    P.H = height; P.W = width; P.C = in_channels; P.cpt = in_channels / 64; P.magic = 65536 / P.cpt + 1;
+    for (int kt = 0; kt < P.K / 64; ++kt)
+        DS_REQUIRE(((kt * P.magic) >> 16) == kt / P.cpt, DS_EUNSUPPORTED, "ds_conv3x3_nhwc: tap arithmetic does not cover %d channels", in_channels);
+    P.ldy = out_channels;
+    return dtype == DS_DTYPE_F16 ? ln_dispatch_conv<0>(P, act, (hipStream_t)stream) : ln_dispatch_conv<1>(P, act, (hipStream_t)stream);
 }

@@ -83,7 +83,7 @@ class DPT(nn.Module):
         after the head's second convolution + ReLU)."""
         l1, l2, l3, l4 = self.pretrained(x)
         s = self.scratch
-        l1, l2, l3, l4 = s.layer1_rn(l1), s.layer2_rn(l2), s.layer3_rn(l3), s.layer4_rn(l4)
+        l1, l2, l3, l4 = vm.conv2d(s.layer1_rn, l1), vm.conv2d(s.layer2_rn, l2), vm.conv2d(s.layer3_rn, l3), vm.conv2d(s.layer4_rn, l4)
         path_4 = s.refinenet4(l4, size=l3.shape[2:])
         path_3 = s.refinenet3(path_4, l3, size=l2.shape[2:])
         path_2 = s.refinenet2(path_3, l2, size=l1.shape[2:])

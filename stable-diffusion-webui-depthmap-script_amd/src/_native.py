@@ -18,7 +18,7 @@ DS_DEPTH_U16, DS_DEPTH_F32, DS_DEPTH_F64 = 0, 1, 2
 FILL_IDS = {"none": 0, "naive": 1, "naive_interpolating": 2, "polylines_soft": 3, "polylines_sharp": 4}
 
 EXPORTS = [
-    "ds_version", "ds_last_error", "ds_normalmap_f64", "ds_reassemble_readout", "ds_bias_act_nhwc", "ds_linear", "ds_ctx_create", "ds_ctx_destroy", "ds_stereo_warp", "ds_depth_minmax",
+    "ds_version", "ds_last_error", "ds_normalmap_f64", "ds_reassemble_readout", "ds_bias_act_nhwc", "ds_linear", "ds_conv3x3_nhwc", "ds_ctx_create", "ds_ctx_destroy", "ds_stereo_warp", "ds_depth_minmax",
     "ds_stereo_last_exact_rows", "ds_copy_view", "ds_overlap_red_cyan", "ds_normalmap", "ds_depth_to_u16",
     "ds_convert_to_i16", "ds_profile_enable", "ds_profile_last_ms", "ds_stereo_last_stats", "ds_attention_fwd", "ds_attention_bias_pack", "ds_colorize_u16", "ds_residual_layernorm", "ds_boost_blend", "ds_upsample_bilinear_nhwc", "ds_dpt_head_tail",
 ]
@@ -72,6 +72,7 @@ def lib():
             L.ds_reassemble_readout.argtypes = [vp, vp, vp, vp, ci, ci, ci, ci, vp]
             L.ds_bias_act_nhwc.argtypes = [vp, vp, vp, vp, vp, vp, i64, ci, ci, ci, vp]
             L.ds_linear.argtypes = [vp, vp, vp, vp, vp, i64, i64, i64, i64, ci, ci, vp]
+            L.ds_conv3x3_nhwc.argtypes = [vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, vp]
             L.ds_profile_enable.argtypes = [vp, ci]
             L.ds_profile_last_ms.argtypes = [vp, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float)]
             for name in EXPORTS:          # fail at load time, not at first use, if a symbol is missing
@@ -372,6 +373,37 @@ def linear(x, weight, bias=None, gelu=False):
     _check(lib().ds_linear(ctx_for(_dev_index(x)), x2.data_ptr(), w.data_ptr(), None if b is None else b.data_ptr(),
                            out.data_ptr(), x2.shape[0], n, k, n, 1 if gelu else 0,
                            1 if x.dtype == torch.float16 else 2, _stream(x)))
+    return out
+
+
+def conv3x3_supported(conv, x):
+    """What ds_conv3x3_nhwc takes: 3x3, stride 1, zero padding 1, no groups / dilation, in % 128 == 0, out % 256 == 0."""
+    return (tuple(conv.kernel_size) == (3, 3) and tuple(conv.stride) == (1, 1) and tuple(conv.padding) == (1, 1)
+            and tuple(conv.dilation) == (1, 1) and conv.groups == 1 and conv.padding_mode == 'zeros'
+            and conv.in_channels % 128 == 0 and conv.out_channels % 256 == 0 and x.dim() == 4 and x.shape[1] == conv.in_channels)
+
+
+def conv3x3(conv, x, relu=False, res1=None, res2=None):
+    """[relu](conv(x) + bias [+ res1] [+ res2]) for a 3x3 nn.Conv2d on a float16 / bfloat16 CUDA activation, channels_last
+    in and out (include/depthstereo.h: ds_conv3x3_nhwc).  The [out, 3, 3, in] weight image is cached on the module."""
+    torch = require_gpu()
+    assert x.is_cuda and x.dtype in (torch.float16, torch.bfloat16) and conv3x3_supported(conv, x)
+    x = x.contiguous(memory_format=torch.channels_last)
+    b, c, h, w = x.shape
+    key = (conv.weight.data_ptr(), conv.weight._version, x.dtype, None if conv.bias is None else conv.bias._version)
+    hit = getattr(conv, "_ds_ohwi", None)
+    if hit is None or hit[0] != key:
+        wk = conv.weight.detach().to(x.dtype).permute(0, 2, 3, 1).contiguous()
+        bk = None if conv.bias is None else conv.bias.detach().to(x.dtype).contiguous()
+        hit = conv._ds_ohwi = (key, wk, bk)
+    _, wk, bk = hit
+    out = torch.empty((b, conv.out_channels, h, w), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+    for r in (res1, res2):
+        assert r is None or (r.shape == out.shape and r.dtype == x.dtype and r.is_contiguous(memory_format=torch.channels_last))
+    _check(lib().ds_conv3x3_nhwc(ctx_for(_dev_index(x)), x.data_ptr(), wk.data_ptr(), None if bk is None else bk.data_ptr(),
+                                 None if res1 is None else res1.data_ptr(), None if res2 is None else res2.data_ptr(),
+                                 out.data_ptr(), b, h, w, c, conv.out_channels, 2 if relu else 0,
+                                 1 if x.dtype == torch.float16 else 2, _stream(x)))
     return out
 
 

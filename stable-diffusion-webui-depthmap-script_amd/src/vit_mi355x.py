@@ -219,6 +219,28 @@ def interpolate_bilinear(x, size=None, scale_factor=None, align_corners=True):
     return F.interpolate(x, scale_factor=scale_factor, mode="bilinear", align_corners=align_corners)
 
 
+# 3x3 decoder convolutions through the in-tree implicit GEMM (csrc/ds_linear.hip) when the launch fills at least half the
+# chip (>= CONV_HIP_MIN_TILES tiles of 256 x 256); "0" keeps every convolution in the library.
+CONV_HIP = os.environ.get("DS_CONV", "1") != "0"
+CONV_HIP_MIN_TILES = 128
+
+
+def conv3x3_hip_ok(conv, x):
+    if not (CONV_HIP and x.is_cuda and x.dtype in (torch.float16, torch.bfloat16) and x.dim() == 4):
+        return False
+    from . import _native
+    tiles = (x.shape[0] * x.shape[2] * x.shape[3] + 255) // 256 * (conv.out_channels // 256)
+    return _native.conv3x3_supported(conv, x) and tiles >= CONV_HIP_MIN_TILES
+
+
+def conv2d(conv, x):
+    """conv(x): ds_conv3x3_nhwc where it applies (scratch.layerN_rn of the decoders), the library otherwise."""
+    if conv3x3_hip_ok(conv, x):
+        from . import _native
+        return _native.conv3x3(conv, x)
+    return conv(x)
+
+
 def residual_conv_unit(conv1, conv2, x, skip=None):
     """[skip +] ( conv2(relu(conv1(relu(x)))) + x ): ResidualConvUnit_custom (dmidas/blocks.py:352-377) / ResidualConvUnit
     (ddepth_anything_v2/.../util/blocks.py:56-85) and, with `skip`, the add of the fusion block around it (:427 / :135).
@@ -228,6 +250,11 @@ def residual_conv_unit(conv1, conv2, x, skip=None):
             and conv2.bias is not None and conv1.out_channels % 8 == 0):
         from . import _native
         xc = x.contiguous(memory_format=torch.channels_last)
+        if conv3x3_hip_ok(conv1, xc) and conv3x3_hip_ok(conv2, xc) and conv1.out_channels == conv2.in_channels:
+            # both convolutions as in-tree implicit GEMMs, the element-wise tails in their epilogues: 3 launches per unit
+            sk = None if skip is None else skip.contiguous(memory_format=torch.channels_last)
+            a = _native.conv3x3(conv1, F.relu(xc), relu=True)
+            return _native.conv3x3(conv2, a, relu=False, res1=xc, res2=sk)
         c1 = conv1._conv_forward(F.relu(xc), conv1.weight, None)          # honours padding_mode (TILING_MODE: circular)
         if c1.is_contiguous(memory_format=torch.channels_last):
             a = _native.bias_act(c1, conv1.bias, relu=True)

@@ -607,3 +607,51 @@ def test_linear_gelu_polynomial_against_erf_everywhere(gpu):
         assert ulp.max().item() <= 1, (r, ulp.max().item())
         bad += int((ulp != 0).sum().item())
     assert bad / vals.numel() < 2e-3, bad
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float16, 2e-3), (torch.bfloat16, 1.6e-2)])
+def test_conv3x3_kernel_matches_float32_convolution(gpu, dtype, tol):
+    """ds_conv3x3_nhwc (the implicit GEMM of csrc/ds_linear.hip) against F.conv2d in float32 on the same rounded operands:
+    image borders inside and across 256-pixel tiles, several images per tile, ragged last tile, 128 / 256 / 512 input
+    channels, no bias (scratch.layerN_rn), bias + ReLU (first half of a residual unit), bias + residual + skip (second
+    half); repeated launches must be bit-identical."""
+    import torch.nn as nn
+    import torch.nn.functional as F
+    from src import _native
+    g = torch.Generator().manual_seed(41)
+    cases = [(1, 16, 16, 128, 256, False), (2, 19, 23, 256, 256, True), (3, 7, 5, 256, 512, True), (1, 40, 33, 512, 256, False)]
+    for (b, h, w, cin, cout, has_bias) in cases:
+        conv = nn.Conv2d(cin, cout, 3, padding=1, bias=has_bias).cuda()
+        with torch.no_grad():
+            conv.weight.copy_(torch.randn(conv.weight.shape, generator=g) * (9 * cin) ** -0.5)
+            if has_bias:
+                conv.bias.copy_(torch.randn(cout, generator=g))
+        mk = lambda c: torch.randn((b, c, h, w), generator=g).to(dtype).cuda().contiguous(memory_format=torch.channels_last)  # noqa: E731
+        x, r1, r2 = mk(cin), mk(cout), mk(cout)
+        wq = conv.weight.detach().to(dtype).float()
+        bq = None if not has_bias else conv.bias.detach().to(dtype).float()
+        base = F.conv2d(x.float(), wq, bq, padding=1)
+        for relu, a, bb in ((False, None, None), (True, None, None), (False, r1, r2), (True, r1, None)):
+            want = base
+            if a is not None:
+                want = want + a.float()
+            if bb is not None:
+                want = want + bb.float()
+            if relu:
+                want = F.relu(want)
+            got = _native.conv3x3(conv, x, relu=relu, res1=a, res2=bb)
+            assert got.shape == want.shape and got.is_contiguous(memory_format=torch.channels_last)
+            err = (got.float() - want).abs().max().item()
+            assert err < tol * (1 + want.abs().max().item()), (b, h, w, cin, cout, relu, err)
+            assert torch.equal(_native.conv3x3(conv, x, relu=relu, res1=a, res2=bb), got)
+    # the residual unit of the decoders at a size that takes the in-tree path (both convolutions + fused tails)
+    from src import vit_mi355x as vm
+    torch.manual_seed(5)
+    c1, c2 = nn.Conv2d(256, 256, 3, padding=1).cuda(), nn.Conv2d(256, 256, 3, padding=1).cuda()
+    x = torch.randn((2, 256, 128, 128), device='cuda')
+    skip = torch.randn((2, 256, 128, 128), device='cuda')
+    want = skip + (c2(F.relu(c1(F.relu(x)))) + x)
+    xh = x.to(dtype).contiguous(memory_format=torch.channels_last)
+    assert vm.conv3x3_hip_ok(c1.to(dtype), xh)
+    got = vm.residual_conv_unit(c1.to(dtype), c2.to(dtype), xh, skip=skip.to(dtype))
+    assert (got.float() - want).abs().max().item() < 4 * tol * (1 + want.abs().max().item())

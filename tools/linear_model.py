@@ -170,13 +170,22 @@ def check_indexing(M=300, N=256, K=128, seed=0):
                     for hb in range(2):
                         for ha in range(2):
                             for rb in range(2):
-                                for lane in range(64):
-                                    m = bm0 + wr * 128 + ha * 64 + rb * 32 + (lane & 31)
-                                    n0 = bn0 + wc * 64 + hb * 32 + 4 * (lane >> 5)
-                                    if m < M:
-                                        for g in range(4):
-                                            for t in range(4):
-                                                y[m, n0 + 8 * g + t] = acc[ha, rb, hb, lane, 4 * g + t]
+                                blk = acc[ha, rb, hb]                       # [64 lanes, 16 registers]
+                                for k in range(2):
+                                    for lane in range(64):
+                                        hi = lane >> 5
+                                        # v_permlane32_swap(vdst = reg 8k+t, src = reg 8k+4+t): lanes 32-63 of vdst <-> lanes 0-31 of src
+                                        v = np.empty(8)
+                                        for t in range(4):
+                                            a_own, b_own = blk[lane, 8 * k + t], blk[lane, 8 * k + 4 + t]
+                                            if hi == 0:
+                                                v[t], v[4 + t] = a_own, blk[lane + 32, 8 * k + t]
+                                            else:
+                                                v[t], v[4 + t] = blk[lane - 32, 8 * k + 4 + t], b_own
+                                        m = bm0 + wr * 128 + ha * 64 + rb * 32 + (lane & 31)
+                                        n0 = bn0 + wc * 64 + hb * 32 + 8 * hi + 16 * k
+                                        if m < M:
+                                            y[m, n0:n0 + 8] = v
     ref = x.astype(np.float64) @ w.astype(np.float64).T
     return np.abs(y - ref).max()
 

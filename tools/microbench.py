@@ -143,7 +143,58 @@ def linear_bench():
                   f"max|hip-lib| {full:.2e} repeat-identical {same}", flush=True)
 
 
+def linear_sweep():
+    """Per-round time of ds_linear as a function of K (fixed cost per tile vs cost per K-tile), one full round of tiles
+    (256) and eight rounds; and the cost of the GELU / residual epilogues."""
+    dev = torch.device("cuda")
+    dt = torch.float16
+    for rounds in (1, 8):
+        m = 256 * 16 * rounds
+        for k in (128, 256, 512, 1024, 2048, 4096, 8192):
+            x = torch.randn(m, k, device=dev, dtype=dt)
+            w = torch.randn(4096, k, device=dev, dtype=dt) * k ** -0.5
+            b = torch.randn(4096, device=dev, dtype=dt)
+            t0 = min(timeit(lambda: nat.linear(x, w, b, False), reps=10, warm=2) for _ in range(3))
+            t1 = min(timeit(lambda: nat.linear(x, w, b, True), reps=10, warm=2) for _ in range(3))
+            print(f"sweep rounds={rounds} K={k:5d}: plain {t0 * 1e3 / rounds:7.2f} us/round  gelu {t1 * 1e3 / rounds:7.2f} us/round  "
+                  f"{2.0 * m * 4096 * k / t0 / 1e9:6.0f} TF", flush=True)
+
+
+def conv_bench():
+    """ds_conv3x3_nhwc against the library convolution (+ the element-wise tail it replaces) at the decoder's shapes."""
+    import torch.nn.functional as F
+    dev = torch.device("cuda")
+    torch.backends.cudnn.benchmark = True
+    shapes = [(32, 128, 128, 256, 256, "refinenet1 RCU conv"), (32, 64, 64, 256, 256, "refinenet2 RCU conv"),
+              (32, 32, 32, 256, 256, "refinenet3 RCU conv"), (32, 64, 64, 512, 256, "layer2_rn"), (32, 32, 32, 1024, 256, "layer3_rn"),
+              (4, 148, 264, 256, 256, "DA-V2 1080p path_1 RCU conv")]
+    for dt in (torch.float16,):
+        for (b, h, w, cin, cout, name) in shapes:
+            conv = nn.Conv2d(cin, cout, 3, padding=1).to(dev, dt).to(memory_format=torch.channels_last)
+            x = torch.randn(b, cin, h, w, device=dev, dtype=dt).contiguous(memory_format=torch.channels_last)
+            r = torch.randn(b, cout, h, w, device=dev, dtype=dt).contiguous(memory_format=torch.channels_last)
+            got = nat.conv3x3(conv, x, relu=False, res1=r)
+            ref = conv._conv_forward(x, conv.weight, None)
+            ref = nat.bias_act(ref, conv.bias, relu=False, res1=r)
+            err = (got.float() - ref.float()).abs().max().item()
+            t_hip, t_lib, t_libc = [], [], []
+            for _ in range(3):
+                t_hip.append(timeit(lambda: nat.conv3x3(conv, x, relu=False, res1=r), reps=10, warm=2))
+                t_lib.append(timeit(lambda: nat.bias_act(conv._conv_forward(x, conv.weight, None), conv.bias, relu=False, res1=r), reps=10, warm=2))
+                t_libc.append(timeit(lambda: conv._conv_forward(x, conv.weight, None), reps=10, warm=2))
+            fl = 2.0 * b * h * w * cout * 9 * cin
+            print(f"conv3x3 {name:28s} {b}x{h}x{w} {cin}->{cout}: hip(+tail) {min(t_hip) * 1e3:7.1f} us {fl / min(t_hip) / 1e9:6.0f} TF | "
+                  f"library+tail {min(t_lib) * 1e3:7.1f} us (conv alone {min(t_libc) * 1e3:7.1f} us {fl / min(t_libc) / 1e9:6.0f} TF) | max|hip-lib| {err:.2e}",
+                  flush=True)
+
+
 if __name__ == "__main__":
+    if "sweep" in sys.argv[1:]:
+        linear_sweep()
+        sys.exit(0)
+    if "conv" in sys.argv[1:]:
+        conv_bench()
+        sys.exit(0)
     if "linear" in sys.argv[1:]:
         linear_bench()
         sys.exit(0)
