@@ -235,7 +235,8 @@ int ds_bias_act_nhwc(ds_ctx *ctx, const void *x, const void *bias, const void *r
  * ln_gelu for the error bound), act = 0 is a plain Linear (fc2, proj, qkv), act = 2 applies ReLU.
  * x [rows, in_features], W [out_features, in_features] (torch.nn.Linear layout), bias [out_features] or NULL,
  * y [rows, ldy] (ldy >= out_features, in elements).  f16/bf16, fp32 accumulation.  out_features % 256 == 0,
- * in_features % 128 == 0; rows is free (the ragged last row panel is masked).  256 x 256 tiles on the MFMA units.
+ * in_features % 128 == 0, rows >= 256 (the last 256-row panel is shifted up to end at the last row).  y must not alias x.
+ * 256 x 256 tiles on the MFMA units.
  */
 int ds_linear(ds_ctx *ctx, const void *x, const void *w, const void *bias, void *y, int64_t rows, int64_t out_features,
               int64_t in_features, int64_t ldy, int act, int dtype, void *stream);
@@ -249,7 +250,7 @@ int ds_linear(ds_ctx *ctx, const void *x, const void *w, const void *bias, void 
  * x [batch, height, width, in_channels] (channels_last), W [out_channels, 3, 3, in_channels] (the channels_last memory of
  * torch's [out, in, 3, 3] weight), bias [out_channels] or NULL, res1 / res2 / y [batch, height, width, out_channels].
  * act: 0 none, 2 ReLU (applied after the adds).  f16/bf16, fp32 accumulation.  in_channels % 128 == 0,
- * out_channels % 256 == 0.
+ * out_channels % 256 == 0, batch * height * width >= 256.  y must not alias x, res1 or res2.
  */
 int ds_conv3x3_nhwc(ds_ctx *ctx, const void *x, const void *w, const void *bias, const void *res1, const void *res2, void *y,
                     int batch, int height, int width, int in_channels, int out_channels, int act, int dtype, void *stream);

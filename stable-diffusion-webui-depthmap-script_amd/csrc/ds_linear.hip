@@ -30,6 +30,7 @@
 // fastest), so the 32 workgroups resident on one XCD share two row panels of x and sweep W together through that L2.
 #include "ds_common.h"
 
+#include <stdlib.h>
 #include <type_traits>
 
 typedef _Float16 lf16x8 __attribute__((ext_vector_type(8)));
@@ -60,6 +61,7 @@ struct LinParams {
     void *y;
     int M, N, K;                // K = reduction length (CONV: 9 * C)
     int nbm, nbn;
+    int ablate;                 // timing experiments (DS_LIN_ABLATE): 1 = no epilogue stores, 2 = no K loop
     int H, W, C, cpt, magic;    // CONV: image height / width, input channels, K-tiles per tap (C / 64), 65536 / cpt + 1
     long long ldy;              // row stride of y (and res1 / res2) in elements
 };
@@ -83,6 +85,19 @@ __device__ __forceinline__ float ln_gelu(float v)
     q = __builtin_fmaf(q, u, 0.9999943375587463f);
     const float h = __builtin_amdgcn_exp2f(-q);
     return __builtin_fmaf(-u, h, fmaxf(v, 0.0f));
+}
+
+// LDS-DMA of 16 bytes per lane (global_load_lds_dwordx4): destination = M0 + 16 * lane.  Written as inline asm so that
+// the address is exactly one loop-invariant 32-bit VGPR offset on a per-K-tile SGPR base (hipcc otherwise keeps 64-bit
+// per-lane pointers alive across the loop and spills), and so that the compiler's own LDS-DMA bookkeeping (a vmcnt wait in
+// front of every later ds_read) stays out of the counted-wait pipeline.
+__device__ __forceinline__ void ln_dma_s(const void *base_uniform, unsigned voff, unsigned lds_uniform)
+{
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(base_uniform), "s"(lds_uniform) : "memory");
+}
+__device__ __forceinline__ void ln_dma_v(const void *ptr, unsigned lds_uniform)
+{
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(ptr), "s"(lds_uniform) : "memory");
 }
 
 #define LN_WAIT_VM(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
@@ -115,7 +130,9 @@ __global__ __launch_bounds__(LN_THREADS) void k_linear256(LinParams P)
     const int orig = blockIdx.x;
     const int xcd = orig & 7, q8 = nwg >> 3, r8 = nwg & 7;
     const int tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (orig >> 3);
-    const int bm0 = (tile / P.nbn) * 256, bn0 = (tile % P.nbn) * 256;
+    // the last row panel is shifted up to end at row M (M >= 256): its first rows are computed twice, identically, by
+    // two workgroups -- no per-row clamping or masking anywhere (y must not alias res1 / res2)
+    const int bm0 = min((tile / P.nbn) * 256, P.M - 256), bn0 = (tile % P.nbn) * 256;
     const int K = P.K;
     const int rowbytes = (CONV ? P.C : K) * (int)sizeof(T);                 // bytes of one row of x (one pixel for CONV)
     const unsigned char *xb = (const unsigned char *)P.x + (size_t)bm0 * rowbytes;
@@ -123,20 +140,19 @@ __global__ __launch_bounds__(LN_THREADS) void k_linear256(LinParams P)
 
     // ---- staging: this thread's two 16-byte pieces of a half-tile (chunk c = 2*wave + i = LDS rows 8c .. 8c+7) -------
     // LDS row j = 8c + (lane >> 3), LDS slot = lane & 7 holds SOURCE slot (lane & 7) ^ ((j >> 1) & 7).
-    unsigned srcA[2][2], srcB[2];
+    unsigned srcA[2], srcB[2];
     unsigned okA = 0;       // CONV: bit 6*(2h+i) + t (t = 0..2): row y-1+t of this piece's pixel is inside the image; + 3 + t: column x-1+t
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int c = 2 * wid + i;
         const int j = 8 * c + (lane >> 3);
         const int slot = (lane & 7) ^ ((j >> 1) & 7);
+        const int row = (j >> 6) * 128 + (j & 63);                          // A half h (+ 64 h rows): wave-row j>>6, row j&63 of its 64
+        srcA[i] = (unsigned)row * (unsigned)rowbytes + slot * 16;
+        if (CONV) {
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            int row = (j >> 6) * 128 + h * 64 + (j & 63);                   // A half h: wave-row j>>6, row j&63 of its 64
-            row = min(row, P.M - 1 - bm0);                                  // ragged last row panel: re-read the last row
-            srcA[h][i] = (unsigned)row * (unsigned)rowbytes + slot * 16;
-            if (CONV) {
-                const unsigned pix = (unsigned)(bm0 + row) % (unsigned)(P.H * P.W);
+            for (int h = 0; h < 2; ++h) {
+                const unsigned pix = (unsigned)(bm0 + row + 64 * h) % (unsigned)(P.H * P.W);
                 const int py = (int)(pix / (unsigned)P.W), px = (int)(pix % (unsigned)P.W);
                 const unsigned bits = (py > 0 ? 1u : 0u) | 2u | (py < P.H - 1 ? 4u : 0u) | (px > 0 ? 8u : 0u) | 16u | (px < P.W - 1 ? 32u : 0u);
                 okA |= bits << (6 * (2 * h + i));
@@ -145,34 +161,33 @@ __global__ __launch_bounds__(LN_THREADS) void k_linear256(LinParams P)
         const int col = (j >> 5) * 64 + (j & 31);                           // B half h adds 32 columns (uniform)
         srcB[i] = (unsigned)col * (unsigned)K * (unsigned)sizeof(T) + slot * 16;
     }
+    const unsigned a_half = 64u * (unsigned)rowbytes;
     const unsigned b_half = 32u * (unsigned)K * (unsigned)sizeof(T);
-    const unsigned lds_stage = (unsigned)(2 * wid) * 1024u;                 // wave-uniform LDS offset of chunk 2*wave
+    const unsigned lds_stage = (unsigned)(size_t)(__attribute__((address_space(3))) void *)lds + (unsigned)(2 * wid) * 1024u;   // LDS address of chunk 2*wave
 
     // kind: 0 A0, 1 A1, 2 B0, 3 B1; kt = K-tile; s = LDS buffer
 #define LN_STAGE(kind, kt, s)                                                                                            \
     do {                                                                                                                 \
         const unsigned koff_ = (unsigned)(kt) * 128u;                                                                    \
-        const unsigned dst_ = ((kind) >> 1) * LN_B_BASE + ((kind) & 1) * 2 * LN_HALF + (s) * LN_HALF + lds_stage;        \
+        const unsigned dst_ = ((kind) >> 1) * LN_B_BASE + ((kind) & 1) * 2 * LN_HALF + (s) * LN_HALF + lds_stage;  /* LDS address */ \
         int dy_ = 0, dx_ = 0, aoff_ = (int)koff_;                                                                        \
         if (CONV && (kind) < 2) {                                                                                        \
             const int tap_ = ((kt) * P.magic) >> 16, cc_ = (kt) - tap_ * P.cpt;                                          \
             dy_ = ((tap_ * 11) >> 5) - 1; dx_ = tap_ - 3 * (dy_ + 1) - 1;                                                \
             aoff_ = cc_ * 128 + (dy_ * P.W + dx_) * rowbytes;                                                            \
         }                                                                                                                \
+        /* uniform 64-bit base of this K-tile (scalar arithmetic) + the thread's loop-invariant 32-bit offset */           \
+        const unsigned char *ub_ = ((kind) < 2) ? xb + ((long)aoff_ + (long)(((kind) & 1) * a_half))                     \
+                                                : wb + (size_t)(((kind) & 1) * b_half + koff_);                          \
         _Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_) {                                                               \
-            unsigned long long g_;                                                                                       \
-            if ((kind) < 2) {                                                                                            \
-                g_ = (unsigned long long)xb + (unsigned long long)(long long)((int)srcA[(kind) & 1][i_] + aoff_);        \
-                if (CONV) {                                                                                              \
-                    const unsigned sh_ = 6 * (2 * ((kind) & 1) + i_);                                                    \
-                    const unsigned ok_ = (okA >> (sh_ + dy_ + 1)) & (okA >> (sh_ + 4 + dx_)) & 1u;                       \
-                    g_ = ok_ ? g_ : (unsigned long long)P.zeros;                                                         \
-                }                                                                                                        \
+            if (CONV && (kind) < 2) {                                                                                    \
+                const unsigned sh_ = 6 * (2 * ((kind) & 1) + i_);                                                        \
+                const unsigned ok_ = (okA >> (sh_ + dy_ + 1)) & (okA >> (sh_ + 4 + dx_)) & 1u;                           \
+                const unsigned char *g_ = ok_ ? ub_ + (size_t)srcA[i_] : (const unsigned char *)P.zeros;                 \
+                ln_dma_v(g_, dst_ + i_ * 1024);                                                                          \
             } else {                                                                                                     \
-                g_ = (unsigned long long)wb + (srcB[i_] + ((kind) & 1) * b_half + koff_);                                \
+                ln_dma_s(ub_, ((kind) < 2) ? srcA[i_] : srcB[i_], dst_ + i_ * 1024);                                     \
             }                                                                                                            \
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g_,                         \
-                                             (__attribute__((address_space(3))) void *)(lds + dst_ + i_ * 1024), 16, 0, 0); \
         }                                                                                                                \
     } while (0)
 
@@ -237,46 +252,57 @@ __global__ __launch_bounds__(LN_THREADS) void k_linear256(LinParams P)
     LN_WAIT_VM(10);                       // 14 issued: A0, B0 of tile 0 have landed
     LN_BARRIER();
     LN_READ_A(0, 0);
-    LN_WAIT_LGKM0();                      // retired here: wave-row 0 re-stages A0 of buffer 0 in its phase 1
+    LN_WAIT_LGKM0();                      // retired here: A0 of buffer 0 is re-staged in phase 1
     if (wr == 1) LN_BARRIER();            // the stagger
+
+    // One phase: memory part | barrier | MFMAs | barrier (wave-row 1 one barrier behind).  A variant with ONE barrier per
+    // phase (wave-row 0 issues its MFMAs before the barrier, wave-row 1 after it, so the hand-over needs no meeting point)
+    // was built and measured: 1.88 us per K-tile against 1.65 us for this one -- the strict alternation wins.
+#define LN_PHASE_END(ha, hb)                                                                                             \
+    do { LN_BARRIER(); LN_WAIT_LGKM0(); LN_MMA(ha, hb); LN_BARRIER(); } while (0)
 
     auto iteration = [&](const int i, auto last_c) {
         constexpr bool LAST = decltype(last_c)::value;
         const int e2 = 2 * i + 2, o2 = 2 * i + 3;
         // phase 0
         LN_READ_B(0, 0); LN_STAGE(1, 2 * i + 1, 1); LN_WAIT_VM(10);
-        LN_BARRIER(); LN_WAIT_LGKM0(); LN_MMA(0, 0); LN_BARRIER();
+        LN_PHASE_END(0, 0);
         // phase 1
         LN_READ_B(1, 0);
         if constexpr (!LAST) { LN_STAGE(0, e2, 0); LN_WAIT_VM(10); } else { LN_WAIT_VM(8); }
-        LN_BARRIER(); LN_WAIT_LGKM0(); LN_MMA(0, 1); LN_BARRIER();
+        LN_PHASE_END(0, 1);
         // phase 2
         LN_READ_A(1, 0);
         if constexpr (!LAST) { LN_STAGE(2, e2, 0); LN_WAIT_VM(10); } else { LN_WAIT_VM(6); }
-        LN_BARRIER(); LN_WAIT_LGKM0(); LN_MMA(1, 1); LN_BARRIER();
+        LN_PHASE_END(1, 1);
         // phase 3
         LN_READ_A(0, 1);
         if constexpr (!LAST) { LN_STAGE(3, e2, 0); LN_WAIT_VM(10); } else { LN_WAIT_VM(4); }
-        LN_BARRIER(); LN_WAIT_LGKM0(); LN_MMA(1, 0); LN_BARRIER();
+        LN_PHASE_END(1, 0);
         // phase 4
         LN_READ_B(0, 1);
         if constexpr (!LAST) { LN_STAGE(1, e2, 0); LN_WAIT_VM(10); } else { LN_WAIT_VM(2); }
-        LN_BARRIER(); LN_WAIT_LGKM0(); LN_MMA(0, 0); LN_BARRIER();
+        LN_PHASE_END(0, 0);
         // phase 5
         LN_READ_B(1, 1);
         if constexpr (!LAST) { LN_STAGE(0, o2, 1); LN_WAIT_VM(10); } else { LN_WAIT_VM(0); }
-        LN_BARRIER(); LN_WAIT_LGKM0(); LN_MMA(0, 1); LN_BARRIER();
+        LN_PHASE_END(0, 1);
         // phase 6
         LN_READ_A(1, 1);
         if constexpr (!LAST) { LN_STAGE(2, o2, 1); LN_WAIT_VM(10); }
-        LN_BARRIER(); LN_WAIT_LGKM0(); LN_MMA(1, 1); LN_BARRIER();
+        LN_PHASE_END(1, 1);
         // phase 7
         if constexpr (!LAST) { LN_READ_A(0, 0); LN_STAGE(3, o2, 1); LN_WAIT_VM(10); }
-        LN_BARRIER(); LN_WAIT_LGKM0(); LN_MMA(1, 0); LN_BARRIER();
+        LN_PHASE_END(1, 0);
     };
-    for (int i = 0; i < ni - 1; ++i) iteration(i, std::false_type());
-    iteration(ni - 1, std::true_type());
-    if (wr == 0) LN_BARRIER();            // wave-row 0 arrives at wave-row 1's last barrier
+    if (P.ablate & 2) {
+        LN_WAIT_VM(0);
+        __syncthreads();
+    } else {
+        for (int i = 0; i < ni - 1; ++i) iteration(i, std::false_type());
+        iteration(ni - 1, std::true_type());
+        if (wr == 0) LN_BARRIER();                         // wave-row 0 arrives at wave-row 1's last barrier
+    }
 
     // ---- epilogue ---------------------------------------------------------------------------------------------------------
     // Register r of a 32 x 32 accumulator block = column (r & 3) + 8 (r >> 2) + 4 (lane >> 5) of row lane & 31: a lane holds
@@ -307,16 +333,14 @@ __global__ __launch_bounds__(LN_THREADS) void k_linear256(LinParams P)
         for (int ha = 0; ha < 2; ++ha) {
             V8 ra[2][2], rb2[2][2];                              // residual pieces [row block][k]
             size_t o0[2];
-            bool live[2];
 #pragma unroll
             for (int rb = 0; rb < 2; ++rb) {
                 const int m = bm0 + wr * 128 + ha * 64 + rb * 32 + (lane & 31);
-                live[rb] = m < P.M;
                 o0[rb] = (size_t)m * P.ldy + n0;
 #pragma unroll
                 for (int k = 0; k < 2; ++k) {
-                    if (RES >= 1 && live[rb]) ra[rb][k] = *(const V8 *)(r1 + o0[rb] + 16 * k);
-                    if (RES >= 2 && live[rb]) rb2[rb][k] = *(const V8 *)(r2 + o0[rb] + 16 * k);
+                    if (RES >= 1) ra[rb][k] = *(const V8 *)(r1 + o0[rb] + 16 * k);
+                    if (RES >= 2) rb2[rb][k] = *(const V8 *)(r2 + o0[rb] + 16 * k);
                 }
             }
 #pragma unroll
@@ -326,11 +350,11 @@ __global__ __launch_bounds__(LN_THREADS) void k_linear256(LinParams P)
                     float v[8];
 #pragma unroll
                     for (int t = 0; t < 4; ++t) {
-                        const unsigned a = __builtin_bit_cast(unsigned, acc[ha][rb][hb][8 * k + t]);
-                        const unsigned b = __builtin_bit_cast(unsigned, acc[ha][rb][hb][8 * k + 4 + t]);
-                        const auto sw = __builtin_amdgcn_permlane32_swap(a, b, false, false);
-                        v[t] = __builtin_bit_cast(float, sw[0]);
-                        v[4 + t] = __builtin_bit_cast(float, sw[1]);
+                        // (copies first: __builtin_bit_cast applied to a vector ELEMENT reads element 0 with this clang)
+                        const float fa = acc[ha][rb][hb][8 * k + t], fb = acc[ha][rb][hb][8 * k + 4 + t];
+                        const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(fa), __float_as_uint(fb), false, false);
+                        v[t] = __uint_as_float(sw[0]);
+                        v[4 + t] = __uint_as_float(sw[1]);
                     }
                     V8 o;
 #pragma unroll
@@ -342,7 +366,8 @@ __global__ __launch_bounds__(LN_THREADS) void k_linear256(LinParams P)
                         if (EPI == 2) u = fmaxf(u, 0.f);
                         o[t] = (T)u;
                     }
-                    if (live[rb]) *(V8 *)(yb + o0[rb] + 16 * k) = o;
+                    if (!(P.ablate & 1)) *(V8 *)(yb + o0[rb] + 16 * k) = o;
+                    else asm volatile("" ::"v"(o));
                 }
             }
         }
@@ -390,7 +415,7 @@ DS_API int ds_linear(ds_ctx *ctx, const void *x, const void *w, const void *bias
                      int64_t in_features, int64_t ldy, int act, int dtype, void *stream)
 {
     DS_REQUIRE(ctx && x && w && y, DS_EINVAL, "ds_linear: null argument");
-    DS_REQUIRE(rows > 0 && rows < (1ll << 31) - 256, DS_EINVAL, "ds_linear: rows out of range");
+    DS_REQUIRE(rows >= 256 && rows < (1ll << 31) - 256, DS_EINVAL, "ds_linear: rows must be >= 256 (one tile)");
     DS_REQUIRE(out_features > 0 && out_features % 256 == 0, DS_EINVAL, "ds_linear: out_features must be a multiple of 256");
     DS_REQUIRE(in_features >= 128 && in_features % 128 == 0 && in_features <= 16384, DS_EINVAL,
                "ds_linear: in_features must be a multiple of 128 (<= 16384)");
@@ -404,6 +429,7 @@ DS_API int ds_linear(ds_ctx *ctx, const void *x, const void *w, const void *bias
     P.M = (int)rows; P.N = (int)out_features; P.K = (int)in_features;
     P.nbm = (int)((rows + 255) / 256); P.nbn = (int)(out_features / 256);
     P.ldy = ldy;
+    P.ablate = getenv("DS_LIN_ABLATE") ? atoi(getenv("DS_LIN_ABLATE")) : 0;
     return dtype == DS_DTYPE_F16 ? ln_dispatch_dense<0>(P, act, (hipStream_t)stream) : ln_dispatch_dense<1>(P, act, (hipStream_t)stream);
 }
 
@@ -412,7 +438,8 @@ DS_API int ds_conv3x3_nhwc(ds_ctx *ctx, const void *x, const void *w, const void
 {
     DS_REQUIRE(ctx && x && w && y, DS_EINVAL, "ds_conv3x3_nhwc: null argument");
     DS_REQUIRE(batch > 0 && height > 0 && width > 0 && height < 32768 && width < 32768, DS_EINVAL, "ds_conv3x3_nhwc: bad image shape");
-    DS_REQUIRE((int64_t)batch * height * width < (1ll << 31) - 256, DS_EINVAL, "ds_conv3x3_nhwc: too many pixels for one launch");
+    DS_REQUIRE((int64_t)batch * height * width < (1ll << 31) - 256 && (int64_t)batch * height * width >= 256, DS_EINVAL,
+               "ds_conv3x3_nhwc: batch * height * width must be in [256, 2^31)");
     DS_REQUIRE(in_channels >= 64 && in_channels % 64 == 0 && (9 * in_channels / 64) % 2 == 0 && in_channels <= 4096, DS_EINVAL,
                "ds_conv3x3_nhwc: in_channels must be a multiple of 128 (<= 4096)");
     DS_REQUIRE(out_channels > 0 && out_channels % 256 == 0, DS_EINVAL, "ds_conv3x3_nhwc: out_channels must be a multiple of 256");
@@ -436,5 +463,6 @@ DS_API int ds_conv3x3_nhwc(ds_ctx *ctx, const void *x, const void *w, const void
     for (int kt = 0; kt < P.K / 64; ++kt)
         DS_REQUIRE(((kt * P.magic) >> 16) == kt / P.cpt, DS_EUNSUPPORTED, "ds_conv3x3_nhwc: tap arithmetic does not cover %d channels", in_channels);
     P.ldy = out_channels;
+    P.ablate = getenv("DS_LIN_ABLATE") ? atoi(getenv("DS_LIN_ABLATE")) : 0;
     return dtype == DS_DTYPE_F16 ? ln_dispatch_conv<0>(P, act, (hipStream_t)stream) : ln_dispatch_conv<1>(P, act, (hipStream_t)stream);
 }

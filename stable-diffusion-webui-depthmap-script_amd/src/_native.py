@@ -363,24 +363,28 @@ def linear(x, weight, bias=None, gelu=False):
     x2 = x.reshape(-1, k)
     if not x2.is_contiguous():
         x2 = x2.contiguous()
+    rows = x2.shape[0]
+    if rows < 256:                       # the kernel's unit is a 256-row tile: tiny inputs are padded, not special-cased
+        x2 = torch.cat([x2, x2.new_zeros((256 - rows, k))])
     w = weight.detach()
     w = w if (w.dtype == x.dtype and w.is_contiguous()) else w.to(x.dtype).contiguous()
     b = None
     if bias is not None:
         b = bias.detach()
         b = b if (b.dtype == x.dtype and b.is_contiguous()) else b.to(x.dtype).contiguous()
-    out = torch.empty(x.shape[:-1] + (n,), dtype=x.dtype, device=x.device)
+    out = torch.empty((x2.shape[0], n), dtype=x.dtype, device=x.device)
     _check(lib().ds_linear(ctx_for(_dev_index(x)), x2.data_ptr(), w.data_ptr(), None if b is None else b.data_ptr(),
                            out.data_ptr(), x2.shape[0], n, k, n, 1 if gelu else 0,
                            1 if x.dtype == torch.float16 else 2, _stream(x)))
-    return out
+    return out[:rows].view(x.shape[:-1] + (n,))
 
 
 def conv3x3_supported(conv, x):
     """What ds_conv3x3_nhwc takes: 3x3, stride 1, zero padding 1, no groups / dilation, in % 128 == 0, out % 256 == 0."""
     return (tuple(conv.kernel_size) == (3, 3) and tuple(conv.stride) == (1, 1) and tuple(conv.padding) == (1, 1)
             and tuple(conv.dilation) == (1, 1) and conv.groups == 1 and conv.padding_mode == 'zeros'
-            and conv.in_channels % 128 == 0 and conv.out_channels % 256 == 0 and x.dim() == 4 and x.shape[1] == conv.in_channels)
+            and conv.in_channels % 128 == 0 and conv.out_channels % 256 == 0 and x.dim() == 4 and x.shape[1] == conv.in_channels
+            and x.shape[0] * x.shape[2] * x.shape[3] >= 256)
 
 
 def conv3x3(conv, x, relu=False, res1=None, res2=None):

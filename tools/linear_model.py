@@ -105,7 +105,7 @@ def stage(lds, kind, kt, s, x, w, bm0, bn0, M, K):
                 slot = (lane & 7) ^ ((j >> 1) & 7)
                 h = {'A0': 0, 'A1': 1, 'B0': 0, 'B1': 1}[kind]
                 if kind[0] == 'A':
-                    row = min((j >> 6) * 128 + h * 64 + (j & 63), M - 1 - bm0)
+                    row = (j >> 6) * 128 + h * 64 + (j & 63)
                     src = x[bm0 + row, kt * 64 + slot * 8: kt * 64 + slot * 8 + 8]
                 else:
                     col = (j >> 5) * 64 + (j & 31) + h * 32
@@ -150,7 +150,7 @@ def check_indexing(M=300, N=256, K=128, seed=0):
     w = rng.standard_normal((N, K)).astype(np.float32)
     y = np.zeros((M, N))
     nt = K // 64
-    for bm0 in range(0, M, 256):
+    for bm0 in [min(p0, M - 256) for p0 in range(0, M, 256)]:      # the last row panel is shifted up to end at row M
         for bn0 in range(0, N, 256):
             lds = np.zeros(131072 // 2, np.float32)
             for wr in range(2):
