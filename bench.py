@@ -392,6 +392,53 @@ def main():
                 "traffic_from_profile": traffic_from_profile("k_attention_fwd", batch) if args.config == "c3" else None,
                 "algorithmic_flops_per_launch": attn_flops, "avg_kernel_ms": attn_ms, "operands": "random (randn)",
                 "launches_per_step": minfo["depth"], "shape": {"batch": batch, "tokens": n_tok, "heads": minfo["heads"], "bias": minfo["bias"]}}
+    # ... and the in-tree MFMA GEMM (csrc/ds_linear.hip) at the shapes it runs at: fc1 + GELU of one encoder block, and the
+    # 3x3 convolution of the decoder's last residual units (256 -> 256 at net/4 resolution), random operands
+    lin = conv_roof = None
+    if model is not None and vm.LINEAR_HIP != "0":
+        m_rows, dim = batch * vm.pad_len(minfo["tokens"]), minfo["dim"]
+        xw = torch.randn(m_rows, dim, device=dev, dtype=torch.float16)
+        ww = torch.randn(4 * dim, dim, device=dev, dtype=torch.float16) * dim ** -0.5
+        bw = torch.randn(4 * dim, device=dev, dtype=torch.float16)
+        if nat.linear_supported(xw, ww):
+            for _ in range(3):
+                nat.linear(xw, ww, bw, True)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(20):
+                nat.linear(xw, ww, bw, True)
+            e1.record()
+            e1.synchronize()
+            lin_ms = e0.elapsed_time(e1) / 20
+            lin_flops = 2.0 * m_rows * 4 * dim * dim
+            lin = {"bound": "mfma", "kernel": "k_linear256 (fc1 + erf-GELU)", "achieved": lin_flops / (lin_ms * 1e-3) / 1e12,
+                   "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": lin_flops / (lin_ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS,
+                   "traffic": None, "traffic_from_profile": traffic_from_profile("k_linear256", batch) if args.config == "c3" else None,
+                   "algorithmic_flops_per_launch": lin_flops, "avg_kernel_ms": lin_ms, "operands": "random (randn)",
+                   "launches_per_step": minfo["depth"], "shape": {"rows": m_rows, "out_features": 4 * dim, "in_features": dim}}
+        del xw, ww, bw
+    if model is not None and vm.CONV_HIP and model_name.startswith("dpt_"):
+        import torch.nn as nn
+        hw = (net_h or net_size) // 4, net_size // 4
+        cv = nn.Conv2d(256, 256, 3, padding=1).to(dev, torch.float16)
+        xc = torch.randn(batch, 256, hw[0], hw[1], device=dev, dtype=torch.float16).contiguous(memory_format=torch.channels_last)
+        if vm.conv3x3_hip_ok(cv, xc):
+            for _ in range(3):
+                nat.conv3x3(cv, xc, relu=True)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(10):
+                nat.conv3x3(cv, xc, relu=True)
+            e1.record()
+            e1.synchronize()
+            cv_ms = e0.elapsed_time(e1) / 10
+            cv_flops = 2.0 * batch * hw[0] * hw[1] * 256 * 9 * 256
+            conv_roof = {"bound": "mfma", "kernel": "k_linear256 (implicit 3x3 convolution + bias + ReLU)",
+                         "achieved": cv_flops / (cv_ms * 1e-3) / 1e12, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": cv_flops / (cv_ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS, "traffic": None,
+                         "algorithmic_flops_per_launch": cv_flops, "avg_kernel_ms": cv_ms, "operands": "random (randn)",
+                         "shape": {"batch": batch, "height": hw[0], "width": hw[1], "in_channels": 256, "out_channels": 256}}
+        del cv, xc
     torch.cuda.synchronize()
 
     funnel = None
@@ -442,10 +489,18 @@ def main():
                        "overlap": "per-pixel kernels of step k on a second stream beside the forward of step k+1" if post is not None else "single stream",
                        "parallelism": f"units sharded over {world} GPU(s), no data-path collective"
                                       + (", ONE RCCL gather of the stereo pairs to rank 0 per step, overlapped" if gather_ok else "")},
-            # the dominant hand-written kernel of the step: the fused attention when a network runs, else the stereo kernel
-            "roofline": attn if attn is not None else stereo_roof,
+            # the dominant hand-written kernel of the step (largest launches x average duration): the fc1 + GELU GEMM or the
+            # fused attention when a network runs, else the stereo kernel; the others follow under their own keys
+            "roofline": stereo_roof,
         }
         if attn is not None:
+            cands = [r for r in (attn, lin) if r is not None]
+            out["roofline"] = max(cands, key=lambda r: r["avg_kernel_ms"] * r["launches_per_step"])
+            out["roofline_attention"] = attn
+            if lin is not None:
+                out["roofline_linear"] = lin
+            if conv_roof is not None:
+                out["roofline_conv3x3"] = conv_roof
             out["roofline_stereo"] = stereo_roof
             enc = vm.count_encoder_flops(minfo["depth"], minfo["tokens"], minfo["dim"]) * batch
             out["encoder_tflops_per_step"] = enc / 1e12

@@ -61,7 +61,8 @@ struct LinParams {
     void *y;
     int M, N, K;                // K = reduction length (CONV: 9 * C)
     int nbm, nbn;
-    int ablate;                 // timing experiments (DS_LIN_ABLATE): 1 = no epilogue stores, 2 = no K loop
+    int ablate;                 // timing experiments (DS_LIN_ABLATE): 1 = no epilogue stores, 2 = no K loop, 4 = full-line store pattern, 8 = nt stores
+    int stagger;                // experiment (DS_LIN_STAGGER_US): every other workgroup of an XCD starts this many 10 ns ticks late
     int H, W, C, cpt, magic;    // CONV: image height / width, input channels, K-tiles per tap (C / 64), 65536 / cpt + 1
     long long ldy;              // row stride of y (and res1 / res2) in elements
 };
@@ -85,6 +86,21 @@ __device__ __forceinline__ float ln_gelu(float v)
     q = __builtin_fmaf(q, u, 0.9999943375587463f);
     const float h = __builtin_amdgcn_exp2f(-q);
     return __builtin_fmaf(-u, h, fmaxf(v, 0.0f));
+}
+// the same on two values at once: the polynomial and the final multiply-add as packed fp32 operations (v_pk_fma_f32), which
+// halves the instruction count of the part of the epilogue that is VALU-bound
+typedef float lf32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ lf32x2 ln_gelu2(lf32x2 v)
+{
+    const lf32x2 u = {fminf(fabsf(v[0]), 6.0f), fminf(fabsf(v[1]), 6.0f)};
+    lf32x2 q = {1.8896206483987044e-06f, 1.8896206483987044e-06f};
+#define LN_PK(c) q = __builtin_elementwise_fma(q, u, (lf32x2){c, c})
+    LN_PK(-6.268127617659047e-05f); LN_PK(0.000938866869546473f); LN_PK(-0.008539456874132156f); LN_PK(0.054020676761865616f);
+    LN_PK(0.45840978622436523f); LN_PK(1.1512691974639893f); LN_PK(0.9999943375587463f);
+#undef LN_PK
+    const lf32x2 h = {__builtin_amdgcn_exp2f(-q[0]), __builtin_amdgcn_exp2f(-q[1])};
+    const lf32x2 r = {fmaxf(v[0], 0.0f), fmaxf(v[1], 0.0f)};
+    return __builtin_elementwise_fma(-u, h, r);
 }
 
 // LDS-DMA of 16 bytes per lane (global_load_lds_dwordx4): destination = M0 + 16 * lane.  Written as inline asm so that
@@ -125,45 +141,56 @@ __global__ __launch_bounds__(LN_THREADS) void k_linear256(LinParams P)
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wid >> 2, wc = wid & 3;
 
-    // ---- XCD-aware tile choice: XCD x takes tiles [start(x), start(x+1)) of the column-fastest tile list ------------
     const int nwg = P.nbm * P.nbn;
-    const int orig = blockIdx.x;
-    const int xcd = orig & 7, q8 = nwg >> 3, r8 = nwg & 7;
-    const int tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (orig >> 3);
-    // the last row panel is shifted up to end at row M (M >= 256): its first rows are computed twice, identically, by
-    // two workgroups -- no per-row clamping or masking anywhere (y must not alias res1 / res2)
-    const int bm0 = min((tile / P.nbn) * 256, P.M - 256), bn0 = (tile % P.nbn) * 256;
     const int K = P.K;
     const int rowbytes = (CONV ? P.C : K) * (int)sizeof(T);                 // bytes of one row of x (one pixel for CONV)
-    const unsigned char *xb = (const unsigned char *)P.x + (size_t)bm0 * rowbytes;
-    const unsigned char *wb = (const unsigned char *)P.w + (size_t)bn0 * K * sizeof(T);
 
     // ---- staging: this thread's two 16-byte pieces of a half-tile (chunk c = 2*wave + i = LDS rows 8c .. 8c+7) -------
     // LDS row j = 8c + (lane >> 3), LDS slot = lane & 7 holds SOURCE slot (lane & 7) ^ ((j >> 1) & 7).
     unsigned srcA[2], srcB[2];
-    unsigned okA = 0;       // CONV: bit 6*(2h+i) + t (t = 0..2): row y-1+t of this piece's pixel is inside the image; + 3 + t: column x-1+t
+    int rowA[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int c = 2 * wid + i;
         const int j = 8 * c + (lane >> 3);
         const int slot = (lane & 7) ^ ((j >> 1) & 7);
-        const int row = (j >> 6) * 128 + (j & 63);                          // A half h (+ 64 h rows): wave-row j>>6, row j&63 of its 64
-        srcA[i] = (unsigned)row * (unsigned)rowbytes + slot * 16;
-        if (CONV) {
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const unsigned pix = (unsigned)(bm0 + row + 64 * h) % (unsigned)(P.H * P.W);
-                const int py = (int)(pix / (unsigned)P.W), px = (int)(pix % (unsigned)P.W);
-                const unsigned bits = (py > 0 ? 1u : 0u) | 2u | (py < P.H - 1 ? 4u : 0u) | (px > 0 ? 8u : 0u) | 16u | (px < P.W - 1 ? 32u : 0u);
-                okA |= bits << (6 * (2 * h + i));
-            }
-        }
+        rowA[i] = (j >> 6) * 128 + (j & 63);                                // A half h (+ 64 h rows): wave-row j>>6, row j&63 of its 64
+        srcA[i] = (unsigned)rowA[i] * (unsigned)rowbytes + slot * 16;
         const int col = (j >> 5) * 64 + (j & 31);                           // B half h adds 32 columns (uniform)
         srcB[i] = (unsigned)col * (unsigned)K * (unsigned)sizeof(T) + slot * 16;
     }
     const unsigned a_half = 64u * (unsigned)rowbytes;
     const unsigned b_half = 32u * (unsigned)K * (unsigned)sizeof(T);
     const unsigned lds_stage = (unsigned)(size_t)(__attribute__((address_space(3))) void *)lds + (unsigned)(2 * wid) * 1024u;   // LDS address of chunk 2*wave
+
+    // ---- the workgroup is persistent: it walks tiles orig = blockIdx.x, + gridDim.x, ... of the XCD-aware tile list (XCD x
+    // takes tiles [start(x), start(x+1)) of the column-fastest list; gridDim.x is a multiple of 8, so a workgroup stays on
+    // its XCD's range).  Per tile: origin, operand bases and (CONV) the border bits of this thread's four pixels.
+    int bm0 = 0, bn0 = 0;
+    const unsigned char *xb = nullptr, *wb = nullptr;
+    unsigned okA = 0;       // CONV: bit 6*(2h+i) + t (t = 0..2): row y-1+t of this piece's pixel is inside the image; + 3 + t: column x-1+t
+    auto set_tile = [&](const int orig) {
+        const int xcd = orig & 7, q8 = nwg >> 3, r8 = nwg & 7;
+        const int tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (orig >> 3);
+        // the last row panel is shifted up to end at row M (M >= 256): its first rows are computed twice, identically, by
+        // two workgroups -- no per-row clamping or masking anywhere (y must not alias res1 / res2)
+        bm0 = min((tile / P.nbn) * 256, P.M - 256);
+        bn0 = (tile % P.nbn) * 256;
+        xb = (const unsigned char *)P.x + (size_t)bm0 * rowbytes;
+        wb = (const unsigned char *)P.w + (size_t)bn0 * K * sizeof(T);
+        if (CONV) {
+            okA = 0;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const unsigned pix = (unsigned)(bm0 + rowA[i] + 64 * h) % (unsigned)(P.H * P.W);
+                    const int py = (int)(pix / (unsigned)P.W), px = (int)(pix % (unsigned)P.W);
+                    const unsigned bits = (py > 0 ? 1u : 0u) | 2u | (py < P.H - 1 ? 4u : 0u) | (px > 0 ? 8u : 0u) | 16u | (px < P.W - 1 ? 32u : 0u);
+                    okA |= bits << (6 * (2 * h + i));
+                }
+        }
+    };
 
     // kind: 0 A0, 1 A1, 2 B0, 3 B1; kt = K-tile; s = LDS buffer
 #define LN_STAGE(kind, kt, s)                                                                                            \
@@ -202,14 +229,6 @@ __global__ __launch_bounds__(LN_THREADS) void k_linear256(LinParams P)
     V8 fa[2][2][4];      // [half][row block][k step]   x fragments
     V8 fb[2][4];         // [half][k step]              W fragments
     lf32x16 acc[2][2][2];  // [x half][row block][W half]
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int b = 0; b < 2; ++b)
-#pragma unroll
-            for (int c = 0; c < 2; ++c)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[a][b][c][r] = 0.f;
 
 #define LN_READ_A(h, s)                                                                                                  \
     _Pragma("unroll") for (int rb_ = 0; rb_ < 2; ++rb_) _Pragma("unroll") for (int ks_ = 0; ks_ < 4; ++ks_)              \
@@ -217,12 +236,10 @@ __global__ __launch_bounds__(LN_THREADS) void k_linear256(LinParams P)
 #define LN_READ_B(h, s)                                                                                                  \
     _Pragma("unroll") for (int ks_ = 0; ks_ < 4; ++ks_)                                                                  \
         fb[h][ks_] = *(const V8 *)(lds + offB[ks_] + ((h) * 2 * LN_HALF + (s) * LN_HALF))
-#define LN_MMA(ha, hb)                                                                                                   \
+#define LN_MMA_PART(ha, hb, k0, k1)                                                                                      \
     do {                                                                                                                 \
-        __builtin_amdgcn_s_setprio(1);                                                                                   \
-        _Pragma("unroll") for (int ks_ = 0; ks_ < 4; ++ks_) _Pragma("unroll") for (int rb_ = 0; rb_ < 2; ++rb_)          \
+        _Pragma("unroll") for (int ks_ = (k0); ks_ < (k1); ++ks_) _Pragma("unroll") for (int rb_ = 0; rb_ < 2; ++rb_)    \
             acc[ha][rb_][hb] = TR::mfma(fb[hb][ks_], fa[ha][rb_][ks_], acc[ha][rb_][hb]);                                \
-        __builtin_amdgcn_s_setprio(0);                                                                                   \
     } while (0)
 
     // ---- schedule ------------------------------------------------------------------------------------------------------
@@ -247,62 +264,93 @@ __global__ __launch_bounds__(LN_THREADS) void k_linear256(LinParams P)
     //     wave-rows have done so before b[2w+1], and every read of phase w+1 is issued after b[2w+1].
     const int nt = K >> 6, ni = nt >> 1;
 
-    LN_STAGE(0, 0, 0); LN_STAGE(2, 0, 0); LN_STAGE(3, 0, 0); LN_STAGE(1, 0, 0);
-    LN_STAGE(0, 1, 1); LN_STAGE(2, 1, 1); LN_STAGE(3, 1, 1);
-    LN_WAIT_VM(10);                       // 14 issued: A0, B0 of tile 0 have landed
-    LN_BARRIER();
-    LN_READ_A(0, 0);
-    LN_WAIT_LGKM0();                      // retired here: A0 of buffer 0 is re-staged in phase 1
-    if (wr == 1) LN_BARRIER();            // the stagger
+    // the first 7 half-tiles of a tile (everything phases 0..5 read, and A0 of K-tile 0 for the read ahead of phase 0)
+#define LN_PROLOGUE()                                                                                                    \
+    do {                                                                                                                 \
+        LN_STAGE(0, 0, 0); LN_STAGE(2, 0, 0); LN_STAGE(3, 0, 0); LN_STAGE(1, 0, 0);                                      \
+        LN_STAGE(0, 1, 1); LN_STAGE(2, 1, 1); LN_STAGE(3, 1, 1);                                                         \
+    } while (0)
 
     // One phase: memory part | barrier | MFMAs | barrier (wave-row 1 one barrier behind).  A variant with ONE barrier per
     // phase (wave-row 0 issues its MFMAs before the barrier, wave-row 1 after it, so the hand-over needs no meeting point)
     // was built and measured: 1.88 us per K-tile against 1.65 us for this one -- the strict alternation wins.
+    // Measured and dropped (same box, K = 1024 / 4096 / 8192, us per round of 256 tiles): issuing the last 2 of a phase's 8
+    // MFMAs after its closing barrier 43.1 / 122.3 / 238.8 against 39.9 / 113.1 / 216.9 for this form; DMA ahead of the
+    // fragment reads and no s_setprio: no difference.
 #define LN_PHASE_END(ha, hb)                                                                                             \
-    do { LN_BARRIER(); LN_WAIT_LGKM0(); LN_MMA(ha, hb); LN_BARRIER(); } while (0)
+    do {                                                                                                                 \
+        LN_BARRIER(); LN_WAIT_LGKM0();                                                                                   \
+        __builtin_amdgcn_s_setprio(1);                                                                                   \
+        LN_MMA_PART(ha, hb, 0, 4);                                                                                       \
+        __builtin_amdgcn_s_setprio(0);                                                                                   \
+        LN_BARRIER();                                                                                                    \
+    } while (0)
+#define LN_MEM(READ, STAGE)                                                                                              \
+    do { READ; STAGE; } while (0)
 
     auto iteration = [&](const int i, auto last_c) {
         constexpr bool LAST = decltype(last_c)::value;
         const int e2 = 2 * i + 2, o2 = 2 * i + 3;
         // phase 0
-        LN_READ_B(0, 0); LN_STAGE(1, 2 * i + 1, 1); LN_WAIT_VM(10);
+        LN_MEM(LN_READ_B(0, 0), LN_STAGE(1, 2 * i + 1, 1)); LN_WAIT_VM(10);
         LN_PHASE_END(0, 0);
         // phase 1
-        LN_READ_B(1, 0);
-        if constexpr (!LAST) { LN_STAGE(0, e2, 0); LN_WAIT_VM(10); } else { LN_WAIT_VM(8); }
+        if constexpr (!LAST) { LN_MEM(LN_READ_B(1, 0), LN_STAGE(0, e2, 0)); LN_WAIT_VM(10); } else { LN_READ_B(1, 0); LN_WAIT_VM(8); }
         LN_PHASE_END(0, 1);
         // phase 2
-        LN_READ_A(1, 0);
-        if constexpr (!LAST) { LN_STAGE(2, e2, 0); LN_WAIT_VM(10); } else { LN_WAIT_VM(6); }
+        if constexpr (!LAST) { LN_MEM(LN_READ_A(1, 0), LN_STAGE(2, e2, 0)); LN_WAIT_VM(10); } else { LN_READ_A(1, 0); LN_WAIT_VM(6); }
         LN_PHASE_END(1, 1);
         // phase 3
-        LN_READ_A(0, 1);
-        if constexpr (!LAST) { LN_STAGE(3, e2, 0); LN_WAIT_VM(10); } else { LN_WAIT_VM(4); }
+        if constexpr (!LAST) { LN_MEM(LN_READ_A(0, 1), LN_STAGE(3, e2, 0)); LN_WAIT_VM(10); } else { LN_READ_A(0, 1); LN_WAIT_VM(4); }
         LN_PHASE_END(1, 0);
         // phase 4
-        LN_READ_B(0, 1);
-        if constexpr (!LAST) { LN_STAGE(1, e2, 0); LN_WAIT_VM(10); } else { LN_WAIT_VM(2); }
+        if constexpr (!LAST) { LN_MEM(LN_READ_B(0, 1), LN_STAGE(1, e2, 0)); LN_WAIT_VM(10); } else { LN_READ_B(0, 1); LN_WAIT_VM(2); }
         LN_PHASE_END(0, 0);
         // phase 5
-        LN_READ_B(1, 1);
-        if constexpr (!LAST) { LN_STAGE(0, o2, 1); LN_WAIT_VM(10); } else { LN_WAIT_VM(0); }
+        if constexpr (!LAST) { LN_MEM(LN_READ_B(1, 1), LN_STAGE(0, o2, 1)); LN_WAIT_VM(10); } else { LN_READ_B(1, 1); LN_WAIT_VM(0); }
         LN_PHASE_END(0, 1);
         // phase 6
-        LN_READ_A(1, 1);
-        if constexpr (!LAST) { LN_STAGE(2, o2, 1); LN_WAIT_VM(10); }
+        if constexpr (!LAST) { LN_MEM(LN_READ_A(1, 1), LN_STAGE(2, o2, 1)); LN_WAIT_VM(10); } else { LN_READ_A(1, 1); }
         LN_PHASE_END(1, 1);
         // phase 7
-        if constexpr (!LAST) { LN_READ_A(0, 0); LN_STAGE(3, o2, 1); LN_WAIT_VM(10); }
+        if constexpr (!LAST) { LN_MEM(LN_READ_A(0, 0), LN_STAGE(3, o2, 1)); LN_WAIT_VM(10); }
         LN_PHASE_END(1, 0);
     };
+    if (P.stagger > 0 && ((blockIdx.x >> 3) & 1)) {
+        const unsigned long long t0 = wall_clock64();
+        while (wall_clock64() - t0 < (unsigned long long)P.stagger) __builtin_amdgcn_s_sleep(32);
+    }
+    set_tile(blockIdx.x);
+    LN_PROLOGUE();
+    for (int orig = blockIdx.x;;) {
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[a][b][c][r] = 0.f;
+    // In the queue ahead of the prologue's 14 loads: nothing (first tile) or the previous tile's epilogue stores, which
+    // retire first (the counter is in order): "all but the last 10" covers A0 and B0 of K-tile 0 either way.
+    LN_WAIT_VM(10);
+    LN_BARRIER();
+    LN_READ_A(0, 0);
+    LN_WAIT_LGKM0();                      // retired here: A0 of buffer 0 is re-staged in phase 1
+    if (wr == 1) LN_BARRIER();            // the stagger
     if (P.ablate & 2) {
         LN_WAIT_VM(0);
-        __syncthreads();
+        if (wr == 0) LN_BARRIER();
     } else {
         for (int i = 0; i < ni - 1; ++i) iteration(i, std::false_type());
         iteration(ni - 1, std::true_type());
         if (wr == 0) LN_BARRIER();                         // wave-row 0 arrives at wave-row 1's last barrier
     }
+    // every fragment read of this tile was retired before that barrier: LDS is free for the next tile's prologue, which is
+    // issued AFTER this tile's epilogue stores (its latency then runs under the drain of the stores; the epilogue's own
+    // loads are all older than the DMA, so the compiler's waits for them never wait for the DMA)
+    const int cbm0 = bm0, cbn0 = bn0;
+    const int next = orig + (int)gridDim.x;
 
     // ---- epilogue ---------------------------------------------------------------------------------------------------------
     // Register r of a 32 x 32 accumulator block = column (r & 3) + 8 (r >> 2) + 4 (lane >> 5) of row lane & 31: a lane holds
@@ -316,7 +364,7 @@ __global__ __launch_bounds__(LN_THREADS) void k_linear256(LinParams P)
     const int hi8 = 8 * (lane >> 5);
 #pragma unroll
     for (int hb = 0; hb < 2; ++hb) {
-        const int n0 = bn0 + wc * 64 + hb * 32 + hi8;          // + 16 k
+        const int n0 = cbn0 + wc * 64 + hb * 32 + hi8;         // + 16 k
         float bv[2][8];
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
@@ -335,7 +383,7 @@ __global__ __launch_bounds__(LN_THREADS) void k_linear256(LinParams P)
             size_t o0[2];
 #pragma unroll
             for (int rb = 0; rb < 2; ++rb) {
-                const int m = bm0 + wr * 128 + ha * 64 + rb * 32 + (lane & 31);
+                const int m = cbm0 + wr * 128 + ha * 64 + rb * 32 + (lane & 31);
                 o0[rb] = (size_t)m * P.ldy + n0;
 #pragma unroll
                 for (int k = 0; k < 2; ++k) {
@@ -358,19 +406,30 @@ __global__ __launch_bounds__(LN_THREADS) void k_linear256(LinParams P)
                     }
                     V8 o;
 #pragma unroll
-                    for (int t = 0; t < 8; ++t) {
-                        float u = v[t] + bv[k][t];
-                        if (RES >= 1) u += (float)ra[rb][k][t];
-                        if (RES >= 2) u += (float)rb2[rb][k][t];
-                        if (EPI == 1) u = ln_gelu(u);
-                        if (EPI == 2) u = fmaxf(u, 0.f);
-                        o[t] = (T)u;
+                    for (int t = 0; t < 8; t += 2) {
+                        lf32x2 u = {v[t] + bv[k][t], v[t + 1] + bv[k][t + 1]};
+                        if (RES >= 1) u += (lf32x2){(float)ra[rb][k][t], (float)ra[rb][k][t + 1]};
+                        if (RES >= 2) u += (lf32x2){(float)rb2[rb][k][t], (float)rb2[rb][k][t + 1]};
+                        if (EPI == 1) u = ln_gelu2(u);
+                        if (EPI == 2) u = (lf32x2){fmaxf(u[0], 0.f), fmaxf(u[1], 0.f)};
+                        o[t] = (T)u[0];
+                        o[t + 1] = (T)u[1];
                     }
-                    if (!(P.ablate & 1)) *(V8 *)(yb + o0[rb] + 16 * k) = o;
+                    if (P.ablate & 4) {            // timing experiment (wrong placement): every store instruction covers 8 full 128-byte lines
+                        const int idx = ((hb * 2 + ha) * 2 + rb) * 2 + k;
+                        *(V8 *)(yb + (size_t)(cbm0 + wr * 128 + idx * 8 + (lane >> 3)) * P.ldy + cbn0 + wc * 64 + (lane & 7) * 8) = o;
+                    } else if (P.ablate & 8) {     // timing experiment: non-temporal stores
+                        __builtin_nontemporal_store(o, (V8 *)(yb + o0[rb] + 16 * k));
+                    } else if (!(P.ablate & 1)) *(V8 *)(yb + o0[rb] + 16 * k) = o;
                     else asm volatile("" ::"v"(o));
                 }
             }
         }
+    }
+    if (next >= nwg) break;
+    orig = next;
+    set_tile(orig);
+    LN_PROLOGUE();
     }
 }
 
@@ -384,7 +443,20 @@ static int ln_launch(const LinParams &P, hipStream_t stream)
         DS_HIP_CHECK(hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, LN_LDS_BYTES));
         attr_set = true;
     }
-    hipLaunchKernelGGL(fn, dim3(P.nbm * P.nbn), dim3(LN_THREADS), LN_LDS_BYTES, stream, P);
+    static int ncu = 0;
+    if (!ncu) {
+        int dev = 0;
+        DS_HIP_CHECK(hipGetDevice(&dev));
+        DS_HIP_CHECK(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev));
+        ncu = ncu >= 8 ? ncu / 8 * 8 : 8;                 // one workgroup per CU (128 KB of LDS each), a multiple of the 8 XCDs
+    }
+    int grid = ncu;
+    if (const char *e = getenv("DS_LIN_GRID")) {          // tests: a small grid makes every workgroup walk many tiles
+        const int g = atoi(e) / 8 * 8;
+        if (g >= 8) grid = g;
+    }
+    const int nwg = P.nbm * P.nbn;
+    hipLaunchKernelGGL(fn, dim3(nwg < grid ? nwg : grid), dim3(LN_THREADS), LN_LDS_BYTES, stream, P);
     DS_HIP_CHECK(hipGetLastError());
     return DS_OK;
 }
@@ -430,6 +502,7 @@ DS_API int ds_linear(ds_ctx *ctx, const void *x, const void *w, const void *bias
     P.nbm = (int)((rows + 255) / 256); P.nbn = (int)(out_features / 256);
     P.ldy = ldy;
     P.ablate = getenv("DS_LIN_ABLATE") ? atoi(getenv("DS_LIN_ABLATE")) : 0;
+    P.stagger = getenv("DS_LIN_STAGGER_US") ? (int)(atof(getenv("DS_LIN_STAGGER_US")) * 100.0) : 0;
     return dtype == DS_DTYPE_F16 ? ln_dispatch_dense<0>(P, act, (hipStream_t)stream) : ln_dispatch_dense<1>(P, act, (hipStream_t)stream);
 }
 
@@ -464,5 +537,6 @@ DS_API int ds_conv3x3_nhwc(ds_ctx *ctx, const void *x, const void *w, const void
         DS_REQUIRE(((kt * P.magic) >> 16) == kt / P.cpt, DS_EUNSUPPORTED, "ds_conv3x3_nhwc: tap arithmetic does not cover %d channels", in_channels);
     P.ldy = out_channels;
     P.ablate = getenv("DS_LIN_ABLATE") ? atoi(getenv("DS_LIN_ABLATE")) : 0;
+    P.stagger = getenv("DS_LIN_STAGGER_US") ? (int)(atof(getenv("DS_LIN_STAGGER_US")) * 100.0) : 0;
     return dtype == DS_DTYPE_F16 ? ln_dispatch_conv<0>(P, act, (hipStream_t)stream) : ln_dispatch_conv<1>(P, act, (hipStream_t)stream);
 }

@@ -577,6 +577,22 @@ def test_linear_kernel_matches_float32_and_is_race_free(gpu, dtype, tol):
         assert err < tol * (1 + want.abs().max().item()), (m, n, k, has_bias, gelu, err)
         for _ in range(3):
             assert torch.equal(_native.linear(x, w, b, gelu), got), "run-to-run difference: a race in the K loop"
+    # the workgroups are persistent (one per CU, each walking a strided list of tiles): a grid of 8 makes every workgroup
+    # walk many tiles, with the next tile's prologue issued behind the previous epilogue
+    import os
+    os.environ["DS_LIN_GRID"] = "8"
+    try:
+        for (m, n, k, has_bias, gelu) in [(2443, 768, 640, True, True), (4352, 2048, 1024, True, False)]:
+            x = torch.randn((m, k), generator=g).to(dtype).cuda()
+            w = (torch.randn((n, k), generator=g) * k ** -0.5).to(dtype).cuda()
+            b = torch.randn(n, generator=g).to(dtype).cuda()
+            want = x.double() @ w.double().T + b.double()
+            want = F.gelu(want) if gelu else want
+            got = _native.linear(x, w, b, gelu)
+            assert (got.double() - want).abs().max().item() < tol * (1 + want.abs().max().item()), (m, n, k)
+            assert torch.equal(_native.linear(x, w, b, gelu), got)
+    finally:
+        del os.environ["DS_LIN_GRID"]
     # a 3-D input and a strided (sliced) weight go through the same entry point
     x3 = torch.randn((2, 130, 256), generator=g).to(dtype).cuda()
     wbig = torch.randn((768, 256), generator=g).to(dtype).cuda()
@@ -644,6 +660,18 @@ def test_conv3x3_kernel_matches_float32_convolution(gpu, dtype, tol):
             err = (got.float() - want).abs().max().item()
             assert err < tol * (1 + want.abs().max().item()), (b, h, w, cin, cout, relu, err)
             assert torch.equal(_native.conv3x3(conv, x, relu=relu, res1=a, res2=bb), got)
+    import os
+    os.environ["DS_LIN_GRID"] = "8"                 # persistent workgroups walking many tiles (see the linear test)
+    try:
+        conv = nn.Conv2d(256, 256, 3, padding=1).cuda()
+        x = torch.randn((2, 256, 37, 41), generator=g).to(dtype).cuda().contiguous(memory_format=torch.channels_last)
+        r1 = torch.randn((2, 256, 37, 41), generator=g).to(dtype).cuda().contiguous(memory_format=torch.channels_last)
+        want = F.relu(F.conv2d(x.float(), conv.weight.detach().to(dtype).float(), conv.bias.detach().to(dtype).float(), padding=1) + r1.float())
+        got = _native.conv3x3(conv, x, relu=True, res1=r1)
+        assert (got.float() - want).abs().max().item() < tol * (1 + want.abs().max().item())
+        assert torch.equal(_native.conv3x3(conv, x, relu=True, res1=r1), got)
+    finally:
+        del os.environ["DS_LIN_GRID"]
     # the residual unit of the decoders at a size that takes the in-tree path (both convolutions + fused tails)
     from src import vit_mi355x as vm
     torch.manual_seed(5)

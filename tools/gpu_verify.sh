@@ -16,7 +16,7 @@ cd /tmp && export TMPDIR=/tmp
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -o k -- python $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline > $O/prof.log 2>&1; tail -1 $O/prof.log | cut -c1-200
 for c in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU" "SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_SALU SQ_INSTS_VMEM_RD TCC_HIT_sum TCC_MISS_sum"; do
   n=$(echo $c | tr ' ' '_' | cut -c1-30)
-  timeout 150 rocprofv3 --pmc $c -d $O/pmc_$n -o a -- python $R/tools/microbench.py attention rln head stereo normalmap > $O/pmc_$n.log 2>&1
+  timeout 150 rocprofv3 --pmc $c -d $O/pmc_$n -o a -- python $R/tools/microbench.py attention rln head stereo normalmap lin1 conv1 > $O/pmc_$n.log 2>&1
 done
 cd $R
 python tools/pmc_summary.py $O/pmc_* > $O/pmc_summary.json 2>&1; head -c 600 $O/pmc_summary.json
@@ -27,5 +27,6 @@ timeout 400 python bench.py --config c4 --steps 3 --warmup 1 > $O/bench_c4_rmax1
 timeout 300 python bench.py --config c4 --steps 2 --warmup 1 --boost-rmax 3000 > $O/bench_c4_rmax3000.json 2>> $O/bench_c4.err; cut -c1-200 $O/bench_c4_rmax3000.json
 timeout 100 python bench.py --model none --no-cpu-baseline > $O/bench_n1_stereo_only.json 2> $O/bench_none.err; cut -c1-200 $O/bench_n1_stereo_only.json
 python tools/microbench.py > $O/microbench.txt 2>&1; grep -v amdgpu.ids $O/microbench.txt
+python tools/microbench.py linear > $O/microbench_linear.txt 2>&1; python tools/microbench.py conv 2>&1 | grep conv3x3 > $O/microbench_conv.txt; python tools/microbench.py sweep > $O/microbench_sweep.txt 2>&1; cat $O/microbench_linear.txt $O/microbench_conv.txt | grep -v amdgpu.ids
 find $O/prof -name "*kernel_trace.csv" -delete; find $O -name "*.db" -size +20M -delete
 ls $O

@@ -31,7 +31,7 @@ def timeit(fn, reps=20, warm=3):
 
 
 def main():
-    which = set(sys.argv[1:]) or {"attention", "head", "rln", "upsample", "stereo", "normalmap", "readout"}
+    which = (set(sys.argv[1:]) - {"lin1", "conv1"}) or {"attention", "head", "rln", "upsample", "stereo", "normalmap", "readout"}
     B = 32
     dev = torch.device("cuda")
     if "attention" in which:
@@ -143,14 +143,31 @@ def linear_bench():
                   f"max|hip-lib| {full:.2e} repeat-identical {same}", flush=True)
 
 
+def single_shapes(which):
+    """One shape per kernel instantiation, a few launches each: what the hardware-counter passes profile."""
+    dev = torch.device("cuda")
+    if "lin1" in which:
+        x = torch.randn(34816, 1024, device=dev, dtype=torch.float16)
+        w = torch.randn(4096, 1024, device=dev, dtype=torch.float16) / 32
+        b = torch.randn(4096, device=dev, dtype=torch.float16)
+        ms = timeit(lambda: nat.linear(x, w, b, True), reps=10, warm=2)
+        print(f"linear fc1+gelu 34816x4096x1024: {ms * 1e3:.1f} us  {2.0 * 34816 * 4096 * 1024 / ms / 1e9:.0f} TF/s")
+    if "conv1" in which:
+        conv = nn.Conv2d(256, 256, 3, padding=1).to(dev, torch.float16)
+        x = torch.randn(32, 256, 128, 128, device=dev, dtype=torch.float16).contiguous(memory_format=torch.channels_last)
+        ms = timeit(lambda: nat.conv3x3(conv, x, relu=True), reps=10, warm=2)
+        print(f"conv3x3 32x128x128 256->256 (+bias, ReLU): {ms * 1e3:.1f} us  {2.0 * 32 * 128 * 128 * 256 * 2304 / ms / 1e9:.0f} TF/s")
+
+
 def linear_sweep():
     """Per-round time of ds_linear as a function of K (fixed cost per tile vs cost per K-tile), one full round of tiles
     (256) and eight rounds; and the cost of the GELU / residual epilogues."""
     dev = torch.device("cuda")
     dt = torch.float16
-    for rounds in (1, 8):
+    ks = [int(v) for v in os.environ.get("DS_SWEEP_K", "128,256,512,1024,2048,4096,8192").split(",")]
+    for rounds in ((8,) if os.environ.get("DS_SWEEP_K") else (1, 8)):
         m = 256 * 16 * rounds
-        for k in (128, 256, 512, 1024, 2048, 4096, 8192):
+        for k in ks:
             x = torch.randn(m, k, device=dev, dtype=dt)
             w = torch.randn(4096, k, device=dev, dtype=dt) * k ** -0.5
             b = torch.randn(4096, device=dev, dtype=dt)
@@ -189,6 +206,10 @@ def conv_bench():
 
 
 if __name__ == "__main__":
+    if "lin1" in sys.argv[1:] or "conv1" in sys.argv[1:]:
+        single_shapes(set(sys.argv[1:]))
+        if not (set(sys.argv[1:]) - {"lin1", "conv1"}):
+            sys.exit(0)
     if "sweep" in sys.argv[1:]:
         linear_sweep()
         sys.exit(0)
