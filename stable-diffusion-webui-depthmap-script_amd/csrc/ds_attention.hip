@@ -309,6 +309,14 @@ __global__ __launch_bounds__(AT_THREADS, 3) void k_attention_fwd(AttnParams P)
 // =====================================================================================================================
 // Version 2 of the kernel (default; DS_ATT_V1=1 selects the first one above for A/B runs).
 //
+// (A version 3 was built and measured in round 2 and removed again -- git history, profiles/round2_attention_v3_experiment.txt:
+// one 8-wave workgroup = two independent 4-wave tasks whose wave-rows alternate, barrier by barrier, between an MFMA part
+// (P.V of tile t, S of tile t+1) and a vector part (fragment reads, LDS-DMA of K / V^T three tiles ahead, softmax), the
+// structure of csrc/ds_linear.hip.  Correct at the benchmark shapes, but 15-35 % SLOWER than this kernel (N = 1025 + bias:
+// 0.344 vs 0.298 ms): with exactly two waves per SIMD the vector part -- ~200 instructions from ONE wave -- is bound by
+// that wave's issue rate, and the softmax of a 64-wide head is as long as its MFMAs; the GEMM's memory part is 16
+// instructions.  What remains is instruction-level interleaving inside a wave, i.e. a hand-scheduled kernel.)
+//
 // What changed, and why (round-1 profile: MFMA busy 20-26 %, ~200 VALU instructions per 16 MFMA with the bias, 3 waves/SIMD):
 //   * 64 query rows per wave (two 32-row blocks), 256 per workgroup: every K / V^T fragment read from LDS feeds TWO MFMAs,
 //     and K / V^T / the staging traffic per query row halve.  Two fat waves per SIMD (<= 256 VGPRs).
@@ -663,329 +671,9 @@ __global__ void k_attention_bias_pack2(const float *__restrict__ bias, typename 
     }
 }
 
-// =====================================================================================================================
-// Version 3 (DS_ATT_VERSION=3): two 4-wave attention workgroups fused into ONE 8-wave workgroup whose wave-rows alternate
-// between the matrix pipe and the vector pipe, with barriers -- the structure of csrc/ds_linear.hip's K loop.
-//
-// Why: version 2's ablations showed softmax VALU time, K / V^T traffic and MFMA time ADDING UP per wave (three waves per
-// SIMD drift into lockstep), 23 % of the MFMA peak.  Here each SIMD holds exactly two waves (one of each wave-row, 256
-// VGPRs each), and one tile of work is split into an MFMA part (O += V^T(t).P(t), then S(t+1) = Bias(t+1).I + K(t+1).Q^T)
-// and a vector part (fragment reads for the next MFMA part, LDS-DMA of tile t+3, softmax of S(t)); wave-row 1 runs one
-// barrier behind wave-row 0, so on every SIMD one wave is always in its MFMA part while the other one is in its vector part.
-//   * each wave-row is an independent task (its own batch / head / 128 query rows, 32 per wave) with its own K / V^T tiles
-//     in its own half of LDS (4 stages x 16 KB): hazards are only between the 4 waves of a row;
-//   * K and V^T tiles arrive by LDS-DMA (no staging registers, no ds_write), natural layout, 128-byte rows with the
-//     source-side XOR swizzle of ds_linear (conflict-free ds_read_b128 for both operands);
-//   * the K ROWS of a tile are placed in the order [0-3, 8-11, 4-7, 12-15] within every 16 keys: the S^T accumulator then
-//     holds, per lane, 8 CONSECUTIVE keys per 16 -- exactly the k-slot layout of the P^T operand -- so V^T needs no
-//     permutation (version 2 permuted V^T at 8-byte granularity in its ds_write pass, which a DMA cannot do) and P needs
-//     no cross-lane exchange.  The packed bias follows the same row order (ds_attention_bias_pack knows the version);
-//   * every VMEM operation of the loop is inline asm (DMA: 4 per tile and thread; bias fragments: 4 x 16 bytes per tile and
-//     lane) and waited for by position in the in-order vmcnt queue; nothing is drained inside the loop.
-#define AT3_THREADS 512
-#define AT3_STAGES 4
-#define AT3_TILE 16384                     // K (8 KB) + V^T (8 KB) of one 64-key tile
-#define AT3_GROUP (AT3_STAGES * AT3_TILE)  // LDS of one wave-row
-#define AT3_LDS (2 * AT3_GROUP)
-
-__device__ __forceinline__ void at3_dma(const void *base_uniform, unsigned voff, unsigned lds_uniform)
-{
-    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(base_uniform), "s"(lds_uniform) : "memory");
-}
-#define AT3_WAIT_VM(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
-#define AT3_WAIT_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
-#define AT3_BARRIER()                             \
-    do {                                          \
-        __builtin_amdgcn_sched_barrier(0);        \
-        __builtin_amdgcn_s_barrier();             \
-        __builtin_amdgcn_sched_barrier(0);        \
-    } while (0)
-// row order of a K tile in LDS: LDS row j holds key at3_pi(j) of the tile (an involution on every 16 rows)
-__host__ __device__ __forceinline__ int at3_pi(int j) { return (j & ~12) | ((j & 4) << 1) | ((j & 8) >> 1); }
-
-template <int BF16, int HAS_BIAS>
-__global__ __launch_bounds__(AT3_THREADS) void k_attention_fwd3(AttnParams P)
-{
-    typedef at_traits<BF16> TR;
-    typedef typename TR::T T;
-    typedef typename TR::V8 V8;
-    extern __shared__ __attribute__((aligned(1024))) unsigned char lds3[];
-    const int tid = threadIdx.x, lane = tid & 63, hi = lane >> 5, l31 = lane & 31;
-    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int grp = wid >> 2, wv = wid & 3;
-    int L = blockIdx.x;
-    if (P.chunk > 0) L = (int)(blockIdx.x & 7) * P.chunk + (int)(blockIdx.x >> 3);      // XCD-aware order (units: workgroups)
-    const int task = 2 * L + grp;
-    const bool grp_live = task < P.total;                       // a dead wave-row only keeps the barrier count
-    const int tsk = grp_live ? task : P.total - 1;
-    const int qblk = tsk % P.nq, b = (tsk / P.nq) % P.B, h = tsk / (P.nq * P.B);
-    const int q0 = qblk * 128 + wv * 32;
-    const int Np = P.Np, H = P.H;
-    const size_t tok_stride = (size_t)2 * H * AT_D;
-    const T *qk = (const T *)P.qk + (size_t)b * Np * tok_stride;
-    const T *q_base = qk + (size_t)h * AT_D;
-    const unsigned char *k_base = (const unsigned char *)(qk + (size_t)(H + h) * AT_D);
-    const unsigned char *v_base = (const unsigned char *)((const T *)P.vt + ((size_t)b * H + h) * AT_D * (size_t)Np);
-    T *out_base = (T *)P.out + (size_t)b * Np * (size_t)(H * AT_D) + (size_t)h * AT_D;
-    const bool wave_live = grp_live && q0 < P.n_valid;
-    if (grp_live && !wave_live && q0 < Np) {                    // padding rows feed the next GEMM: keep them finite (zero)
-        const int row = q0 + lane;
-        if (row < Np && lane < 32) {
-            uint4 z = make_uint4(0, 0, 0, 0);
-#pragma unroll
-            for (int c = 0; c < 8; c++) *reinterpret_cast<uint4 *>(out_base + (size_t)row * (H * AT_D) + 8 * c) = z;
-        }
-    }
-
-    // Q fragments: asm loads like every other VMEM operation of this kernel (a load the compiler counts would make it wait
-    // vmcnt(0) at the first use INSIDE the loop, on every iteration, draining the DMA queue); waited for by position below
-    u32x4 qraw[4];
-    {
-        const int qrow = min(q0 + l31, Np - 1);
-        const T *qp = q_base + (size_t)qrow * tok_stride + 8 * hi;
-        asm volatile("global_load_dwordx4 %0, %4, off\n\tglobal_load_dwordx4 %1, %4, off offset:32\n\t"
-                     "global_load_dwordx4 %2, %4, off offset:64\n\tglobal_load_dwordx4 %3, %4, off offset:96"
-                     : "=&v"(qraw[0]), "=&v"(qraw[1]), "=&v"(qraw[2]), "=&v"(qraw[3]) : "v"(qp) : "memory");
-    }
-    V8 qf[4];
-    V8 ident[2];
-#pragma unroll
-    for (int s = 0; s < 2; s++)
-#pragma unroll
-        for (int t = 0; t < 8; t++) ident[s][t] = TR::from_f32((16 * s + 8 * hi + t) == l31 ? 1.0f : 0.0f);
-    f32x16 o_acc[2], s_acc[2];
-#pragma unroll
-    for (int d = 0; d < 2; d++)
-#pragma unroll
-        for (int r = 0; r < 16; r++) { o_acc[d][r] = 0.f; s_acc[d][r] = 0.f; }
-    float m_run = -__builtin_inff(), l_run = 0.f;
-
-    // ---- staging: chunks c = 2 wv + i (rows 8c .. 8c+7) of the K tile and of the V^T tile; LDS slot = lane & 7 holds source
-    // slot (lane & 7) ^ ((row >> 1) & 7)
-    unsigned srcK[2], srcV[2];
-#pragma unroll
-    for (int i = 0; i < 2; i++) {
-        const int c = 2 * wv + i, j = 8 * c + (lane >> 3);
-        const unsigned slot = (unsigned)((lane & 7) ^ ((j >> 1) & 7)) << 4;
-        srcK[i] = (unsigned)at3_pi(j) * (unsigned)(tok_stride * sizeof(T)) + slot;
-        srcV[i] = (unsigned)j * (unsigned)(Np * sizeof(T)) + slot;
-    }
-    const unsigned lds_grp = (unsigned)(size_t)(__attribute__((address_space(3))) void *)lds3 + (unsigned)grp * AT3_GROUP;
-    const unsigned lds_stage = lds_grp + (unsigned)(2 * wv) * 1024u;
-#define A3_DMA(kt_) do {                                                                                               \
-        const unsigned char *kb_ = k_base + (size_t)(kt_) * AT_KB * tok_stride * sizeof(T);                             \
-        const unsigned char *vb_ = v_base + (size_t)(kt_) * AT_KB * sizeof(T);                                          \
-        const unsigned dst_ = lds_stage + (unsigned)((kt_) & (AT3_STAGES - 1)) * AT3_TILE;                              \
-        at3_dma(kb_, srcK[0], dst_); at3_dma(kb_, srcK[1], dst_ + 1024);                                                \
-        at3_dma(vb_, srcV[0], dst_ + 8192); at3_dma(vb_, srcV[1], dst_ + 8192 + 1024);                                  \
-    } while (0)
-    // ---- fragment reads: row l31 of a 32-row block, slot 2 s + hi, swizzled ------------------------------------------------
-    unsigned off[4];
-#pragma unroll
-    for (int s = 0; s < 4; s++) off[s] = (unsigned)grp * AT3_GROUP + (unsigned)l31 * 128u + ((unsigned)((2 * s + hi) ^ ((l31 >> 1) & 7)) << 4);
-    V8 kf[2][4], vf[2][2][2];           // K: [key block][d slice]; V^T: [d block][key block][16-key slice]
-#define A3_READ_K(kt_) do {                                                                                            \
-        const unsigned st_ = (unsigned)((kt_) & (AT3_STAGES - 1)) * AT3_TILE;                                           \
-        _Pragma("unroll") for (int kb_ = 0; kb_ < 2; kb_++) _Pragma("unroll") for (int s_ = 0; s_ < 4; s_++)           \
-            kf[kb_][s_] = *reinterpret_cast<const V8 *>(lds3 + off[s_] + st_ + kb_ * 4096);                             \
-    } while (0)
-#define A3_READ_V(kt_) do {                                                                                            \
-        const unsigned st_ = (unsigned)((kt_) & (AT3_STAGES - 1)) * AT3_TILE + 8192;                                    \
-        _Pragma("unroll") for (int d_ = 0; d_ < 2; d_++) _Pragma("unroll") for (int s_ = 0; s_ < 4; s_++)              \
-            vf[d_][s_ >> 1][s_ & 1] = *reinterpret_cast<const V8 *>(lds3 + off[s_] + st_ + d_ * 4096);                  \
-    } while (0)
-    // ---- bias fragments: [head][32-query block][64-key tile][chunk c = 2 kb + s][64 lanes][8], K-row order (pack, version 3)
-    u32x4 breg[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
-    const int n_kt = Np / AT_KB;
-    const unsigned char *b_base = (const unsigned char *)P.bias
-        + (HAS_BIAS ? ((size_t)h * (Np / 32) + (size_t)min(q0, Np - 32) / 32) * n_kt * 2048 * sizeof(T) : 0);
-    const unsigned b_off = (unsigned)lane * 16u;
-#define A3_FETCH_BIAS(kt_) do {                                                                                        \
-        const unsigned char *bb_ = b_base + (size_t)(kt_) * 2048 * sizeof(T);                                           \
-        asm volatile("global_load_dwordx4 %0, %4, %5\n\tglobal_load_dwordx4 %1, %4, %5 offset:1024\n\t"                 \
-                     "global_load_dwordx4 %2, %4, %5 offset:2048\n\tglobal_load_dwordx4 %3, %4, %5 offset:3072"         \
-                     : "=&v"(breg[0]), "=&v"(breg[1]), "=&v"(breg[2]), "=&v"(breg[3]) : "v"(b_off), "s"(bb_) : "memory");  \
-    } while (0)
-#define A3_WAIT_BIAS(n) asm volatile("s_waitcnt vmcnt(" #n ")" : "+v"(breg[0]), "+v"(breg[1]), "+v"(breg[2]), "+v"(breg[3]) :: "memory")
-
-    const int ntiles = (P.n_valid + AT_KB - 1) / AT_KB;
-    const float c_ = P.c_exp;
-    const float thr_x = AT2_THR / c_;
-    V8 pf[2][2];
-    float alpha = 1.f;
-    bool grow = false;
-
-    // S^T(kt) = Bias^T.I (+) K.Q^T into s_acc; the bias fragments must have been waited for
-#define A3_S() do {                                                                                                    \
-        _Pragma("unroll") for (int kb_ = 0; kb_ < 2; kb_++) {                                                           \
-            if (HAS_BIAS) {                                                                                             \
-                f32x16 z_;                                                                                              \
-                _Pragma("unroll") for (int r_ = 0; r_ < 16; r_++) z_[r_] = 0.f;                                         \
-                union { u32x4 u; V8 v; } b0_, b1_;                                                                      \
-                b0_.u = breg[2 * kb_]; b1_.u = breg[2 * kb_ + 1];                                                       \
-                s_acc[kb_] = TR::mfma(b0_.v, ident[0], z_);                                                             \
-                s_acc[kb_] = TR::mfma(b1_.v, ident[1], s_acc[kb_]);                                                     \
-            } else {                                                                                                    \
-                _Pragma("unroll") for (int r_ = 0; r_ < 16; r_++) s_acc[kb_][r_] = 0.f;                                 \
-            }                                                                                                           \
-        }                                                                                                               \
-        _Pragma("unroll") for (int s_ = 0; s_ < 4; s_++) _Pragma("unroll") for (int kb_ = 0; kb_ < 2; kb_++)           \
-            s_acc[kb_] = TR::mfma(kf[kb_][s_], qf[s_], s_acc[kb_]);                                                     \
-    } while (0)
-#define A3_PV() do {                                                                                                   \
-        _Pragma("unroll") for (int kb_ = 0; kb_ < 2; kb_++) _Pragma("unroll") for (int j_ = 0; j_ < 2; j_++)           \
-        _Pragma("unroll") for (int d_ = 0; d_ < 2; d_++)                                                                \
-            o_acc[d_] = TR::mfma(vf[d_][kb_][j_], pf[kb_][j_], o_acc[d_]);                                              \
-    } while (0)
-    // online softmax of S(kt) (deferred maximum, exp2 domain): register r of key block kb = key 32 kb + 16 (r >> 3) + 8 hi + (r & 7)
-#define A3_SOFTMAX(kt_, MASKED_) do {                                                                                  \
-        if (MASKED_) {                                                                                                  \
-            _Pragma("unroll") for (int kb_ = 0; kb_ < 2; kb_++) _Pragma("unroll") for (int r_ = 0; r_ < 16; r_++)       \
-                if ((kt_) * AT_KB + kb_ * 32 + 16 * (r_ >> 3) + 8 * hi + (r_ & 7) >= P.n_valid) s_acc[kb_][r_] = -__builtin_inff(); \
-        }                                                                                                               \
-        float mx_ = at_max3(s_acc[0][0], s_acc[1][0], s_acc[0][1]);                                                     \
-        mx_ = at_max3(mx_, s_acc[1][1], s_acc[0][2]);                                                                   \
-        mx_ = at_max3(mx_, s_acc[1][2], s_acc[0][3]);                                                                   \
-        _Pragma("unroll") for (int r_ = 3; r_ < 15; r_ += 2) {                                                          \
-            mx_ = at_max3(mx_, s_acc[1][r_], s_acc[0][r_ + 1]);                                                         \
-            mx_ = at_max3(mx_, s_acc[1][r_ + 1], s_acc[0][r_ + 2]);                                                     \
-        }                                                                                                               \
-        mx_ = at_max3(mx_, s_acc[1][15], mx_);                                                                          \
-        mx_ = at_max3(mx_, __shfl_xor(mx_, 32, 64), mx_);                                                               \
-        grow = mx_ > m_run + thr_x;                                                                                     \
-        const float mn_ = grow ? mx_ : m_run;                                                                           \
-        alpha = __builtin_amdgcn_exp2f((m_run - mn_) * c_);                                                             \
-        m_run = mn_;                                                                                                    \
-        const float mc_ = -mn_ * c_;                                                                                    \
-        float l0_ = 0.f, l1_ = 0.f;                                                                                     \
-        _Pragma("unroll") for (int kb_ = 0; kb_ < 2; kb_++) _Pragma("unroll") for (int j_ = 0; j_ < 2; j_++)           \
-        _Pragma("unroll") for (int t_ = 0; t_ < 8; t_ += 2) {                                                           \
-            const float p0_ = __builtin_amdgcn_exp2f(__builtin_fmaf(s_acc[kb_][8 * j_ + t_], c_, mc_));                 \
-            const float p1_ = __builtin_amdgcn_exp2f(__builtin_fmaf(s_acc[kb_][8 * j_ + t_ + 1], c_, mc_));             \
-            pf[kb_][j_][t_] = TR::from_f32(p0_);                                                                        \
-            pf[kb_][j_][t_ + 1] = TR::from_f32(p1_);                                                                    \
-            l0_ += p0_; l1_ += p1_;                                                                                     \
-        }                                                                                                               \
-        l_run = l_run * alpha + (l0_ + l1_);                                                                            \
-        if (__any(grow)) {                                                                                              \
-            _Pragma("unroll") for (int d_ = 0; d_ < 2; d_++) _Pragma("unroll") for (int r_ = 0; r_ < 16; r_++) o_acc[d_][r_] *= alpha; \
-        }                                                                                                               \
-    } while (0)
-
-    // ---- prologue: tiles 0, 1, 2 requested; S(0) ---------------------------------------------------------------------------
-    if (grp_live) {
-        A3_DMA(0);
-        if (HAS_BIAS && wave_live) A3_FETCH_BIAS(0);
-        if (ntiles > 1) A3_DMA(1);
-        if (ntiles > 2) A3_DMA(2);
-    }
-    // Q (the oldest entries), tile 0 and its bias fragments have landed: younger are DMA(1), DMA(2)
-    if (ntiles > 2) {
-        asm volatile("s_waitcnt vmcnt(8)" : "+v"(qraw[0]), "+v"(qraw[1]), "+v"(qraw[2]), "+v"(qraw[3]), "+v"(breg[0]), "+v"(breg[1]), "+v"(breg[2]), "+v"(breg[3]) :: "memory");
-    } else {
-        asm volatile("s_waitcnt vmcnt(0)" : "+v"(qraw[0]), "+v"(qraw[1]), "+v"(qraw[2]), "+v"(qraw[3]), "+v"(breg[0]), "+v"(breg[1]), "+v"(breg[2]), "+v"(breg[3]) :: "memory");
-    }
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int s = 0; s < 4; s++) { union { u32x4 u; V8 v; } c; c.u = qraw[s]; qf[s] = c.v; }
-    AT3_BARRIER();
-    if (wave_live) {
-        A3_READ_K(0);
-        AT3_WAIT_LGKM0();
-        __builtin_amdgcn_sched_barrier(0);
-        A3_S();
-        __builtin_amdgcn_sched_barrier(0);
-        if (HAS_BIAS && ntiles > 1) A3_FETCH_BIAS(1);
-    }
-    // tile 1 landed (younger than it: DMA(2) and, with a bias, the fragments just requested)
-    if (ntiles > 2) { if (HAS_BIAS && wave_live) AT3_WAIT_VM(8); else AT3_WAIT_VM(4); } else AT3_WAIT_VM(0);
-    AT3_BARRIER();
-    if (grp == 1) AT3_BARRIER();                                   // the stagger
-
-    // One tile: vector part | barrier | MFMA part | barrier.  STEADY: tile kt + 3 exists (exact positional waits), else the
-    // waits drain.  LAST: kt is the last tile (no S(kt+1)); MASKED: pad keys in tile kt.
-    auto tile = [&](const int kt, auto steady_c, auto last_c, auto masked_c) {
-        constexpr bool STEADY = decltype(steady_c)::value, LAST = decltype(last_c)::value, MASKED = decltype(masked_c)::value;
-        // ---- vector part: fragments of the next MFMA part, DMA of tile kt + 3, softmax of S(kt)
-        if (wave_live) {
-            A3_READ_V(kt);
-            if (!LAST) A3_READ_K(kt + 1);
-        }
-        if (STEADY && grp_live) A3_DMA(kt + 3);
-        if (wave_live) {
-            A3_SOFTMAX(kt, MASKED);
-            AT3_WAIT_LGKM0();
-        }
-        AT3_BARRIER();
-        // ---- MFMA part: O += V^T(kt).P(kt); S(kt + 1)
-        if (wave_live) {
-            __builtin_amdgcn_s_setprio(1);
-            A3_PV();
-            if (!LAST) {
-                if (HAS_BIAS) {                                   // bias(kt + 1): younger than it, only DMA(kt + 3)
-                    if (STEADY) A3_WAIT_BIAS(4); else A3_WAIT_BIAS(0);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-                A3_S();
-            }
-            __builtin_amdgcn_s_setprio(0);
-            __builtin_amdgcn_sched_barrier(0);
-            if (HAS_BIAS && !LAST && kt + 2 < ntiles) A3_FETCH_BIAS(kt + 2);
-        }
-        // tile kt + 2 landed (it is read in the next vector part): younger than DMA(kt + 2) are bias(kt + 1), DMA(kt + 3), bias(kt + 2)
-        if (!LAST) { if (STEADY) { if (HAS_BIAS && wave_live) AT3_WAIT_VM(12); else AT3_WAIT_VM(4); } else AT3_WAIT_VM(0); }
-        AT3_BARRIER();
-    };
-    const bool pad_keys = (P.n_valid & (AT_KB - 1)) != 0;
-    int kt = 0;
-    for (; kt + 3 < ntiles; kt++) tile(kt, std::true_type(), std::false_type(), std::false_type());
-    for (; kt + 1 < ntiles; kt++) tile(kt, std::false_type(), std::false_type(), std::false_type());
-    if (pad_keys) tile(kt, std::false_type(), std::true_type(), std::true_type());
-    else tile(kt, std::false_type(), std::true_type(), std::false_type());
-    if (grp == 0) AT3_BARRIER();                                   // wave-row 0 meets wave-row 1's last barrier
-    if (!wave_live) return;
-    {
-        const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
-        const float inv = 1.0f / l_tot;
-        const int qrow = q0 + l31;
-        if (qrow < Np) {
-            T *op = out_base + (size_t)qrow * (size_t)(H * AT_D);
-#pragma unroll
-            for (int d = 0; d < 2; d++)
-#pragma unroll
-                for (int g = 0; g < 4; g++) {
-                    T v4[4];
-#pragma unroll
-                    for (int t = 0; t < 4; t++) v4[t] = TR::from_f32(o_acc[d][4 * g + t] * inv);
-                    *reinterpret_cast<uint2 *>(op + d * 32 + 8 * g + 4 * hi) = *reinterpret_cast<const uint2 *>(v4);
-                }
-        }
-    }
-}
-
-// bias operand of version 3: version 2's layout with the K-row order of version 3 (key = 32 kb + at3_pi(lane & 31))
-template <int BF16>
-__global__ void k_attention_bias_pack3(const float *__restrict__ bias, typename at_traits<BF16>::T *__restrict__ out,
-                                       int H, int n, int Np, float mul)
-{
-    typedef at_traits<BF16> TR;
-    const long long total = (long long)H * Np * Np;
-    const int n_kt = Np / AT_KB, nq32 = Np / 32;
-    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
-        const int t = (int)(idx & 7), lane = (int)((idx >> 3) & 63), c = (int)((idx >> 9) & 3);
-        const long long tile = idx >> 11;
-        const int kt = (int)(tile % n_kt), qb = (int)((tile / n_kt) % nq32), h = (int)(tile / ((long long)n_kt * nq32));
-        const int q = qb * 32 + 16 * (c & 1) + 8 * (lane >> 5) + t;
-        const int k = kt * AT_KB + 32 * (c >> 1) + at3_pi(lane & 31);
-        const float v = (q < n && k < n) ? bias[((size_t)h * n + q) * n + k] * mul : 0.f;
-        out[idx] = TR::from_f32(v);
-    }
-}
-
 static int at_version()
 {
-    static const int v = (getenv("DS_ATT_V1") && atoi(getenv("DS_ATT_V1"))) ? 1
-                         : ((getenv("DS_ATT_VERSION") && atoi(getenv("DS_ATT_VERSION")) == 3) ? 3 : 2);
+    static const int v = (getenv("DS_ATT_V1") && atoi(getenv("DS_ATT_V1"))) ? 1 : 2;
     return v;
 }
 
@@ -1018,10 +706,7 @@ DS_API int ds_attention_bias_pack(ds_ctx *ctx, const float *bias, int H, int n, 
     const int blocks = (int)std::min<long long>((total + 255) / 256, 65536);
     hipStream_t st = (hipStream_t)stream;
     const float log2e = 1.4426950408889634f;
-    if (at_version() == 3) {
-        if (dtype == DS_DTYPE_F16) hipLaunchKernelGGL((k_attention_bias_pack3<0>), dim3(blocks), dim3(256), 0, st, bias, (_Float16 *)packed, H, n, Np, 8.0f);
-        else hipLaunchKernelGGL((k_attention_bias_pack3<1>), dim3(blocks), dim3(256), 0, st, bias, (__bf16 *)packed, H, n, Np, 8.0f);
-    } else if (at_version() == 2) {        // A fragments of the bias MFMA, in units of 1/scale (head_dim 64: x 8, exact)
+    if (at_version() == 2) {               // A fragments of the bias MFMA, in units of 1/scale (head_dim 64: x 8, exact)
         if (dtype == DS_DTYPE_F16) hipLaunchKernelGGL((k_attention_bias_pack2<0>), dim3(blocks), dim3(256), 0, st, bias, (_Float16 *)packed, H, n, Np, 8.0f);
         else hipLaunchKernelGGL((k_attention_bias_pack2<1>), dim3(blocks), dim3(256), 0, st, bias, (__bf16 *)packed, H, n, Np, 8.0f);
     } else if (dtype == DS_DTYPE_F16) hipLaunchKernelGGL((k_attention_bias_pack<0>), dim3(blocks), dim3(256), 0, st, bias, (_Float16 *)packed, H, n, Np, log2e);
@@ -1046,31 +731,6 @@ DS_API int ds_attention_fwd(ds_ctx *ctx, const void *qk, const void *vt, const v
     P.qk = qk; P.vt = vt; P.bias = bias; P.out = out;
     P.B = B; P.Np = Np; P.H = H; P.n_valid = n_valid;
     const float log2e = 1.4426950408889634f;
-    if (at_version() == 3) {
-        DS_REQUIRE(!bias || scale == 0.125f, DS_EUNSUPPORTED, "ds_attention_fwd: the packed bias is stored in units of 1/scale for "
-                   "head_dim 64 (scale 0.125); got scale %g", (double)scale);
-        DS_REQUIRE(((uintptr_t)out & 15) == 0, DS_EINVAL, "ds_attention_fwd: out must be 16-byte aligned");
-        DS_REQUIRE((size_t)Np * 2 * H * AT_D * 2 < (1ull << 31) && (size_t)AT_D * Np * 2 < (1ull << 31), DS_EUNSUPPORTED,
-                   "ds_attention_fwd: one image's K or V^T exceeds the 32-bit staging offsets");
-        P.c_exp = scale * log2e; P.k_logit = 1.0f; P.flags = 0;
-        P.nq = (Np + 127) / 128;
-        P.total = P.nq * H * B;                                  // wave-row tasks; a workgroup takes two
-        const int nwg = (P.total + 1) / 2;
-        P.chunk = (nwg + 7) / 8;
-        hipStream_t st3 = (hipStream_t)stream;
-#define A3_LAUNCH(BF_, BI_) do {                                                                                       \
-            static bool attr_ = false;                                                                                  \
-            if (!attr_) {                                                                                               \
-                DS_HIP_CHECK(hipFuncSetAttribute((const void *)k_attention_fwd3<BF_, BI_>, hipFuncAttributeMaxDynamicSharedMemorySize, AT3_LDS)); \
-                attr_ = true;                                                                                           \
-            }                                                                                                           \
-            hipLaunchKernelGGL((k_attention_fwd3<BF_, BI_>), dim3(8 * P.chunk), dim3(AT3_THREADS), AT3_LDS, st3, P);    \
-        } while (0)
-        if (dtype == DS_DTYPE_F16) { if (bias) A3_LAUNCH(0, 1); else A3_LAUNCH(0, 0); }
-        else { if (bias) A3_LAUNCH(1, 1); else A3_LAUNCH(1, 0); }
-        DS_HIP_CHECK(hipGetLastError());
-        return DS_OK;
-    }
     if (at_version() == 2) {
         DS_REQUIRE(!bias || scale == 0.125f, DS_EUNSUPPORTED, "ds_attention_fwd: the packed bias is stored in units of 1/scale for "
                    "head_dim 64 (scale 0.125); got scale %g", (double)scale);

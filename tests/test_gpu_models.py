@@ -51,10 +51,7 @@ def test_attention_kernel_matches_definition(gpu, dtype, with_bias):
                 mul = vm.LOG2E
             else:
                 qq = (16 * (c[:, None, None] & 1) + 8 * (lane[None, :, None] >> 5) + j[None, None, :]).expand(4, 64, 8)
-                row = lane & 31
-                if os.environ.get("DS_ATT_VERSION") == "3":     # third generation: K rows of a tile in the order [0-3, 8-11, 4-7, 12-15]
-                    row = (row & ~12) | ((row & 4) << 1) | ((row & 8) >> 1)
-                key = (32 * (c[:, None, None] >> 1) + row[None, :, None]).expand(4, 64, 8)
+                key = (32 * (c[:, None, None] >> 1) + (lane & 31)[None, :, None]).expand(4, 64, 8)
                 mul = 8.0
             for qb in (0, npad // 32 - 1):
                 for kt in (0, npad // 64 - 1):
