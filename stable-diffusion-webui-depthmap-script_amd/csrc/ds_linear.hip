@@ -26,8 +26,8 @@
 //     accumulator (not on a rounded half); a half-wave exchange (v_permlane32_swap) widens that to 8 columns = one 16-byte
 //     store per lane.
 //
-// Workgroup -> tile mapping is XCD-aware: the eight XCDs take contiguous ranges of the tile list (column index
-// fastest), so the 32 workgroups resident on one XCD share two row panels of x and sweep W together through that L2.
+// Workgroup -> tile mapping is XCD-aware: the eight XCDs take contiguous ranges of the tile list, which is ordered so that
+// the 32 workgroups resident on one XCD work on 8 row panels x 4 column panels at a time.
 #include "ds_common.h"
 
 #include <stdlib.h>
@@ -174,8 +174,14 @@ __global__ __launch_bounds__(LN_THREADS) void k_linear256(LinParams P)
         const int tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (orig >> 3);
         // the last row panel is shifted up to end at row M (M >= 256): its first rows are computed twice, identically, by
         // two workgroups -- no per-row clamping or masking anywhere (y must not alias res1 / res2)
-        bm0 = min((tile / P.nbn) * 256, P.M - 256);
-        bn0 = (tile % P.nbn) * 256;
+        // the tile list is ordered in groups of 8 row panels, rows fastest inside a group: the 32 tiles an XCD has in flight
+        // are then 8 row panels x 4 column panels (12 operand panels per K-slice through that L2 instead of the 18 of a
+        // column-fastest list)
+        const int grp8 = tile / (8 * P.nbn), rem8 = tile - grp8 * (8 * P.nbn);
+        const int rows8 = min(8, P.nbm - 8 * grp8);
+        const int bn = rem8 / rows8, bm = 8 * grp8 + (rem8 - bn * rows8);
+        bm0 = min(bm * 256, P.M - 256);
+        bn0 = bn * 256;
         xb = (const unsigned char *)P.x + (size_t)bm0 * rowbytes;
         wb = (const unsigned char *)P.w + (size_t)bn0 * K * sizeof(T);
         if (CONV) {
