@@ -61,7 +61,7 @@ struct LinParams {
     void *y;
     int M, N, K;                // K = reduction length (CONV: 9 * C)
     int nbm, nbn;
-    int ablate;                 // timing experiments (DS_LIN_ABLATE): 1 = no epilogue stores, 2 = no K loop, 4 = full-line store pattern, 8 = nt stores
+    int ablate;                 // timing experiments (DS_LIN_ABLATE): 1 = no epilogue stores, 2 = no K loop
     int stagger;                // experiment (DS_LIN_STAGGER_US): every other workgroup of an XCD starts this many 10 ns ticks late
     int H, W, C, cpt, magic;    // CONV: image height / width, input channels, K-tiles per tap (C / 64), 65536 / cpt + 1
     long long ldy;              // row stride of y (and res1 / res2) in elements
@@ -127,7 +127,8 @@ __device__ __forceinline__ void ln_dma_v(const void *ptr, unsigned lds_uniform)
 
 // EPI: 0 none, 1 erf-GELU, 2 ReLU.  RES: number of residual addends (res1, res2).  CONV: 0 = x is a dense [M, K] matrix; 1 = x is an NHWC image [batch, H, W, C] and the
 // GEMM is the implicit one of a 3 x 3, stride 1, zero-padded convolution: row m = output pixel, K-tile kt = 64 channels
-// (kt % cpt) of tap kt / cpt, whose source is the same 128 bytes of the pixel shifted by (dy, dx) -- or the zero line.
+// kt / 9 of tap kt % 9 (tap-fastest: the pixels of a chunk are fetched once and hit in L2 for the other eight taps), whose
+// source is the same 128 bytes of the pixel shifted by (dy, dx) -- or the zero line.
 template <int BF16, int EPI, int CONV, int RES>
 __global__ __launch_bounds__(LN_THREADS) void k_linear256(LinParams P)
 {
@@ -177,6 +178,7 @@ __global__ __launch_bounds__(LN_THREADS) void k_linear256(LinParams P)
         // the tile list is ordered in groups of 8 row panels, rows fastest inside a group: the 32 tiles an XCD has in flight
         // are then 8 row panels x 4 column panels (12 operand panels per K-slice through that L2 instead of the 18 of a
         // column-fastest list)
+        // (measured against chunks of 4 column panels outermost, which would keep W in L2: fc1 316-319 vs 328-331 us)
         const int grp8 = tile / (8 * P.nbn), rem8 = tile - grp8 * (8 * P.nbn);
         const int rows8 = min(8, P.nbm - 8 * grp8);
         const int bn = rem8 / rows8, bm = 8 * grp8 + (rem8 - bn * rows8);
@@ -201,13 +203,14 @@ __global__ __launch_bounds__(LN_THREADS) void k_linear256(LinParams P)
     // kind: 0 A0, 1 A1, 2 B0, 3 B1; kt = K-tile; s = LDS buffer
 #define LN_STAGE(kind, kt, s)                                                                                            \
     do {                                                                                                                 \
-        const unsigned koff_ = (unsigned)(kt) * 128u;                                                                    \
+        unsigned koff_ = (unsigned)(kt) * 128u;                                                                          \
         const unsigned dst_ = ((kind) >> 1) * LN_B_BASE + ((kind) & 1) * 2 * LN_HALF + (s) * LN_HALF + lds_stage;  /* LDS address */ \
         int dy_ = 0, dx_ = 0, aoff_ = (int)koff_;                                                                        \
-        if (CONV && (kind) < 2) {                                                                                        \
-            const int tap_ = ((kt) * P.magic) >> 16, cc_ = (kt) - tap_ * P.cpt;                                          \
+        if (CONV) {              /* K-tile kt = tap kt % 9 of channel chunk kt / 9: the nine taps of one 64-channel chunk */ \
+            const int cc_ = ((kt) * 7282) >> 16, tap_ = (kt) - 9 * cc_;      /* follow each other, their pixels stay in L2 */ \
             dy_ = ((tap_ * 11) >> 5) - 1; dx_ = tap_ - 3 * (dy_ + 1) - 1;                                                \
             aoff_ = cc_ * 128 + (dy_ * P.W + dx_) * rowbytes;                                                            \
+            koff_ = (unsigned)(tap_ * P.cpt + cc_) * 128u;               /* the weights stay [out][tap][in] */             \
         }                                                                                                                \
         /* uniform 64-bit base of this K-tile (scalar arithmetic) + the thread's loop-invariant 32-bit offset */           \
         const unsigned char *ub_ = ((kind) < 2) ? xb + ((long)aoff_ + (long)(((kind) & 1) * a_half))                     \
@@ -362,43 +365,48 @@ __global__ __launch_bounds__(LN_THREADS) void k_linear256(LinParams P)
     // Register r of a 32 x 32 accumulator block = column (r & 3) + 8 (r >> 2) + 4 (lane >> 5) of row lane & 31: a lane holds
     // 4-column groups g = r >> 2, the other half-wave holds the groups in between.  One v_permlane32_swap per register pair
     // (g = 2k, 2k+1) exchanges them so that lanes 0-31 end up with columns 16k .. 16k+7 and lanes 32-63 with 16k+8 .. 16k+15
-    // of their row, in fp32: bias, residuals and the activation are then applied on 8 consecutive columns and the row
-    // segment leaves as ONE 16-byte store (residuals arrive as 16-byte loads, all issued before the arithmetic).
+    // of their row, in fp32: bias, residuals (16-byte loads, all issued before the arithmetic) and the activation are applied
+    // on 8 consecutive columns and the result leaves as one 16-byte store per lane (32 bytes of a row per instruction).
+    // TRANSPOSE (the plain dense GEMM only): the 16-byte results of a 32-row block take a turn through the wave's own 16 KB
+    // of LDS (free since the last barrier; rows of 128 bytes, 16-byte slot ^= row & 7: conflict-free both ways) and leave as
+    // FULL 128-byte lines, 8 lanes per row -- a store instruction then touches 8 lines instead of 32.  Measured on one box
+    // (direct -> transposed): plain GEMMs qk 160 -> 152 us, proj 90 -> 88, K = 1024 round 34.8 -> 33.1; but fc1 + GELU
+    // 303 -> 311 (its epilogue is VALU-bound and hides the stores) and the convolution with a residual 598 -> 645: those
+    // keep the direct store.
+    constexpr bool TRANSPOSE = (CONV == 0 && EPI == 0 && RES == 0);
     T *yb = (T *)P.y;
     const T *bias = (const T *)P.bias;
     const T *r1 = (const T *)P.res1, *r2 = (const T *)P.res2;
     const int hi8 = 8 * (lane >> 5);
+    V8 bv[2][2];                                                // [W half][k]: 8 columns each, kept packed
 #pragma unroll
-    for (int hb = 0; hb < 2; ++hb) {
-        const int n0 = cbn0 + wc * 64 + hb * 32 + hi8;         // + 16 k
-        float bv[2][8];
+    for (int hb = 0; hb < 2; ++hb)
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
             if (bias) {
-                const V8 b8 = *(const V8 *)(bias + n0 + 16 * k);
-#pragma unroll
-                for (int t = 0; t < 8; ++t) bv[k][t] = (float)b8[t];
+                bv[hb][k] = *(const V8 *)(bias + cbn0 + wc * 64 + hb * 32 + hi8 + 16 * k);
             } else {
 #pragma unroll
-                for (int t = 0; t < 8; ++t) bv[k][t] = 0.f;
+                for (int t = 0; t < 8; ++t) bv[hb][k][t] = (T)0.f;
             }
         }
+    unsigned char *tl = lds + wid * 16384;                      // this wave's transpose area: 128 rows x 128 bytes
 #pragma unroll
-        for (int ha = 0; ha < 2; ++ha) {
-            V8 ra[2][2], rb2[2][2];                              // residual pieces [row block][k]
-            size_t o0[2];
+    for (int ha = 0; ha < 2; ++ha)
 #pragma unroll
-            for (int rb = 0; rb < 2; ++rb) {
-                const int m = cbm0 + wr * 128 + ha * 64 + rb * 32 + (lane & 31);
-                o0[rb] = (size_t)m * P.ldy + n0;
+        for (int rb = 0; rb < 2; ++rb) {
+            const int rl = ha * 64 + rb * 32 + (lane & 31);     // row inside the wave tile
+            const size_t o0 = (size_t)(cbm0 + wr * 128 + rl) * P.ldy + cbn0 + wc * 64 + hi8;
+            V8 ra[2][2], rb2[2][2];                              // residual pieces [W half][k]
+#pragma unroll
+            for (int hb = 0; hb < 2; ++hb)
 #pragma unroll
                 for (int k = 0; k < 2; ++k) {
-                    if (RES >= 1) ra[rb][k] = *(const V8 *)(r1 + o0[rb] + 16 * k);
-                    if (RES >= 2) rb2[rb][k] = *(const V8 *)(r2 + o0[rb] + 16 * k);
+                    if (RES >= 1) ra[hb][k] = *(const V8 *)(r1 + o0 + hb * 32 + 16 * k);
+                    if (RES >= 2) rb2[hb][k] = *(const V8 *)(r2 + o0 + hb * 32 + 16 * k);
                 }
-            }
 #pragma unroll
-            for (int rb = 0; rb < 2; ++rb) {
+            for (int hb = 0; hb < 2; ++hb)
 #pragma unroll
                 for (int k = 0; k < 2; ++k) {
                     float v[8];
@@ -413,25 +421,33 @@ __global__ __launch_bounds__(LN_THREADS) void k_linear256(LinParams P)
                     V8 o;
 #pragma unroll
                     for (int t = 0; t < 8; t += 2) {
-                        lf32x2 u = {v[t] + bv[k][t], v[t + 1] + bv[k][t + 1]};
-                        if (RES >= 1) u += (lf32x2){(float)ra[rb][k][t], (float)ra[rb][k][t + 1]};
-                        if (RES >= 2) u += (lf32x2){(float)rb2[rb][k][t], (float)rb2[rb][k][t + 1]};
+                        lf32x2 u = {v[t] + (float)bv[hb][k][t], v[t + 1] + (float)bv[hb][k][t + 1]};
+                        if (RES >= 1) u += (lf32x2){(float)ra[hb][k][t], (float)ra[hb][k][t + 1]};
+                        if (RES >= 2) u += (lf32x2){(float)rb2[hb][k][t], (float)rb2[hb][k][t + 1]};
                         if (EPI == 1) u = ln_gelu2(u);
                         if (EPI == 2) u = (lf32x2){fmaxf(u[0], 0.f), fmaxf(u[1], 0.f)};
                         o[t] = (T)u[0];
                         o[t + 1] = (T)u[1];
                     }
-                    if (P.ablate & 4) {            // timing experiment (wrong placement): every store instruction covers 8 full 128-byte lines
-                        const int idx = ((hb * 2 + ha) * 2 + rb) * 2 + k;
-                        *(V8 *)(yb + (size_t)(cbm0 + wr * 128 + idx * 8 + (lane >> 3)) * P.ldy + cbn0 + wc * 64 + (lane & 7) * 8) = o;
-                    } else if (P.ablate & 8) {     // timing experiment: non-temporal stores
-                        __builtin_nontemporal_store(o, (V8 *)(yb + o0[rb] + 16 * k));
-                    } else if (!(P.ablate & 1)) *(V8 *)(yb + o0[rb] + 16 * k) = o;
+                    if (!TRANSPOSE) {
+                        if (!(P.ablate & 1)) *(V8 *)(yb + o0 + hb * 32 + 16 * k) = o;
+                        else asm volatile("" ::"v"(o));
+                    } else {
+                        const int piece = hb * 4 + k * 2 + (lane >> 5);
+                        *(V8 *)(tl + rl * 128 + ((piece ^ (rl & 7)) << 4)) = o;
+                    }
+                }
+            if (TRANSPOSE) {
+#pragma unroll
+                for (int idx = 0; idx < 4; ++idx) {
+                    const int r2l = ha * 64 + rb * 32 + idx * 8 + (lane >> 3), piece = lane & 7;
+                    const V8 o = *(const V8 *)(tl + r2l * 128 + ((piece ^ (r2l & 7)) << 4));
+                    if (!(P.ablate & 1)) *(V8 *)(yb + (size_t)(cbm0 + wr * 128 + r2l) * P.ldy + cbn0 + wc * 64 + piece * 8) = o;
                     else asm volatile("" ::"v"(o));
                 }
             }
         }
-    }
+    if (TRANSPOSE) LN_BARRIER();                                // every wave is done with its transpose area: LDS is free again
     if (next >= nwg) break;
     orig = next;
     set_tile(orig);
@@ -540,7 +556,7 @@ DS_API int ds_conv3x3_nhwc(ds_ctx *ctx, const void *x, const void *w, const void
     P.nbm = (P.M + 255) / 256; P.nbn = out_channels / 256;
     P.H = height; P.W = width; P.C = in_channels; P.cpt = in_channels / 64; P.magic = 65536 / P.cpt + 1;
     for (int kt = 0; kt < P.K / 64; ++kt)
-        DS_REQUIRE(((kt * P.magic) >> 16) == kt / P.cpt, DS_EUNSUPPORTED, "ds_conv3x3_nhwc: tap arithmetic does not cover %d channels", in_channels);
+        DS_REQUIRE(((kt * 7282) >> 16) == kt / 9, DS_EUNSUPPORTED, "ds_conv3x3_nhwc: K-tile arithmetic does not cover %d channels", in_channels);
     P.ldy = out_channels;
     P.ablate = getenv("DS_LIN_ABLATE") ? atoi(getenv("DS_LIN_ABLATE")) : 0;
     P.stagger = getenv("DS_LIN_STAGGER_US") ? (int)(atof(getenv("DS_LIN_STAGGER_US")) * 100.0) : 0;
