@@ -542,20 +542,23 @@ def test_hip_graph_replay_equals_eager_forward(gpu):
         gf = GraphedForward(lambda x, net=net, call=call: call(net, x))
         for shape in ((1, 96, 128, 3), (1, 96, 128, 3), (2, 64, 96, 3), (1, 96, 128, 3)):
             x = torch.randint(0, 256, shape, generator=g, dtype=torch.uint8).cuda()
-            want = call(net, x)
+            # The library kernels under these small float16 networks are not bit-reproducible run to run (stream-K GEMMs sum
+            # in arrival order; measured by tools/determinism_check.py with every in-tree kernel switched off as well: 1e-3 of
+            # the maximum for the ViT, 1-7 % for the random-init hybrid, which amplifies it), and inside a capture MIOpen
+            # falls back to solvers that need no workspace.  So: the eager noise floor is measured here, and a replay has to
+            # agree with the eager forward within a few times that floor -- and follow its input (no stale static buffers).
+            runs = [call(net, x) for _ in range(4)]
+            want = runs[0]
+            noise = max((r - want).abs().max().item() for r in runs[1:])
+            tol = 5 * noise + 2e-2 * want.abs().max().item()
             got = gf(x)
             assert got.shape == want.shape and torch.isfinite(got).all()
-            # inside a capture the library convolutions cannot take a workspace and fall back to other solvers than the
-            # eager call (MIOpen logs it): the two float16 forwards agree to float16-network accuracy, not bit for bit ...
-            assert (got - want).abs().max().item() <= 6e-2 * want.abs().max().item(), shape
-            # (nor is a replay bit-identical to the previous one: the library's stream-K GEMMs sum in arrival order)
-            # ... and a replay follows its input: no stale static buffers
-            assert (gf(x) - got).abs().max().item() <= 6e-2 * want.abs().max().item()
+            assert (got - want).abs().max().item() <= tol, (shape, noise)
+            assert (gf(x) - got).abs().max().item() <= tol, (shape, noise)
             x2 = torch.randint(0, 256, shape, generator=g, dtype=torch.uint8).cuda()
-            want2 = call(net, x2)
             got2 = gf(x2)
-            assert (got2 - want2).abs().max().item() <= 6e-2 * want2.abs().max().item()
-            assert (got2 - got).abs().max().item() > 0
+            assert (got2 - call(net, x2)).abs().max().item() <= tol, (shape, noise)
+            assert (got2 - got).abs().mean().item() > 0
         assert len(gf.graphs) == 2 and not gf.failed
 
 
