@@ -111,8 +111,7 @@ class DinoVisionTransformer(nn.Module):
         patch_pos_embed = patch_pos_embed.permute(0, 2, 3, 1).reshape(1, -1, dim)
         out = torch.cat((class_pos_embed.unsqueeze(0), patch_pos_embed), dim=1).to(dtype)
         if not torch.is_grad_enabled():
-            self._pos_cache.clear()
-            self._pos_cache[key] = out
+            vm.cache_store(self._pos_cache, key, out)
         return out
 
     def prepare_tokens(self, x):

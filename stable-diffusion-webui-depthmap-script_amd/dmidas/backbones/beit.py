@@ -79,6 +79,8 @@ class Block(vm.EncoderBlock):
         key = (qb._version, qb.data_ptr(), qb.dtype)
         hit = getattr(self, "_bqk", None)
         if hit is None or hit[0] != key:
+            if hit is not None:
+                vm.cache_evicted()              # a live hipGraph may still read the old tensor
             b_qk = torch.cat((qb, torch.zeros_like(qb)))                                 # k_bias == 0 (beit.py:71)
             hit = (key, b_qk)
             if not torch.is_grad_enabled():
@@ -125,7 +127,9 @@ class Block(vm.EncoderBlock):
             if dtype == torch.float32 or device.type != 'cuda':
                 heads = a.relative_position_bias_table.shape[1]
                 if heads * n_pad * n_pad * 4 > DENSE_BIAS_BYTES_MAX:
-                    self._bias_cache.clear()
+                    if self._bias_cache:
+                        self._bias_cache.clear()
+                        vm.cache_evicted()
                     return _LazyBias(self._resized_table(tuple(grid_hw)).to(device=device, dtype=dtype), tuple(grid_hw), n_pad)
                 bias = self.rel_pos_bias(tuple(grid_hw))                                 # H, N, N (query, key)
                 n = bias.shape[-1]
@@ -134,9 +138,7 @@ class Block(vm.EncoderBlock):
             else:                                   # operand of the HIP kernel (register order, log2 units)
                 from src import _native
                 bt = _native.attention_bias_pack(self.rel_pos_bias(tuple(grid_hw)).to(device), n_pad, dtype)
-        self._bias_cache.clear()
-        self._bias_cache[key] = bt
-        return bt
+        return vm.cache_store(self._bias_cache, key, bt, entries=2)     # the packed bias is large (H * Np^2): two sizes at most
 
 
 DENSE_BIAS_BYTES_MAX = 256 << 20
@@ -148,8 +150,7 @@ def _relative_position_index(window_size, device):
     key = (tuple(window_size), str(device))
     hit = _index_cache.get(key)
     if hit is None:
-        _index_cache.clear()
-        hit = _index_cache[key] = gen_relative_position_index(window_size).to(device)
+        hit = vm.cache_store(_index_cache, key, gen_relative_position_index(window_size).to(device))
     return hit
 
 
@@ -228,6 +229,8 @@ class ProjectReadout(nn.Module):       # utils.py:28-39
         key = (lin.weight._version, lin.weight.data_ptr(), lin.weight.dtype)
         hit = getattr(self, "_w_split", None)
         if hit is None or hit[0] != key:
+            if hit is not None:
+                vm.cache_evicted()
             c = lin.in_features // 2
             hit = (key, lin.weight[:, :c].contiguous(), lin.weight[:, c:].contiguous())
             if not torch.is_grad_enabled():

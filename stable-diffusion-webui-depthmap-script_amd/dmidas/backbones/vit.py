@@ -51,6 +51,8 @@ class StdConv2dSame(nn.Conv2d):
         var = wf.var(dim=1, keepdim=True, unbiased=False)
         ws = ((wf - mean) / torch.sqrt(var + self.eps)).reshape_as(w).to(w.dtype)
         if not torch.is_grad_enabled():
+            if self._std_cache is not None:
+                vm.cache_evicted()
             self._std_cache = (key, ws)
         return ws
 
@@ -211,8 +213,7 @@ class VisionTransformer(nn.Module):
         grid = grid.permute(0, 2, 3, 1).reshape(1, gs_h * gs_w, -1)
         out = torch.cat([tok, grid], dim=1).to(dtype)
         if not torch.is_grad_enabled():
-            self._pos_cache.clear()
-            self._pos_cache[key] = out
+            vm.cache_store(self._pos_cache, key, out)
         return out
 
     def forward_taps(self, x, hooks, n_stage_taps):

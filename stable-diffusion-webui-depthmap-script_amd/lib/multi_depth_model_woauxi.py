@@ -32,6 +32,8 @@ def _folded(conv, bn, cache_holder):
     if w.is_cuda:
         wf = wf.contiguous(memory_format=torch.channels_last)
     if not torch.is_grad_enabled():
+        if c is not None:
+            vm.cache_evicted()
         cache_holder._fold_cache = (key, wf, bf)
     return wf, bf
 

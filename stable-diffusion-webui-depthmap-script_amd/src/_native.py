@@ -397,6 +397,9 @@ def conv3x3(conv, x, relu=False, res1=None, res2=None):
     key = (conv.weight.data_ptr(), conv.weight._version, x.dtype, None if conv.bias is None else conv.bias._version)
     hit = getattr(conv, "_ds_ohwi", None)
     if hit is None or hit[0] != key:
+        if hit is not None:
+            from . import vit_mi355x as _vm
+            _vm.cache_evicted()                 # a live hipGraph may still read the old weight image
         wk = conv.weight.detach().to(x.dtype).permute(0, 2, 3, 1).contiguous()
         bk = None if conv.bias is None else conv.bias.detach().to(x.dtype).contiguous()
         hit = conv._ds_ohwi = (key, wk, bk)
@@ -479,6 +482,9 @@ def dpt_head_tail(x, size, conv3, conv1, relu_out=True):
     key = tuple((p.data_ptr(), p._version) for p in (conv3.weight, conv3.bias, conv1.weight, conv1.bias)) + (x.dtype, x.device)
     hit = getattr(conv3, "_ds_head_cache", None)
     if hit is None or hit[0] != key:
+        if hit is not None:
+            from . import vit_mi355x as _vm
+            _vm.cache_evicted()
         w = conv3.weight.detach().to(x.dtype)                                   # [co, ci, ky, kx]
         # fragment order: [tap = ky*3+kx][slice s][half][co][j] with ci = 16 s + 8 half + j
         wf = w.permute(2, 3, 1, 0).reshape(9, 8, 2, 8, 32).permute(0, 1, 2, 4, 3).contiguous()

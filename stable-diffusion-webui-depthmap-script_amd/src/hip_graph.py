@@ -9,6 +9,12 @@ behind the C ABI launch on torch's current stream and never synchronise or alloc
 two eager warm-up calls that precede the capture.  The reference has no counterpart (it launches eagerly, one image at a
 time: src/core.py:133); results are those of the eager forward (same kernels, same order).
 
+A captured graph holds raw pointers to every tensor its kernels read, including the parameter- and size-derived operands
+the modules cache.  Those caches keep several sizes and bump ``vit_mi355x.CACHE_EPOCH`` whenever they drop an entry; a
+new epoch makes this class discard its graphs and capture again on demand.  (Found the hard way: a one-entry
+position-embedding cache made the graph of the FIRST shape read freed memory once a second shape had been seen --
+deterministically wrong depth, NaN when the memory had been reused by something else.)
+
 A capture is VALIDATED before it is used: the first replay must be finite and reproduce the eager warm-up result to
 float16-network accuracy, else the shape stays eager (loudly, once).  Reason: inside a capture MIOpen cannot be given a
 workspace and falls back to other solvers than the eager call ("GetSolutionsFallback ... workspace required, provided
@@ -18,6 +24,8 @@ kernels are bit-reproducible run to run (tools/determinism_check.py); the librar
 """
 import torch
 
+from . import vit_mi355x as vm
+
 
 class GraphedForward:
     def __init__(self, fn, warmup=2, accept=0.25):
@@ -26,11 +34,15 @@ class GraphedForward:
         self.accept = accept             # validation bound of a capture, relative to the eager result's maximum
         self.graphs = {}                 # (shape, dtype, device) -> (graph, static_in, static_out)
         self.failed = set()
+        self.epoch = vm.CACHE_EPOCH[0]   # module caches evicted something since? then the graphs hold dangling pointers
 
     def __call__(self, x):
         key = (tuple(x.shape), x.dtype, x.device)
         if key in self.failed or not x.is_cuda:
             return self.fn(x)
+        if self.epoch != vm.CACHE_EPOCH[0]:                  # a cached operand was dropped: capture again on demand
+            self.graphs.clear()
+            self.epoch = vm.CACHE_EPOCH[0]
         hit = self.graphs.get(key)
         if hit is None:
             try:
@@ -66,5 +78,8 @@ class GraphedForward:
         if not err <= self.accept * scale + 1e-30:
             raise RuntimeError(f"hipGraph replay of shape {key[0]} does not reproduce the eager forward (max |difference| {err:.3e} "
                                f"of {scale:.3e}): this shape stays eager")
+        if self.epoch != vm.CACHE_EPOCH[0]:                  # the warm-up itself evicted entries older graphs may read
+            self.graphs.clear()
+            self.epoch = vm.CACHE_EPOCH[0]
         self.graphs[key] = (g, static_in, static_out)
         return self.graphs[key]

@@ -32,6 +32,27 @@ SEQ_ALIGN = 64
 
 _CONSTANTS = {}
 
+# Tensors derived from parameters or from the input size are cached on the modules (resized position embeddings, packed
+# relative-position bias, folded / repacked weights).  A captured hipGraph (src/hip_graph.py) holds raw POINTERS to the
+# cache entries its kernels read, so an entry that is dropped while such a graph is alive would be read after its memory
+# was reused.  Every eviction therefore bumps this epoch; GraphedForward drops its graphs when it sees a new epoch and
+# captures again on demand.  (Size-keyed caches keep a few entries so that alternating between shapes evicts nothing.)
+CACHE_EPOCH = [0]
+SIZE_CACHE_ENTRIES = 6
+
+
+def cache_evicted():
+    CACHE_EPOCH[0] += 1
+
+
+def cache_store(cache, key, value, entries=None):
+    """Insert into a size-keyed module cache; when it is full everything goes (and the epoch moves)."""
+    if len(cache) >= (SIZE_CACHE_ENTRIES if entries is None else entries):
+        cache.clear()
+        cache_evicted()
+    cache[key] = value
+    return value
+
 
 def device_constant(values, device, dtype=torch.float32):
     """Small constant tensor (ImageNet mean/std, filter taps ...) resident on ``device``, created ONCE per
@@ -111,6 +132,8 @@ def folded_proj_bias(proj, b_v):
         return hit[1]
     out = proj.bias + F.linear(b_v.to(proj.weight.dtype), proj.weight)
     if not torch.is_grad_enabled():
+        if hit is not None:
+            cache_evicted()
         proj._folded_bias = (key, out)
     return out
 

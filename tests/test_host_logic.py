@@ -232,3 +232,26 @@ def test_funnel_group_plan():
         assert [len(x) for x in core._plan_groups([a] * 3, [None] * 3, True)] == [1, 1, 1]
     finally:
         core.FUNNEL_BATCH_PIXELS = old
+
+
+def test_module_caches_keep_sizes_and_move_the_epoch_on_eviction():
+    """src/vit_mi355x.cache_store / CACHE_EPOCH: the size-keyed module caches keep several entries, and every eviction moves
+    the epoch that makes src/hip_graph.GraphedForward drop graphs that may hold pointers to the dropped tensors.  Pinned on
+    the DINOv2 position-embedding cache (the one whose single entry once made a captured graph read freed memory)."""
+    import torch
+    from src import vit_mi355x as vm
+    from ddepth_anything_v2.depth_anything_v2.dinov2 import DINOv2
+    e0 = vm.CACHE_EPOCH[0]
+    cache = {}
+    for i in range(vm.SIZE_CACHE_ENTRIES):
+        vm.cache_store(cache, i, i)
+    assert len(cache) == vm.SIZE_CACHE_ENTRIES and vm.CACHE_EPOCH[0] == e0
+    vm.cache_store(cache, "x", 1)
+    assert list(cache) == ["x"] and vm.CACHE_EPOCH[0] == e0 + 1
+    net = DINOv2('vits').eval()
+    with torch.no_grad():
+        a = net.interpolate_pos_encoding(25, 70, 70, torch.float32)
+        e1 = vm.CACHE_EPOCH[0]
+        b = net.interpolate_pos_encoding(30, 84, 70, torch.float32)
+        a2 = net.interpolate_pos_encoding(25, 70, 70, torch.float32)
+    assert a2 is a and b is not a and vm.CACHE_EPOCH[0] == e1          # both sizes stay cached: nothing was evicted
