@@ -544,8 +544,9 @@ DS_API int ds_conv3x3_nhwc(ds_ctx *ctx, const void *x, const void *w, const void
                DS_EINVAL, "ds_conv3x3_nhwc: y, bias, res1 and res2 must be 16-byte aligned");
     int rc = ds_ctx_reserve(ctx, &ctx->zero_line, &ctx->zero_line_bytes, 256);
     if (rc != DS_OK) return rc;
-    if (!ctx->zero_line_cleared) {
-        DS_HIP_CHECK(hipMemsetAsync(ctx->zero_line, 0, 256, (hipStream_t)stream));
+    if (!ctx->zero_line_cleared) {          // once per context; waited for, so that a second stream of the same context never
+        DS_HIP_CHECK(hipMemsetAsync(ctx->zero_line, 0, 256, (hipStream_t)stream));          // reads the line before it is zero
+        DS_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
         ctx->zero_line_cleared = 1;
     }
     LinParams P;
