@@ -22,3 +22,9 @@ def test_lds_image_is_bank_conflict_free():
 
 def test_index_chain_reproduces_the_product():
     assert lm.check_indexing(M=300, N=256, K=128) < 1e-9
+
+
+def test_convolution_gather_reproduces_a_direct_convolution():
+    """border bits, zero line, tap-fastest K order, [out][tap][in] weight offsets, several images per tile, shifted last panel"""
+    assert lm.check_conv_indexing(B=1, H=11, W=25, C=128, N=256) < 1e-9
+    assert lm.check_conv_indexing(B=3, H=9, W=10, C=256, N=256, seed=2) < 1e-9

@@ -190,6 +190,48 @@ def check_indexing(M=300, N=256, K=128, seed=0):
     return np.abs(y - ref).max()
 
 
+def check_conv_indexing(B=1, H=11, W=25, C=128, N=256, seed=1):
+    """The implicit 3x3 convolution of ds_conv3x3_nhwc: K-tile kt = tap kt % 9 of the 64-channel chunk kt / 9, the DMA source
+    is the pixel shifted by the tap or the zero line (border bits of the thread's pixels), weights stay [out][tap][in]
+    (K offset (tap * cpt + cc) * 64), the last row panel is shifted up.  One wave-level emulation per tile is enough here:
+    the LDS image / fragment path is check_indexing's; this one pins the gather.  Returns max |error| vs a direct convolution."""
+    rng = np.random.default_rng(seed)
+    x = rng.standard_normal((B, H, W, C))
+    w = rng.standard_normal((N, 3, 3, C))
+    M = B * H * W
+    cpt = C // 64
+    nt = 9 * cpt
+    xf = x.reshape(M, C)
+    wf = w.reshape(N, 9 * C)
+    y = np.zeros((M, N))
+    for bm0 in [min(p0, M - 256) for p0 in range(0, M, 256)]:
+        acc = np.zeros((256, N))
+        for kt in range(nt):
+            cc = (kt * 7282) >> 16
+            tap = kt - 9 * cc
+            assert cc == kt // 9
+            dy = ((tap * 11) >> 5) - 1
+            dx = tap - 3 * (dy + 1) - 1
+            a = np.zeros((256, 64))
+            for row in range(256):
+                pix = (bm0 + row) % (H * W)
+                py, px = pix // W, pix % W
+                bits = (1 if py > 0 else 0) | 2 | (4 if py < H - 1 else 0) | (8 if px > 0 else 0) | 16 | (32 if px < W - 1 else 0)
+                ok = (bits >> (dy + 1)) & (bits >> (4 + dx)) & 1
+                if ok:
+                    src = bm0 + row + dy * W + dx                      # xb + srcA + aoff: the same pixel index, shifted
+                    a[row] = xf[src, cc * 64: cc * 64 + 64]
+            koff = (tap * cpt + cc) * 64
+            acc += a @ wf[:, koff: koff + 64].T
+        y[bm0: bm0 + 256] = acc
+    ref = np.zeros((B, H, W, N))
+    xp = np.pad(x, ((0, 0), (1, 1), (1, 1), (0, 0)))
+    for ky in range(3):
+        for kx in range(3):
+            ref += xp[:, ky: ky + H, kx: kx + W, :] @ w[:, ky, kx, :].T
+    return np.abs(y - ref.reshape(M, N)).max()
+
+
 def bank_conflicts():
     """16-lane groups of a fragment read must hit 16 distinct 16-byte slots of the 256-byte bank row."""
     worst = 0
@@ -209,3 +251,4 @@ if __name__ == '__main__':
         print('schedule nt=%d:' % nt, 'ok' if not p else p[:4])
     print('bank conflicts (missing slots per 16-lane group):', bank_conflicts())
     print('indexing max |err|:', check_indexing())
+    print('convolution gather max |err|:', check_conv_indexing())
