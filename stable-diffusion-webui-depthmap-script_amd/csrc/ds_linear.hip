@@ -1,30 +1,35 @@
-// ds_linear: y = act(x . W^T + b) for the token GEMMs of the ViT encoders (fc1 + GELU, fc2, proj, qkv) as ONE in-tree
-// MFMA kernel with the epilogue fused, instead of a library GEMM followed by an element-wise pass.
+// ds_linear / ds_conv3x3_nhwc: y = act(x . W^T + b [+ residuals]) as ONE in-tree MFMA kernel with the epilogue fused,
+// instead of a library GEMM / convolution followed by element-wise passes.  Two front ends on one K loop:
+//   * dense:  the token GEMMs of the ViT encoders.  In the networks it runs `fc1 -> nn.GELU` of every encoder block (timm's
+//     Mlp as called from dmidas/backbones/beit.py:93-107; ddepth_anything_v2/depth_anything_v2/dinov2_layers/mlp.py:33-39);
+//     qk / proj / fc2 can be routed here too (DS_LINEAR=all) but stay library calls: tuned hipBLASLt is ahead on them.
+//   * conv:   the 3x3 convolutions of the DPT decoders as an implicit GEMM with bias / ReLU / residual / skip in the epilogue
+//     (ResidualConvUnit_custom dmidas/blocks.py:352-377, scratch.layerN_rn :64-80, util/blocks.py:56-85 of Depth-Anything-V2).
 //
-// Replaces, per encoder block of the reference: `self.fc1 -> self.act (nn.GELU)` of timm's Mlp as called from
-// dmidas/backbones/beit.py:93-107 (block_forward) and ddepth_anything_v2/depth_anything_v2/dinov2_layers/mlp.py:33-39.
+// Shape of the problem on an MI355X: x is [M, K] (M = batch x padded tokens, 34 816 at the benchmark; pixels for the
+// convolution), W is [N, K] (torch Linear layout: both operands K-contiguous, i.e. the "NT" GEMM whose MFMA fragments are
+// plain 16-byte reads).
 //
-// Shape of the problem on an MI355X: x is [M, K] (M = batch x padded tokens, 34 816 at the benchmark), W is [N, K]
-// (torch Linear layout: both operands K-contiguous, i.e. the "NT" GEMM whose MFMA fragments are plain 16-byte reads).
-//
-// Structure (one workgroup = one 256 x 256 tile of y, 8 waves as 2 (rows) x 4 (columns), wave tile 128 x 64):
+// Structure (one workgroup = 256 x 256 tiles of y, 8 waves as 2 (rows) x 4 (columns), wave tile 128 x 64; one PERSISTENT
+// workgroup per CU walks a strided list of tiles):
 //   * K is walked in tiles of 64.  A K-tile of x and of W is kept in LDS as FOUR half-tiles of 128 rows x 64 k (16 KB):
 //     A0/A1 = the first/second 64 rows of every wave-row's 128, B0/B1 = the first/second 32 columns of every
 //     wave-column's 64 -- the halves follow the QUADRANTS of the wave tile, so a half-tile is read in exactly one of the
 //     four phases of a K-tile and can be re-staged two phases later.  Two K-tiles are resident (128 KB of the 160 KB).
 //   * staging is LDS-DMA (`global_load_lds_dwordx4`): no staging registers, no ds_write pass.  The DMA writes
 //     lane-linear, so the bank swizzle is applied to the per-lane SOURCE address and undone by the same XOR on the
-//     fragment read (16-byte slot ^= (row >> 1) & 7 inside a 128-byte row: a 16-lane group of a ds_read_b128 then covers
-//     all 16 slots of the 256-byte bank row; the XOR stays inside one 128-byte line, so global coalescing is intact).
+//     fragment read (16-byte slot ^= (row >> 1) & 7 inside a 128-byte row: every 16-lane group of a ds_read_b128 then
+//     covers all 16 slots of the 256-byte bank row; the XOR stays inside one 128-byte line, so global coalescing is intact).
 //   * the K loop is 8 phases per two K-tiles.  Each phase = {fragment reads of ONE half-tile, DMA issue of ONE
 //     half-tile, counted vmcnt} barrier {8 MFMA 32x32x16 on one quadrant} barrier.  The two wave-rows run staggered
 //     by one barrier, so at any time one wave of a SIMD is in its MFMA part while the other one is in its memory part.
 //     A half-tile is staged 6 phases before it is read; `s_waitcnt vmcnt(10)` (5 half-tiles stay in flight) never
-//     drains the queue.  Hazards (both directions) are argued next to the schedule table below.
+//     drains the queue.  Hazards (both directions) are argued next to the schedule table below and checked by
+//     tools/linear_model.py (tests/test_linear_model.py).
 //   * operands go into the MFMA swapped (W fragment as "A", x fragment as "B"), so an accumulator register holds 4
-//     consecutive output COLUMNS of one row: the epilogue adds the bias, applies the activation in fp32 on the
-//     accumulator (not on a rounded half); a half-wave exchange (v_permlane32_swap) widens that to 8 columns = one 16-byte
-//     store per lane.
+//     consecutive output COLUMNS of one row: the epilogue adds the bias / residuals and applies the activation in fp32 on
+//     the accumulator (not on a rounded half); a half-wave exchange (v_permlane32_swap) widens that to 8 columns = one
+//     16-byte store per lane.
 //
 // Workgroup -> tile mapping is XCD-aware: the eight XCDs take contiguous ranges of the tile list, which is ordered so that
 // the 32 workgroups resident on one XCD work on 8 row panels x 4 column panels at a time.
