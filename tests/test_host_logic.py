@@ -255,3 +255,37 @@ def test_module_caches_keep_sizes_and_move_the_epoch_on_eviction():
         b = net.interpolate_pos_encoding(30, 84, 70, torch.float32)
         a2 = net.interpolate_pos_encoding(25, 70, 70, torch.float32)
     assert a2 is a and b is not a and vm.CACHE_EPOCH[0] == e1          # both sizes stay cached: nothing was evicted
+
+
+def test_linear_and_conv_dispatch_rules_host_side():
+    """src/vit_mi355x.linear / conv2d / residual_conv_unit: float32 and CPU tensors take the plain torch definition (what the
+    parity tests against the reference's modules run); the shape rules of the in-tree kernel are those of the C ABI."""
+    import torch
+    import torch.nn as nn
+    import torch.nn.functional as F
+    from src import _native
+    from src import vit_mi355x as vm
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn((3, 7, 128), generator=g)
+    lin = nn.Linear(128, 256)
+    assert torch.equal(vm.linear(x, lin.weight, lin.bias), F.linear(x, lin.weight, lin.bias))
+    assert torch.equal(vm.linear(x, lin.weight, lin.bias, gelu=True), F.gelu(F.linear(x, lin.weight, lin.bias)))
+    mlp = vm.Mlp(128, 512)
+    assert torch.allclose(mlp(x), mlp.fc2(F.gelu(mlp.fc1(x))))
+    # shapes the kernel takes: out % 256 == 0, in % 128 == 0
+    assert _native.linear_supported(x, torch.empty(256, 128)) and _native.linear_supported(x, torch.empty(1536, 384))
+    assert not _native.linear_supported(x, torch.empty(200, 128)) and not _native.linear_supported(x, torch.empty(256, 64))
+    conv = nn.Conv2d(256, 256, 3, padding=1)
+    img = torch.randn((1, 256, 16, 16), generator=g)
+    assert _native.conv3x3_supported(conv, img)
+    assert not vm.conv3x3_hip_ok(conv, img)                                   # CPU tensor / float32: the library
+    assert torch.equal(vm.conv2d(conv, img), conv(img))
+    for bad in (nn.Conv2d(256, 256, 3, padding=1, padding_mode='circular'), nn.Conv2d(256, 256, 3, padding=1, stride=2),
+                nn.Conv2d(256, 128, 3, padding=1), nn.Conv2d(64, 256, 3, padding=1), nn.Conv2d(256, 256, 1)):
+        xin = torch.randn((1, bad.in_channels, 16, 16), generator=g)
+        assert not _native.conv3x3_supported(bad, xin)
+    assert not _native.conv3x3_supported(conv, torch.randn((1, 256, 8, 8)))   # fewer than 256 pixels: below one tile
+    c1, c2 = nn.Conv2d(16, 16, 3, padding=1), nn.Conv2d(16, 16, 3, padding=1)
+    xr, sk = torch.randn((2, 16, 9, 11), generator=g), torch.randn((2, 16, 9, 11), generator=g)
+    want = sk + (c2(F.relu(c1(F.relu(xr)))) + xr)
+    assert torch.allclose(vm.residual_conv_unit(c1, c2, xr, skip=sk), want)
