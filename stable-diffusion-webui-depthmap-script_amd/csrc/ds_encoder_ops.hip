@@ -291,6 +291,108 @@ __global__ __launch_bounds__(256) void k_dpt_head_tail(HeadTailParams P)
     }
 }
 
+// Persistent variant (DS_HEAD_PERSIST=1; prepared at the end of round 2, NOT yet measured -- the default stays the kernel above).
+// The kernel above is bound by L2 traffic, not by its MFMAs: per 4 x 32 tile every wave re-reads all 72 weight fragments
+// (288 KB per workgroup, 18.9 GB per launch at batch 32) and the 6 x 34 halo tile is gathered with four 16-byte loads per
+// upsampled pixel and channel chunk (209 KB per workgroup).  Here ONE workgroup of 8 waves per CU keeps the 73.7 KB of
+// weight fragments in LDS for its whole life (lane-linear, conflict-free reads), walks 8 x 32 tiles (10 x 34 halo tile =
+// 87 KB: 160.8 KB of the 160 KB = 163 840 B of LDS) in an XCD-aware order, one output row per wave: weight traffic from L2
+// drops to 73.7 KB per CU, the halo overhead of the gather from 1.59x to 1.33x.
+#define HTP_TH 8
+#define HTP_NPIX ((HTP_TH + 2) * HT_PW)
+#define HTP_W_BYTES (9 * 8 * 2 * 32 * 8 * 2)
+
+template <int BF16>
+__global__ __launch_bounds__(512) void k_dpt_head_tail_p(HeadTailParams P, int tiles_x, int tiles_y, int ntiles, int chunk)
+{
+    typedef typename eo_traits<BF16>::T T;
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_all[];
+    unsigned char *s_w = s_all, *s_act = s_all + HTP_W_BYTES;   // weights | [HTP_NPIX][16 chunks of 16 B], chunk ^ (pix & 15)
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, hi = lane >> 5, l31 = lane & 31;
+    for (int i = tid; i < HTP_W_BYTES / 16; i += 512)
+        reinterpret_cast<uint4 *>(s_w)[i] = reinterpret_cast<const uint4 *>(P.wfrag)[i];
+    for (int orig = blockIdx.x; orig < 8 * chunk; orig += gridDim.x) {
+        const int tile = (orig & 7) * chunk + (orig >> 3);         // XCD x walks tiles [x * chunk, (x + 1) * chunk)
+        if (tile >= ntiles) continue;                               // (uniform per workgroup)
+        const int txi = tile % tiles_x, tyi = (tile / tiles_x) % tiles_y, b = tile / (tiles_x * tiles_y);
+        const int ty0 = tyi * HTP_TH, tx0 = txi * HT_TW;
+        const T *x = (const T *)P.x + (size_t)b * P.ih * P.iw * 128;
+        __syncthreads();                                            // the previous tile's fragment reads are done (first pass: the weights are in)
+        // ---- upsampled activations of the tile + halo; outside the image = the convolution's zero padding ------------------
+        for (int i0 = tid; i0 < HTP_NPIX * 16; i0 += 512 * 4) {
+            T a[4][8], bq[4][8], cq[4][8], d[4][8];
+            float w00[4], w01[4], w10[4], w11[4];
+            bool inside[4], live[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int i = i0 + u * 512;
+                live[u] = i < HTP_NPIX * 16;
+                const int pix = min(i, HTP_NPIX * 16 - 1) >> 4, chunk16 = i & 15;
+                const int r = pix / HT_PW, c = pix - r * HT_PW;
+                const int oy = ty0 - 1 + r, ox = tx0 - 1 + c;
+                inside[u] = live[u] && oy >= 0 && oy < P.oh && ox >= 0 && ox < P.ow;
+                const float fy = P.sy * max(oy, 0), fx = P.sx * max(ox, 0);
+                const int y0 = min((int)fy, P.ih - 1), x0 = min((int)fx, P.iw - 1);
+                const int y1 = min(y0 + 1, P.ih - 1), x1 = min(x0 + 1, P.iw - 1);
+                const float ty = fy - y0, tx = fx - x0;
+                w00[u] = (1.f - ty) * (1.f - tx); w01[u] = (1.f - ty) * tx; w10[u] = ty * (1.f - tx); w11[u] = ty * tx;
+                __builtin_memcpy(a[u], x + ((size_t)y0 * P.iw + x0) * 128 + chunk16 * 8, 16);
+                __builtin_memcpy(bq[u], x + ((size_t)y0 * P.iw + x1) * 128 + chunk16 * 8, 16);
+                __builtin_memcpy(cq[u], x + ((size_t)y1 * P.iw + x0) * 128 + chunk16 * 8, 16);
+                __builtin_memcpy(d[u], x + ((size_t)y1 * P.iw + x1) * 128 + chunk16 * 8, 16);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                if (!live[u]) continue;
+                const int i = i0 + u * 512;
+                const int pix = i >> 4, chunk16 = i & 15;
+                T o[8];
+#pragma unroll
+                for (int k = 0; k < 8; k++)
+                    o[k] = inside[u] ? (T)(w00[u] * (float)a[u][k] + w01[u] * (float)bq[u][k] + w10[u] * (float)cq[u][k] + w11[u] * (float)d[u][k])
+                                     : (T)0.f;
+                __builtin_memcpy(s_act + pix * 256 + ((chunk16 ^ (pix & 15)) << 4), o, 16);
+            }
+        }
+        __syncthreads();
+        // ---- implicit GEMM: D[co][pixel] += W[co][tap, ci] * act[pixel + tap][ci]; this wave: output row `wave` ----------------
+        ht_f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[r] = 0.f;
+        const unsigned char *wf = s_w + ((size_t)hi * 32 + l31) * 16;
+#pragma unroll
+        for (int tap = 0; tap < 9; tap++) {
+            const int dy = tap / 3, dx = tap - dy * 3;
+            const int pix = (wave + dy) * HT_PW + l31 + dx;
+#pragma unroll
+            for (int s8 = 0; s8 < 8; s8++) {
+                const uint4 wraw = *reinterpret_cast<const uint4 *>(wf + (size_t)(tap * 8 + s8) * 2 * 32 * 16);
+                const uint4 araw = *reinterpret_cast<const uint4 *>(s_act + pix * 256 + (((2 * s8 + hi) ^ (pix & 15)) << 4));
+                if (BF16) {
+                    union { uint4 u; ht_bf16x8 v; } wa, ab; wa.u = wraw; ab.u = araw;
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa.v, ab.v, acc, 0, 0, 0);
+                } else {
+                    union { uint4 u; ht_f16x8 v; } wa, ab; wa.u = wraw; ab.u = araw;
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wa.v, ab.v, acc, 0, 0, 0);
+                }
+            }
+        }
+        // ---- epilogue: lane holds channels crow(r, hi) of pixel l31: + bias, ReLU, dot with the 1x1 weights, + bias, ReLU --------
+        float part = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int ch = (r & 3) + 8 * (r >> 2) + 4 * hi;
+            const float v = fmaxf(acc[r] + P.b2[ch], 0.f);
+            part += P.w3[ch] * v;
+        }
+        part += __shfl_xor(part, 32, 64);
+        float res = part + P.b3;
+        if (P.relu_out) res = fmaxf(res, 0.f);
+        const int oy = ty0 + wave, ox = tx0 + l31;
+        if (hi == 0 && oy < P.oh && ox < P.ow) ((T *)P.out)[((size_t)b * P.oh + oy) * P.ow + ox] = (T)res;
+    }
+}
+
 DS_API int ds_dpt_head_tail(ds_ctx *ctx, const void *x, int batch, int in_h, int in_w, int out_h, int out_w,
                             const void *conv3_wfrag, const float *conv3_bias, const float *conv1_weight, float conv1_bias,
                             int relu_out, void *out, int dtype, void *stream)
@@ -305,6 +407,29 @@ DS_API int ds_dpt_head_tail(ds_ctx *ctx, const void *x, int batch, int in_h, int
     P.B = batch; P.ih = in_h; P.iw = in_w; P.oh = out_h; P.ow = out_w; P.relu_out = relu_out;
     P.sy = out_h > 1 ? (float)(in_h - 1) / (float)(out_h - 1) : 0.f;
     P.sx = out_w > 1 ? (float)(in_w - 1) / (float)(out_w - 1) : 0.f;
+    static int s_persist = -1;                               // DS_HEAD_PERSIST=1: the persistent variant (weights resident in LDS)
+    if (s_persist < 0) { const char *e = getenv("DS_HEAD_PERSIST"); s_persist = (e && atoi(e) == 1) ? 1 : 0; }
+    if (s_persist) {
+        const int tiles_x = (out_w + HT_TW - 1) / HT_TW, tiles_y = (out_h + HTP_TH - 1) / HTP_TH;
+        const long long nt = (long long)tiles_x * tiles_y * batch;
+        DS_REQUIRE(nt < (1ll << 30), DS_EUNSUPPORTED, "ds_dpt_head_tail: too many tiles");
+        int ncu = 0, dev = 0;
+        DS_HIP_CHECK(hipGetDevice(&dev));
+        DS_HIP_CHECK(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev));
+        ncu = ncu >= 8 ? ncu / 8 * 8 : 8;
+        const int chunk = (int)((nt + 7) / 8);
+        const int grid = (int)std::min<long long>(ncu, 8ll * chunk);
+        const size_t ldsp = (size_t)HTP_W_BYTES + (size_t)HTP_NPIX * 256;
+        if (dtype == DS_DTYPE_F16) {
+            DS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_dpt_head_tail_p<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsp));
+            hipLaunchKernelGGL((k_dpt_head_tail_p<0>), dim3(grid), dim3(512), ldsp, (hipStream_t)stream, P, tiles_x, tiles_y, (int)nt, chunk);
+        } else {
+            DS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_dpt_head_tail_p<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsp));
+            hipLaunchKernelGGL((k_dpt_head_tail_p<1>), dim3(grid), dim3(512), ldsp, (hipStream_t)stream, P, tiles_x, tiles_y, (int)nt, chunk);
+        }
+        DS_HIP_CHECK(hipGetLastError());
+        return DS_OK;
+    }
     static int s_rpw = 0;                                    // DS_HEAD_RPW: output rows per wave (tile height = 4x), 1 or 2
     if (s_rpw == 0) { const char *e = getenv("DS_HEAD_RPW"); s_rpw = (e && atoi(e) == 2) ? 2 : 1; }
     const int th = 4 * s_rpw;
