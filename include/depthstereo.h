@@ -242,6 +242,15 @@ int ds_linear(ds_ctx *ctx, const void *x, const void *w, const void *bias, void 
               int64_t in_features, int64_t ldy, int act, int dtype, void *stream);
 
 /*
+ * ds_linear_residual -- y = res + [gamma *] (x . W^T + bias): ds_linear with the residual add (and, when gamma is not NULL,
+ * the LayerScale factor per output feature) in the epilogue: `x + gamma_1 * attn.proj(...)` of the encoder blocks
+ * (dmidas/backbones/beit.py:99-103; dinov2_layers/block.py:88-96).  res and y [rows, out_features]; y must not alias res.
+ * Shapes as ds_linear.  (Opt-in in the host code: DS_LINEAR=proj.)
+ */
+int ds_linear_residual(ds_ctx *ctx, const void *x, const void *w, const void *bias, const void *gamma, const void *res, void *y,
+                       int64_t rows, int64_t out_features, int64_t in_features, int dtype, void *stream);
+
+/*
  * ds_conv3x3_nhwc -- y = act(conv3x3(x, W) + bias [+ res1] [+ res2]), stride 1, zero padding 1, as the implicit GEMM of
  * csrc/ds_linear.hip (same 256 x 256 MFMA tiles; a K-tile is 64 channels of one tap, fetched by LDS-DMA from the shifted
  * pixel or from a zero line for the padding ring): the 3x3 convolutions of the DPT decoders with their element-wise tails

@@ -70,6 +70,7 @@ struct LinParams {
     int stagger;                // experiment (DS_LIN_STAGGER_US): every other workgroup of an XCD starts this many 10 ns ticks late
     int H, W, C, cpt, magic;    // CONV: image height / width, input channels, K-tiles per tap (C / 64), 65536 / cpt + 1
     long long ldy;              // row stride of y (and res1 / res2) in elements
+    const void *gamma;          // EPI 3: per-column factor applied to (acc + bias) before the addends (LayerScale)
 };
 
 // erf-GELU on the fp32 accumulator.  GELU(v) = v Phi(v) = max(v, 0) - |v| Phi(-|v|), and Phi(-u) = 2^-Q(u) with
@@ -130,7 +131,7 @@ __device__ __forceinline__ void ln_dma_v(const void *ptr, unsigned lds_uniform)
         __builtin_amdgcn_sched_barrier(0);        \
     } while (0)
 
-// EPI: 0 none, 1 erf-GELU, 2 ReLU.  RES: number of residual addends (res1, res2).  CONV: 0 = x is a dense [M, K] matrix; 1 = x is an NHWC image [batch, H, W, C] and the
+// EPI: 0 none, 1 erf-GELU, 2 ReLU, 3 per-column scale (LayerScale: y = res1 + gamma * (x.W^T + b)).  RES: number of residual addends (res1, res2).  CONV: 0 = x is a dense [M, K] matrix; 1 = x is an NHWC image [batch, H, W, C] and the
 // GEMM is the implicit one of a 3 x 3, stride 1, zero-padded convolution: row m = output pixel, K-tile kt = 64 channels
 // kt / 9 of tap kt % 9 (tap-fastest: the pixels of a chunk are fetched once and hit in L2 for the other eight taps), whose
 // source is the same 128 bytes of the pixel shifted by (dy, dx) -- or the zero line.
@@ -395,6 +396,13 @@ __global__ __launch_bounds__(LN_THREADS) void k_linear256(LinParams P)
                 for (int t = 0; t < 8; ++t) bv[hb][k][t] = (T)0.f;
             }
         }
+    V8 gv[2][2];                                                // EPI 3: the per-column factors, packed like the bias
+    if (EPI == 3) {
+#pragma unroll
+        for (int hb = 0; hb < 2; ++hb)
+#pragma unroll
+            for (int k = 0; k < 2; ++k) gv[hb][k] = *(const V8 *)((const T *)P.gamma + cbn0 + wc * 64 + hb * 32 + hi8 + 16 * k);
+    }
     unsigned char *tl = lds + wid * 16384;                      // this wave's transpose area: 128 rows x 128 bytes
 #pragma unroll
     for (int ha = 0; ha < 2; ++ha)
@@ -427,6 +435,7 @@ __global__ __launch_bounds__(LN_THREADS) void k_linear256(LinParams P)
 #pragma unroll
                     for (int t = 0; t < 8; t += 2) {
                         lf32x2 u = {v[t] + (float)bv[hb][k][t], v[t + 1] + (float)bv[hb][k][t + 1]};
+                        if (EPI == 3) u *= (lf32x2){(float)gv[hb][k][t], (float)gv[hb][k][t + 1]};
                         if (RES >= 1) u += (lf32x2){(float)ra[hb][k][t], (float)ra[hb][k][t + 1]};
                         if (RES >= 2) u += (lf32x2){(float)rb2[hb][k][t], (float)rb2[hb][k][t + 1]};
                         if (EPI == 1) u = ln_gelu2(u);
@@ -531,6 +540,30 @@ DS_API int ds_linear(ds_ctx *ctx, const void *x, const void *w, const void *bias
     P.ablate = getenv("DS_LIN_ABLATE") ? atoi(getenv("DS_LIN_ABLATE")) : 0;
     P.stagger = getenv("DS_LIN_STAGGER_US") ? (int)(atof(getenv("DS_LIN_STAGGER_US")) * 100.0) : 0;
     return dtype == DS_DTYPE_F16 ? ln_dispatch_dense<0>(P, act, (hipStream_t)stream) : ln_dispatch_dense<1>(P, act, (hipStream_t)stream);
+}
+
+// y = res + [gamma *] (x . W^T + b): the output projection of an encoder block with its LayerScale and residual add in the
+// epilogue (prepared at the end of round 2, opt-in through DS_LINEAR=proj; not yet measured on hardware).
+DS_API int ds_linear_residual(ds_ctx *ctx, const void *x, const void *w, const void *bias, const void *gamma, const void *res, void *y,
+                              int64_t rows, int64_t out_features, int64_t in_features, int dtype, void *stream)
+{
+    DS_REQUIRE(ctx && x && w && y && res, DS_EINVAL, "ds_linear_residual: null argument");
+    DS_REQUIRE(rows >= 256 && rows < (1ll << 31) - 256, DS_EINVAL, "ds_linear_residual: rows must be >= 256 (one tile)");
+    DS_REQUIRE(out_features > 0 && out_features % 256 == 0, DS_EINVAL, "ds_linear_residual: out_features must be a multiple of 256");
+    DS_REQUIRE(in_features >= 128 && in_features % 128 == 0 && in_features <= 16384, DS_EINVAL,
+               "ds_linear_residual: in_features must be a multiple of 128 (<= 16384)");
+    DS_REQUIRE(dtype == DS_DTYPE_F16 || dtype == DS_DTYPE_BF16, DS_EINVAL, "ds_linear_residual: dtype must be f16 or bf16");
+    DS_REQUIRE(((uintptr_t)y & 15) == 0 && ((uintptr_t)res & 15) == 0 && ((uintptr_t)bias & 15) == 0 && ((uintptr_t)gamma & 15) == 0 && y != res,
+               DS_EINVAL, "ds_linear_residual: y, res, bias and gamma must be 16-byte aligned, and y must not alias res");
+    LinParams P;
+    memset(&P, 0, sizeof(P));
+    P.x = x; P.w = w; P.bias = bias; P.gamma = gamma; P.res1 = res; P.y = y;
+    P.M = (int)rows; P.N = (int)out_features; P.K = (int)in_features;
+    P.nbm = (int)((rows + 255) / 256); P.nbn = (int)(out_features / 256);
+    P.ldy = out_features;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == DS_DTYPE_F16) return gamma ? ln_launch<0, 3, 0, 1>(P, st) : ln_launch<0, 0, 0, 1>(P, st);
+    return gamma ? ln_launch<1, 3, 0, 1>(P, st) : ln_launch<1, 0, 0, 1>(P, st);
 }
 
 DS_API int ds_conv3x3_nhwc(ds_ctx *ctx, const void *x, const void *w, const void *bias, const void *res1, const void *res2, void *y,

@@ -18,7 +18,7 @@ DS_DEPTH_U16, DS_DEPTH_F32, DS_DEPTH_F64 = 0, 1, 2
 FILL_IDS = {"none": 0, "naive": 1, "naive_interpolating": 2, "polylines_soft": 3, "polylines_sharp": 4}
 
 EXPORTS = [
-    "ds_version", "ds_last_error", "ds_normalmap_f64", "ds_reassemble_readout", "ds_bias_act_nhwc", "ds_linear", "ds_conv3x3_nhwc", "ds_ctx_create", "ds_ctx_destroy", "ds_stereo_warp", "ds_depth_minmax",
+    "ds_version", "ds_last_error", "ds_normalmap_f64", "ds_reassemble_readout", "ds_bias_act_nhwc", "ds_linear", "ds_linear_residual", "ds_conv3x3_nhwc", "ds_ctx_create", "ds_ctx_destroy", "ds_stereo_warp", "ds_depth_minmax",
     "ds_stereo_last_exact_rows", "ds_copy_view", "ds_overlap_red_cyan", "ds_normalmap", "ds_depth_to_u16",
     "ds_convert_to_i16", "ds_profile_enable", "ds_profile_last_ms", "ds_stereo_last_stats", "ds_attention_fwd", "ds_attention_bias_pack", "ds_colorize_u16", "ds_residual_layernorm", "ds_boost_blend", "ds_upsample_bilinear_nhwc", "ds_dpt_head_tail",
 ]
@@ -72,6 +72,7 @@ def lib():
             L.ds_reassemble_readout.argtypes = [vp, vp, vp, vp, ci, ci, ci, ci, vp]
             L.ds_bias_act_nhwc.argtypes = [vp, vp, vp, vp, vp, vp, i64, ci, ci, ci, vp]
             L.ds_linear.argtypes = [vp, vp, vp, vp, vp, i64, i64, i64, i64, ci, ci, vp]
+            L.ds_linear_residual.argtypes = [vp, vp, vp, vp, vp, vp, vp, i64, i64, i64, ci, vp]
             L.ds_conv3x3_nhwc.argtypes = [vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, vp]
             L.ds_profile_enable.argtypes = [vp, ci]
             L.ds_profile_last_ms.argtypes = [vp, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float)]
@@ -377,6 +378,29 @@ def linear(x, weight, bias=None, gelu=False):
                            out.data_ptr(), x2.shape[0], n, k, n, 1 if gelu else 0,
                            1 if x.dtype == torch.float16 else 2, _stream(x)))
     return out[:rows].view(x.shape[:-1] + (n,))
+
+
+def linear_residual(x, weight, bias, gamma, residual):
+    """residual + [gamma *] (x @ weight.T + bias) (include/depthstereo.h: ds_linear_residual).  x [..., K], residual [..., N]
+    float16 / bfloat16 CUDA, at least 256 rows; gamma [N] or None."""
+    torch = require_gpu()
+    assert x.is_cuda and x.dtype in (torch.float16, torch.bfloat16) and linear_supported(x, weight)
+    k, n = x.shape[-1], weight.shape[0]
+    x2 = x.reshape(-1, k).contiguous()
+    r2 = residual.reshape(-1, n).contiguous()
+    assert x2.shape[0] == r2.shape[0] >= 256 and r2.dtype == x.dtype
+
+    def prep(t):
+        if t is None:
+            return None
+        t = t.detach()
+        return t if (t.dtype == x.dtype and t.is_contiguous()) else t.to(x.dtype).contiguous()
+    w, b, g = prep(weight), prep(bias), prep(gamma)
+    out = torch.empty_like(r2)
+    _check(lib().ds_linear_residual(ctx_for(_dev_index(x)), x2.data_ptr(), w.data_ptr(), None if b is None else b.data_ptr(),
+                                    None if g is None else g.data_ptr(), r2.data_ptr(), out.data_ptr(), x2.shape[0], n, k,
+                                    1 if x.dtype == torch.float16 else 2, _stream(x)))
+    return out.view(residual.shape)
 
 
 def conv3x3_supported(conv, x):

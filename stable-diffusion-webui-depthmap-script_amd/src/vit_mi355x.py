@@ -143,6 +143,7 @@ LOG2E = 1.4426950408889634
 
 # Which token GEMMs take the in-tree MFMA kernel (csrc/ds_linear.hip) on float16 / bfloat16 CUDA tensors:
 #   "gelu" (default) fc1 + GELU only -- the fused epilogue removes the stand-alone GELU pass;
+#   "proj"           "gelu" + the attention output projection with LayerScale and the residual add in its epilogue (opt-in);
 #   "all"            every Linear of the encoder blocks;        "0"  none (library GEMMs + aten GELU).
 LINEAR_HIP = os.environ.get("DS_LINEAR", "gelu")
 
@@ -150,7 +151,7 @@ LINEAR_HIP = os.environ.get("DS_LINEAR", "gelu")
 def linear(x, weight, bias=None, gelu=False):
     """[gelu](x @ weight.T + bias).  float16 / bfloat16 on a GPU: ds_linear when the switch above selects it (erf-GELU
     on the fp32 accumulator); everything else: the library GEMM and aten's exact GELU."""
-    if x.is_cuda and x.dtype in (torch.float16, torch.bfloat16) and (LINEAR_HIP == "all" or (gelu and LINEAR_HIP == "gelu")):
+    if x.is_cuda and x.dtype in (torch.float16, torch.bfloat16) and (LINEAR_HIP == "all" or (gelu and LINEAR_HIP in ("gelu", "proj"))):
         from . import _native
         if _native.linear_supported(x, weight):
             return _native.linear(x, weight, bias, gelu)
@@ -183,13 +184,17 @@ class EncoderBlock(nn.Module):
     def attention_bias(self, n_pad, grid_hw, dtype, device):
         return None
 
-    def attend(self, h, n_valid, grid_hw):
-        """LayerNorm-ed tokens -> projected attention output (before LayerScale / residual)."""
+    def attend_o(self, h, n_valid, grid_hw):
+        """LayerNorm-ed tokens -> (attention output before the projection, V bias to fold into the projection bias)."""
         b, npad, c = h.shape
         w_qk, b_qk, w_v, b_v = self.qkv_weights()
         qk = linear(h, w_qk, b_qk).view(b, npad, 2, self.num_heads, HEAD_DIM)
         vt = v_transposed(w_v, h)                               # [B, C, Np]: V transposed, straight out of the GEMM
-        o = fused_attention(qk, vt, n_valid, self.scale, self.attention_bias(npad, grid_hw, h.dtype, h.device))
+        return fused_attention(qk, vt, n_valid, self.scale, self.attention_bias(npad, grid_hw, h.dtype, h.device)), b_v
+
+    def attend(self, h, n_valid, grid_hw):
+        """LayerNorm-ed tokens -> projected attention output (before LayerScale / residual)."""
+        o, b_v = self.attend_o(h, n_valid, grid_hw)
         return self.proj(o, b_v)                                # V bias folded into the projection bias
 
     def forward_padded(self, x, n_valid, grid_hw=None):
@@ -218,8 +223,16 @@ def run_blocks(blocks, x, n_valid, grid_hw, take):
     _, h = _native.residual_layernorm(x, None, None, blocks[0].norm1.weight, blocks[0].norm1.bias, blocks[0].norm1.eps)
     for i, blk in enumerate(blocks):
         g1, g2 = blk.gammas()
-        p = blk.attend(h, n_valid, grid_hw)
-        x, h2 = _native.residual_layernorm(x, p, g1, blk.norm2.weight, blk.norm2.bias, blk.norm2.eps)
+        pr = getattr(getattr(blk, "attn", None), "proj", None)
+        if (LINEAR_HIP == "proj" and pr is not None and x.shape[0] * x.shape[1] >= 256 and _native.linear_supported(x, pr.weight)):
+            # opt-in (prepared at the end of round 2, to be measured): the projection GEMM adds LayerScale and the residual in
+            # its epilogue, the LayerNorm pass then reads x once instead of x and the branch
+            o, b_v = blk.attend_o(h, n_valid, grid_hw)
+            x = _native.linear_residual(o, pr.weight, folded_proj_bias(pr, b_v), g1, x)
+            _, h2 = _native.residual_layernorm(x, None, None, blk.norm2.weight, blk.norm2.bias, blk.norm2.eps)
+        else:
+            p = blk.attend(h, n_valid, grid_hw)
+            x, h2 = _native.residual_layernorm(x, p, g1, blk.norm2.weight, blk.norm2.bias, blk.norm2.eps)
         m = blk.mlp(h2)
         if i + 1 < n:
             nxt = blocks[i + 1].norm1
