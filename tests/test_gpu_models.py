@@ -708,3 +708,90 @@ def test_conv3x3_kernel_matches_float32_convolution(gpu, dtype, tol):
     assert vm.conv3x3_hip_ok(c1.to(dtype), xh)
     got = vm.residual_conv_unit(c1.to(dtype), c2.to(dtype), xh, skip=skip.to(dtype))
     assert (got.float() - want).abs().max().item() < 4 * tol * (1 + want.abs().max().item())
+
+
+@pytest.mark.parametrize("m,n,k,gelu", [(34816, 4096, 1024, True), (34816, 1024, 4096, False), (34816, 2048, 1024, False),
+                                        (34816, 1024, 1024, False)])
+def test_linear_kernel_at_benchmark_shapes(gpu, m, n, k, gelu):
+    """ds_linear at the shapes ONE encoder block of dpt_beit_large_512 launches at batch 32 (the bench's step): 34 816
+    rows = 136 row panels, i.e. the whole XCD-aware tile list of ~2 000 tiles over all 256 persistent workgroups (the
+    smaller tests walk at most 17 panels).  Every element against a float32 GEMM of the same rounded operands."""
+    import torch.nn.functional as F
+    from src import _native
+    g = torch.Generator().manual_seed(m + n + k)
+    x = torch.randn((m, k), generator=g).half().cuda()
+    w = (torch.randn((n, k), generator=g) * k ** -0.5).half().cuda()
+    b = torch.randn(n, generator=g).half().cuda()
+    got = _native.linear(x, w, b, gelu)
+    assert got.shape == (m, n) and got.dtype == torch.float16
+    worst, scale = 0.0, 0.0
+    wf, bf = w.float(), b.float()
+    for r0 in range(0, m, 4352):
+        want = x[r0:r0 + 4352].float() @ wf.T + bf
+        want = F.gelu(want) if gelu else want
+        worst = max(worst, (got[r0:r0 + 4352].float() - want).abs().max().item())
+        scale = max(scale, want.abs().max().item())
+    assert worst < 1.5e-3 * (1 + scale), (m, n, k, worst, scale)
+    assert torch.equal(_native.linear(x, w, b, gelu), got), "run-to-run difference at the benchmark shape"
+
+
+def test_conv3x3_kernel_at_benchmark_shape(gpu):
+    """ds_conv3x3_nhwc at refinenet1's shape in the bench's step: 32 x 128 x 128, 256 -> 256, bias + residual
+    (2 048 tiles), every output against F.conv2d in float32 on the same rounded operands."""
+    import torch.nn as nn
+    import torch.nn.functional as F
+    from src import _native
+    g = torch.Generator().manual_seed(43)
+    conv = nn.Conv2d(256, 256, 3, padding=1).cuda()
+    with torch.no_grad():
+        conv.weight.copy_(torch.randn(conv.weight.shape, generator=g) * 2304 ** -0.5)
+        conv.bias.copy_(torch.randn(256, generator=g))
+    mk = lambda: torch.randn((32, 256, 128, 128), generator=g).half().cuda().contiguous(memory_format=torch.channels_last)  # noqa: E731
+    x, r1 = mk(), mk()
+    got = _native.conv3x3(conv.half(), x, relu=False, res1=r1)
+    wq, bq = conv.weight.detach().float(), conv.bias.detach().float()
+    worst, scale = 0.0, 0.0
+    for i in range(0, 32, 4):
+        want = F.conv2d(x[i:i + 4].float(), wq, bq, padding=1) + r1[i:i + 4].float()
+        worst = max(worst, (got[i:i + 4].float() - want).abs().max().item())
+        scale = max(scale, want.abs().max().item())
+    assert worst < 2e-3 * (1 + scale), (worst, scale)
+    assert torch.equal(_native.conv3x3(conv, x, relu=False, res1=r1), got)
+
+
+def test_infer_batch_gpu_vs_reference_get_raw_prediction(gpu):
+    """uint8 image -> depth at image size ON THE DEVICE (pre-resize + normalise + forward + bicubic / bilinear back, SURVEY
+    8f-1) against the reference's own ModelHolder.get_raw_prediction -> estimatemidas / estimatedepthanything_v2 run on the
+    CPU in float32 (tests/golden/make_golden_infer.py; src/depthmap_generation.py:375-403,455-499,548-559): float32 at 1e-4,
+    float16 (the reference's GPU default) at 2e-2, also through the product's ModelHolder-level predictor with a batch of 2."""
+    import make_golden_infer as mgi
+    from ddepth_anything_v2 import DepthAnythingV2
+    from dmidas.dpt_depth import DPTDepthModel
+    z = np.load(os.path.join(os.path.dirname(GOLD), "infer_cases.npz"))
+    rel = lambda a, b: float(np.abs(a - b).max() / np.abs(b).max())  # noqa: E731
+    m = DPTDepthModel(path=None, backbone="beitb16_384", non_negative=True).eval()
+    m.load_state_dict(mw.fill_state_dict_beit(m.state_dict()), strict=True)
+    m = m.cuda()
+    for name, h, w, nw, nh, seed in mgi.MIDAS_CASES:
+        img = torch.from_numpy(z[f"midas__{name}__image"]).cuda()
+        got = m.infer_batch(img[None], net_size=nw, resize_mode="minimal", net_h=nh)[0].cpu().numpy()
+        assert got.shape == (h, w) and rel(got, z[f"midas__{name}__pred"]) < 1e-4, (name, rel(got, z[f"midas__{name}__pred"]))
+        both = m.infer_batch(torch.stack([img, img.flip(0)]), net_size=nw, resize_mode="minimal", net_h=nh)
+        assert rel(both[0].cpu().numpy(), z[f"midas__{name}__pred"]) < 1e-4
+    m16 = m.half()
+    for name, h, w, nw, nh, seed in mgi.MIDAS_CASES:
+        img = torch.from_numpy(z[f"midas__{name}__image"]).cuda()
+        got = m16.infer_batch(img[None], net_size=nw, resize_mode="minimal", net_h=nh)[0].cpu().numpy()
+        assert rel(got, z[f"midas__{name}__pred"]) < 2e-2, (name, rel(got, z[f"midas__{name}__pred"]))
+    d = DepthAnythingV2('vits', features=64, out_channels=[48, 96, 192, 384]).eval()
+    d.load_state_dict(mw.fill_state_dict(d.state_dict()), strict=True)
+    d = d.cuda()
+    for name, h, w, size, seed in mgi.DAV2_CASES:
+        img = torch.from_numpy(z[f"dav2__{name}__image"]).cuda()
+        got = d.infer_batch(img[None], size)[0].cpu().numpy()
+        assert got.shape == (h, w) and rel(got, z[f"dav2__{name}__pred"]) < 1e-4, (name, rel(got, z[f"dav2__{name}__pred"]))
+    d16 = d.half()
+    for name, h, w, size, seed in mgi.DAV2_CASES:
+        img = torch.from_numpy(z[f"dav2__{name}__image"]).cuda()
+        got = d16.infer_batch(img[None], size)[0].cpu().numpy()
+        assert rel(got, z[f"dav2__{name}__pred"]) < 2e-2, (name, rel(got, z[f"dav2__{name}__pred"]))

@@ -179,6 +179,26 @@ def test_normalmap_vs_oracle(gpu, oracle):
                 assert np.array_equal(want, got), (dep.shape, inv, args, int((want != got).sum()))
 
 
+def test_normalmap_reference_goldens(gpu):
+    """The HIP normal-map kernels against outputs of the REFERENCE's own create_normalmap (tests/golden/
+    make_golden_normalmap.py runs src/normalmap_generation.py:5-56 unmodified with an exact-integer cv2.Sobel stub):
+    bit-exact for every Sobel aperture, np.gradient, both inversions and every input dtype; one LSB for the cases made
+    with a stand-in Gaussian blur."""
+    import src.normalmap_generation as nm
+    z, index = util.load_normalmap_golden()
+    exact = 0
+    for c in index:
+        d = z[c['depth'] + '__depth']
+        got = np.asarray(nm.create_normalmap(d, c['pre_blur'], c['sobel'], c['post_blur'], c['invert']))
+        want = z[c['key'] + '__out']
+        if c['standin']:
+            assert np.abs(got.astype(np.int16) - want.astype(np.int16)).max() <= 1, c['key']
+        else:
+            assert np.array_equal(got, want), (c['key'], int((got != want).sum()))
+            exact += 1
+    assert exact >= 60
+
+
 def test_normalmap_blur_paths_vs_oracle(gpu, oracle):
     """Gaussian pre/post blur: parity with the oracle's restatement (OpenCV's own summation order is unpinned)."""
     import src.normalmap_generation as nm
@@ -417,11 +437,30 @@ def test_full_frame_1024_all_rows_vs_oracle(sg, native, oracle, gpu, fill):
         bad = int((want != got[i]).sum())
         assert bad == 0, (fill, i, bad, np.argwhere((want != got[i]).any(axis=2))[:5].tolist())
     # the regimes are what they claim to be: the batch as a whole produced general pixels and exact-fallback rows
-    assert general > 0 and exact_rows >= 0
-    # each image alone: regime 1 is dominated by general pixels
+    assert general > 0 and exact_rows > 0
+    # each image alone: regime 1 is dominated by general pixels, regime 2 sends rows to the exact fallback
     sg.create_stereoimages_batch(it[1:2], dt[1:2], 2.5, 0.0, ['left-right'], 0.0, 1.0, fill)
     _, g1 = native.last_stats(it)
     assert g1 > 0
+    sg.create_stereoimages_batch(it[2:3], dt[2:3], 2.5, 0.0, ['left-right'], 0.0, 1.0, fill)
+    e2, _ = native.last_stats(it)
+    assert e2 > 0
+
+
+@pytest.mark.parametrize("fill,div,sep,bal,exp", [("polylines_sharp", 4.0, 1.0, 0.3, 2.0), ("polylines_soft", 2.5, -1.5, -0.6, 0.5)])
+def test_full_frame_1024_non_default_parameters(sg, native, oracle, gpu, fill, div, sep, bal, exp):
+    """The same three regimes at 1024 x 1024 with every stereo parameter off its default: separation (a constant shift of
+    both eyes), stereo balance (unequal divergence per eye), and an exponent != 1 (the pow LUT of :84-85 / :176), every row
+    of both eyes bit-exact against the oracle.  src/stereoimage_generation.py:13-92,162-283."""
+    torch = gpu
+    dep = _full_frame_depths()
+    img = np.random.default_rng(79).integers(0, 256, (3, 1024, 1024, 3), dtype=np.uint8)
+    it, dt = torch.from_numpy(img).cuda(), torch.from_numpy(dep).cuda()
+    got = sg.create_stereoimages_batch(it, dt, div, sep, ['left-right'], bal, exp, fill)[0].cpu().numpy()
+    for i in range(3):
+        want = oracle.create_stereoimages_arrays(img[i], dep[i], div, sep, ['left-right'], bal, exp, fill)[0]
+        bad = int((want != got[i]).sum())
+        assert bad == 0, (fill, i, bad, np.argwhere((want != got[i]).any(axis=2))[:5].tolist())
 
 
 def test_funnel_batched_schedule_equals_image_by_image(gpu, oracle, monkeypatch):

@@ -386,3 +386,28 @@ def test_dpt_preprocess_matches_reference_transform_chain():
         want = z[name]
         assert x.shape == want.shape and x.dtype == want.dtype, (name, x.shape, want.shape)
         assert np.abs(x - want).max() < 5e-5, (name, float(np.abs(x - want).max()))
+
+
+def test_infer_batch_matches_reference_get_raw_prediction():
+    """The image -> raw prediction path end to end, CPU float32: DPTDepthModel.infer_batch and DepthAnythingV2.infer_batch
+    against the reference's OWN ModelHolder.get_raw_prediction -> estimatemidas / estimatedepthanything_v2
+    (src/depthmap_generation.py:375-403,455-499,548-559; dmidas/transforms.py:105-160) run unmodified on the same pixels
+    and name-seeded weights (tests/golden/make_golden_infer.py: cv2.resize replaced by the numpy restatement of its cubic
+    kernel, the only stand-in on the path): channel order, /255, resize rule, normalisation, forward, resize back."""
+    import make_golden_infer as mgi
+    from ddepth_anything_v2 import DepthAnythingV2
+    from dmidas.dpt_depth import DPTDepthModel
+    z = np.load(os.path.join(os.path.dirname(GOLD), "infer_cases.npz"))
+    m = DPTDepthModel(path=None, backbone="beitb16_384", non_negative=True).eval()
+    m.load_state_dict(mw.fill_state_dict_beit(m.state_dict()), strict=True)
+    for name, h, w, nw, nh, seed in mgi.MIDAS_CASES:
+        img = z[f"midas__{name}__image"]
+        assert np.array_equal(img, mgi.image(h, w, seed))
+        got = m.infer_batch(torch.from_numpy(img)[None], net_size=nw, resize_mode="minimal", net_h=nh)[0].numpy()
+        assert got.shape == (h, w) and _rel(got, z[f"midas__{name}__pred"]) < 1e-4, name
+    m = DepthAnythingV2('vits', features=64, out_channels=[48, 96, 192, 384]).eval()
+    m.load_state_dict(mw.fill_state_dict(m.state_dict()), strict=True)
+    for name, h, w, size, seed in mgi.DAV2_CASES:
+        img = z[f"dav2__{name}__image"]
+        got = m.infer_batch(torch.from_numpy(img)[None], size)[0].numpy()
+        assert got.shape == (h, w) and _rel(got, z[f"dav2__{name}__pred"]) < 1e-4, name

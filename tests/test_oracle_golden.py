@@ -56,6 +56,26 @@ def test_oracle_normalmap_known_answers(oracle):
     assert h16(nm) == 'c3a9ce0f64a2f5e3' and int(nm.sum()) == 4218191
 
 
+def test_oracle_normalmap_matches_reference_golden(oracle):
+    """oracle.create_normalmap_array against outputs of the REFERENCE's own create_normalmap (src/normalmap_generation.py
+    :5-56, imported unmodified by tests/golden/make_golden_normalmap.py with an exact-integer stub for cv2.Sobel): every
+    Sobel aperture (1/3/5/7), np.gradient, both inversions, uint16 / uint8 / int32 / float32 / float64 depth -- bit for bit.
+    The Gaussian-blur cases were made with a documented-formula stand-in for cv2.GaussianBlur (standin=1): one LSB."""
+    z, index = util.load_normalmap_golden()
+    exact = 0
+    for c in index:
+        d = z[c['depth'] + '__depth']
+        got = oracle.create_normalmap_array(d, c['pre_blur'], c['sobel'], c['post_blur'], c['invert'])
+        want = z[c['key'] + '__out']
+        assert got.shape == want.shape and got.dtype == np.uint8, c['key']
+        if c['standin']:
+            assert np.abs(got.astype(np.int16) - want.astype(np.int16)).max() <= 1, c['key']
+        else:
+            assert np.array_equal(got, want), (c['key'], int((got != want).sum()))
+            exact += 1
+    assert exact >= 60
+
+
 def test_oracle_normalmap_c_equals_numpy(oracle):
     # the fused C paths (Sobel 3, np.gradient) against the generic numpy restatement
     rng = np.random.default_rng(5)

@@ -20,6 +20,13 @@ def load_funnel_golden():
     return z, index
 
 
+def load_normalmap_golden():
+    """tests/golden/make_golden_normalmap.py: outputs of the reference's own create_normalmap (stub cv2, see there)."""
+    z = np.load(os.path.join(GOLDEN, "normalmap_cases.npz"))
+    index = json.loads(bytes(z["__index__"]).decode())
+    return z, index
+
+
 def golden_inputs(case):
     import make_golden as mg        # pure-numpy generators; importing it does not touch /root/reference
     return mg.gen_inputs(case)
