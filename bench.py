@@ -26,8 +26,10 @@ kept profile lines (profiles/round2_*).
 
 Contract: `python bench.py --gpus N --steps K --warmup W`; for N > 1 the driver launches one rank per GPU with
 torch.distributed.run.  Units are sharded across ranks (weak scaling: every rank renders its own batch, no data-path
-collective) and the collated stereo pairs are gathered to rank 0 with ONE RCCL gather per step, overlapped with the next
-step's kernels (--no-gather to leave it out).  Rank 0 prints ONE JSON line.
+collective) and the collated outputs (stereo pair + uint16 depth + normal map, packed into one byte buffer) are gathered
+to rank 0 with ONE RCCL gather per step, overlapped with the next step's kernels (--no-gather to leave it out).  Rank 0
+prints ONE JSON line; on one GPU the metric's config also carries `funnel`: the same batch through the drop-in boundary
+(core_generation_funnel, PIL in -> PIL out), reported beside `value`, never as it.
 """
 import argparse
 import contextlib
@@ -210,7 +212,9 @@ def main():
     ap.add_argument("--graph", action="store_true", help="replay the network forward as a hipGraph (default for the batch-1 config c2)")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-gather", action="store_true", help="N > 1: do not gather the collated outputs to rank 0")
-    ap.add_argument("--funnel", action="store_true", help="also time the drop-in funnel (PIL in -> PIL out) on the same batch")
+    ap.add_argument("--funnel", action="store_true", help="also time the drop-in funnel (PIL in -> PIL out) on the same batch "
+                                                        "(default for the metric's config c3 on one GPU; reported beside `value`, never as it)")
+    ap.add_argument("--no-funnel", action="store_true")
     ap.add_argument("--depth", default="steps", choices=["steps", "smooth"],
                     help="--model none only: synthetic prediction with steps + occluders (default), or smooth only")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -291,8 +295,11 @@ def main():
     gather_ok = world > 1 and not args.no_gather
     side = torch.cuda.Stream(device=dev) if gather_ok else None
     gathered = None
+    # the collated output of a unit is its stereo pair, its uint16 depth map and its normal map (north_star: "a single RCCL
+    # gather ... for the collated output"): packed into ONE byte buffer per rank, ONE gather per step
+    unit_bytes = H * 2 * W * 3 + H * W * 2 + (H * W * 3 if normalmap else 0)
     if gather_ok and rank == 0:
-        gathered = [torch.empty((batch, H, 2 * W, 3), dtype=torch.uint8, device=dev) for _ in range(world)]
+        gathered = [torch.empty((batch, unit_bytes), dtype=torch.uint8, device=dev) for _ in range(world)]
 
     # --overlap: the per-pixel kernels (float64 VALU / LDS bound) of step k run on their own stream beside the network forward
     # of step k+1 (MFMA bound); the units of every step are still complete inside the timed region.  Default: one stream.
@@ -323,12 +330,14 @@ def main():
             sbs = sg.create_stereoimages_batch(img, d16, 2.5, 0.0, ['left-right'], 0.0, 1.0, args.fill)[0]
             nmap = nmg.create_normalmap_batch(d16) if normalmap else None
             if gather_ok:
+                parts = [sbs.view(batch, -1), d16.view(torch.uint8).view(batch, -1)] + ([nmap.view(batch, -1)] if normalmap else [])
+                packed = torch.cat(parts, dim=1)
                 ev = torch.cuda.Event()
                 ev.record()
                 with torch.cuda.stream(side):
                     side.wait_event(ev)
-                    dist.gather(sbs, gathered if rank == 0 else None, dst=0)
-                    sbs.record_stream(side)
+                    dist.gather(packed, gathered if rank == 0 else None, dst=0)
+                    packed.record_stream(side)
         return sbs, nmap, d16
 
     step(check=True)            # priming pass, never timed: library kernel selection (MIOpen find), bias operands, allocator
@@ -442,7 +451,8 @@ def main():
     torch.cuda.synchronize()
 
     funnel = None
-    if args.funnel and rank == 0 and model is not None:
+    want_funnel = args.funnel or (args.config == "c3" and world == 1 and args.model is None and args.batch is None)
+    if want_funnel and not args.no_funnel and rank == 0 and model is not None:
         funnel = funnel_leg(model, model_name, img_np, net_size, net_h, normalmap)
 
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
@@ -488,7 +498,9 @@ def main():
                        "forward_launch": ("hipGraph replay" if (fwd is not None and fwd.graphs) else "eager"),
                        "overlap": "per-pixel kernels of step k on a second stream beside the forward of step k+1" if post is not None else "single stream",
                        "parallelism": f"units sharded over {world} GPU(s), no data-path collective"
-                                      + (", ONE RCCL gather of the stereo pairs to rank 0 per step, overlapped" if gather_ok else "")},
+                                      + (", ONE RCCL gather of the collated outputs (stereo pair + uint16 depth"
+                                         + (" + normal map" if normalmap else "") + f", {unit_bytes} bytes per unit) to rank 0 per step, overlapped"
+                                         if gather_ok else "")},
             # the dominant hand-written kernel of the step (largest launches x average duration): the fc1 + GELU GEMM or the
             # fused attention when a network runs, else the stereo kernel; the others follow under their own keys
             "roofline": stereo_roof,

@@ -187,9 +187,14 @@ int ds_attention_fwd(ds_ctx *ctx, const void *qk, const void *vt, const void *bi
  * ds_attention_bias_pack -- prepares the additive logits bias of ds_attention_fwd (the relative position bias of
  * dmidas/backbones/beit.py:29-62,84-88: bias[h][query][key], one table per block, constant per input resolution).
  *   bias    [H, n, n] float32, natural units (what the reference adds to q.k*scale)
- *   packed  H*Np*Np elements of dtype: the same values times log2(e) (the kernel works in the exp2 domain), zero padded
- *           to Np x Np and reordered to [H][Np/32 query blocks][Np/64 key tiles][4][64 lanes][8] -- the register order of
- *           the kernel's logits tile, so that a wave reads its 32 x 64 bias tile with four coalesced 16-byte loads.
+ *   packed  H*Np*Np elements of dtype, OPAQUE to the caller -- only ds_attention_fwd of the same library build reads it.
+ *           Layout (informative): the bias enters the logits through the matrix pipe (S^T = K.Q^T + Bias^T.I), so the operand
+ *           is stored as the MFMA A fragments of that product, in units of 1/scale (head_dim 64: the values times 8, exact in
+ *           f16/bf16 up to the rounding of the value itself), zero padded to Np x Np:
+ *           [H][Np/32 query blocks][Np/64 key tiles][4 chunks c = 2*kb + s][64 lanes][8 values t], where lane (hi = lane >> 5,
+ *           l = lane & 31) of chunk c holds bias[query 32*qblock + 16*s + 8*hi + t][key 64*ktile + 32*kb + l] / scale.
+ *           A wave reads its 32 x 64 bias tile with four coalesced 16-byte loads.  ds_attention_fwd therefore requires
+ *           scale == 0.125 when a packed bias is given (DS_EUNSUPPORTED otherwise).
  * Run once per (block, resolution); the packed operand is reused by every forward.
  */
 int ds_attention_bias_pack(ds_ctx *ctx, const float *bias, int H, int n, int Np, int dtype, void *packed, void *stream);

@@ -21,6 +21,12 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fn
          "-mllvm", "-amdgpu-mfma-vgpr-form=1"]
 
 
+if os.environ.get("DS_EXPERIMENTS"):
+    # timing ablations / superseded kernel generations (DS_ATT_ABLATE, DS_ATT_V1, DS_LIN_ABLATE, DS_PL_DEBUG ...): some of them
+    # produce WRONG results by design, so they are compiled only on request and never into the default library
+    FLAGS.append("-DDS_EXPERIMENTS")
+
+
 def hipcc():
     for cand in (shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
         if cand and os.path.exists(cand):

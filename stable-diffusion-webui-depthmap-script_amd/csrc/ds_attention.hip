@@ -75,6 +75,7 @@ struct AttnParams {
                                  // 1 with one (the packed bias is in log2 units)
 };
 
+#ifdef DS_EXPERIMENTS          // the first kernel generation: A/B runs only (DS_ATT_V1=1), not in the shipped library
 template <int BF16, int HAS_BIAS>
 __global__ __launch_bounds__(AT_THREADS, 3) void k_attention_fwd(AttnParams P)
 {
@@ -306,8 +307,10 @@ __global__ __launch_bounds__(AT_THREADS, 3) void k_attention_fwd(AttnParams P)
 }
 
 
+#endif  // DS_EXPERIMENTS
+
 // =====================================================================================================================
-// Version 2 of the kernel (default; DS_ATT_V1=1 selects the first one above for A/B runs).
+// Version 2 of the kernel (the only one in the shipped library; -DDS_EXPERIMENTS builds keep the first one behind DS_ATT_V1=1).
 //
 // (A version 3 was built and measured in round 2 and removed again -- git history, profiles/round2_attention_v3_experiment.txt:
 // one 8-wave workgroup = two independent 4-wave tasks whose wave-rows alternate, barrier by barrier, between an MFMA part
@@ -342,7 +345,8 @@ __device__ __forceinline__ float at_max3(float a, float b, float c)
 #define AT2_QB 256                      // query rows per workgroup
 #define AT2_THR 6.0f                    // deferred-max threshold, log2 units
 
-// ABL != 0: the same kernel with parts compiled out (timing experiments only, DS_ATT_ABLATE; results are WRONG), a bit mask:
+// ABL bits below 256: the same kernel with parts compiled out (timing experiments, results are WRONG) -- instantiated only in
+// -DDS_EXPERIMENTS builds (DS_ATT_ABLATE); the shipped library has no switch that selects them.  A bit mask:
 //   1 softmax reduced to a conversion   2 no K / V^T / bias fetch, no stash after the first tile   4 no barrier in the loop
 //   8 no P.V MFMAs   16 no S MFMAs   32 fragments are not read from LDS (a register stands in)
 // Bits 256 and up are OPTIONS with correct results (DS_ATT_OPT, A/B experiments):
@@ -671,6 +675,7 @@ __global__ void k_attention_bias_pack2(const float *__restrict__ bias, typename 
     }
 }
 
+#ifdef DS_EXPERIMENTS
 static int at_version()
 {
     static const int v = (getenv("DS_ATT_V1") && atoi(getenv("DS_ATT_V1"))) ? 1 : 2;
@@ -696,6 +701,10 @@ __global__ void k_attention_bias_pack(const float *__restrict__ bias, typename a
     }
 }
 
+#else
+static constexpr int at_version() { return 2; }
+#endif
+
 DS_API int ds_attention_bias_pack(ds_ctx *ctx, const float *bias, int H, int n, int Np, int dtype, void *packed, void *stream)
 {
     DS_REQUIRE(ctx && bias && packed, DS_EINVAL, "ds_attention_bias_pack: null argument");
@@ -705,12 +714,15 @@ DS_API int ds_attention_bias_pack(ds_ctx *ctx, const float *bias, int H, int n, 
     const long long total = (long long)H * Np * Np;
     const int blocks = (int)std::min<long long>((total + 255) / 256, 65536);
     hipStream_t st = (hipStream_t)stream;
-    const float log2e = 1.4426950408889634f;
+    [[maybe_unused]] const float log2e = 1.4426950408889634f;
     if (at_version() == 2) {               // A fragments of the bias MFMA, in units of 1/scale (head_dim 64: x 8, exact)
         if (dtype == DS_DTYPE_F16) hipLaunchKernelGGL((k_attention_bias_pack2<0>), dim3(blocks), dim3(256), 0, st, bias, (_Float16 *)packed, H, n, Np, 8.0f);
         else hipLaunchKernelGGL((k_attention_bias_pack2<1>), dim3(blocks), dim3(256), 0, st, bias, (__bf16 *)packed, H, n, Np, 8.0f);
-    } else if (dtype == DS_DTYPE_F16) hipLaunchKernelGGL((k_attention_bias_pack<0>), dim3(blocks), dim3(256), 0, st, bias, (_Float16 *)packed, H, n, Np, log2e);
+    }
+#ifdef DS_EXPERIMENTS
+    else if (dtype == DS_DTYPE_F16) hipLaunchKernelGGL((k_attention_bias_pack<0>), dim3(blocks), dim3(256), 0, st, bias, (_Float16 *)packed, H, n, Np, log2e);
     else hipLaunchKernelGGL((k_attention_bias_pack<1>), dim3(blocks), dim3(256), 0, st, bias, (__bf16 *)packed, H, n, Np, log2e);
+#endif
     DS_HIP_CHECK(hipGetLastError());
     return DS_OK;
 }
@@ -749,21 +761,27 @@ DS_API int ds_attention_fwd(ds_ctx *ctx, const void *qk, const void *vt, const v
         P.chunk = (P.total + 7) / 8;
         dim3 grid2(8 * P.chunk);
         hipStream_t st2 = (hipStream_t)stream;
+        static const int late_env = getenv("DS_ATT_LATE") ? atoi(getenv("DS_ATT_LATE")) : -1;        // A/B switch, see option 4096
+        const int late = late_env >= 0 ? late_env : (bias ? 0 : 1);
+#ifdef DS_EXPERIMENTS
         static const int ablate = (getenv("DS_ATT_ABLATE") ? atoi(getenv("DS_ATT_ABLATE")) : 0)    // timing experiments, wrong results
                                   | (getenv("DS_ATT_OPT") ? atoi(getenv("DS_ATT_OPT")) : 0);        // options, correct results
         P.flags = ablate;
-        static const int late_env = getenv("DS_ATT_LATE") ? atoi(getenv("DS_ATT_LATE")) : -1;        // A/B switch, see option 4096
-        const int late = late_env >= 0 ? late_env : (bias ? 0 : 1);
 #define A2_ABL(BI_, M_) case M_: hipLaunchKernelGGL((k_attention_fwd2<0, BI_, 2, M_>), grid2, dim3(AT_THREADS), 0, st2, P); break;
-#define A2_LAUNCH(BF_, BI_) do {                                                                                       \
+#define A2_EXPERIMENT(BF_, BI_)                                                                                         \
             if (ablate && BF_ == 0 && nqb == 2) {                                                                       \
                 switch (ablate) {                                                                                       \
                 A2_ABL(BI_, 1) A2_ABL(BI_, 2) A2_ABL(BI_, 4) A2_ABL(BI_, 6) A2_ABL(BI_, 7) A2_ABL(BI_, 8) A2_ABL(BI_, 16) A2_ABL(BI_, 32) \
                 A2_ABL(BI_, 38) A2_ABL(BI_, 39) A2_ABL(BI_, 512) A2_ABL(BI_, 1024) A2_ABL(BI_, 2048)                     \
                 default: ds_set_error("ds_attention_fwd: DS_ATT_ABLATE/OPT=%d is not an instantiated mask", ablate); return DS_EINVAL; \
                 }                                                                                                       \
-            }                                                                                                           \
-            else if (nqb == 1 && late) hipLaunchKernelGGL((k_attention_fwd2<BF_, BI_, 1, 256 + 4096>), grid2, dim3(AT_THREADS), 0, st2, P); \
+            } else
+#else
+#define A2_EXPERIMENT(BF_, BI_)
+#endif
+#define A2_LAUNCH(BF_, BI_) do {                                                                                       \
+            A2_EXPERIMENT(BF_, BI_)                                                                                     \
+            if (nqb == 1 && late) hipLaunchKernelGGL((k_attention_fwd2<BF_, BI_, 1, 256 + 4096>), grid2, dim3(AT_THREADS), 0, st2, P); \
             else if (nqb == 1) hipLaunchKernelGGL((k_attention_fwd2<BF_, BI_, 1, 256>), grid2, dim3(AT_THREADS), 0, st2, P); \
             else hipLaunchKernelGGL((k_attention_fwd2<BF_, BI_, 2, 256>), grid2, dim3(AT_THREADS), 0, st2, P);          \
         } while (0)
@@ -772,6 +790,7 @@ DS_API int ds_attention_fwd(ds_ctx *ctx, const void *qk, const void *vt, const v
         DS_HIP_CHECK(hipGetLastError());
         return DS_OK;
     }
+#ifdef DS_EXPERIMENTS
     P.c_exp = bias ? 1.0f : scale * log2e;                  // the packed bias is in log2 units
     P.k_logit = scale * log2e;
     static const int att_flags = getenv("DS_ATT_FLAGS") ? atoi(getenv("DS_ATT_FLAGS")) : 1;   // setprio around the MFMA clusters: +2.5 % with bias
@@ -791,4 +810,8 @@ DS_API int ds_attention_fwd(ds_ctx *ctx, const void *qk, const void *vt, const v
     }
     DS_HIP_CHECK(hipGetLastError());
     return DS_OK;
+#else
+    ds_set_error("ds_attention_fwd: unreachable");
+    return DS_EINVAL;
+#endif
 }

@@ -36,6 +36,7 @@
 #include "ds_common.h"
 
 #include <stdlib.h>
+#include <atomic>
 #include <type_traits>
 
 typedef _Float16 lf16x8 __attribute__((ext_vector_type(8)));
@@ -66,8 +67,8 @@ struct LinParams {
     void *y;
     int M, N, K;                // K = reduction length (CONV: 9 * C)
     int nbm, nbn;
-    int ablate;                 // timing experiments (DS_LIN_ABLATE): 1 = no epilogue stores, 2 = no K loop
-    int stagger;                // experiment (DS_LIN_STAGGER_US): every other workgroup of an XCD starts this many 10 ns ticks late
+    int ablate;                 // -DDS_EXPERIMENTS builds only (DS_LIN_ABLATE, results are WRONG): 1 = no epilogue stores, 2 = no K loop
+    int stagger;                // -DDS_EXPERIMENTS builds only (DS_LIN_STAGGER_US): every other workgroup of an XCD starts this many 10 ns ticks late
     int H, W, C, cpt, magic;    // CONV: image height / width, input channels, K-tiles per tap (C / 64), 65536 / cpt + 1
     long long ldy;              // row stride of y (and res1 / res2) in elements
     const void *gamma;          // EPI 3: per-column factor applied to (acc + bias) before the addends (LayerScale)
@@ -122,6 +123,15 @@ __device__ __forceinline__ void ln_dma_v(const void *ptr, unsigned lds_uniform)
     asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(ptr), "s"(lds_uniform) : "memory");
 }
 
+// Timing experiments that change results (or the start of a workgroup) exist only in -DDS_EXPERIMENTS builds: the shipped
+// library has no switch that can produce wrong output.
+#ifdef DS_EXPERIMENTS
+#define LN_ABLATE(bit) (P.ablate & (bit))
+#define LN_STAGGER() (P.stagger)
+#else
+#define LN_ABLATE(bit) 0
+#define LN_STAGGER() 0
+#endif
 #define LN_WAIT_VM(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
 #define LN_WAIT_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 #define LN_BARRIER()                              \
@@ -331,9 +341,9 @@ __global__ __launch_bounds__(LN_THREADS) void k_linear256(LinParams P)
         if constexpr (!LAST) { LN_MEM(LN_READ_A(0, 0), LN_STAGE(3, o2, 1)); LN_WAIT_VM(10); }
         LN_PHASE_END(1, 0);
     };
-    if (P.stagger > 0 && ((blockIdx.x >> 3) & 1)) {
+    if (LN_STAGGER() > 0 && ((blockIdx.x >> 3) & 1)) {
         const unsigned long long t0 = wall_clock64();
-        while (wall_clock64() - t0 < (unsigned long long)P.stagger) __builtin_amdgcn_s_sleep(32);
+        while (wall_clock64() - t0 < (unsigned long long)LN_STAGGER()) __builtin_amdgcn_s_sleep(32);
     }
     set_tile(blockIdx.x);
     LN_PROLOGUE();
@@ -353,7 +363,7 @@ __global__ __launch_bounds__(LN_THREADS) void k_linear256(LinParams P)
     LN_READ_A(0, 0);
     LN_WAIT_LGKM0();                      // retired here: A0 of buffer 0 is re-staged in phase 1
     if (wr == 1) LN_BARRIER();            // the stagger
-    if (P.ablate & 2) {
+    if (LN_ABLATE(2)) {
         LN_WAIT_VM(0);
         if (wr == 0) LN_BARRIER();
     } else {
@@ -444,7 +454,7 @@ __global__ __launch_bounds__(LN_THREADS) void k_linear256(LinParams P)
                         o[t + 1] = (T)u[1];
                     }
                     if (!TRANSPOSE) {
-                        if (!(P.ablate & 1)) *(V8 *)(yb + o0 + hb * 32 + 16 * k) = o;
+                        if (!LN_ABLATE(1)) *(V8 *)(yb + o0 + hb * 32 + 16 * k) = o;
                         else asm volatile("" ::"v"(o));
                     } else {
                         const int piece = hb * 4 + k * 2 + (lane >> 5);
@@ -456,7 +466,7 @@ __global__ __launch_bounds__(LN_THREADS) void k_linear256(LinParams P)
                 for (int idx = 0; idx < 4; ++idx) {
                     const int r2l = ha * 64 + rb * 32 + idx * 8 + (lane >> 3), piece = lane & 7;
                     const V8 o = *(const V8 *)(tl + r2l * 128 + ((piece ^ (r2l & 7)) << 4));
-                    if (!(P.ablate & 1)) *(V8 *)(yb + (size_t)(cbm0 + wr * 128 + r2l) * P.ldy + cbn0 + wc * 64 + piece * 8) = o;
+                    if (!LN_ABLATE(1)) *(V8 *)(yb + (size_t)(cbm0 + wr * 128 + r2l) * P.ldy + cbn0 + wc * 64 + piece * 8) = o;
                     else asm volatile("" ::"v"(o));
                 }
             }
@@ -471,22 +481,25 @@ __global__ __launch_bounds__(LN_THREADS) void k_linear256(LinParams P)
 
 // ---- C ABI -------------------------------------------------------------------------------------------------------------
 template <int BF16, int EPI, int CONV, int RES>
-static int ln_launch(const LinParams &P, hipStream_t stream)
+static int ln_launch(ds_ctx *ctx, const LinParams &P, hipStream_t stream)
 {
-    static bool attr_set = false;
+    // per DEVICE, not per process: the dynamic-LDS attribute belongs to the function on one device, and the grid is that
+    // device's CU count (a process may drive several GPUs through several contexts).  Setting the attribute twice is harmless,
+    // so the bit mask needs no lock.
+    static std::atomic<uint64_t> attr_done{0};
     auto fn = k_linear256<BF16, EPI, CONV, RES>;
-    if (!attr_set) {
+    DS_HIP_CHECK(hipSetDevice(ctx->device));
+    const uint64_t bit = 1ull << (ctx->device & 63);
+    if (!(attr_done.load(std::memory_order_relaxed) & bit)) {
         DS_HIP_CHECK(hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, LN_LDS_BYTES));
-        attr_set = true;
+        attr_done.fetch_or(bit, std::memory_order_relaxed);
     }
-    static int ncu = 0;
-    if (!ncu) {
-        int dev = 0;
-        DS_HIP_CHECK(hipGetDevice(&dev));
-        DS_HIP_CHECK(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev));
-        ncu = ncu >= 8 ? ncu / 8 * 8 : 8;                 // one workgroup per CU (128 KB of LDS each), a multiple of the 8 XCDs
+    if (!ctx->ncu) {
+        int ncu = 0;
+        DS_HIP_CHECK(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, ctx->device));
+        ctx->ncu = ncu >= 8 ? ncu / 8 * 8 : 8;            // one workgroup per CU (128 KB of LDS each), a multiple of the 8 XCDs
     }
-    int grid = ncu;
+    int grid = ctx->ncu;
     if (const char *e = getenv("DS_LIN_GRID")) {          // tests: a small grid makes every workgroup walk many tiles
         const int g = atoi(e) / 8 * 8;
         if (g >= 8) grid = g;
@@ -498,25 +511,25 @@ static int ln_launch(const LinParams &P, hipStream_t stream)
 }
 
 template <int BF16>
-static int ln_dispatch_dense(const LinParams &P, int act, hipStream_t st)
+static int ln_dispatch_dense(ds_ctx *ctx, const LinParams &P, int act, hipStream_t st)
 {
-    if (act == 1) return ln_launch<BF16, 1, 0, 0>(P, st);
-    if (act == 2) return ln_launch<BF16, 2, 0, 0>(P, st);
-    return ln_launch<BF16, 0, 0, 0>(P, st);
+    if (act == 1) return ln_launch<BF16, 1, 0, 0>(ctx, P, st);
+    if (act == 2) return ln_launch<BF16, 2, 0, 0>(ctx, P, st);
+    return ln_launch<BF16, 0, 0, 0>(ctx, P, st);
 }
 
 template <int BF16>
-static int ln_dispatch_conv(const LinParams &P, int act, hipStream_t st)
+static int ln_dispatch_conv(ds_ctx *ctx, const LinParams &P, int act, hipStream_t st)
 {
     const int res = P.res1 ? (P.res2 ? 2 : 1) : 0;
     if (act == 2) {
-        if (res == 2) return ln_launch<BF16, 2, 1, 2>(P, st);
-        if (res == 1) return ln_launch<BF16, 2, 1, 1>(P, st);
-        return ln_launch<BF16, 2, 1, 0>(P, st);
+        if (res == 2) return ln_launch<BF16, 2, 1, 2>(ctx, P, st);
+        if (res == 1) return ln_launch<BF16, 2, 1, 1>(ctx, P, st);
+        return ln_launch<BF16, 2, 1, 0>(ctx, P, st);
     }
-    if (res == 2) return ln_launch<BF16, 0, 1, 2>(P, st);
-    if (res == 1) return ln_launch<BF16, 0, 1, 1>(P, st);
-    return ln_launch<BF16, 0, 1, 0>(P, st);
+    if (res == 2) return ln_launch<BF16, 0, 1, 2>(ctx, P, st);
+    if (res == 1) return ln_launch<BF16, 0, 1, 1>(ctx, P, st);
+    return ln_launch<BF16, 0, 1, 0>(ctx, P, st);
 }
 
 DS_API int ds_linear(ds_ctx *ctx, const void *x, const void *w, const void *bias, void *y, int64_t rows, int64_t out_features,
@@ -528,7 +541,8 @@ DS_API int ds_linear(ds_ctx *ctx, const void *x, const void *w, const void *bias
     DS_REQUIRE(in_features >= 128 && in_features % 128 == 0 && in_features <= 16384, DS_EINVAL,
                "ds_linear: in_features must be a multiple of 128 (<= 16384)");
     DS_REQUIRE(ldy >= out_features && ldy % 8 == 0, DS_EINVAL, "ds_linear: ldy must be >= out_features and a multiple of 8");
-    DS_REQUIRE(((uintptr_t)y & 15) == 0 && (!bias || ((uintptr_t)bias & 15) == 0), DS_EINVAL, "ds_linear: y and bias must be 16-byte aligned");
+    DS_REQUIRE(((uintptr_t)x & 15) == 0 && ((uintptr_t)w & 15) == 0 && ((uintptr_t)y & 15) == 0 && (!bias || ((uintptr_t)bias & 15) == 0), DS_EINVAL,
+               "ds_linear: x, w (the LDS-DMA sources), y and bias must be 16-byte aligned");
     DS_REQUIRE(act >= 0 && act <= 2, DS_EINVAL, "ds_linear: act must be 0 (none), 1 (erf-GELU) or 2 (ReLU)");
     DS_REQUIRE(dtype == DS_DTYPE_F16 || dtype == DS_DTYPE_BF16, DS_EINVAL, "ds_linear: dtype must be f16 or bf16");
     LinParams P;
@@ -537,9 +551,11 @@ DS_API int ds_linear(ds_ctx *ctx, const void *x, const void *w, const void *bias
     P.M = (int)rows; P.N = (int)out_features; P.K = (int)in_features;
     P.nbm = (int)((rows + 255) / 256); P.nbn = (int)(out_features / 256);
     P.ldy = ldy;
+#ifdef DS_EXPERIMENTS
     P.ablate = getenv("DS_LIN_ABLATE") ? atoi(getenv("DS_LIN_ABLATE")) : 0;
     P.stagger = getenv("DS_LIN_STAGGER_US") ? (int)(atof(getenv("DS_LIN_STAGGER_US")) * 100.0) : 0;
-    return dtype == DS_DTYPE_F16 ? ln_dispatch_dense<0>(P, act, (hipStream_t)stream) : ln_dispatch_dense<1>(P, act, (hipStream_t)stream);
+#endif
+    return dtype == DS_DTYPE_F16 ? ln_dispatch_dense<0>(ctx, P, act, (hipStream_t)stream) : ln_dispatch_dense<1>(ctx, P, act, (hipStream_t)stream);
 }
 
 // y = res + [gamma *] (x . W^T + b): the output projection of an encoder block with its LayerScale and residual add in the
@@ -553,8 +569,9 @@ DS_API int ds_linear_residual(ds_ctx *ctx, const void *x, const void *w, const v
     DS_REQUIRE(in_features >= 128 && in_features % 128 == 0 && in_features <= 16384, DS_EINVAL,
                "ds_linear_residual: in_features must be a multiple of 128 (<= 16384)");
     DS_REQUIRE(dtype == DS_DTYPE_F16 || dtype == DS_DTYPE_BF16, DS_EINVAL, "ds_linear_residual: dtype must be f16 or bf16");
-    DS_REQUIRE(((uintptr_t)y & 15) == 0 && ((uintptr_t)res & 15) == 0 && ((uintptr_t)bias & 15) == 0 && ((uintptr_t)gamma & 15) == 0 && y != res,
-               DS_EINVAL, "ds_linear_residual: y, res, bias and gamma must be 16-byte aligned, and y must not alias res");
+    DS_REQUIRE(((uintptr_t)x & 15) == 0 && ((uintptr_t)w & 15) == 0 && ((uintptr_t)y & 15) == 0 && ((uintptr_t)res & 15) == 0 &&
+               ((uintptr_t)bias & 15) == 0 && ((uintptr_t)gamma & 15) == 0 && y != res,
+               DS_EINVAL, "ds_linear_residual: x, w, y, res, bias and gamma must be 16-byte aligned, and y must not alias res");
     LinParams P;
     memset(&P, 0, sizeof(P));
     P.x = x; P.w = w; P.bias = bias; P.gamma = gamma; P.res1 = res; P.y = y;
@@ -562,8 +579,8 @@ DS_API int ds_linear_residual(ds_ctx *ctx, const void *x, const void *w, const v
     P.nbm = (int)((rows + 255) / 256); P.nbn = (int)(out_features / 256);
     P.ldy = out_features;
     hipStream_t st = (hipStream_t)stream;
-    if (dtype == DS_DTYPE_F16) return gamma ? ln_launch<0, 3, 0, 1>(P, st) : ln_launch<0, 0, 0, 1>(P, st);
-    return gamma ? ln_launch<1, 3, 0, 1>(P, st) : ln_launch<1, 0, 0, 1>(P, st);
+    if (dtype == DS_DTYPE_F16) return gamma ? ln_launch<0, 3, 0, 1>(ctx, P, st) : ln_launch<0, 0, 0, 1>(ctx, P, st);
+    return gamma ? ln_launch<1, 3, 0, 1>(ctx, P, st) : ln_launch<1, 0, 0, 1>(ctx, P, st);
 }
 
 DS_API int ds_conv3x3_nhwc(ds_ctx *ctx, const void *x, const void *w, const void *bias, const void *res1, const void *res2, void *y,
@@ -578,8 +595,9 @@ DS_API int ds_conv3x3_nhwc(ds_ctx *ctx, const void *x, const void *w, const void
     DS_REQUIRE(out_channels > 0 && out_channels % 256 == 0, DS_EINVAL, "ds_conv3x3_nhwc: out_channels must be a multiple of 256");
     DS_REQUIRE(act == 0 || act == 2, DS_EINVAL, "ds_conv3x3_nhwc: act must be 0 (none) or 2 (ReLU)");
     DS_REQUIRE(dtype == DS_DTYPE_F16 || dtype == DS_DTYPE_BF16, DS_EINVAL, "ds_conv3x3_nhwc: dtype must be f16 or bf16");
-    DS_REQUIRE(((uintptr_t)y & 15) == 0 && (!bias || ((uintptr_t)bias & 15) == 0) && ((uintptr_t)res1 & 15) == 0 && ((uintptr_t)res2 & 15) == 0,
-               DS_EINVAL, "ds_conv3x3_nhwc: y, bias, res1 and res2 must be 16-byte aligned");
+    DS_REQUIRE(((uintptr_t)x & 15) == 0 && ((uintptr_t)w & 15) == 0 && ((uintptr_t)y & 15) == 0 && (!bias || ((uintptr_t)bias & 15) == 0) &&
+               ((uintptr_t)res1 & 15) == 0 && ((uintptr_t)res2 & 15) == 0,
+               DS_EINVAL, "ds_conv3x3_nhwc: x, w, y, bias, res1 and res2 must be 16-byte aligned");
     int rc = ds_ctx_reserve(ctx, &ctx->zero_line, &ctx->zero_line_bytes, 256);
     if (rc != DS_OK) return rc;
     if (!ctx->zero_line_cleared) {          // once per context; waited for, so that a second stream of the same context never
@@ -597,7 +615,9 @@ DS_API int ds_conv3x3_nhwc(ds_ctx *ctx, const void *x, const void *w, const void
     for (int kt = 0; kt < P.K / 64; ++kt)
         DS_REQUIRE(((kt * 7282) >> 16) == kt / 9, DS_EUNSUPPORTED, "ds_conv3x3_nhwc: K-tile arithmetic does not cover %d channels", in_channels);
     P.ldy = out_channels;
+#ifdef DS_EXPERIMENTS
     P.ablate = getenv("DS_LIN_ABLATE") ? atoi(getenv("DS_LIN_ABLATE")) : 0;
     P.stagger = getenv("DS_LIN_STAGGER_US") ? (int)(atof(getenv("DS_LIN_STAGGER_US")) * 100.0) : 0;
-    return dtype == DS_DTYPE_F16 ? ln_dispatch_conv<0>(P, act, (hipStream_t)stream) : ln_dispatch_conv<1>(P, act, (hipStream_t)stream);
+#endif
+    return dtype == DS_DTYPE_F16 ? ln_dispatch_conv<0>(ctx, P, act, (hipStream_t)stream) : ln_dispatch_conv<1>(ctx, P, act, (hipStream_t)stream);
 }

@@ -57,6 +57,13 @@
 #define PL_KMAX 4            // general pixels: candidate segments are examined 64 at a time, up to PL_KMAX words
 #define PL_PT_PAD 10         // pt[] entries past the last real point (tail sentinel + fast-path over-read)
 
+// timing ablations that produce WRONG pixels exist only in -DDS_EXPERIMENTS builds
+#ifdef DS_EXPERIMENTS
+#define PL_DBG() (P.dbg)
+#else
+#define PL_DBG() 0
+#endif
+
 struct PolyParams {
     const uint8_t *img;
     const void *depth;
@@ -80,7 +87,7 @@ struct PolyParams {
     unsigned long long *gq;    // queue of general pixels: one segment of gq_cap entries per workgroup of k_polylines
     int *gq_count;             // entries in each segment
     int gq_cap, gq_segments;   // entry = (row id << 32) | column, row id = (image * n_eyes + eye) * h + row
-    int dbg;                   // DS_PL_DEBUG ablation knob (0 = off); results are WRONG when set
+    int dbg;                   // -DDS_EXPERIMENTS builds only: DS_PL_DEBUG ablation knob (0 = off); results are WRONG when set
     unsigned long long *prof;  // optional (DS_PL_PROF=1): 8 cycle accumulators, wave 0 of every workgroup
 };
 
@@ -558,7 +565,7 @@ __global__ __launch_bounds__(PL_THREADS, 4) void k_polylines(PolyParams P)
             const int nbytes = tn * C;
 #pragma unroll
             for (int e = 0; e < NE; e++) {
-                if (P.dbg == 3) break;
+                if (PL_DBG() == 3) break;
                 uint8_t *dst = P.out[e] + (int64_t)img * P.ois[e] + (int64_t)row * P.ors[e] + (size_t)c0 * C;
                 const uint8_t *src = s_out + e * L.outstride;
                 if ((((uintptr_t)dst) & 15) == 0) {
@@ -709,7 +716,7 @@ __global__ __launch_bounds__(PL_THREADS, 4) void k_polylines(PolyParams P)
         if (bad) { atomicOr(&s_misc[2], 1); atomicOr(&s_misc[3], 1); }
 
         // ---- P2: one lane per output pixel, both eyes in one straight line -----------------------------------
-        if (P.dbg != 1)
+        if (PL_DBG() != 1)
         for (int p0 = 0; p0 < tn; p0 += PL_THREADS) {
             const int p = p0 + tid;
             const bool inb = p < tn;
@@ -1208,7 +1215,9 @@ int ds_polylines_launch(ds_ctx *ctx, const uint8_t *image, const void *depth, in
     memset(&P, 0, sizeof(P));
     P.img = image; P.depth = depth; P.depth_dtype = depth_dtype; P.minmax = minmax; P.lut = lut;
     P.n = n; P.h = h; P.w = w; P.n_eyes = n_eyes;
+#ifdef DS_EXPERIMENTS
     { const char *e = getenv("DS_PL_DEBUG"); P.dbg = e ? atoi(e) : 0; }
+#endif
     DS_REQUIRE(depth_dtype == DS_DEPTH_U16 || depth_dtype == DS_DEPTH_F32 || depth_dtype == DS_DEPTH_F64, DS_EINVAL,
                "unknown depth dtype %d", depth_dtype);
     for (int e = 0; e < n_eyes; e++) {

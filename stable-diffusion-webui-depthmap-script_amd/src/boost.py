@@ -297,11 +297,13 @@ def _gather_ragged(local, counts, group, dst):
     per = max(max(counts), 1)
     send = local.new_zeros((per,) + tuple(local.shape[1:]))
     send[:local.shape[0]] = local
+    from .multigpu import global_rank
+    gdst = global_rank(group, dst)          # `dst` is a rank of the group; the collective wants the global rank
     if rank == dst:
         bufs = [torch.empty_like(send) for _ in range(world)]
-        dist.gather(send, bufs, dst=dst, group=group)
+        dist.gather(send, bufs, dst=gdst, group=group)
         return torch.cat([bufs[r][:counts[r]] for r in range(world)], dim=0)
-    dist.gather(send, None, dst=dst, group=group)
+    dist.gather(send, None, dst=gdst, group=group)
     return None
 
 
@@ -350,13 +352,15 @@ def estimateboost(image_u8, net, model_type, pix2pix, whole_size_threshold=1600,
         rect_t = torch.tensor([list(info['rect']) for _, info in patchset], dtype=torch.int64, device=dev).reshape(-1, 4)
         head[0], head[1], head[2] = a, b, rect_t.shape[0]
     if multi:
-        dist.broadcast(head, src=dst, group=group)
+        from .multigpu import global_rank
+        gsrc = global_rank(group, dst)       # `dst` / `rank` are ranks of the group; broadcast's src is a global rank
+        dist.broadcast(head, src=gsrc, group=group)
         a, b = int(head[0]), int(head[1])
         if rank != dst:
             rect_t = torch.zeros((int(head[2]), 4), dtype=torch.int64, device=dev)
             img_r = _resize_hwc(img, (a, b), 'bicubic')
         if rect_t.shape[0]:
-            dist.broadcast(rect_t, src=dst, group=group)
+            dist.broadcast(rect_t, src=gsrc, group=group)
     mergein_scale = H / img_r.shape[0]                                                                         # :866
     size_m = (round(img_r.shape[0] * mergein_scale), round(img_r.shape[1] * mergein_scale))
     rgb_image = _resize_hwc(img_r, size_m, 'bicubic')
@@ -365,7 +369,7 @@ def estimateboost(image_u8, net, model_type, pix2pix, whole_size_threshold=1600,
     else:
         base = torch.empty(size_m, dtype=torch.float32, device=dev)
     if multi:
-        dist.broadcast(base, src=dst, group=group)           # every rank merges against the SAME base estimate
+        dist.broadcast(base, src=gsrc, group=group)          # every rank merges against the SAME base estimate
     dst_img = base.clone() if rank == dst else None
 
     rects, patches, base_patches = [], [], []

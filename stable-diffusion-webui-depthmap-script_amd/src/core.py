@@ -133,13 +133,13 @@ def _postprocess_batch(pred, invert, inp):
         elif inp[go.CLIPDEPTH_MODE] == 'Outliers':                                               # :199-201
             # np.percentile on the device: exact order statistics by bisection on the float32 bit pattern, numpy's
             # linear interpolation; np.clip(float32 array, float64 bounds) promotes to float64 (NumPy >= 2)
-            from .video_mode import _global_percentiles
+            from .video_mode import _LOCAL, _global_percentiles
             rows = []
             for i in range(out.shape[0]):
                 if broken[i]:
                     rows.append(out[i].double())
                     continue
-                fb, nb = _global_percentiles(out[i], [float(inp[go.CLIPDEPTH_FAR]) * 100.0, float(inp[go.CLIPDEPTH_NEAR]) * 100.0], None)
+                fb, nb = _global_percentiles(out[i], [float(inp[go.CLIPDEPTH_FAR]) * 100.0, float(inp[go.CLIPDEPTH_NEAR]) * 100.0], _LOCAL)   # per image: never a collective
                 rows.append(torch.clamp(out[i].double(), min=fb, max=nb))
             out = torch.stack(rows)
     return out, prediction_copy, broken
@@ -211,9 +211,12 @@ def _launch_group(gen, idxs, inputimages, inputdepthmaps, inp, device):
         return st.to(device, non_blocking=True)
 
     img_t = None
+    if want_stereo and np.asarray(images[0]).ndim != 3:                                          # :252 np.array(image)
+        # a single-channel image fails in the reference's stereo step (:55 `h, w, c = original_image.shape`), i.e. AFTER the
+        # image's depth outputs were yielded: the group is rendered without stereo and _emit_group raises at that point
+        g["stereo_error"] = ValueError('not enough values to unpack (expected 3, got %d)' % np.asarray(images[0]).ndim)
+        want_stereo = False
     if want_stereo:
-        if np.asarray(images[0]).ndim != 3:                                                      # :252 np.array(image)
-            raise ValueError('not enough values to unpack (expected 3, got %d)' % np.asarray(images[0]).ndim)
         img_t = upload_pixels("img", lambda im: np.asarray(im, dtype=np.uint8))
     mesh_source = None
     if custom:
@@ -322,6 +325,8 @@ def _emit_group(g, outpath, inp, device):
                     (image, convert_i16_to_rgb(img_depth, np.asarray(image))), axis=axis))))
             else:
                 out.append(('depth', Image.fromarray(img_depth.copy())))
+        if g.get("stereo_error") is not None:
+            return out                                       # the reference raised here, inside create_stereoimages
         if inp[go.GEN_STEREO]:
             for c in range(g["n_stereo"]):
                 out.append((inp[go.STEREO_MODES][c], Image.fromarray(host["stereo%d" % c][j].copy())))
@@ -338,6 +343,8 @@ def _emit_group(g, outpath, inp, device):
             image = g["images"][j]
             for kind, res in (futures[j].result() if futures is not None else render(j)):
                 yield count, kind, res
+            if g.get("stereo_error") is not None:
+                raise g["stereo_error"]
             if inp[go.GEN_SIMPLE_MESH]:                                                              # :277-306
                 from . import mesh_generation as mg
                 mt = inp[go.MODEL_TYPE]              # callers pass the numeric id; the option's default is a display name
@@ -390,9 +397,17 @@ def core_generation_funnel(outpath, inputimages, inputdepthmaps, inputnames, inp
         groups = _plan_groups(inputimages, inputdepthmaps, batchable=not inp[go.BOOST])
         pending = None
         for gi, idxs in enumerate(groups):
-            launched = _launch_group(gi & 1, idxs, inputimages, inputdepthmaps, inp, device)
+            # group k+1 is enqueued before group k is handed out (host conversion overlaps device work); whatever goes wrong
+            # while enqueueing it (a bad image, out of memory) must not swallow the finished results of group k: the
+            # reference's per-image loop (:133-329) would have yielded them before reaching the failing image
+            try:
+                launched, failure = _launch_group(gi & 1, idxs, inputimages, inputdepthmaps, inp, device), None
+            except Exception as e:          # noqa: BLE001 -- re-raised below, after the results that precede it
+                launched, failure = None, e
             if pending is not None:
                 yield from _emit_group(pending, outpath, inp, device)
+            if failure is not None:
+                raise failure
             pending = launched
         if pending is not None:
             yield from _emit_group(pending, outpath, inp, device)

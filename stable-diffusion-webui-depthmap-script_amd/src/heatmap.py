@@ -22,13 +22,13 @@ def colormap_table(cmap='inferno'):
 def colorize_batch(depth_u16, cmap='inferno', lo=2.0, hi=85.0):
     """depth_u16: CUDA tensor [n, h, w] uint16 -> CUDA tensor [n, h, w, 4] uint8 (RGBA)."""
     from . import _native
-    from .video_mode import _global_percentiles
+    from .video_mode import _LOCAL, _global_percentiles
     torch = _native.require_gpu()
     lut = colormap_table(cmap)
     if lut.shape[0] > 256:
         raise NotImplementedError("colormaps with more than 256 entries are not built")
     # uint16 has few torch kernels: widen through the int16 bit pattern (exact)
     wide = (depth_u16.contiguous().view(torch.int16).to(torch.int32) & 0xFFFF).to(torch.float32)
-    vmm = [_global_percentiles(wide[i], [lo, hi], None) for i in range(depth_u16.shape[0])]
+    vmm = [_global_percentiles(wide[i], [lo, hi], _LOCAL) for i in range(depth_u16.shape[0])]
     return _native.colorize_u16(depth_u16.contiguous(), torch.tensor(vmm, dtype=torch.float64),
                                 torch.from_numpy(lut))

@@ -16,7 +16,7 @@ position-embedding cache made the graph of the FIRST shape read freed memory onc
 deterministically wrong depth, NaN when the memory had been reused by something else.)
 
 A capture is VALIDATED before it is used: the first replay must be finite and reproduce the eager warm-up result to
-float16-network accuracy, else the shape stays eager (loudly, once).  Reason: inside a capture MIOpen cannot be given a
+float16-network accuracy (3 % of full scale + 4 x the eager run-to-run noise), else the shape stays eager (loudly, once).  Reason: inside a capture MIOpen cannot be given a
 workspace and falls back to other solvers than the eager call ("GetSolutionsFallback ... workspace required, provided
 ptr: 0" in its log); at the end of a long GPU test session one replay of a small hybrid network came back non-finite while
 the eager forward of the same input was fine (the same test passes on its own; the cause was not isolated).  The in-tree
@@ -28,10 +28,11 @@ from . import vit_mi355x as vm
 
 
 class GraphedForward:
-    def __init__(self, fn, warmup=2, accept=0.25):
+    def __init__(self, fn, warmup=2, accept=3e-2):
         self.fn = fn
         self.warmup = warmup
-        self.accept = accept             # validation bound of a capture, relative to the eager result's maximum
+        self.accept = accept             # validation bound of a capture, relative to the eager result's maximum (plus 4 x the
+                                         # eager forward's own run-to-run difference, measured on the warm-up calls)
         self.graphs = {}                 # (shape, dtype, device) -> (graph, static_in, static_out)
         self.failed = set()
         self.epoch = vm.CACHE_EPOCH[0]   # module caches evicted something since? then the graphs hold dangling pointers
@@ -62,10 +63,10 @@ class GraphedForward:
         static_in = x.clone()
         side = torch.cuda.Stream(device=x.device)
         side.wait_stream(torch.cuda.current_stream(x.device))
-        ref = None
+        ref, prev = None, None
         with torch.cuda.stream(side), torch.no_grad():
-            for _ in range(max(1, self.warmup)):             # fills every cache, picks the library kernels
-                ref = self.fn(static_in)
+            for _ in range(max(2, self.warmup)):             # fills every cache, picks the library kernels
+                prev, ref = ref, self.fn(static_in)
         torch.cuda.current_stream(x.device).wait_stream(side)
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
@@ -75,7 +76,11 @@ class GraphedForward:
         torch.cuda.synchronize()
         scale = ref.float().abs().max().item()
         err = (static_out.float() - ref.float()).abs().max().item() if bool(torch.isfinite(static_out).all()) else float("inf")
-        if not err <= self.accept * scale + 1e-30:
+        # a graph that reads a stale or dangling operand gives a visibly different depth map, not fp16 noise: the bound is a
+        # few percent of full scale (a float16 network is pinned to 2e-2 of its float32 reference in the tests) plus the
+        # noise floor the eager forward shows against itself (library GEMMs are not bit-reproducible run to run)
+        noise = (ref.float() - prev.float()).abs().max().item()
+        if not err <= self.accept * scale + 4.0 * noise + 1e-30:
             raise RuntimeError(f"hipGraph replay of shape {key[0]} does not reproduce the eager forward (max |difference| {err:.3e} "
                                f"of {scale:.3e}): this shape stays eager")
         if self.epoch != vm.CACHE_EPOCH[0]:                  # the warm-up itself evicted entries older graphs may read

@@ -25,8 +25,15 @@ def my_shard(n_units, rank, world_size):
     return shard_bounds(n_units, world_size)[rank]
 
 
+def global_rank(group, group_rank):
+    """The GLOBAL rank of member `group_rank` of `group`: what torch.distributed's src= / dst= arguments mean, also when
+    the collective runs on a sub-group (dist.get_rank(group) is group-local)."""
+    import torch.distributed as dist
+    return group_rank if group is None else dist.get_global_rank(group, group_rank)
+
+
 def gather_units(local, n_units, group=None, dst=0):
-    """Collate per-rank results on rank `dst`.
+    """Collate per-rank results on rank `dst` (a rank OF THE GROUP: sub-groups are translated for the collective).
 
     local: tensor [n_local, ...] with this rank's units (n_local may be 0, and differs by at most `per` across ranks).
     Returns the full [n_units, ...] tensor on `dst`, None elsewhere.  One gather: shards are padded to the common
@@ -47,12 +54,13 @@ def gather_units(local, n_units, group=None, dst=0):
         send = torch.cat([local, pad], dim=0)
     else:
         send = local.contiguous()
+    gdst = global_rank(group, dst)
     if rank == dst:
         bufs = [torch.empty_like(send) for _ in range(world)]
-        dist.gather(send, bufs, dst=dst, group=group)
+        dist.gather(send, bufs, dst=gdst, group=group)
         parts = [bufs[r][: bounds[r][1] - bounds[r][0]] for r in range(world)]
         return torch.cat(parts, dim=0)
-    dist.gather(send, None, dst=dst, group=group)
+    dist.gather(send, None, dst=gdst, group=group)
     return None
 
 

@@ -39,6 +39,16 @@ def process_predicitons(predictions, smoothening='none'):
 _LOCAL = object()          # group sentinel: treat `local` as the whole clip even inside an initialised process group
 
 
+def _is_multi(group):
+    """True when `group` names more than one rank.  The _LOCAL sentinel is never collective: callers that work on data one
+    rank holds completely (process_predicitons, the funnel's per-image 'Outliers' clipping, Boost's rank-0 post-processing)
+    must not issue collectives other ranks do not take part in."""
+    if group is _LOCAL:
+        return False
+    import torch.distributed as dist
+    return dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+
+
 # ---- sharded over ranks -------------------------------------------------------------------------------------------------------
 def _f32_key(t):
     """Order-preserving map float32 -> int64 (sign-magnitude bit pattern -> two's-complement order)."""
@@ -58,11 +68,12 @@ def _kth_smallest(keys, k, group):
     all-reduce of a count per step (33 steps for the float32 key range)."""
     import torch
     import torch.distributed as dist
+    multi = _is_multi(group)
     lo, hi = -(1 << 31) - 1, (1 << 31)
     while hi - lo > 1:                                      # invariant: count(keys <= lo) <= k < count(keys <= hi)
         mid = (lo + hi) // 2
         c = (keys <= mid).sum().to(torch.int64).reshape(1)
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        if multi:
             dist.all_reduce(c, op=dist.ReduceOp.SUM, group=group)
         if int(c.item()) > k:
             hi = mid
@@ -72,11 +83,12 @@ def _kth_smallest(keys, k, group):
 
 
 def _global_percentiles(local, qs, group):
-    """np.percentile(all values of all ranks, qs) with numpy's default linear interpolation, float32 data."""
+    """np.percentile(all values of all ranks, qs) with numpy's default linear interpolation, float32 data.
+    group=_LOCAL: the values of THIS rank only, no collective (even inside an initialised multi-rank process)."""
     import torch
     import torch.distributed as dist
     n = torch.tensor([local.numel()], dtype=torch.int64, device=local.device)
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+    if _is_multi(group):
         dist.all_reduce(n, op=dist.ReduceOp.SUM, group=group)
     n = int(n.item())
     keys = _f32_key(local.reshape(-1).float())
@@ -102,9 +114,7 @@ def process_predictions_sharded(local, smoothening='none', group=None):
     'experimental', like numpy's promotion with the float64 percentiles; float32 for 'none')."""
     import torch
     import torch.distributed as dist
-    multi = group is not _LOCAL and dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
-    if group is _LOCAL:
-        group = None
+    multi = _is_multi(group)               # the _LOCAL sentinel is handed on as it is: the percentile helpers honour it too
     if smoothening == 'none':
         mm = torch.stack((local.min(), -local.max())) if local.numel() else torch.tensor([float('inf')] * 2, device=local.device)
         if multi:

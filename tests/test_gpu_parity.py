@@ -540,3 +540,33 @@ def test_funnel_batched_schedule_equals_image_by_image(gpu, oracle, monkeypatch)
         assert np.array_equal(np.asarray(res[2 * i][2]), d16)
         assert np.array_equal(np.asarray(res[2 * i + 1][2]),
                               oracle.create_stereoimages_arrays(imgs[i], d16, 2.5, 0.0, ['left-right'], 0.0, 1.0, 'polylines_sharp')[0])
+
+
+def test_funnel_failure_in_a_later_group_keeps_earlier_results(gpu):
+    """The pipelined funnel enqueues group k+1 before group k is handed out; a failure while preparing k+1 must not swallow
+    group k, and a single-channel image with GEN_STEREO fails where the reference fails: inside its stereo step, AFTER the
+    image's own 'depth' was yielded (src/core.py:133-259, src/stereoimage_generation.py:55)."""
+    from PIL import Image
+    import src.core as core
+    rng = np.random.default_rng(41)
+    rgb = [Image.fromarray(rng.integers(0, 256, (24, 40, 3), dtype=np.uint8)) for _ in range(2)]
+    gray = Image.fromarray(rng.integers(0, 256, (24, 40), dtype=np.uint8))            # mode 'L': np.asarray(...).ndim == 2
+    deps = [Image.fromarray(rng.integers(0, 65536, (24, 40), dtype=np.uint16)) for _ in range(3)]
+    got = []
+    with pytest.raises(ValueError, match='not enough values to unpack'):
+        for item in core.core_generation_funnel(None, rgb + [gray], deps, None, {'gen_stereo': True, 'stereo_modes': ['left-right']}):
+            got.append((item[0], item[1]))
+    assert got == [(0, 'depth'), (0, 'left-right'), (1, 'depth'), (1, 'left-right'), (2, 'depth')], got
+
+    class Boom:                                                   # a depth source that fails when it is turned into an array
+        size, mode, height, width = (40, 24), 'I;16', 24, 40
+
+        def __array__(self, *a, **k):
+            raise RuntimeError('decode failed')
+
+    got = []
+    with pytest.raises(Exception):
+        for item in core.core_generation_funnel(None, rgb + [Image.fromarray(rng.integers(0, 256, (30, 44, 3), dtype=np.uint8))],
+                                                deps[:2] + [Boom()], None, {'gen_stereo': True, 'stereo_modes': ['left-right']}):
+            got.append((item[0], item[1]))
+    assert got == [(0, 'depth'), (0, 'left-right'), (1, 'depth'), (1, 'left-right')], got

@@ -234,3 +234,87 @@ def test_boost_patch_sharding_is_rank_count_invariant(tmp_path):
         got = np.load(path)
         assert int(np.load(path + ".patches.npy")[0]) == stats["patches"]
         assert got.shape == want.shape and np.array_equal(got, want), (world, float(np.abs(got - want).max()))
+
+
+def _boost_subgroup_worker(rank, world, port, result_path):
+    for p in (conftest.ROOT, conftest.PKG):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(2)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sub = dist.new_group(ranks=[1, 2])                           # every rank creates it; global rank 0 is NOT a member
+    if rank in (1, 2):
+        from src import boost
+        boost.MASK_SIZE = 301
+        # dst = 0 is a rank OF THE GROUP (global rank 1): broadcast / gather need the translation (src/multigpu.global_rank)
+        out = boost.estimateboost(_boost_image(), _StubDepth(), 0, _StubMerge(), whole_size_threshold=1400, chunk=2,
+                                  group=sub, dst=0, blend=_oracle_blend)
+        if rank == 1:
+            assert out is not None
+            np.save(result_path, out.numpy())
+        else:
+            assert out is None
+        from src.multigpu import gather_units
+        mine = torch.full((2, 3), float(rank))
+        g = gather_units(mine, 4, group=sub, dst=1)              # group rank 1 = global rank 2 collects
+        assert (g is None) == (rank == 1)
+        if rank == 2:
+            assert torch.equal(g, torch.tensor([[1.0] * 3] * 2 + [[2.0] * 3] * 2))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_boost_and_gather_on_a_sub_group(tmp_path):
+    """`group` may be a real sub-group (global ranks [1, 2] of a world of 3): `dst` is a rank of the group, while
+    dist.broadcast / dist.gather take GLOBAL ranks -- the result equals the single-process run."""
+    for p in (conftest.ROOT, conftest.PKG):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    from src import boost
+    old = boost.MASK_SIZE
+    boost.MASK_SIZE = 301
+    try:
+        want = boost.estimateboost(_boost_image(), _StubDepth(), 0, _StubMerge(), whole_size_threshold=1400, chunk=2,
+                                   blend=_oracle_blend).numpy()
+    finally:
+        boost.MASK_SIZE = old
+    path = str(tmp_path / "boost_sub.npy")
+    mp.spawn(_boost_subgroup_worker, args=(3, _free_port(), path), nprocs=3, join=True)
+    assert np.array_equal(np.load(path), want)
+
+
+def _local_only_worker(rank, world, port, result_path):
+    for p in (conftest.ROOT, conftest.PKG):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    if rank == 0:                                                # ONLY rank 0 calls: any collective inside would hang / time out
+        from src import video_mode as vm
+        rng = np.random.default_rng(3)
+        preds = [rng.standard_normal((6, 9)).astype(np.float32) for _ in range(5)]
+        out = vm.process_predicitons(preds, 'experimental')
+        a = vm._global_percentiles(torch.from_numpy(preds[0]), [2.0, 98.0], vm._LOCAL)
+        assert np.array_equal(np.asarray(a), np.percentile(preds[0], [2.0, 98.0]))
+        np.save(result_path, np.stack(out))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_local_percentiles_issue_no_collective_inside_a_process_group(tmp_path):
+    """process_predicitons('experimental') and the per-image percentiles of the funnel's 'Outliers' clipping are LOCAL
+    operations: called on one rank of an initialised world-2 group (what Boost's rank-0 post-processing does) they must
+    not issue collectives -- this test would dead-lock otherwise -- and must give the single-process result."""
+    for p in (conftest.ROOT, conftest.PKG):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    from src import video_mode as vm
+    rng = np.random.default_rng(3)
+    preds = [rng.standard_normal((6, 9)).astype(np.float32) for _ in range(5)]
+    want = np.stack(vm.process_predicitons(preds, 'experimental'))
+    path = str(tmp_path / "local.npy")
+    mp.spawn(_local_only_worker, args=(2, _free_port(), path), nprocs=2, join=True)
+    assert np.array_equal(np.load(path), want)
