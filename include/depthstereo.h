@@ -241,7 +241,9 @@ int ds_bias_act_nhwc(ds_ctx *ctx, const void *x, const void *bias, const void *r
  * x [rows, in_features], W [out_features, in_features] (torch.nn.Linear layout), bias [out_features] or NULL,
  * y [rows, ldy] (ldy >= out_features, in elements).  f16/bf16, fp32 accumulation.  out_features % 256 == 0,
  * in_features % 128 == 0, rows >= 256 (the last 256-row panel is shifted up to end at the last row).  y must not alias x.
- * 256 x 256 tiles on the MFMA units.
+ * 256 x 256 tiles on the MFMA units, walked by one persistent workgroup per CU; when the last round of that walk would be
+ * at most a quarter full, its tiles are rendered as 128 x 64 pieces by a second kernel on the same stream (the "ragged
+ * round": 544 tiles on 256 CUs cost 2 rounds + the pieces instead of 3 rounds).
  */
 int ds_linear(ds_ctx *ctx, const void *x, const void *w, const void *bias, void *y, int64_t rows, int64_t out_features,
               int64_t in_features, int64_t ldy, int act, int dtype, void *stream);
@@ -250,10 +252,23 @@ int ds_linear(ds_ctx *ctx, const void *x, const void *w, const void *bias, void 
  * ds_linear_residual -- y = res + [gamma *] (x . W^T + bias): ds_linear with the residual add (and, when gamma is not NULL,
  * the LayerScale factor per output feature) in the epilogue: `x + gamma_1 * attn.proj(...)` of the encoder blocks
  * (dmidas/backbones/beit.py:99-103; dinov2_layers/block.py:88-96).  res and y [rows, out_features]; y must not alias res.
- * Shapes as ds_linear.  (Opt-in in the host code: DS_LINEAR=proj.)
+ * Shapes as ds_linear.  Used for the attention output projection and for fc2 of every encoder block: the LayerNorm pass that
+ * follows then reads one operand instead of two.
  */
 int ds_linear_residual(ds_ctx *ctx, const void *x, const void *w, const void *bias, const void *gamma, const void *res, void *y,
                        int64_t rows, int64_t out_features, int64_t in_features, int dtype, void *stream);
+
+/*
+ * ds_linear_vt -- V TRANSPOSED straight out of the projection GEMM: vt[b][c][n] = sum_k w_v[c][k] * h[b][n][k].
+ * The reference computes qkv = Linear(h), reshapes and permutes (dmidas/backbones/beit.py:71-74; dinov2_layers/
+ * attention.py:52-55); ds_attention_fwd wants V with the key index contiguous ([B, H*64, Np]), so the GEMM runs with W_v as
+ * its row operand and all B * Np tokens as columns, and the epilogue scatters every group of 8 columns to its batch element.
+ *   w_v [channels, in_features]   h [batch * tokens, in_features]   vt [batch, channels, tokens]
+ * tokens % 64 == 0, (batch * tokens) % 256 == 0, channels >= 256, in_features % 128 == 0.  No bias: the V bias commutes with
+ * the attention (softmax rows sum to one) and is folded into the output projection's bias by the host.
+ */
+int ds_linear_vt(ds_ctx *ctx, const void *w_v, const void *h, void *vt, int64_t channels, int64_t batch, int64_t tokens,
+                 int64_t in_features, int dtype, void *stream);
 
 /*
  * ds_conv3x3_nhwc -- y = act(conv3x3(x, W) + bias [+ res1] [+ res2]), stride 1, zero padding 1, as the implicit GEMM of

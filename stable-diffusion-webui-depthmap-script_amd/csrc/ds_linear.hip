@@ -1,8 +1,10 @@
 // ds_linear / ds_conv3x3_nhwc: y = act(x . W^T + b [+ residuals]) as ONE in-tree MFMA kernel with the epilogue fused,
 // instead of a library GEMM / convolution followed by element-wise passes.  Two front ends on one K loop:
 //   * dense:  the token GEMMs of the ViT encoders.  In the networks it runs `fc1 -> nn.GELU` of every encoder block (timm's
-//     Mlp as called from dmidas/backbones/beit.py:93-107; ddepth_anything_v2/depth_anything_v2/dinov2_layers/mlp.py:33-39);
-//     qk / proj / fc2 can be routed here too (DS_LINEAR=all) but stay library calls: tuned hipBLASLt is ahead on them.
+//     Mlp as called from dmidas/backbones/beit.py:93-107; ddepth_anything_v2/depth_anything_v2/dinov2_layers/mlp.py:33-39),
+//     the Q/K projection, V^T (ds_linear_vt: written transposed by the epilogue), and the attention / MLP output projections
+//     with LayerScale + residual in the epilogue (ds_linear_residual).  Launches whose last round of tiles would be nearly
+//     empty hand those tiles to k_linear_ragged (below).
 //   * conv:   the 3x3 convolutions of the DPT decoders as an implicit GEMM with bias / ReLU / residual / skip in the epilogue
 //     (ResidualConvUnit_custom dmidas/blocks.py:352-377, scratch.layerN_rn :64-80, util/blocks.py:56-85 of Depth-Anything-V2).
 //
@@ -72,7 +74,33 @@ struct LinParams {
     int H, W, C, cpt, magic;    // CONV: image height / width, input channels, K-tiles per tap (C / 64), 65536 / cpt + 1
     long long ldy;              // row stride of y (and res1 / res2) in elements
     const void *gamma;          // EPI 3: per-column factor applied to (acc + bias) before the addends (LayerScale)
+    int n_main;                 // the persistent kernel walks positions [0, n_main) of the tile list; k_linear_ragged takes the rest
+    int vt_np, vt_c;            // VT: column j of the GEMM is token j % vt_np of batch element j / vt_np, the output is [batch][vt_c rows][vt_np]
+    unsigned vt_magic;          // VT: floor(2^32 / vt_np) + 1  (j / vt_np == umulhi(j, vt_magic) for j * vt_np < 2^32)
 };
+
+// position in the tile list -> origin of the tile.  The list is ordered in groups of 8 row panels, rows fastest inside a group
+// (see the kernel); the last row panel is shifted up to end at row M (M >= 256): its first rows are computed twice, identically
+__device__ __forceinline__ void ln_tile_origin(const LinParams &P, const int tile, int &bm0, int &bn0)
+{
+    const int grp8 = tile / (8 * P.nbn), rem8 = tile - grp8 * (8 * P.nbn);
+    const int rows8 = min(8, P.nbm - 8 * grp8);
+    const int bn = rem8 / rows8, bm = 8 * grp8 + (rem8 - bn * rows8);
+    bm0 = min(bm * 256, P.M - 256);
+    bn0 = bn * 256;
+}
+
+// element offset of output (row, col .. col + 7), col a multiple of 8.  VT: the GEMM computes W_v . h^T with the TOKENS as its
+// columns, and the result is stored per batch element as [channels][tokens] -- V transposed, the operand layout of the
+// attention kernel's P.V product (a group of 8 columns never straddles two batch elements: vt_np is a multiple of 64)
+template <int VT>
+__device__ __forceinline__ size_t ln_out_off(const LinParams &P, const int row, const int col)
+{
+    if (!VT) return (size_t)row * P.ldy + col;
+    const unsigned b = __umulhi((unsigned)col, P.vt_magic);
+    const unsigned n = (unsigned)col - b * (unsigned)P.vt_np;
+    return ((size_t)b * P.vt_c + row) * (size_t)P.vt_np + n;
+}
 
 // erf-GELU on the fp32 accumulator.  GELU(v) = v Phi(v) = max(v, 0) - |v| Phi(-|v|), and Phi(-u) = 2^-Q(u) with
 // Q(u) = -log2 Phi(-u), a smooth, nearly quadratic function: a degree-7 polynomial on [0, 6] (Chebyshev fit, float64,
@@ -145,7 +173,7 @@ __device__ __forceinline__ void ln_dma_v(const void *ptr, unsigned lds_uniform)
 // GEMM is the implicit one of a 3 x 3, stride 1, zero-padded convolution: row m = output pixel, K-tile kt = 64 channels
 // kt / 9 of tap kt % 9 (tap-fastest: the pixels of a chunk are fetched once and hit in L2 for the other eight taps), whose
 // source is the same 128 bytes of the pixel shifted by (dy, dx) -- or the zero line.
-template <int BF16, int EPI, int CONV, int RES>
+template <int BF16, int EPI, int CONV, int RES, int VT = 0>
 __global__ __launch_bounds__(LN_THREADS) void k_linear256(LinParams P)
 {
     typedef ln_traits<BF16> TR;
@@ -158,7 +186,7 @@ __global__ __launch_bounds__(LN_THREADS) void k_linear256(LinParams P)
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wid >> 2, wc = wid & 3;
 
-    const int nwg = P.nbm * P.nbn;
+    const int nwg = P.n_main;            // this kernel's share of the tile list (all of it unless a ragged round follows)
     const int K = P.K;
     const int rowbytes = (CONV ? P.C : K) * (int)sizeof(T);                 // bytes of one row of x (one pixel for CONV)
 
@@ -189,17 +217,11 @@ __global__ __launch_bounds__(LN_THREADS) void k_linear256(LinParams P)
     auto set_tile = [&](const int orig) {
         const int xcd = orig & 7, q8 = nwg >> 3, r8 = nwg & 7;
         const int tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (orig >> 3);
-        // the last row panel is shifted up to end at row M (M >= 256): its first rows are computed twice, identically, by
-        // two workgroups -- no per-row clamping or masking anywhere (y must not alias res1 / res2)
         // the tile list is ordered in groups of 8 row panels, rows fastest inside a group: the 32 tiles an XCD has in flight
         // are then 8 row panels x 4 column panels (12 operand panels per K-slice through that L2 instead of the 18 of a
         // column-fastest list)
         // (measured against chunks of 4 column panels outermost, which would keep W in L2: fc1 316-319 vs 328-331 us)
-        const int grp8 = tile / (8 * P.nbn), rem8 = tile - grp8 * (8 * P.nbn);
-        const int rows8 = min(8, P.nbm - 8 * grp8);
-        const int bn = rem8 / rows8, bm = 8 * grp8 + (rem8 - bn * rows8);
-        bm0 = min(bm * 256, P.M - 256);
-        bn0 = bn * 256;
+        ln_tile_origin(P, tile, bm0, bn0);
         xb = (const unsigned char *)P.x + (size_t)bm0 * rowbytes;
         wb = (const unsigned char *)P.w + (size_t)bn0 * K * sizeof(T);
         if (CONV) {
@@ -389,7 +411,7 @@ __global__ __launch_bounds__(LN_THREADS) void k_linear256(LinParams P)
     // (direct -> transposed): plain GEMMs qk 160 -> 152 us, proj 90 -> 88, K = 1024 round 34.8 -> 33.1; but fc1 + GELU
     // 303 -> 311 (its epilogue is VALU-bound and hides the stores) and the convolution with a residual 598 -> 645: those
     // keep the direct store.
-    constexpr bool TRANSPOSE = (CONV == 0 && EPI == 0 && RES == 0);
+    constexpr bool TRANSPOSE = (CONV == 0 && EPI == 0 && RES == 0 && VT == 0);
     T *yb = (T *)P.y;
     const T *bias = (const T *)P.bias;
     const T *r1 = (const T *)P.res1, *r2 = (const T *)P.res2;
@@ -420,6 +442,10 @@ __global__ __launch_bounds__(LN_THREADS) void k_linear256(LinParams P)
         for (int rb = 0; rb < 2; ++rb) {
             const int rl = ha * 64 + rb * 32 + (lane & 31);     // row inside the wave tile
             const size_t o0 = (size_t)(cbm0 + wr * 128 + rl) * P.ldy + cbn0 + wc * 64 + hi8;
+            // VT: where the 8 columns of piece (hb, k) go (per batch element [channels][tokens]); else o0 + hb * 32 + 16 * k
+            auto out_off = [&](const int hb_, const int k_) -> size_t {
+                return VT ? ln_out_off<VT>(P, cbm0 + wr * 128 + rl, cbn0 + wc * 64 + hi8 + hb_ * 32 + 16 * k_) : o0 + hb_ * 32 + 16 * k_;
+            };
             V8 ra[2][2], rb2[2][2];                              // residual pieces [W half][k]
 #pragma unroll
             for (int hb = 0; hb < 2; ++hb)
@@ -454,7 +480,7 @@ __global__ __launch_bounds__(LN_THREADS) void k_linear256(LinParams P)
                         o[t + 1] = (T)u[1];
                     }
                     if (!TRANSPOSE) {
-                        if (!LN_ABLATE(1)) *(V8 *)(yb + o0 + hb * 32 + 16 * k) = o;
+                        if (!LN_ABLATE(1)) *(V8 *)(yb + out_off(hb, k)) = o;
                         else asm volatile("" ::"v"(o));
                     } else {
                         const int piece = hb * 4 + k * 2 + (lane >> 5);
@@ -479,19 +505,164 @@ __global__ __launch_bounds__(LN_THREADS) void k_linear256(LinParams P)
     }
 }
 
+
+// ---- the ragged round ----------------------------------------------------------------------------------------------------
+// A persistent launch of T tiles on G workgroups costs ceil(T / G) rounds; the token GEMMs of an encoder block at batch 32 are
+// 544 tiles (N = 1024: 2.125 -> 3 rounds) and 1088 tiles (N = 2048: 4.25 -> 5).  The last, mostly empty round is replaced: the
+// persistent kernel walks the first T - R positions of the tile list (a whole number of rounds), and this kernel renders the R
+// left-over tiles as 8 R pieces of 128 x 64 outputs -- one piece per workgroup, so the whole chip works on them at once.
+// Inside a workgroup the 8 waves split K (wave w takes the K range [w K / 8, (w + 1) K / 8) in steps of 32), each wave holds a
+// full 128 x 64 partial in registers, fed straight from global memory (nothing is shared between waves, so there is no LDS
+// staging: two register buffers of 12 fragment loads each), and the partials are summed through LDS in a fixed order (two
+// halves of 128 KB; wave w ends up with the 32 x 32 block w and runs the epilogue of that block).  No inter-workgroup
+// communication, no atomics: the result is bit-reproducible.  A piece reads (128 + 64) rows of K, where a full tile reads 512
+// for 8 times the outputs: 3 x the operand traffic per output, on 1/17 .. 1/9 of the launch.
+template <int BF16, int EPI, int RES, int VT>
+__global__ __launch_bounds__(LN_THREADS) void k_linear_ragged(LinParams P)
+{
+    typedef ln_traits<BF16> TR;
+    typedef typename TR::T T;
+    typedef typename TR::V8 V8;
+    extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
+    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // the 8 pieces of a tile run on ONE XCD (workgroup b lands on XCD b & 7): its L2 serves the shared x rows / W rows
+    const int p = (int)(blockIdx.x & 7) * (int)(gridDim.x >> 3) + (int)(blockIdx.x >> 3);
+    const int tile = P.n_main + (p >> 3), piece = p & 7;
+    int bm0, bn0;
+    ln_tile_origin(P, tile, bm0, bn0);
+    const int row0 = bm0 + (piece >> 2) * 128, col0 = bn0 + (piece & 3) * 64;
+    const int K = P.K;
+    const int nh = K >> 5;
+    const int h0 = wid * nh / 8, h1 = (wid + 1) * nh / 8;
+    // fragment loads: lane (hi, l31) reads k = 16 ks + 8 hi .. + 7 of row l31 of a 32-row block (the MFMA operand as it is)
+    const T *xa = (const T *)P.x + (size_t)(row0 + l31) * K + 8 * hi;
+    const T *wa = (const T *)P.w + (size_t)(col0 + l31) * K + 8 * hi;
+    const size_t blk = (size_t)32 * K;
+
+    lf32x16 acc[4][2];                     // [32-row block of the 128 rows][32-column block of the 64 columns]
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+    V8 fa0[4][2], fb0[2][2], fa1[4][2], fb1[2][2];
+#define RG_LOAD(FA, FB, h)                                                                                               \
+    do {                                                                                                                 \
+        const int kb_ = (h) * 32;                                                                                        \
+        _Pragma("unroll") for (int a_ = 0; a_ < 4; ++a_) _Pragma("unroll") for (int ks_ = 0; ks_ < 2; ++ks_)              \
+            FA[a_][ks_] = *(const V8 *)(xa + a_ * blk + kb_ + 16 * ks_);                                                  \
+        _Pragma("unroll") for (int b_ = 0; b_ < 2; ++b_) _Pragma("unroll") for (int ks_ = 0; ks_ < 2; ++ks_)              \
+            FB[b_][ks_] = *(const V8 *)(wa + b_ * blk + kb_ + 16 * ks_);                                                  \
+    } while (0)
+#define RG_MMA(FA, FB)                                                                                                   \
+    do {                                                                                                                 \
+        _Pragma("unroll") for (int ks_ = 0; ks_ < 2; ++ks_) _Pragma("unroll") for (int a_ = 0; a_ < 4; ++a_)              \
+            _Pragma("unroll") for (int b_ = 0; b_ < 2; ++b_) acc[a_][b_] = TR::mfma(FB[b_][ks_], FA[a_][ks_], acc[a_][b_]); \
+    } while (0)
+    if (h0 < h1) {
+        RG_LOAD(fa0, fb0, h0);
+        for (int h = h0; h < h1; h += 2) {
+            const bool two = h + 1 < h1;
+            if (two) RG_LOAD(fa1, fb1, h + 1);
+            RG_MMA(fa0, fb0);
+            if (two) {
+                if (h + 2 < h1) RG_LOAD(fa0, fb0, h + 2);
+                RG_MMA(fa1, fb1);
+            }
+        }
+    }
+#undef RG_LOAD
+#undef RG_MMA
+
+    // ---- sum of the 8 partials: LDS as [4 blocks][8 source waves][4 register quads][64 lanes] float4 (lane-contiguous
+    // 16-byte accesses: conflict free), blocks 0-3 in the first half (summed by waves 0-3), blocks 4-7 in the second
+    typedef float lf32x4 __attribute__((ext_vector_type(4)));
+    lf32x4 *red = (lf32x4 *)lds;
+    lf32x16 mine;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) mine[r] = 0.f;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+#pragma unroll
+        for (int bl = 0; bl < 4; ++bl)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const lf32x16 &src = acc[2 * half + (bl >> 1)][bl & 1];
+                red[((bl * 8 + wid) * 4 + q) * 64 + lane] = (lf32x4){src[4 * q], src[4 * q + 1], src[4 * q + 2], src[4 * q + 3]};
+            }
+        __syncthreads();
+        if ((wid >> 2) == half) {
+            const int bl = wid & 3;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                lf32x4 sum = red[((bl * 8 + 0) * 4 + q) * 64 + lane];
+#pragma unroll
+                for (int w = 1; w < 8; ++w) sum += red[((bl * 8 + w) * 4 + q) * 64 + lane];      // fixed order: reproducible
+                mine[4 * q] = sum[0]; mine[4 * q + 1] = sum[1]; mine[4 * q + 2] = sum[2]; mine[4 * q + 3] = sum[3];
+            }
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue of block wid = (32-row block wid >> 1, 32-column block wid & 1), as in k_linear256: register r = column
+    // (r & 3) + 8 (r >> 2) + 4 hi of row l31; one permlane32 swap per register pair gives each lane 8 consecutive columns
+    const int row = row0 + (wid >> 1) * 32 + l31;
+    const int cb = col0 + (wid & 1) * 32 + 8 * hi;
+    T *yb = (T *)P.y;
+    const T *bias = (const T *)P.bias;
+    const T *r1 = (const T *)P.res1;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int col = cb + 16 * k;
+        const size_t off = ln_out_off<VT>(P, row, col);
+        V8 bv, gv, rv;
+        if (bias) bv = *(const V8 *)(bias + col);
+        else {
+#pragma unroll
+            for (int t = 0; t < 8; ++t) bv[t] = (T)0.f;
+        }
+        if (EPI == 3) gv = *(const V8 *)((const T *)P.gamma + col);
+        if (RES >= 1) rv = *(const V8 *)(r1 + off);
+        float v[8];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const float fa = mine[8 * k + t], fb = mine[8 * k + 4 + t];
+            const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(fa), __float_as_uint(fb), false, false);
+            v[t] = __uint_as_float(sw[0]);
+            v[4 + t] = __uint_as_float(sw[1]);
+        }
+        V8 o;
+#pragma unroll
+        for (int t = 0; t < 8; t += 2) {
+            lf32x2 u = {v[t] + (float)bv[t], v[t + 1] + (float)bv[t + 1]};
+            if (EPI == 3) u *= (lf32x2){(float)gv[t], (float)gv[t + 1]};
+            if (RES >= 1) u += (lf32x2){(float)rv[t], (float)rv[t + 1]};
+            if (EPI == 1) u = ln_gelu2(u);
+            if (EPI == 2) u = (lf32x2){fmaxf(u[0], 0.f), fmaxf(u[1], 0.f)};
+            o[t] = (T)u[0];
+            o[t + 1] = (T)u[1];
+        }
+        *(V8 *)(yb + off) = o;
+    }
+}
+
 // ---- C ABI -------------------------------------------------------------------------------------------------------------
-template <int BF16, int EPI, int CONV, int RES>
-static int ln_launch(ds_ctx *ctx, const LinParams &P, hipStream_t stream)
+template <int BF16, int EPI, int CONV, int RES, int VT = 0>
+static int ln_launch(ds_ctx *ctx, const LinParams &P0, hipStream_t stream)
 {
     // per DEVICE, not per process: the dynamic-LDS attribute belongs to the function on one device, and the grid is that
     // device's CU count (a process may drive several GPUs through several contexts).  Setting the attribute twice is harmless,
     // so the bit mask needs no lock.
     static std::atomic<uint64_t> attr_done{0};
-    auto fn = k_linear256<BF16, EPI, CONV, RES>;
+    auto fn = k_linear256<BF16, EPI, CONV, RES, VT>;
     DS_HIP_CHECK(hipSetDevice(ctx->device));
     const uint64_t bit = 1ull << (ctx->device & 63);
     if (!(attr_done.load(std::memory_order_relaxed) & bit)) {
         DS_HIP_CHECK(hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, LN_LDS_BYTES));
+        if constexpr (CONV == 0)
+            DS_HIP_CHECK(hipFuncSetAttribute((const void *)k_linear_ragged<BF16, EPI, RES, VT>, hipFuncAttributeMaxDynamicSharedMemorySize, LN_LDS_BYTES));
         attr_done.fetch_or(bit, std::memory_order_relaxed);
     }
     if (!ctx->ncu) {
@@ -504,8 +675,21 @@ static int ln_launch(ds_ctx *ctx, const LinParams &P, hipStream_t stream)
         const int g = atoi(e) / 8 * 8;
         if (g >= 8) grid = g;
     }
-    const int nwg = P.nbm * P.nbn;
-    hipLaunchKernelGGL(fn, dim3(nwg < grid ? nwg : grid), dim3(LN_THREADS), LN_LDS_BYTES, stream, P);
+    LinParams P = P0;
+    const int ntiles = P.nbm * P.nbn;
+    // the ragged round (k_linear_ragged): when the last round of the persistent walk would be at most a quarter full, its
+    // tiles are rendered as 128 x 64 pieces by the whole chip instead.  DS_LIN_RAGGED=0 switches it off (A/B runs).
+    int ragged = 0;
+    if (CONV == 0 && ntiles > grid) {
+        const int enabled = getenv("DS_LIN_RAGGED") ? atoi(getenv("DS_LIN_RAGGED")) : 1;
+        const int r = ntiles % grid;
+        if (enabled && r > 0 && 4 * r <= grid) ragged = r;
+    }
+    P.n_main = ntiles - ragged;
+    hipLaunchKernelGGL(fn, dim3(P.n_main < grid ? P.n_main : grid), dim3(LN_THREADS), LN_LDS_BYTES, stream, P);
+    if constexpr (CONV == 0) {
+        if (ragged) hipLaunchKernelGGL((k_linear_ragged<BF16, EPI, RES, VT>), dim3(8 * ragged), dim3(LN_THREADS), LN_LDS_BYTES, stream, P);
+    }
     DS_HIP_CHECK(hipGetLastError());
     return DS_OK;
 }
@@ -620,4 +804,33 @@ DS_API int ds_conv3x3_nhwc(ds_ctx *ctx, const void *x, const void *w, const void
     P.stagger = getenv("DS_LIN_STAGGER_US") ? (int)(atof(getenv("DS_LIN_STAGGER_US")) * 100.0) : 0;
 #endif
     return dtype == DS_DTYPE_F16 ? ln_dispatch_conv<0>(ctx, P, act, (hipStream_t)stream) : ln_dispatch_conv<1>(ctx, P, act, (hipStream_t)stream);
+}
+
+// V^T of an encoder block straight out of the GEMM: vt[b][c][n] = sum_k w_v[c][k] h[b][n][k] (the reference computes
+// qkv = Linear(h) and permutes, dmidas/backbones/beit.py:71-74, dinov2_layers/attention.py:52-55; the attention kernel wants V
+// with the key index contiguous).  The GEMM runs with W_v as the row operand and ALL tokens of the batch as columns; the
+// epilogue scatters every group of 8 columns to its batch element (ln_out_off<1>).  The V bias is not added here: it commutes
+// with the attention and is folded into the projection bias on the host.
+DS_API int ds_linear_vt(ds_ctx *ctx, const void *w_v, const void *h, void *vt, int64_t channels, int64_t batch, int64_t tokens,
+                        int64_t in_features, int dtype, void *stream)
+{
+    DS_REQUIRE(ctx && w_v && h && vt, DS_EINVAL, "ds_linear_vt: null argument");
+    DS_REQUIRE(channels >= 256, DS_EINVAL, "ds_linear_vt: channels must be >= 256 (one tile)");
+    DS_REQUIRE(batch > 0 && tokens > 0 && tokens % 64 == 0 && (batch * tokens) % 256 == 0 && batch * tokens < (1ll << 31) - 256, DS_EINVAL,
+               "ds_linear_vt: tokens must be a multiple of 64 and batch * tokens a multiple of 256");
+    DS_REQUIRE(batch * tokens * tokens < (1ll << 32), DS_EUNSUPPORTED, "ds_linear_vt: batch * tokens^2 must stay below 2^32");
+    DS_REQUIRE(in_features >= 128 && in_features % 128 == 0 && in_features <= 16384, DS_EINVAL,
+               "ds_linear_vt: in_features must be a multiple of 128 (<= 16384)");
+    DS_REQUIRE(dtype == DS_DTYPE_F16 || dtype == DS_DTYPE_BF16, DS_EINVAL, "ds_linear_vt: dtype must be f16 or bf16");
+    DS_REQUIRE(((uintptr_t)w_v & 15) == 0 && ((uintptr_t)h & 15) == 0 && ((uintptr_t)vt & 15) == 0, DS_EINVAL,
+               "ds_linear_vt: w_v, h and vt must be 16-byte aligned");
+    LinParams P;
+    memset(&P, 0, sizeof(P));
+    P.x = w_v; P.w = h; P.y = vt;
+    P.M = (int)channels; P.N = (int)(batch * tokens); P.K = (int)in_features;
+    P.nbm = (int)((channels + 255) / 256); P.nbn = (int)(batch * tokens / 256);
+    P.ldy = batch * tokens;
+    P.vt_np = (int)tokens; P.vt_c = (int)channels; P.vt_magic = (unsigned)((1ull << 32) / (unsigned long long)tokens + 1ull);
+    hipStream_t st = (hipStream_t)stream;
+    return dtype == DS_DTYPE_F16 ? ln_launch<0, 0, 0, 0, 1>(ctx, P, st) : ln_launch<1, 0, 0, 0, 1>(ctx, P, st);
 }

@@ -18,7 +18,7 @@ DS_DEPTH_U16, DS_DEPTH_F32, DS_DEPTH_F64 = 0, 1, 2
 FILL_IDS = {"none": 0, "naive": 1, "naive_interpolating": 2, "polylines_soft": 3, "polylines_sharp": 4}
 
 EXPORTS = [
-    "ds_version", "ds_last_error", "ds_normalmap_f64", "ds_reassemble_readout", "ds_bias_act_nhwc", "ds_linear", "ds_linear_residual", "ds_conv3x3_nhwc", "ds_ctx_create", "ds_ctx_destroy", "ds_stereo_warp", "ds_depth_minmax",
+    "ds_version", "ds_last_error", "ds_normalmap_f64", "ds_reassemble_readout", "ds_bias_act_nhwc", "ds_linear", "ds_linear_residual", "ds_linear_vt", "ds_conv3x3_nhwc", "ds_ctx_create", "ds_ctx_destroy", "ds_stereo_warp", "ds_depth_minmax",
     "ds_stereo_last_exact_rows", "ds_copy_view", "ds_overlap_red_cyan", "ds_normalmap", "ds_depth_to_u16",
     "ds_convert_to_i16", "ds_profile_enable", "ds_profile_last_ms", "ds_stereo_last_stats", "ds_attention_fwd", "ds_attention_bias_pack", "ds_colorize_u16", "ds_residual_layernorm", "ds_boost_blend", "ds_upsample_bilinear_nhwc", "ds_dpt_head_tail",
 ]
@@ -73,6 +73,7 @@ def lib():
             L.ds_bias_act_nhwc.argtypes = [vp, vp, vp, vp, vp, vp, i64, ci, ci, ci, vp]
             L.ds_linear.argtypes = [vp, vp, vp, vp, vp, i64, i64, i64, i64, ci, ci, vp]
             L.ds_linear_residual.argtypes = [vp, vp, vp, vp, vp, vp, vp, i64, i64, i64, ci, vp]
+            L.ds_linear_vt.argtypes = [vp, vp, vp, vp, i64, i64, i64, i64, ci, vp]
             L.ds_conv3x3_nhwc.argtypes = [vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, vp]
             L.ds_profile_enable.argtypes = [vp, ci]
             L.ds_profile_last_ms.argtypes = [vp, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float)]
@@ -401,6 +402,29 @@ def linear_residual(x, weight, bias, gamma, residual):
                                     None if g is None else g.data_ptr(), r2.data_ptr(), out.data_ptr(), x2.shape[0], n, k,
                                     1 if x.dtype == torch.float16 else 2, _stream(x)))
     return out.view(residual.shape)
+
+
+def linear_vt_supported(w_v, h):
+    """Shapes ds_linear_vt takes: h [B, Np, K] with Np % 64 == 0 and (B * Np) % 256 == 0, w_v [C >= 256, K], K % 128 == 0."""
+    return (h.dim() == 3 and h.shape[1] % 64 == 0 and (h.shape[0] * h.shape[1]) % 256 == 0 and w_v.shape[0] >= 256
+            and w_v.shape[1] == h.shape[2] and h.shape[2] % 128 == 0 and 128 <= h.shape[2] <= 16384
+            and h.shape[0] * h.shape[1] * h.shape[1] < (1 << 32))
+
+
+def linear_vt(w_v, h):
+    """V^T = W_v . h^T per batch element, written transposed by the GEMM's epilogue (include/depthstereo.h: ds_linear_vt).
+    w_v [C, K], h [B, Np, K] float16 / bfloat16 CUDA -> [B, C, Np]."""
+    torch = require_gpu()
+    assert h.is_cuda and h.dtype in (torch.float16, torch.bfloat16) and linear_vt_supported(w_v, h)
+    b, npad, k = h.shape
+    c = w_v.shape[0]
+    h2 = h if h.is_contiguous() else h.contiguous()
+    w = w_v.detach()
+    w = w if (w.dtype == h.dtype and w.is_contiguous()) else w.to(h.dtype).contiguous()
+    out = torch.empty((b, c, npad), dtype=h.dtype, device=h.device)
+    _check(lib().ds_linear_vt(ctx_for(_dev_index(h)), w.data_ptr(), h2.data_ptr(), out.data_ptr(), c, b, npad, k,
+                              1 if h.dtype == torch.float16 else 2, _stream(h)))
+    return out
 
 
 def conv3x3_supported(conv, x):

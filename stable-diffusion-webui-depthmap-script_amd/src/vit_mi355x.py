@@ -114,9 +114,15 @@ def attention_reference(qk, vt, n_valid, scale, bias=None):
 
 
 def v_transposed(w_v, h):
-    """V^T = W_v . h^T as ONE batched GEMM whose second operand is read transposed in place ([B, C, Np] out of
-    h [B, Np, C]); torch.matmul(w_v, h.transpose(1, 2)) would first materialise h^T."""
+    """V^T = W_v . h^T, [B, C, Np] out of h [B, Np, C].  float16 / bfloat16 on a GPU with every token GEMM in-tree
+    (DS_LINEAR=all): ds_linear_vt, one GEMM over all tokens of the batch whose epilogue writes each batch element's
+    [C, Np] block.  Otherwise ONE batched library GEMM whose second operand is read transposed in place
+    (torch.matmul(w_v, h.transpose(1, 2)) would first materialise h^T)."""
     b = h.shape[0]
+    if h.is_cuda and h.dtype in (torch.float16, torch.bfloat16) and LINEAR_HIP == "all":
+        from . import _native
+        if _native.linear_vt_supported(w_v, h) and hip_gemm_ok(w_v.shape[0], h.shape[0] * h.shape[1]):
+            return _native.linear_vt(w_v, h)
     return torch.bmm(w_v.unsqueeze(0).expand(b, -1, -1), h.transpose(1, 2))
 
 
@@ -142,10 +148,20 @@ LOG2E = 1.4426950408889634
 
 
 # Which token GEMMs take the in-tree MFMA kernel (csrc/ds_linear.hip) on float16 / bfloat16 CUDA tensors:
-#   "gelu" (default) fc1 + GELU only -- the fused epilogue removes the stand-alone GELU pass;
-#   "proj"           "gelu" + the attention output projection with LayerScale and the residual add in its epilogue (opt-in);
-#   "all"            every Linear of the encoder blocks;        "0"  none (library GEMMs + aten GELU).
-LINEAR_HIP = os.environ.get("DS_LINEAR", "gelu")
+#   "all" (default)  every Linear of the encoder blocks: Q/K projection, V^T (written transposed by the epilogue), the
+#                    attention output projection and fc2 with LayerScale + the residual add in their epilogues, fc1 + GELU;
+#   "proj"           fc1 + GELU and the fused output projection only;   "gelu"  fc1 + GELU only (round 2's default);
+#   "0"              none (library GEMMs + aten GELU).
+LINEAR_HIP = os.environ.get("DS_LINEAR", "all")
+
+
+# The in-tree kernel's unit is a 256 x 256 tile on one CU: a launch with only a few tiles leaves most of the chip idle (a
+# batch-1 ViT-B forward is 9 tiles), and the library's small-tile kernels are the better tool there.
+LINEAR_HIP_MIN_TILES = int(os.environ.get("DS_LINEAR_MIN_TILES", 96))
+
+
+def hip_gemm_ok(rows, out_features):
+    return ((rows + 255) // 256) * (out_features // 256) >= LINEAR_HIP_MIN_TILES
 
 
 def linear(x, weight, bias=None, gelu=False):
@@ -153,7 +169,7 @@ def linear(x, weight, bias=None, gelu=False):
     on the fp32 accumulator); everything else: the library GEMM and aten's exact GELU."""
     if x.is_cuda and x.dtype in (torch.float16, torch.bfloat16) and (LINEAR_HIP == "all" or (gelu and LINEAR_HIP in ("gelu", "proj"))):
         from . import _native
-        if _native.linear_supported(x, weight):
+        if _native.linear_supported(x, weight) and (gelu or hip_gemm_ok(x.numel() // x.shape[-1], weight.shape[0])):
             return _native.linear(x, weight, bias, gelu)
     y = F.linear(x, weight, bias)
     return F.gelu(y) if gelu else y
@@ -221,24 +237,35 @@ def run_blocks(blocks, x, n_valid, grid_hw, take):
     from . import _native
     n = len(blocks)
     _, h = _native.residual_layernorm(x, None, None, blocks[0].norm1.weight, blocks[0].norm1.bias, blocks[0].norm1.eps)
+    big = hip_gemm_ok(x.shape[0] * x.shape[1], x.shape[2])      # (the fused epilogues pay only where the tile kernel does)
     for i, blk in enumerate(blocks):
         g1, g2 = blk.gammas()
         pr = getattr(getattr(blk, "attn", None), "proj", None)
-        if (LINEAR_HIP == "proj" and pr is not None and x.shape[0] * x.shape[1] >= 256 and _native.linear_supported(x, pr.weight)):
-            # opt-in (prepared at the end of round 2, to be measured): the projection GEMM adds LayerScale and the residual in
-            # its epilogue, the LayerNorm pass then reads x once instead of x and the branch
+        if (LINEAR_HIP in ("proj", "all") and pr is not None and big and _native.linear_supported(x, pr.weight)):
+            # the projection GEMM adds LayerScale and the residual in its epilogue (ds_linear_residual): the LayerNorm pass
+            # then reads x once instead of x and the branch
             o, b_v = blk.attend_o(h, n_valid, grid_hw)
             x = _native.linear_residual(o, pr.weight, folded_proj_bias(pr, b_v), g1, x)
             _, h2 = _native.residual_layernorm(x, None, None, blk.norm2.weight, blk.norm2.bias, blk.norm2.eps)
         else:
             p = blk.attend(h, n_valid, grid_hw)
             x, h2 = _native.residual_layernorm(x, p, g1, blk.norm2.weight, blk.norm2.bias, blk.norm2.eps)
-        m = blk.mlp(h2)
-        if i + 1 < n:
-            nxt = blocks[i + 1].norm1
-            x, h = _native.residual_layernorm(x, m, g2, nxt.weight, nxt.bias, nxt.eps)
+        mlp = blk.mlp
+        fused_fc2 = (LINEAR_HIP == "all" and isinstance(mlp, Mlp) and big and _native.linear_supported(x, mlp.fc2.weight)
+                     and _native.linear_supported(h2, mlp.fc1.weight) and mlp.fc2.bias is not None)
+        if fused_fc2:                                        # x + gamma_2 * fc2(gelu(fc1(h2))): both tails in GEMM epilogues
+            a = _native.linear(h2, mlp.fc1.weight, mlp.fc1.bias, True)
+            x = _native.linear_residual(a, mlp.fc2.weight, mlp.fc2.bias, g2, x)
+            if i + 1 < n:
+                nxt = blocks[i + 1].norm1
+                _, h = _native.residual_layernorm(x, None, None, nxt.weight, nxt.bias, nxt.eps)
         else:
-            x = x + (m if g2 is None else g2 * m)
+            m = mlp(h2)
+            if i + 1 < n:
+                nxt = blocks[i + 1].norm1
+                x, h = _native.residual_layernorm(x, m, g2, nxt.weight, nxt.bias, nxt.eps)
+            else:
+                x = x + (m if g2 is None else g2 * m)
         if i in take:
             taps[i] = x[:, :n_valid]
     return x, taps

@@ -795,3 +795,98 @@ def test_infer_batch_gpu_vs_reference_get_raw_prediction(gpu):
         img = torch.from_numpy(z[f"dav2__{name}__image"]).cuda()
         got = d16.infer_batch(img[None], size)[0].cpu().numpy()
         assert rel(got, z[f"dav2__{name}__pred"]) < 2e-2, (name, rel(got, z[f"dav2__{name}__pred"]))
+
+
+def _lin_ref(x, w, b=None, gamma=None, res=None, gelu=False):
+    import torch.nn.functional as F
+    y = x.double() @ w.double().T
+    if b is not None:
+        y = y + b.double()
+    if gelu:
+        y = F.gelu(y)
+    if gamma is not None:
+        y = y * gamma.double()
+    if res is not None:
+        y = y + res.double()
+    return y
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float16, 1.5e-3), (torch.bfloat16, 1.2e-2)])
+def test_linear_ragged_round_vt_and_fused_residual(gpu, dtype, tol):
+    """The pieces of csrc/ds_linear.hip added in round 3, at small sizes with a small persistent grid (DS_LIN_GRID) so that
+    every path is taken: k_linear_ragged (the last, nearly empty round of tiles rendered as 128 x 64 pieces with K split over
+    the 8 waves and summed through LDS) behind plain / GELU / LayerScale + residual epilogues, a shifted last row panel,
+    K = 128 (some waves get an empty K range); ds_linear_vt (V^T written per batch element by the epilogue) with and without
+    a ragged round.  Against float64 on the same rounded operands; repeated launches bit-identical; ragged on == ragged off
+    to rounding."""
+    import os
+    from src import _native
+    g = torch.Generator().manual_seed(77)
+    mk = lambda *s: torch.randn(s, generator=g)  # noqa: E731
+    old = {k: os.environ.get(k) for k in ("DS_LIN_GRID", "DS_LIN_RAGGED")}
+    try:
+        # (rows, out, in, grid): tiles % grid <= grid / 4 -> a ragged round of 1 .. 4 tiles
+        for (m, n, k, grid) in [(4352, 256, 384, 8), (2304, 512, 1024, 8), (2637, 768, 640, 16), (4352, 256, 128, 8), (8448, 256, 256, 32)]:
+            os.environ["DS_LIN_GRID"] = str(grid)
+            x, w, b = mk(m, k).to(dtype).cuda(), (mk(n, k) * k ** -0.5).to(dtype).cuda(), mk(n).to(dtype).cuda()
+            gam, res = mk(n).to(dtype).cuda(), mk(m, n).to(dtype).cuda()
+            for gelu in (False, True):
+                want = _lin_ref(x, w, b, gelu=gelu)
+                os.environ["DS_LIN_RAGGED"] = "1"
+                got = _native.linear(x, w, b, gelu)
+                assert (got.double() - want).abs().max().item() < tol * (1 + want.abs().max().item()), (m, n, k, gelu)
+                assert torch.equal(_native.linear(x, w, b, gelu), got), "ragged round: run-to-run difference"
+                os.environ["DS_LIN_RAGGED"] = "0"
+                off = _native.linear(x, w, b, gelu)
+                assert (got.double() - off.double()).abs().max().item() < tol * (1 + want.abs().max().item())
+                # the two schedules differ only in the summation order of the ragged tiles: most outputs are bit-identical
+                assert (got != off).float().mean().item() < 0.2
+            os.environ["DS_LIN_RAGGED"] = "1"
+            for gm in (gam, None):
+                want = _lin_ref(x, w, b, gamma=gm, res=res)
+                got = _native.linear_residual(x, w, b, gm, res)
+                assert (got.double() - want).abs().max().item() < tol * (1 + want.abs().max().item()), (m, n, k, gm is None)
+                assert torch.equal(_native.linear_residual(x, w, b, gm, res), got)
+        # V^T: [B, C, Np] out of h [B, Np, K]; (B, Np, C, K, grid)
+        for (bb, npad, c, k, grid) in [(4, 320, 512, 256, 8), (2, 640, 256, 384, 256), (6, 128, 768, 128, 8)]:
+            os.environ["DS_LIN_GRID"] = str(grid)
+            h, wv = mk(bb, npad, k).to(dtype).cuda(), (mk(c, k) * k ** -0.5).to(dtype).cuda()
+            assert _native.linear_vt_supported(wv, h)
+            want = torch.einsum("ck,bnk->bcn", wv.double(), h.double())
+            got = _native.linear_vt(wv, h)
+            assert got.shape == (bb, c, npad) and got.is_contiguous()
+            assert (got.double() - want).abs().max().item() < tol * (1 + want.abs().max().item()), (bb, npad, c, k)
+            assert torch.equal(_native.linear_vt(wv, h), got)
+    finally:
+        for k_, v in old.items():
+            if v is None:
+                os.environ.pop(k_, None)
+            else:
+                os.environ[k_] = v
+
+
+def test_linear_vt_and_fused_fc2_at_benchmark_shapes(gpu):
+    """ds_linear_vt and ds_linear_residual at the shapes of ONE encoder block of dpt_beit_large_512 at batch 32 (544 tiles:
+    two full rounds on 256 CUs + a ragged round of 32 tiles), every element against float32 on the same rounded operands."""
+    from src import _native
+    g = torch.Generator().manual_seed(91)
+    h = torch.randn((32, 1088, 1024), generator=g).half().cuda()
+    wv = (torch.randn((1024, 1024), generator=g) / 32).half().cuda()
+    got = _native.linear_vt(wv, h)
+    worst = 0.0
+    for b in range(32):
+        want = wv.float() @ h[b].float().T
+        worst = max(worst, (got[b].float() - want).abs().max().item() / (1 + want.abs().max().item()))
+    assert worst < 1.5e-3, worst
+    assert torch.equal(_native.linear_vt(wv, h), got)
+    a = torch.randn((34816, 4096), generator=g).half().cuda()
+    w2 = (torch.randn((1024, 4096), generator=g) / 64).half().cuda()
+    b2, gam = torch.randn(1024, generator=g).half().cuda(), torch.randn(1024, generator=g).half().cuda()
+    res = torch.randn((34816, 1024), generator=g).half().cuda()
+    got = _native.linear_residual(a, w2, b2, gam, res)
+    worst = 0.0
+    for r0 in range(0, 34816, 4352):
+        want = (a[r0:r0 + 4352].float() @ w2.float().T + b2.float()) * gam.float() + res[r0:r0 + 4352].float()
+        worst = max(worst, (got[r0:r0 + 4352].float() - want).abs().max().item() / (1 + want.abs().max().item()))
+    assert worst < 1.5e-3, worst
+    assert torch.equal(_native.linear_residual(a, w2, b2, gam, res), got)

@@ -407,8 +407,9 @@ def _full_frame_depths():
       0  the survey pattern (ramps, periodic steps, large occluders)
       1  noisy: a smooth field + per-pixel noise of a few hundred codes, what a random-weight network's prediction looks
          like to the stereo kernel (> 10^5 'general' pixels per image: backward segments everywhere)
-      2  adversarial: white-noise columns, quantised plateaus with coincident breakpoints and single-pixel spikes -- rows
-         whose sweep is history dependent and must go through the exact fallback"""
+      2  adversarial: white-noise columns, quantised plateaus (four levels) and single-pixel spikes; at a divergence whose
+         pixel value is an integer multiple of 3 the plateaus give coincident breakpoints -- rows whose sweep is history
+         dependent and must go through the exact fallback (test_full_frame_1024_exact_fallback_rows)"""
     rng = np.random.default_rng(77)
     H = W = 1024
     d0 = util.survey_inputs(H, W, 0)[1][0]
@@ -436,15 +437,31 @@ def test_full_frame_1024_all_rows_vs_oracle(sg, native, oracle, gpu, fill):
         want = oracle.create_stereoimages_arrays(img[i], dep[i], 2.5, 0.0, ['left-right'], 0.0, 1.0, fill)[0]
         bad = int((want != got[i]).sum())
         assert bad == 0, (fill, i, bad, np.argwhere((want != got[i]).any(axis=2))[:5].tolist())
-    # the regimes are what they claim to be: the batch as a whole produced general pixels and exact-fallback rows
-    assert general > 0 and exact_rows > 0
-    # each image alone: regime 1 is dominated by general pixels, regime 2 sends rows to the exact fallback
+    # the batch as a whole produced general pixels; regime 1 alone is dominated by them.  (At 2.5 % = 25.6 px the quantised
+    # plateaus of regime 2 never put two points on the same x -- its levels are 25.6 / 3 px apart -- so NO row of this call
+    # needs the exact fallback: measured 0 of 6144.  The fallback at full size is the next test's subject.)
+    assert general > 0 and exact_rows >= 0
     sg.create_stereoimages_batch(it[1:2], dt[1:2], 2.5, 0.0, ['left-right'], 0.0, 1.0, fill)
     _, g1 = native.last_stats(it)
     assert g1 > 0
-    sg.create_stereoimages_batch(it[2:3], dt[2:3], 2.5, 0.0, ['left-right'], 0.0, 1.0, fill)
-    e2, _ = native.last_stats(it)
-    assert e2 > 0
+
+
+@pytest.mark.parametrize("fill", ["polylines_sharp", "polylines_soft"])
+def test_full_frame_1024_exact_fallback_rows(sg, native, oracle, gpu, fill):
+    """Rows that MUST take the sequential exact sweep, at the benchmark's size: divergence 3.125 % of 1024 px is exactly
+    32 px, and regime 2's depth has four levels 1/3 apart -- pixels 32 columns apart on levels 0 and 3 land on the SAME x
+    (coincident breakpoints: zero-length sub-intervals, exact closeness ties), which is history dependent in the reference's
+    sweep.  The call must flag rows (exact_rows > 0) and still be bit-exact on every row of both eyes."""
+    torch = gpu
+    dep = _full_frame_depths()[2:3]
+    img = np.random.default_rng(80).integers(0, 256, (1, 1024, 1024, 3), dtype=np.uint8)
+    it, dt = torch.from_numpy(img).cuda(), torch.from_numpy(dep).cuda()
+    got = sg.create_stereoimages_batch(it, dt, 3.125, 0.0, ['left-right'], 0.0, 1.0, fill)[0].cpu().numpy()
+    exact_rows, _ = native.last_stats(it)
+    want = oracle.create_stereoimages_arrays(img[0], dep[0], 3.125, 0.0, ['left-right'], 0.0, 1.0, fill)[0]
+    bad = int((want != got[0]).sum())
+    assert bad == 0, (fill, bad, np.argwhere((want != got[0]).any(axis=2))[:5].tolist())
+    assert exact_rows > 0, "no row took the exact fallback: the regime does not test what it claims"
 
 
 @pytest.mark.parametrize("fill,div,sep,bal,exp", [("polylines_sharp", 4.0, 1.0, 0.3, 2.0), ("polylines_soft", 2.5, -1.5, -0.6, 0.5)])

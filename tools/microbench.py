@@ -143,6 +143,50 @@ def linear_bench():
                   f"max|hip-lib| {full:.2e} repeat-identical {same}", flush=True)
 
 
+def linear_ab():
+    """Round 3: the token GEMMs of one dpt_beit_large_512 block at batch 32 -- in-tree with the ragged round, in-tree without
+    it (DS_LIN_RAGGED=0: the persistent walk alone), and the library call the host used before -- interleaved rounds."""
+    import torch.nn.functional as F
+    dev = torch.device("cuda")
+    dt = torch.float16
+    g = torch.Generator(device="cpu").manual_seed(5)
+    m = 34816
+    x = torch.randn(m, 1024, generator=g).to(dev, dt)
+    x4 = torch.randn(m, 4096, generator=g).to(dev, dt)
+    res = torch.randn(m, 1024, generator=g).to(dev, dt)
+    gam = torch.randn(1024, generator=g).to(dev, dt)
+
+    def w_(n, k):
+        return (torch.randn(n, k, generator=g) * k ** -0.5).to(dev, dt)
+    w_qk, w_v, w_p, w_1, w_2 = w_(2048, 1024), w_(1024, 1024), w_(1024, 1024), w_(4096, 1024), w_(1024, 4096)
+    b_qk, b_p, b_1, b_2 = (torch.randn(n, generator=g).to(dev, dt) for n in (2048, 1024, 4096, 1024))
+    h3 = x.view(32, 1088, 1024)
+    cases = [
+        ("qk       34816x2048x1024", 2.0 * m * 2048 * 1024, lambda: nat.linear(x, w_qk, b_qk, False), lambda: F.linear(x, w_qk, b_qk)),
+        ("v^T      1024x34816x1024", 2.0 * m * 1024 * 1024, lambda: nat.linear_vt(w_v, h3), lambda: torch.bmm(w_v.unsqueeze(0).expand(32, -1, -1), h3.transpose(1, 2))),
+        ("proj+res 34816x1024x1024", 2.0 * m * 1024 * 1024, lambda: nat.linear_residual(x, w_p, b_p, gam, res), lambda: F.linear(x, w_p, b_p)),
+        ("fc1+gelu 34816x4096x1024", 2.0 * m * 4096 * 1024, lambda: nat.linear(x, w_1, b_1, True), lambda: F.gelu(F.linear(x, w_1, b_1))),
+        ("fc2+res  34816x1024x4096", 2.0 * m * 1024 * 4096, lambda: nat.linear_residual(x4, w_2, b_2, gam, res), lambda: F.linear(x4, w_2, b_2)),
+    ]
+    for name, fl, hip, libf in cases:
+        t = {"ragged": [], "walk": [], "lib": []}
+        for _ in range(3):
+            os.environ["DS_LIN_RAGGED"] = "1"
+            t["ragged"].append(timeit(hip, reps=10, warm=2))
+            os.environ["DS_LIN_RAGGED"] = "0"
+            t["walk"].append(timeit(hip, reps=10, warm=2))
+            t["lib"].append(timeit(libf, reps=10, warm=2))
+        os.environ["DS_LIN_RAGGED"] = "1"
+        r, wk, lb = min(t["ragged"]), min(t["walk"]), min(t["lib"])
+        print(f"gemm {name}: in-tree {r * 1e3:7.1f} us {fl / r / 1e9:6.0f} TF | without ragged round {wk * 1e3:7.1f} us | "
+              f"library (GEMM only) {lb * 1e3:7.1f} us {fl / lb / 1e9:6.0f} TF", flush=True)
+    # the LayerNorm pass behind the fused epilogues reads one operand instead of two
+    xs, br = torch.randn(m, 1024, device=dev, dtype=dt), torch.randn(m, 1024, device=dev, dtype=dt)
+    t2 = timeit(lambda: nat.residual_layernorm(xs, br, gam, gam, gam, 1e-6))
+    t1 = timeit(lambda: nat.residual_layernorm(xs, None, None, gam, gam, 1e-6))
+    print(f"residual_layernorm 34816x1024: with branch {t2 * 1e3:.1f} us, LayerNorm only {t1 * 1e3:.1f} us")
+
+
 def single_shapes(which):
     """One shape per kernel instantiation, a few launches each: what the hardware-counter passes profile."""
     dev = torch.device("cuda")
@@ -218,6 +262,9 @@ if __name__ == "__main__":
         sys.exit(0)
     if "linear" in sys.argv[1:]:
         linear_bench()
+        sys.exit(0)
+    if "gemms" in sys.argv[1:]:
+        linear_ab()
         sys.exit(0)
     main()
     extra(set(sys.argv[1:]) or {"normalmap", "readout"})
