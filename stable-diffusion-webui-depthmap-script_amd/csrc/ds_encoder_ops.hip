@@ -407,8 +407,11 @@ DS_API int ds_dpt_head_tail(ds_ctx *ctx, const void *x, int batch, int in_h, int
     P.B = batch; P.ih = in_h; P.iw = in_w; P.oh = out_h; P.ow = out_w; P.relu_out = relu_out;
     P.sy = out_h > 1 ? (float)(in_h - 1) / (float)(out_h - 1) : 0.f;
     P.sx = out_w > 1 ? (float)(in_w - 1) / (float)(out_w - 1) : 0.f;
-    static int s_persist = -1;                               // DS_HEAD_PERSIST=1: the persistent variant (weights resident in LDS)
-    if (s_persist < 0) { const char *e = getenv("DS_HEAD_PERSIST"); s_persist = (e && atoi(e) == 1) ? 1 : 0; }
+    // the persistent variant (weights resident in LDS, one workgroup per CU) is the default since round 3: value-tested on
+    // hardware, 1.90 -> 1.67 ms at 32 x 256^2 -> 512^2 (profiles/round3_head_tail_ab.txt); DS_HEAD_PERSIST=0 selects the
+    // tile-per-workgroup kernel (A/B runs)
+    static int s_persist = -1;
+    if (s_persist < 0) { const char *e = getenv("DS_HEAD_PERSIST"); s_persist = (e && atoi(e) == 0) ? 0 : 1; }
     if (s_persist) {
         const int tiles_x = (out_w + HT_TW - 1) / HT_TW, tiles_y = (out_h + HTP_TH - 1) / HTP_TH;
         const long long nt = (long long)tiles_x * tiles_y * batch;
