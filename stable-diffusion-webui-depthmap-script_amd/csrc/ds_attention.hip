@@ -368,7 +368,14 @@ __global__ __launch_bounds__(AT_THREADS, NQB == 2 ? 2 : ((ABL & 4096) ? 4 : 3)) 
         L = (int)(blockIdx.x & 7) * P.chunk + (int)(blockIdx.x >> 3);
         if (L >= P.total) return;
     }
-    const int qblk = L % P.nq, b = (L / P.nq) % P.B, h = L / (P.nq * P.B);
+    // Work order inside an XCD's range.  Default: query blocks fastest -- the workgroups in flight on one L2 share the K / V^T
+    // of one (batch, head), and a head's bias (2.4 MB at 1088 tokens) is read by one XCD only.  P.flags & 2: BATCH fastest
+    // -- for sequences whose bias no longer fits an L2 (4160 tokens: 34.6 MB per head) the workgroups in flight then read
+    // the SAME bias tiles at the same time (B of them per tile: one HBM read serves the batch), at the price of B times as
+    // many K / V^T streams through that L2 (1 MB each).
+    int qblk, b, h;
+    if (P.flags & 2) { b = L % P.B; qblk = (L / P.B) % P.nq; h = L / (P.B * P.nq); }
+    else { qblk = L % P.nq; b = (L / P.nq) % P.B; h = L / (P.nq * P.B); }
     const int q0 = qblk * (128 * NQB) + wave * (32 * NQB);
     const int Np = P.Np, H = P.H;
     const size_t tok_stride = (size_t)2 * H * AT_D;
@@ -763,10 +770,12 @@ DS_API int ds_attention_fwd(ds_ctx *ctx, const void *qk, const void *vt, const v
         hipStream_t st2 = (hipStream_t)stream;
         static const int late_env = getenv("DS_ATT_LATE") ? atoi(getenv("DS_ATT_LATE")) : -1;        // A/B switch, see option 4096
         const int late = late_env >= 0 ? late_env : (bias ? 0 : 1);
+        // batch-fastest work order when one head's packed bias exceeds an L2 (see the kernel); DS_ATT_ORDER=0/1 overrides
+        static const int order_env = getenv("DS_ATT_ORDER") ? atoi(getenv("DS_ATT_ORDER")) : -1;
+        const int batch_fastest = order_env >= 0 ? order_env : (bias && B > 1 && (size_t)Np * Np * 2 > (size_t)(3u << 20) ? 1 : 0);
 #ifdef DS_EXPERIMENTS
         static const int ablate = (getenv("DS_ATT_ABLATE") ? atoi(getenv("DS_ATT_ABLATE")) : 0)    // timing experiments, wrong results
                                   | (getenv("DS_ATT_OPT") ? atoi(getenv("DS_ATT_OPT")) : 0);        // options, correct results
-        P.flags = ablate;
 #define A2_ABL(BI_, M_) case M_: hipLaunchKernelGGL((k_attention_fwd2<0, BI_, 2, M_>), grid2, dim3(AT_THREADS), 0, st2, P); break;
 #define A2_EXPERIMENT(BF_, BI_)                                                                                         \
             if (ablate && BF_ == 0 && nqb == 2) {                                                                       \
@@ -785,6 +794,7 @@ DS_API int ds_attention_fwd(ds_ctx *ctx, const void *qk, const void *vt, const v
             else if (nqb == 1) hipLaunchKernelGGL((k_attention_fwd2<BF_, BI_, 1, 256>), grid2, dim3(AT_THREADS), 0, st2, P); \
             else hipLaunchKernelGGL((k_attention_fwd2<BF_, BI_, 2, 256>), grid2, dim3(AT_THREADS), 0, st2, P);          \
         } while (0)
+        if (batch_fastest) P.flags |= 2;
         if (dtype == DS_DTYPE_F16) { if (bias) A2_LAUNCH(0, 1); else A2_LAUNCH(0, 0); }
         else { if (bias) A2_LAUNCH(1, 1); else A2_LAUNCH(1, 0); }
         DS_HIP_CHECK(hipGetLastError());

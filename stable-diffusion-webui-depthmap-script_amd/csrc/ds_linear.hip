@@ -510,15 +510,21 @@ __global__ __launch_bounds__(LN_THREADS) void k_linear256(LinParams P)
 // A persistent launch of T tiles on G workgroups costs ceil(T / G) rounds; the token GEMMs of an encoder block at batch 32 are
 // 544 tiles (N = 1024: 2.125 -> 3 rounds) and 1088 tiles (N = 2048: 4.25 -> 5).  The last, mostly empty round is replaced: the
 // persistent kernel walks the first T - R positions of the tile list (a whole number of rounds), and this kernel renders the R
-// left-over tiles as 8 R pieces of 128 x 64 outputs -- one piece per workgroup, so the whole chip works on them at once.
-// Inside a workgroup the 8 waves split K (wave w takes the K range [w K / 8, (w + 1) K / 8) in steps of 32), each wave holds a
-// full 128 x 64 partial in registers, fed straight from global memory (nothing is shared between waves, so there is no LDS
-// staging: two register buffers of 12 fragment loads each), and the partials are summed through LDS in a fixed order (two
-// halves of 128 KB; wave w ends up with the 32 x 32 block w and runs the epilogue of that block).  No inter-workgroup
-// communication, no atomics: the result is bit-reproducible.  A piece reads (128 + 64) rows of K, where a full tile reads 512
-// for 8 times the outputs: 3 x the operand traffic per output, on 1/17 .. 1/9 of the launch.
+// left-over tiles as 8 R pieces of 128 x 64 outputs -- one piece per workgroup, two workgroups per CU, so the whole chip works
+// on them at once.  A piece is a small LDS-staged GEMM of its own: 8 waves as 4 x 2 blocks of 32 x 32 (one MFMA accumulator
+// each), K in tiles of 64 staged by LDS-DMA into a ring of three 24 KB slots (x: 128 rows, W: 64 rows, 128 bytes each, the
+// swizzle of k_linear256: applied to the source address, undone on the fragment read), one barrier per K-tile:
+//     wait for K-tile t (counted: t + 1 stays in flight) | barrier | stage K-tile t + 2 into the slot of t - 1 | fragments | 4 MFMAs
+//   read-after-write: every wave has waited for ITS pieces of K-tile t before the barrier, the reads come after it;
+//   write-after-read: the slot of K-tile t - 1 is re-staged after the barrier of iteration t, which every wave reaches only
+//     after its MFMAs of iteration t - 1 have consumed its fragments of that slot.
+// (Round 3's first version split K over the 8 waves and fed every wave from global memory with fragment-shaped loads --
+// 32-byte pieces of 32 different lines per instruction: 29 us per piece at K = 1024 and 88 us at K = 4096, slower than the
+// round it replaced; profiles/round3_microbench_gemms_v1.txt.)  No inter-workgroup communication, bit-reproducible.
+#define RG_SLOT 24576            // one K-tile in LDS: x rows 0..127 (16 KB) | W rows 0..63 (8 KB)
+#define RG_LDS_BYTES (3 * RG_SLOT)
 template <int BF16, int EPI, int RES, int VT>
-__global__ __launch_bounds__(LN_THREADS) void k_linear_ragged(LinParams P)
+__global__ __launch_bounds__(LN_THREADS, 4) void k_linear_ragged(LinParams P)
 {
     typedef ln_traits<BF16> TR;
     typedef typename TR::T T;
@@ -532,79 +538,63 @@ __global__ __launch_bounds__(LN_THREADS) void k_linear_ragged(LinParams P)
     int bm0, bn0;
     ln_tile_origin(P, tile, bm0, bn0);
     const int row0 = bm0 + (piece >> 2) * 128, col0 = bn0 + (piece & 3) * 64;
-    const int K = P.K;
-    const int nh = K >> 5;
-    const int h0 = wid * nh / 8, h1 = (wid + 1) * nh / 8;
-    // fragment loads: lane (hi, l31) reads k = 16 ks + 8 hi .. + 7 of row l31 of a 32-row block (the MFMA operand as it is)
-    const T *xa = (const T *)P.x + (size_t)(row0 + l31) * K + 8 * hi;
-    const T *wa = (const T *)P.w + (size_t)(col0 + l31) * K + 8 * hi;
-    const size_t blk = (size_t)32 * K;
-
-    lf32x16 acc[4][2];                     // [32-row block of the 128 rows][32-column block of the 64 columns]
+    const int K = P.K, nt = K >> 6;
+    const unsigned rowbytes = (unsigned)K * (unsigned)sizeof(T);
+    // staging: a 1 KB chunk = 8 rows x 128 bytes, LDS row j = 8 c + (lane >> 3), LDS slot lane & 7 holds SOURCE slot
+    // (lane & 7) ^ ((j >> 1) & 7).  Wave w stages x chunks 2 w, 2 w + 1 (rows 16 w .. 16 w + 15) and W chunk w (rows 8 w .. + 7)
+    unsigned srcA[2], srcB;
 #pragma unroll
-    for (int a = 0; a < 4; ++a)
-#pragma unroll
-        for (int b = 0; b < 2; ++b)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
-    V8 fa0[4][2], fb0[2][2], fa1[4][2], fb1[2][2];
-#define RG_LOAD(FA, FB, h)                                                                                               \
-    do {                                                                                                                 \
-        const int kb_ = (h) * 32;                                                                                        \
-        _Pragma("unroll") for (int a_ = 0; a_ < 4; ++a_) _Pragma("unroll") for (int ks_ = 0; ks_ < 2; ++ks_)              \
-            FA[a_][ks_] = *(const V8 *)(xa + a_ * blk + kb_ + 16 * ks_);                                                  \
-        _Pragma("unroll") for (int b_ = 0; b_ < 2; ++b_) _Pragma("unroll") for (int ks_ = 0; ks_ < 2; ++ks_)              \
-            FB[b_][ks_] = *(const V8 *)(wa + b_ * blk + kb_ + 16 * ks_);                                                  \
-    } while (0)
-#define RG_MMA(FA, FB)                                                                                                   \
-    do {                                                                                                                 \
-        _Pragma("unroll") for (int ks_ = 0; ks_ < 2; ++ks_) _Pragma("unroll") for (int a_ = 0; a_ < 4; ++a_)              \
-            _Pragma("unroll") for (int b_ = 0; b_ < 2; ++b_) acc[a_][b_] = TR::mfma(FB[b_][ks_], FA[a_][ks_], acc[a_][b_]); \
-    } while (0)
-    if (h0 < h1) {
-        RG_LOAD(fa0, fb0, h0);
-        for (int h = h0; h < h1; h += 2) {
-            const bool two = h + 1 < h1;
-            if (two) RG_LOAD(fa1, fb1, h + 1);
-            RG_MMA(fa0, fb0);
-            if (two) {
-                if (h + 2 < h1) RG_LOAD(fa0, fb0, h + 2);
-                RG_MMA(fa1, fb1);
-            }
-        }
+    for (int i = 0; i < 2; ++i) {
+        const int j = 8 * (2 * wid + i) + (lane >> 3);
+        srcA[i] = (unsigned)j * rowbytes + (unsigned)(((lane & 7) ^ ((j >> 1) & 7)) << 4);
     }
-#undef RG_LOAD
-#undef RG_MMA
-
-    // ---- sum of the 8 partials: LDS as [4 blocks][8 source waves][4 register quads][64 lanes] float4 (lane-contiguous
-    // 16-byte accesses: conflict free), blocks 0-3 in the first half (summed by waves 0-3), blocks 4-7 in the second
-    typedef float lf32x4 __attribute__((ext_vector_type(4)));
-    lf32x4 *red = (lf32x4 *)lds;
+    {
+        const int j = 8 * wid + (lane >> 3);
+        srcB = (unsigned)j * rowbytes + (unsigned)(((lane & 7) ^ ((j >> 1) & 7)) << 4);
+    }
+    const unsigned char *xb = (const unsigned char *)P.x + (size_t)row0 * rowbytes;
+    const unsigned char *wb = (const unsigned char *)P.w + (size_t)col0 * rowbytes;
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) void *)lds;
+#define RG_STAGE(kt_)                                                                                                    \
+    do {                                                                                                                 \
+        const int kc_ = min((kt_), nt - 1);            /* past the end: a harmless re-load into a slot nobody reads */      \
+        const unsigned sl_ = lds0 + (unsigned)((kt_) % 3) * RG_SLOT;                                                      \
+        const unsigned char *xa_ = xb + (size_t)kc_ * 128, *wa_ = wb + (size_t)kc_ * 128;                                 \
+        ln_dma_s(xa_, srcA[0], sl_ + (unsigned)(2 * wid) * 1024u);                                                        \
+        ln_dma_s(xa_, srcA[1], sl_ + (unsigned)(2 * wid + 1) * 1024u);                                                    \
+        ln_dma_s(wa_, srcB, sl_ + 16384u + (unsigned)wid * 1024u);                                                        \
+    } while (0)
+    // fragment reads: lane reads LDS row l31 of its 32-row block, 16-byte slot 2 ks + hi, swizzled by the row
+    const int br = wid >> 1, bc = wid & 1;               // this wave's 32 x 32 block of the piece: rows 32 br, columns 32 bc
+    unsigned offA[4], offB[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        const unsigned sl = (unsigned)((2 * ks + hi) ^ ((lane >> 1) & 7)) << 4;
+        offA[ks] = (unsigned)(br * 32 + l31) * 128u + sl;
+        offB[ks] = 16384u + (unsigned)(bc * 32 + l31) * 128u + sl;
+    }
     lf32x16 mine;
 #pragma unroll
     for (int r = 0; r < 16; ++r) mine[r] = 0.f;
+
+    RG_STAGE(0);
+    RG_STAGE(1);
+    for (int kt = 0; kt < nt; ++kt) {
+        LN_WAIT_VM(3);                                   // this wave's pieces of K-tile kt have landed (kt + 1 stays in flight)
+        LN_BARRIER();
+        RG_STAGE(kt + 2);
+        const unsigned char *sb = lds + (kt % 3) * RG_SLOT;
+        V8 fa[4], fb[4];
 #pragma unroll
-    for (int half = 0; half < 2; ++half) {
-#pragma unroll
-        for (int bl = 0; bl < 4; ++bl)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const lf32x16 &src = acc[2 * half + (bl >> 1)][bl & 1];
-                red[((bl * 8 + wid) * 4 + q) * 64 + lane] = (lf32x4){src[4 * q], src[4 * q + 1], src[4 * q + 2], src[4 * q + 3]};
-            }
-        __syncthreads();
-        if ((wid >> 2) == half) {
-            const int bl = wid & 3;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                lf32x4 sum = red[((bl * 8 + 0) * 4 + q) * 64 + lane];
-#pragma unroll
-                for (int w = 1; w < 8; ++w) sum += red[((bl * 8 + w) * 4 + q) * 64 + lane];      // fixed order: reproducible
-                mine[4 * q] = sum[0]; mine[4 * q + 1] = sum[1]; mine[4 * q + 2] = sum[2]; mine[4 * q + 3] = sum[3];
-            }
+        for (int ks = 0; ks < 4; ++ks) {
+            fa[ks] = *(const V8 *)(sb + offA[ks]);
+            fb[ks] = *(const V8 *)(sb + offB[ks]);
         }
-        __syncthreads();
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) mine = TR::mfma(fb[ks], fa[ks], mine);
     }
+    LN_WAIT_VM(0);                                       // the trailing re-loads: nothing may still be writing LDS at exit
+#undef RG_STAGE
 
     // ---- epilogue of block wid = (32-row block wid >> 1, 32-column block wid & 1), as in k_linear256: register r = column
     // (r & 3) + 8 (r >> 2) + 4 hi of row l31; one permlane32 swap per register pair gives each lane 8 consecutive columns
@@ -662,7 +652,7 @@ static int ln_launch(ds_ctx *ctx, const LinParams &P0, hipStream_t stream)
     if (!(attr_done.load(std::memory_order_relaxed) & bit)) {
         DS_HIP_CHECK(hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, LN_LDS_BYTES));
         if constexpr (CONV == 0)
-            DS_HIP_CHECK(hipFuncSetAttribute((const void *)k_linear_ragged<BF16, EPI, RES, VT>, hipFuncAttributeMaxDynamicSharedMemorySize, LN_LDS_BYTES));
+            DS_HIP_CHECK(hipFuncSetAttribute((const void *)k_linear_ragged<BF16, EPI, RES, VT>, hipFuncAttributeMaxDynamicSharedMemorySize, RG_LDS_BYTES));
         attr_done.fetch_or(bit, std::memory_order_relaxed);
     }
     if (!ctx->ncu) {
@@ -688,7 +678,7 @@ static int ln_launch(ds_ctx *ctx, const LinParams &P0, hipStream_t stream)
     P.n_main = ntiles - ragged;
     hipLaunchKernelGGL(fn, dim3(P.n_main < grid ? P.n_main : grid), dim3(LN_THREADS), LN_LDS_BYTES, stream, P);
     if constexpr (CONV == 0) {
-        if (ragged) hipLaunchKernelGGL((k_linear_ragged<BF16, EPI, RES, VT>), dim3(8 * ragged), dim3(LN_THREADS), LN_LDS_BYTES, stream, P);
+        if (ragged) hipLaunchKernelGGL((k_linear_ragged<BF16, EPI, RES, VT>), dim3(8 * ragged), dim3(LN_THREADS), RG_LDS_BYTES, stream, P);
     }
     DS_HIP_CHECK(hipGetLastError());
     return DS_OK;
