@@ -74,6 +74,7 @@ struct LinParams {
     int H, W, C, cpt, magic;    // CONV: image height / width, input channels, K-tiles per tap (C / 64), 65536 / cpt + 1
     long long ldy;              // row stride of y (and res1 / res2) in elements
     const void *gamma;          // EPI 3: per-column factor applied to (acc + bias) before the addends (LayerScale)
+    int early;                  // 1: the next tile's prologue DMAs are issued BEFORE this tile's epilogue (see the tile loop)
     int n_main;                 // the persistent kernel walks positions [0, n_main) of the tile list; k_linear_ragged takes the rest
     int vt_np, vt_c;            // VT: column j of the GEMM is token j % vt_np of batch element j / vt_np, the output is [batch][vt_c rows][vt_np]
     unsigned vt_magic;          // VT: floor(2^32 / vt_np) + 1  (j / vt_np == umulhi(j, vt_magic) for j * vt_np < 2^32)
@@ -273,6 +274,25 @@ __global__ __launch_bounds__(LN_THREADS) void k_linear256(LinParams P)
         offA[ks] = (unsigned)(wr * 64 + (lane & 31)) * 128u + sl;
         offB[ks] = LN_B_BASE + (unsigned)(wc * 32 + (lane & 31)) * 128u + sl;
     }
+    V8 bv[2][2];         // epilogue: bias of this wave's columns, [W half][k]: 8 columns each, kept packed
+    // loaded BEFORE the last iteration of a tile (in flight under its MFMAs).  Always exactly 4 loads -- a null bias reads 16
+    // valid bytes of W instead and is zeroed afterwards -- because the last iteration's counted waits include them.  (The
+    // LayerScale vector of EPI 3 is loaded in the epilogue next to the residuals: that variant waits there anyway.)
+#define LN_LOAD_BIAS()                                                                                                   \
+    do {                                                                                                                 \
+        const T *bias_ = (const T *)P.bias;                                                                              \
+        _Pragma("unroll") for (int hb_ = 0; hb_ < 2; ++hb_) _Pragma("unroll") for (int k_ = 0; k_ < 2; ++k_) {           \
+            const int c_ = bn0 + wc * 64 + hb_ * 32 + 8 * (lane >> 5) + 16 * k_;                                         \
+            bv[hb_][k_] = *(const V8 *)(bias_ ? bias_ + c_ : (const T *)P.w);                                            \
+        }                                                                                                                \
+    } while (0)
+#define LN_ZERO_NULL_BIAS()                                                                                              \
+    do {                                                                                                                 \
+        if (!P.bias) {                                                                                                   \
+            _Pragma("unroll") for (int hb_ = 0; hb_ < 2; ++hb_) _Pragma("unroll") for (int k_ = 0; k_ < 2; ++k_)         \
+                _Pragma("unroll") for (int t_ = 0; t_ < 8; ++t_) bv[hb_][k_][t_] = (T)0.f;                               \
+        }                                                                                                                \
+    } while (0)
     V8 fa[2][2][4];      // [half][row block][k step]   x fragments
     V8 fb[2][4];         // [half][k step]              W fragments
     lf32x16 acc[2][2][2];  // [x half][row block][W half]
@@ -335,24 +355,42 @@ __global__ __launch_bounds__(LN_THREADS) void k_linear256(LinParams P)
 #define LN_MEM(READ, STAGE)                                                                                              \
     do { READ; STAGE; } while (0)
 
-    auto iteration = [&](const int i, auto last_c) {
-        constexpr bool LAST = decltype(last_c)::value;
+    // KIND 0: an iteration in the middle of a tile; 1: the last one (nothing left to stage, the queue is drained 10, 8, .. 0);
+    // 2: the FIRST iteration of a tile in early mode.  There the queue of this wave holds, oldest first, the 14 prologue DMAs
+    // (issued before the previous tile's epilogue), that epilogue's 16 stores, then this iteration's DMAs: "everything but
+    // the last 5 half-tiles has landed" is vmcnt(10 + 16) as long as the awaited DMA is OLDER than the stores -- phases 0..4
+    // wait for prologue half-tiles -- and the usual vmcnt(10) from phase 5 on (which then also waits for the stores to
+    // retire: by that time they have had five phases of MFMA work to drain under).  The counter is in order, so a count
+    // that is too high would under-wait: the 16 is exact (one 16-byte store per (ha, rb, hb, k) in every epilogue variant;
+    // the residual loads of an epilogue are consumed, i.e. retired, before its stores are issued).
+    auto iteration = [&](const int i, auto kind_c) {
+        constexpr int KIND = decltype(kind_c)::value;
+        constexpr bool LAST = KIND == 1;
         const int e2 = 2 * i + 2, o2 = 2 * i + 3;
+        // (KIND 1: the 4 bias loads issued just before this iteration are YOUNGER than every DMA its phases
+        // 0..4 wait for, so they add to the count; phase 5 waits for everything)
+#define LN_WAIT_HEAD()                                                                                                   \
+        do {                                                                                                             \
+            if constexpr (KIND == 2) LN_WAIT_VM(26);                                                                     \
+            else if constexpr (KIND == 1) LN_WAIT_VM(14);                                                                \
+            else LN_WAIT_VM(10);                                                                                         \
+        } while (0)
         // phase 0
-        LN_MEM(LN_READ_B(0, 0), LN_STAGE(1, 2 * i + 1, 1)); LN_WAIT_VM(10);
+        LN_MEM(LN_READ_B(0, 0), LN_STAGE(1, 2 * i + 1, 1)); LN_WAIT_HEAD();
         LN_PHASE_END(0, 0);
         // phase 1
-        if constexpr (!LAST) { LN_MEM(LN_READ_B(1, 0), LN_STAGE(0, e2, 0)); LN_WAIT_VM(10); } else { LN_READ_B(1, 0); LN_WAIT_VM(8); }
+        if constexpr (!LAST) { LN_MEM(LN_READ_B(1, 0), LN_STAGE(0, e2, 0)); LN_WAIT_HEAD(); } else { LN_READ_B(1, 0); LN_WAIT_VM(12); }
         LN_PHASE_END(0, 1);
         // phase 2
-        if constexpr (!LAST) { LN_MEM(LN_READ_A(1, 0), LN_STAGE(2, e2, 0)); LN_WAIT_VM(10); } else { LN_READ_A(1, 0); LN_WAIT_VM(6); }
+        if constexpr (!LAST) { LN_MEM(LN_READ_A(1, 0), LN_STAGE(2, e2, 0)); LN_WAIT_HEAD(); } else { LN_READ_A(1, 0); LN_WAIT_VM(10); }
         LN_PHASE_END(1, 1);
         // phase 3
-        if constexpr (!LAST) { LN_MEM(LN_READ_A(0, 1), LN_STAGE(3, e2, 0)); LN_WAIT_VM(10); } else { LN_READ_A(0, 1); LN_WAIT_VM(4); }
+        if constexpr (!LAST) { LN_MEM(LN_READ_A(0, 1), LN_STAGE(3, e2, 0)); LN_WAIT_HEAD(); } else { LN_READ_A(0, 1); LN_WAIT_VM(8); }
         LN_PHASE_END(1, 0);
         // phase 4
-        if constexpr (!LAST) { LN_MEM(LN_READ_B(0, 1), LN_STAGE(1, e2, 0)); LN_WAIT_VM(10); } else { LN_READ_B(0, 1); LN_WAIT_VM(2); }
+        if constexpr (!LAST) { LN_MEM(LN_READ_B(0, 1), LN_STAGE(1, e2, 0)); LN_WAIT_HEAD(); } else { LN_READ_B(0, 1); LN_WAIT_VM(6); }
         LN_PHASE_END(0, 0);
+#undef LN_WAIT_HEAD
         // phase 5
         if constexpr (!LAST) { LN_MEM(LN_READ_B(1, 1), LN_STAGE(0, o2, 1)); LN_WAIT_VM(10); } else { LN_READ_B(1, 1); LN_WAIT_VM(0); }
         LN_PHASE_END(0, 1);
@@ -367,6 +405,16 @@ __global__ __launch_bounds__(LN_THREADS) void k_linear256(LinParams P)
         const unsigned long long t0 = wall_clock64();
         while (wall_clock64() - t0 < (unsigned long long)LN_STAGGER()) __builtin_amdgcn_s_sleep(32);
     }
+    // ---- the tile loop.  Early mode (P.early, the default): the NEXT tile's 14 prologue DMAs are issued right after this
+    // tile's last barrier, BEFORE its epilogue -- their latency runs under the epilogue's arithmetic, and the epilogue's 16
+    // stores drain under the first phases of the next tile instead of in front of them (iteration KIND 2 counts them).  The
+    // bias / LayerScale vectors of the epilogue are loaded before the last iteration and waited for before the DMAs are
+    // issued: a compiler-generated wait for a load issued AFTER the DMAs would wait for the DMAs too (the counter is in
+    // order and the compiler does not see inline-asm loads).  The residual loads of the RES variants stay where they were:
+    // their wait covers the DMAs, which have had the bias arithmetic of the first rows to land under.
+    // Late mode (DS_LIN_EARLY=0, round 2's order): prologue after the epilogue's stores.
+    const bool early = P.early != 0;
+    bool stores_ahead = false;
     set_tile(blockIdx.x);
     LN_PROLOGUE();
     for (int orig = blockIdx.x;;) {
@@ -378,26 +426,48 @@ __global__ __launch_bounds__(LN_THREADS) void k_linear256(LinParams P)
             for (int c = 0; c < 2; ++c)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[a][b][c][r] = 0.f;
-    // In the queue ahead of the prologue's 14 loads: nothing (first tile) or the previous tile's epilogue stores, which
-    // retire first (the counter is in order): "all but the last 10" covers A0 and B0 of K-tile 0 either way.
-    LN_WAIT_VM(10);
+    // Late mode: in the queue ahead of the prologue's 14 loads is nothing (first tile) or the previous tile's epilogue stores,
+    // which retire first (the counter is in order): "all but the last 10" covers A0 and B0 of K-tile 0 either way.
+    // Early mode: [14 DMAs, 16 stores]: A0 and B0 of K-tile 0 are the 4 oldest of 30; the first tile of a workgroup has no
+    // stores behind its DMAs and simply waits for all of them (iteration KIND 2's counts then never under-wait).
+    if (!early) LN_WAIT_VM(10);
+    else if (stores_ahead) LN_WAIT_VM(26);
+    else LN_WAIT_VM(0);
     LN_BARRIER();
     LN_READ_A(0, 0);
     LN_WAIT_LGKM0();                      // retired here: A0 of buffer 0 is re-staged in phase 1
     if (wr == 1) LN_BARRIER();            // the stagger
     if (LN_ABLATE(2)) {
+        LN_LOAD_BIAS();
         LN_WAIT_VM(0);
         if (wr == 0) LN_BARRIER();
     } else {
-        for (int i = 0; i < ni - 1; ++i) iteration(i, std::false_type());
-        iteration(ni - 1, std::true_type());
+        int i0 = 0;
+        if (early && ni >= 2) { iteration(0, std::integral_constant<int, 2>()); i0 = 1; }
+        for (int i = i0; i < ni - 1; ++i) iteration(i, std::integral_constant<int, 0>());
+        LN_LOAD_BIAS();
+        iteration(ni - 1, std::integral_constant<int, 1>());
         if (wr == 0) LN_BARRIER();                         // wave-row 0 arrives at wave-row 1's last barrier
     }
-    // every fragment read of this tile was retired before that barrier: LDS is free for the next tile's prologue, which is
-    // issued AFTER this tile's epilogue stores (its latency then runs under the drain of the stores; the epilogue's own
-    // loads are all older than the DMA, so the compiler's waits for them never wait for the DMA)
+    // every fragment read of this tile was retired before that barrier: LDS is free for the next tile's prologue
     const int cbm0 = bm0, cbn0 = bn0;
     const int next = orig + (int)gridDim.x;
+    const int hi8 = 8 * (lane >> 5);
+    LN_ZERO_NULL_BIAS();
+    T *yb = (T *)P.y;
+    const T *r1 = (const T *)P.res1, *r2 = (const T *)P.res2;
+    if (early && next < nwg) {
+        // the bias vectors have been in flight since before the last iteration: waiting for them HERE (the empty
+        // asm statement uses them) keeps every compiler-generated wait for them in front of the DMAs
+#pragma unroll
+        for (int hb = 0; hb < 2; ++hb)
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                asm volatile("" ::"v"(bv[hb][k]));
+            }
+        set_tile(next);
+        LN_PROLOGUE();
+    }
 
     // ---- epilogue ---------------------------------------------------------------------------------------------------------
     // Register r of a 32 x 32 accumulator block = column (r & 3) + 8 (r >> 2) + 4 (lane >> 5) of row lane & 31: a lane holds
@@ -405,37 +475,15 @@ __global__ __launch_bounds__(LN_THREADS) void k_linear256(LinParams P)
     // (g = 2k, 2k+1) exchanges them so that lanes 0-31 end up with columns 16k .. 16k+7 and lanes 32-63 with 16k+8 .. 16k+15
     // of their row, in fp32: bias, residuals (16-byte loads, all issued before the arithmetic) and the activation are applied
     // on 8 consecutive columns and the result leaves as one 16-byte store per lane (32 bytes of a row per instruction).
-    // TRANSPOSE (the plain dense GEMM only): the 16-byte results of a 32-row block take a turn through the wave's own 16 KB
-    // of LDS (free since the last barrier; rows of 128 bytes, 16-byte slot ^= row & 7: conflict-free both ways) and leave as
-    // FULL 128-byte lines, 8 lanes per row -- a store instruction then touches 8 lines instead of 32.  Measured on one box
-    // (direct -> transposed): plain GEMMs qk 160 -> 152 us, proj 90 -> 88, K = 1024 round 34.8 -> 33.1; but fc1 + GELU
-    // 303 -> 311 (its epilogue is VALU-bound and hides the stores) and the convolution with a residual 598 -> 645: those
-    // keep the direct store.
-    constexpr bool TRANSPOSE = (CONV == 0 && EPI == 0 && RES == 0 && VT == 0);
-    T *yb = (T *)P.y;
-    const T *bias = (const T *)P.bias;
-    const T *r1 = (const T *)P.res1, *r2 = (const T *)P.res2;
-    const int hi8 = 8 * (lane >> 5);
-    V8 bv[2][2];                                                // [W half][k]: 8 columns each, kept packed
-#pragma unroll
-    for (int hb = 0; hb < 2; ++hb)
-#pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            if (bias) {
-                bv[hb][k] = *(const V8 *)(bias + cbn0 + wc * 64 + hb * 32 + hi8 + 16 * k);
-            } else {
-#pragma unroll
-                for (int t = 0; t < 8; ++t) bv[hb][k][t] = (T)0.f;
-            }
-        }
-    V8 gv[2][2];                                                // EPI 3: the per-column factors, packed like the bias
+    // (Round 2 sent the plain GEMM's results through LDS to store full 128-byte lines: qk 160 -> 152 us.  In early mode that
+    // LDS already holds the next tile's operands, and the variant is gone.)
+    V8 gv[2][2];                                                // EPI 3: the per-column LayerScale factors, packed like the bias
     if (EPI == 3) {
 #pragma unroll
         for (int hb = 0; hb < 2; ++hb)
 #pragma unroll
             for (int k = 0; k < 2; ++k) gv[hb][k] = *(const V8 *)((const T *)P.gamma + cbn0 + wc * 64 + hb * 32 + hi8 + 16 * k);
     }
-    unsigned char *tl = lds + wid * 16384;                      // this wave's transpose area: 128 rows x 128 bytes
 #pragma unroll
     for (int ha = 0; ha < 2; ++ha)
 #pragma unroll
@@ -479,29 +527,17 @@ __global__ __launch_bounds__(LN_THREADS) void k_linear256(LinParams P)
                         o[t] = (T)u[0];
                         o[t + 1] = (T)u[1];
                     }
-                    if (!TRANSPOSE) {
-                        if (!LN_ABLATE(1)) *(V8 *)(yb + out_off(hb, k)) = o;
-                        else asm volatile("" ::"v"(o));
-                    } else {
-                        const int piece = hb * 4 + k * 2 + (lane >> 5);
-                        *(V8 *)(tl + rl * 128 + ((piece ^ (rl & 7)) << 4)) = o;
-                    }
-                }
-            if (TRANSPOSE) {
-#pragma unroll
-                for (int idx = 0; idx < 4; ++idx) {
-                    const int r2l = ha * 64 + rb * 32 + idx * 8 + (lane >> 3), piece = lane & 7;
-                    const V8 o = *(const V8 *)(tl + r2l * 128 + ((piece ^ (r2l & 7)) << 4));
-                    if (!LN_ABLATE(1)) *(V8 *)(yb + (size_t)(cbm0 + wr * 128 + r2l) * P.ldy + cbn0 + wc * 64 + piece * 8) = o;
+                    if (!LN_ABLATE(1)) *(V8 *)(yb + out_off(hb, k)) = o;
                     else asm volatile("" ::"v"(o));
                 }
-            }
         }
-    if (TRANSPOSE) LN_BARRIER();                                // every wave is done with its transpose area: LDS is free again
     if (next >= nwg) break;
     orig = next;
-    set_tile(orig);
-    LN_PROLOGUE();
+    if (!early) {
+        set_tile(orig);
+        LN_PROLOGUE();
+    }
+    stores_ahead = true;
     }
 }
 
@@ -512,19 +548,20 @@ __global__ __launch_bounds__(LN_THREADS) void k_linear256(LinParams P)
 // persistent kernel walks the first T - R positions of the tile list (a whole number of rounds), and this kernel renders the R
 // left-over tiles as 8 R pieces of 128 x 64 outputs -- one piece per workgroup, two workgroups per CU, so the whole chip works
 // on them at once.  A piece is a small LDS-staged GEMM of its own: 8 waves as 4 x 2 blocks of 32 x 32 (one MFMA accumulator
-// each), K in tiles of 64 staged by LDS-DMA into a ring of three 24 KB slots (x: 128 rows, W: 64 rows, 128 bytes each, the
+// each), K in tiles of 64 staged by LDS-DMA into a ring of S 24 KB slots (x: 128 rows, W: 64 rows, 128 bytes each, the
 // swizzle of k_linear256: applied to the source address, undone on the fragment read), one barrier per K-tile:
-//     wait for K-tile t (counted: t + 1 stays in flight) | barrier | stage K-tile t + 2 into the slot of t - 1 | fragments | 4 MFMAs
+//     wait for K-tile t (counted: t + 1 .. t + S - 2 stay in flight) | barrier | stage K-tile t + S - 1 into the slot of t - 1 | fragments | 4 MFMAs
 //   read-after-write: every wave has waited for ITS pieces of K-tile t before the barrier, the reads come after it;
 //   write-after-read: the slot of K-tile t - 1 is re-staged after the barrier of iteration t, which every wave reaches only
 //     after its MFMAs of iteration t - 1 have consumed its fragments of that slot.
 // (Round 3's first version split K over the 8 waves and fed every wave from global memory with fragment-shaped loads --
 // 32-byte pieces of 32 different lines per instruction: 29 us per piece at K = 1024 and 88 us at K = 4096, slower than the
 // round it replaced; profiles/round3_microbench_gemms_v1.txt.)  No inter-workgroup communication, bit-reproducible.
+// S = slots of the ring: 3 (72 KB: two workgroups per CU, for launches with more pieces than CUs) or 6 (144 KB, one
+// workgroup per CU with five K-tiles in flight: a piece is bound by the latency of its DMA chain, not by its 4 MFMAs per K-tile)
 #define RG_SLOT 24576            // one K-tile in LDS: x rows 0..127 (16 KB) | W rows 0..63 (8 KB)
-#define RG_LDS_BYTES (3 * RG_SLOT)
-template <int BF16, int EPI, int RES, int VT>
-__global__ __launch_bounds__(LN_THREADS, 4) void k_linear_ragged(LinParams P)
+template <int BF16, int EPI, int RES, int VT, int S>
+__global__ __launch_bounds__(LN_THREADS, S == 3 ? 4 : 2) void k_linear_ragged(LinParams P)
 {
     typedef ln_traits<BF16> TR;
     typedef typename TR::T T;
@@ -558,7 +595,7 @@ __global__ __launch_bounds__(LN_THREADS, 4) void k_linear_ragged(LinParams P)
 #define RG_STAGE(kt_)                                                                                                    \
     do {                                                                                                                 \
         const int kc_ = min((kt_), nt - 1);            /* past the end: a harmless re-load into a slot nobody reads */      \
-        const unsigned sl_ = lds0 + (unsigned)((kt_) % 3) * RG_SLOT;                                                      \
+        const unsigned sl_ = lds0 + (unsigned)((kt_) % S) * RG_SLOT;                                                      \
         const unsigned char *xa_ = xb + (size_t)kc_ * 128, *wa_ = wb + (size_t)kc_ * 128;                                 \
         ln_dma_s(xa_, srcA[0], sl_ + (unsigned)(2 * wid) * 1024u);                                                        \
         ln_dma_s(xa_, srcA[1], sl_ + (unsigned)(2 * wid + 1) * 1024u);                                                    \
@@ -577,13 +614,14 @@ __global__ __launch_bounds__(LN_THREADS, 4) void k_linear_ragged(LinParams P)
 #pragma unroll
     for (int r = 0; r < 16; ++r) mine[r] = 0.f;
 
-    RG_STAGE(0);
-    RG_STAGE(1);
+#pragma unroll
+    for (int t = 0; t < S - 1; ++t) RG_STAGE(t);
     for (int kt = 0; kt < nt; ++kt) {
-        LN_WAIT_VM(3);                                   // this wave's pieces of K-tile kt have landed (kt + 1 stays in flight)
+        // this wave's pieces of K-tile kt have landed (the S - 2 younger K-tiles, 3 DMAs each, stay in flight)
+        if constexpr (S == 3) LN_WAIT_VM(3); else LN_WAIT_VM(12);
         LN_BARRIER();
-        RG_STAGE(kt + 2);
-        const unsigned char *sb = lds + (kt % 3) * RG_SLOT;
+        RG_STAGE(kt + S - 1);                            // into the slot of K-tile kt - 1
+        const unsigned char *sb = lds + (kt % S) * RG_SLOT;
         V8 fa[4], fb[4];
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
@@ -651,8 +689,10 @@ static int ln_launch(ds_ctx *ctx, const LinParams &P0, hipStream_t stream)
     const uint64_t bit = 1ull << (ctx->device & 63);
     if (!(attr_done.load(std::memory_order_relaxed) & bit)) {
         DS_HIP_CHECK(hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, LN_LDS_BYTES));
-        if constexpr (CONV == 0)
-            DS_HIP_CHECK(hipFuncSetAttribute((const void *)k_linear_ragged<BF16, EPI, RES, VT>, hipFuncAttributeMaxDynamicSharedMemorySize, RG_LDS_BYTES));
+        if constexpr (CONV == 0) {
+            DS_HIP_CHECK(hipFuncSetAttribute((const void *)k_linear_ragged<BF16, EPI, RES, VT, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * RG_SLOT));
+            DS_HIP_CHECK(hipFuncSetAttribute((const void *)k_linear_ragged<BF16, EPI, RES, VT, 6>, hipFuncAttributeMaxDynamicSharedMemorySize, 6 * RG_SLOT));
+        }
         attr_done.fetch_or(bit, std::memory_order_relaxed);
     }
     if (!ctx->ncu) {
@@ -666,6 +706,10 @@ static int ln_launch(ds_ctx *ctx, const LinParams &P0, hipStream_t stream)
         if (g >= 8) grid = g;
     }
     LinParams P = P0;
+    P.early = getenv("DS_LIN_EARLY") ? atoi(getenv("DS_LIN_EARLY")) : 1;      // A/B switch (both orders give the same values)
+#ifdef DS_EXPERIMENTS
+    if (P.ablate) P.early = 0;               // the no-store ablation changes the store count the early mode's waits rely on
+#endif
     const int ntiles = P.nbm * P.nbn;
     // the ragged round (k_linear_ragged): when the last round of the persistent walk would be at most a quarter full, its
     // tiles are rendered as 128 x 64 pieces by the whole chip instead.  DS_LIN_RAGGED=0 switches it off (A/B runs).
@@ -678,7 +722,9 @@ static int ln_launch(ds_ctx *ctx, const LinParams &P0, hipStream_t stream)
     P.n_main = ntiles - ragged;
     hipLaunchKernelGGL(fn, dim3(P.n_main < grid ? P.n_main : grid), dim3(LN_THREADS), LN_LDS_BYTES, stream, P);
     if constexpr (CONV == 0) {
-        if (ragged) hipLaunchKernelGGL((k_linear_ragged<BF16, EPI, RES, VT>), dim3(8 * ragged), dim3(LN_THREADS), RG_LDS_BYTES, stream, P);
+        const int deep = getenv("DS_LIN_RAGGED_RING") ? atoi(getenv("DS_LIN_RAGGED_RING")) == 6 : 8 * ragged <= grid;
+        if (ragged && deep) hipLaunchKernelGGL((k_linear_ragged<BF16, EPI, RES, VT, 6>), dim3(8 * ragged), dim3(LN_THREADS), 6 * RG_SLOT, stream, P);
+        else if (ragged) hipLaunchKernelGGL((k_linear_ragged<BF16, EPI, RES, VT, 3>), dim3(8 * ragged), dim3(LN_THREADS), 3 * RG_SLOT, stream, P);
     }
     DS_HIP_CHECK(hipGetLastError());
     return DS_OK;

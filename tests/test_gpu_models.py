@@ -823,7 +823,7 @@ def test_linear_ragged_round_vt_and_fused_residual(gpu, dtype, tol):
     from src import _native
     g = torch.Generator().manual_seed(77)
     mk = lambda *s: torch.randn(s, generator=g)  # noqa: E731
-    old = {k: os.environ.get(k) for k in ("DS_LIN_GRID", "DS_LIN_RAGGED")}
+    old = {k: os.environ.get(k) for k in ("DS_LIN_GRID", "DS_LIN_RAGGED", "DS_LIN_EARLY", "DS_LIN_RAGGED_RING")}
     try:
         # (rows, out, in, grid): tiles % grid <= grid / 4 -> a ragged round of 1 .. 4 tiles
         for (m, n, k, grid) in [(4352, 256, 384, 8), (2304, 512, 1024, 8), (2637, 768, 640, 16), (4352, 256, 128, 8), (8448, 256, 256, 32)]:
@@ -847,6 +847,19 @@ def test_linear_ragged_round_vt_and_fused_residual(gpu, dtype, tol):
                 got = _native.linear_residual(x, w, b, gm, res)
                 assert (got.double() - want).abs().max().item() < tol * (1 + want.abs().max().item()), (m, n, k, gm is None)
                 assert torch.equal(_native.linear_residual(x, w, b, gm, res), got)
+        # schedule switches that must not change a single bit: the order of prologue DMAs and epilogue (DS_LIN_EARLY), the ring
+        # depth of the ragged kernel -- on a many-tiles-per-workgroup walk with every epilogue variant
+        os.environ["DS_LIN_GRID"] = "8"
+        x, w, b = mk(4352, 384).to(dtype).cuda(), (mk(256, 384) * 384 ** -0.5).to(dtype).cuda(), mk(256).to(dtype).cuda()
+        gam, res = mk(256).to(dtype).cuda(), mk(4352, 256).to(dtype).cuda()
+        outs = []
+        for early, ring in (("1", "3"), ("0", "3"), ("1", "6"), ("0", "6")):
+            os.environ["DS_LIN_EARLY"], os.environ["DS_LIN_RAGGED_RING"] = early, ring
+            outs.append((_native.linear(x, w, b, True), _native.linear(x, w, None, False), _native.linear_residual(x, w, b, gam, res)))
+        os.environ.pop("DS_LIN_EARLY"); os.environ.pop("DS_LIN_RAGGED_RING")
+        for o in outs[1:]:
+            assert all(torch.equal(a, c) for a, c in zip(o, outs[0])), "DS_LIN_EARLY / ring depth changed the values"
+        assert (outs[0][1].double() - _lin_ref(x, w)).abs().max().item() < tol * 10
         # V^T: [B, C, Np] out of h [B, Np, K]; (B, Np, C, K, grid)
         for (bb, npad, c, k, grid) in [(4, 320, 512, 256, 8), (2, 640, 256, 384, 256), (6, 128, 768, 128, 8)]:
             os.environ["DS_LIN_GRID"] = str(grid)

@@ -169,17 +169,19 @@ def linear_ab():
         ("fc2+res  34816x1024x4096", 2.0 * m * 1024 * 4096, lambda: nat.linear_residual(x4, w_2, b_2, gam, res), lambda: F.linear(x4, w_2, b_2)),
     ]
     for name, fl, hip, libf in cases:
-        t = {"ragged": [], "walk": [], "lib": []}
+        t = {"ragged": [], "walk": [], "lib": [], "late": []}
         for _ in range(3):
-            os.environ["DS_LIN_RAGGED"] = "1"
+            os.environ["DS_LIN_RAGGED"], os.environ["DS_LIN_EARLY"] = "1", "1"
             t["ragged"].append(timeit(hip, reps=10, warm=2))
-            os.environ["DS_LIN_RAGGED"] = "0"
+            os.environ["DS_LIN_EARLY"] = "0"
+            t["late"].append(timeit(hip, reps=10, warm=2))
+            os.environ["DS_LIN_RAGGED"], os.environ["DS_LIN_EARLY"] = "0", "1"
             t["walk"].append(timeit(hip, reps=10, warm=2))
             t["lib"].append(timeit(libf, reps=10, warm=2))
         os.environ["DS_LIN_RAGGED"] = "1"
-        r, wk, lb = min(t["ragged"]), min(t["walk"]), min(t["lib"])
-        print(f"gemm {name}: in-tree {r * 1e3:7.1f} us {fl / r / 1e9:6.0f} TF | without ragged round {wk * 1e3:7.1f} us | "
-              f"library (GEMM only) {lb * 1e3:7.1f} us {fl / lb / 1e9:6.0f} TF", flush=True)
+        r, wk, lb, lt = min(t["ragged"]), min(t["walk"]), min(t["lib"]), min(t["late"])
+        print(f"gemm {name}: in-tree {r * 1e3:7.1f} us {fl / r / 1e9:6.0f} TF | prologue after the epilogue (round 2 order) {lt * 1e3:7.1f} us | "
+              f"without ragged round {wk * 1e3:7.1f} us | library (GEMM only) {lb * 1e3:7.1f} us {fl / lb / 1e9:6.0f} TF", flush=True)
     # the LayerNorm pass behind the fused epilogues reads one operand instead of two
     xs, br = torch.randn(m, 1024, device=dev, dtype=dt), torch.randn(m, 1024, device=dev, dtype=dt)
     t2 = timeit(lambda: nat.residual_layernorm(xs, br, gam, gam, gam, 1e-6))
