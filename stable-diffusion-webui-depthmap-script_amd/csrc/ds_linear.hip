@@ -610,9 +610,9 @@ __global__ __launch_bounds__(LN_THREADS, S == 3 ? 4 : 2) void k_linear_ragged(Li
         offA[ks] = (unsigned)(br * 32 + l31) * 128u + sl;
         offB[ks] = 16384u + (unsigned)(bc * 32 + l31) * 128u + sl;
     }
-    lf32x16 mine;
+    lf32x16 mine, mine2;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) mine[r] = 0.f;
+    for (int r = 0; r < 16; ++r) mine[r] = mine2[r] = 0.f;
 
 #pragma unroll
     for (int t = 0; t < S - 1; ++t) RG_STAGE(t);
@@ -622,16 +622,25 @@ __global__ __launch_bounds__(LN_THREADS, S == 3 ? 4 : 2) void k_linear_ragged(Li
         LN_BARRIER();
         RG_STAGE(kt + S - 1);                            // into the slot of K-tile kt - 1
         const unsigned char *sb = lds + (kt % S) * RG_SLOT;
+        // all 8 fragment reads in flight at once, ONE wait, then two independent accumulation chains (a dependent MFMA
+        // costs its full 64-cycle latency; the first version -- read two, wait, one MFMA, four times -- spent 0.64 us per K-tile)
         V8 fa[4], fb[4];
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
             fa[ks] = *(const V8 *)(sb + offA[ks]);
             fb[ks] = *(const V8 *)(sb + offB[ks]);
         }
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) mine = TR::mfma(fb[ks], fa[ks], mine);
+        __builtin_amdgcn_sched_barrier(0);
+        LN_WAIT_LGKM0();
+        __builtin_amdgcn_sched_barrier(0);
+        mine = TR::mfma(fb[0], fa[0], mine);
+        mine2 = TR::mfma(fb[1], fa[1], mine2);
+        mine = TR::mfma(fb[2], fa[2], mine);
+        mine2 = TR::mfma(fb[3], fa[3], mine2);
     }
     LN_WAIT_VM(0);                                       // the trailing re-loads: nothing may still be writing LDS at exit
+#pragma unroll
+    for (int r = 0; r < 16; ++r) mine[r] += mine2[r];
 #undef RG_STAGE
 
     // ---- epilogue of block wid = (32-row block wid >> 1, 32-column block wid & 1), as in k_linear256: register r = column
