@@ -49,7 +49,8 @@ import numpy as np  # noqa: E402
 H = W = 1024
 HBM_PEAK_GBPS = 8000.0            # MI355X HBM3E spec peak (guides/MI355X_MICROARCH.md)
 MFMA_PEAK_TFLOPS = 2500.0         # dense f16/bf16 MFMA peak (same guide)
-PMC_SUMMARY = "profiles/round2_pmc_summary.json"
+PMC_SUMMARY = "profiles/round3_pmc_summary.json"      # tools/pmc_summary.py over rocprofv3 --pmc passes of THIS command
+KERNEL_STATS = "profiles/round3_kernel_stats.csv"     # rocprofv3 --kernel-trace --stats of THIS command
 
 DEPTH_KIND = "steps"
 
@@ -180,17 +181,41 @@ def cpu_baseline(model_name, net_size, net_h, distinct_units, seed, min_seconds,
 
 
 def traffic_from_profile(kernel, batch):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC summary (separate --pmc passes, FETCH_SIZE doubled
-    as MI355X_MICROARCH.md prescribes for gfx950).  bench.py cannot read PMC counters itself: this is a figure FROM A
-    PROFILE of the same command, labelled as such; None when the summary is missing or was taken at another batch size."""
+    """HBM bytes per launch of the kernel whose name contains `kernel`, from the committed rocprofv3 PMC summary of the default
+    bench command (separate --pmc passes for FETCH_SIZE and WRITE_SIZE, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes
+    for gfx950).  bench.py cannot read PMC counters itself: this is a figure FROM A PROFILE of the same command, labelled as
+    such; None when the summary is missing, was taken at another batch size, or lacks the kernel."""
     try:
         with open(os.path.join(ROOT, PMC_SUMMARY)) as f:
             j = json.load(f)
         if int(j.get("batch", -1)) != int(batch):
             return None
-        return {"hbm_bytes_per_launch": float(j[kernel]["hbm_bytes_per_launch"]), "source": PMC_SUMMARY}
+        for name, row in j.items():
+            if isinstance(row, dict) and kernel in name and "hbm_read_bytes" in row and "hbm_write_bytes" in row:
+                return {"hbm_bytes_per_launch": float(row["hbm_read_bytes"]) + float(row["hbm_write_bytes"]),
+                        "hbm_read_bytes": float(row["hbm_read_bytes"]), "hbm_write_bytes": float(row["hbm_write_bytes"]),
+                        "kernel": name, "dispatches": row.get("dispatches"), "source": PMC_SUMMARY}
     except Exception:
-        return None
+        pass
+    return None
+
+
+def in_step_from_profile(kernel, work, peak, unit_scale):
+    """Average duration of the kernel whose name contains `kernel` INSIDE the timed step, from the committed rocprofv3
+    --kernel-trace --stats summary of the default bench command, and what that duration means for `work` (flops or bytes per
+    launch): the microbenchmark figures beside it run the same launch shape on randn operands."""
+    try:
+        import csv
+        with open(os.path.join(ROOT, KERNEL_STATS)) as f:
+            for row in csv.DictReader(f):
+                if kernel in row["Name"]:
+                    ms = float(row["AverageNs"]) * 1e-6
+                    ach = work / (ms * 1e-3) / unit_scale
+                    return {"avg_kernel_ms": ms, "calls": int(row["Calls"]), "achieved": ach, "frac": ach / peak, "kernel": row["Name"],
+                            "source": KERNEL_STATS}
+    except Exception:
+        pass
+    return None
 
 
 def main():
@@ -398,8 +423,10 @@ def main():
         attn = {"bound": "mfma", "kernel": "k_attention_fwd", "achieved": attn_flops / (attn_ms * 1e-3) / 1e12,
                 "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": attn_flops / (attn_ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS,
                 "traffic": None,                          # PMC counters cannot be read from inside the run ...
-                "traffic_from_profile": traffic_from_profile("k_attention_fwd", batch) if args.config == "c3" else None,
+                "traffic_from_profile": traffic_from_profile("k_attention_fwd2", batch) if args.config == "c3" else None,
+                "in_step_from_profile": in_step_from_profile("k_attention_fwd2", attn_flops, MFMA_PEAK_TFLOPS, 1e12) if args.config == "c3" else None,
                 "algorithmic_flops_per_launch": attn_flops, "avg_kernel_ms": attn_ms, "operands": "random (randn)",
+                "source": "microbenchmark: separate launches at the in-step shape on randn operands, HIP events on the launch stream",
                 "launches_per_step": minfo["depth"], "shape": {"batch": batch, "tokens": n_tok, "heads": minfo["heads"], "bias": minfo["bias"]}}
     # ... and the in-tree MFMA GEMM (csrc/ds_linear.hip) at the shapes it runs at: fc1 + GELU of one encoder block, and the
     # 3x3 convolution of the decoder's last residual units (256 -> 256 at net/4 resolution), random operands
@@ -422,8 +449,10 @@ def main():
             lin_flops = 2.0 * m_rows * 4 * dim * dim
             lin = {"bound": "mfma", "kernel": "k_linear256 (fc1 + erf-GELU)", "achieved": lin_flops / (lin_ms * 1e-3) / 1e12,
                    "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": lin_flops / (lin_ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS,
-                   "traffic": None, "traffic_from_profile": traffic_from_profile("k_linear256", batch) if args.config == "c3" else None,
+                   "traffic": None, "traffic_from_profile": traffic_from_profile("k_linear256<0, 1, 0, 0, 0>", batch) if args.config == "c3" else None,
+                   "in_step_from_profile": in_step_from_profile("k_linear256<0, 1, 0, 0, 0>", lin_flops, MFMA_PEAK_TFLOPS, 1e12) if args.config == "c3" else None,
                    "algorithmic_flops_per_launch": lin_flops, "avg_kernel_ms": lin_ms, "operands": "random (randn)",
+                   "source": "microbenchmark: separate launches at the in-step shape on randn operands, HIP events on the launch stream",
                    "launches_per_step": minfo["depth"], "shape": {"rows": m_rows, "out_features": 4 * dim, "in_features": dim}}
         del xw, ww, bw
     if model is not None and vm.CONV_HIP and model_name.startswith("dpt_"):
@@ -446,6 +475,7 @@ def main():
                          "achieved": cv_flops / (cv_ms * 1e-3) / 1e12, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": cv_flops / (cv_ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS, "traffic": None,
                          "algorithmic_flops_per_launch": cv_flops, "avg_kernel_ms": cv_ms, "operands": "random (randn)",
+                         "source": "microbenchmark: separate launches at the in-step shape on randn operands, HIP events on the launch stream",
                          "shape": {"batch": batch, "height": hw[0], "width": hw[1], "in_channels": 256, "out_channels": 256}}
         del cv, xc
     torch.cuda.synchronize()
@@ -466,7 +496,9 @@ def main():
         achieved = batch * algo_bytes_stereo() / avg_render_s / 1e9
         stereo_roof = {"bound": "hbm", "kernel": "k_polylines", "achieved": achieved, "peak": HBM_PEAK_GBPS,
                        "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
-                       "traffic_from_profile": traffic_from_profile("k_polylines", batch) if (H, W) == (1024, 1024) else None,
+                       "traffic_from_profile": traffic_from_profile("k_polylines<", batch) if (H, W) == (1024, 1024) else None,
+                       "traffic_general_pass_from_profile": traffic_from_profile("k_polylines_general", batch) if (H, W) == (1024, 1024) else None,
+                       "source": "HIP events inside the C ABI around k_polylines + k_polylines_general, in the step, on the network's own depth",
                        "algorithmic_bytes_per_launch": batch * algo_bytes_stereo(),
                        "avg_kernel_ms": float(np.mean(render_ms)), "exact_fallback_ms": float(np.mean(exact_ms)),
                        "exact_fallback_rows": exact_rows, "general_pixels": general_px,

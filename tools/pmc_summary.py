@@ -41,6 +41,10 @@ def main():
         if "WRITE_SIZE" in row:
             row["hbm_write_bytes"] = row["WRITE_SIZE"] * 1024
         out[k] = row
+    for a in sys.argv[1:]:                      # --set key=value: header fields of the summary (round, batch, command)
+        if a.startswith("--set="):
+            k, v = a[6:].split("=", 1)
+            out[k] = int(v) if v.isdigit() else v
     print(json.dumps(out, indent=1, sort_keys=True))
 
 
