@@ -408,7 +408,7 @@ def _full_frame_depths():
       1  noisy: a smooth field + per-pixel noise of a few hundred codes, what a random-weight network's prediction looks
          like to the stereo kernel (> 10^5 'general' pixels per image: backward segments everywhere)
       2  adversarial: white-noise columns, quantised plateaus (four levels) and single-pixel spikes; at a divergence whose
-         pixel value is an integer multiple of 3 the plateaus give coincident breakpoints -- rows whose sweep is history
+         pixel value is an integer the plateaus give coincident breakpoints -- rows whose sweep is history
          dependent and must go through the exact fallback (test_full_frame_1024_exact_fallback_rows)"""
     rng = np.random.default_rng(77)
     H = W = 1024
