@@ -168,6 +168,7 @@ int ds_convert_to_i16(ds_ctx *ctx, const void *arr, int is_f64, int64_t count, u
 /* element types of the tensor-core entry points */
 #define DS_DTYPE_F16  1
 #define DS_DTYPE_BF16 2
+#define DS_DTYPE_F32  3       /* ds_preprocess_bicubic only */
 
 /*
  * ds_attention_fwd -- fused attention forward of one transformer block; replaces the q@k^T -> (+bias) -> softmax -> @v
@@ -198,6 +199,19 @@ int ds_attention_fwd(ds_ctx *ctx, const void *qk, const void *vt, const void *bi
  * Run once per (block, resolution); the packed operand is reused by every forward.
  */
 int ds_attention_bias_pack(ds_ctx *ctx, const float *bias, int H, int n, int Np, int dtype, void *packed, void *stream);
+
+/*
+ * ds_preprocess_bicubic -- image -> network input in one pass: the chain `cv2.cvtColor(.., COLOR_BGR2RGB) / 255.0`
+ * (src/depthmap_generation.py:381) -> Resize(.., INTER_CUBIC) -> NormalizeImage -> PrepareForNet (:457-476, dmidas/transforms.py;
+ * ddepth_anything_v2/depth_anything_v2/dpt.py:196-221) that estimatemidas / estimatedepthanything_v2 run on the host.
+ *   images  uint8 [batch, in_h, in_w, 3]
+ *   out     [batch, 3, out_h, out_w] in channels_last memory (physically [batch, out_h, out_w, 3]) of `dtype` (f16 / bf16 / f32):
+ *           out[b][c][y][x] = (bicubic(images[b][:, :, flip_channels ? 2 - c : c] / 255)(y, x) - mean[c]) / std[c]
+ * Resampling: the cubic convolution kernel (A = -0.75) on half-pixel centres, replicated border, no antialiasing -- cv2's
+ * INTER_CUBIC definition as torch's upsample_bicubic2d evaluates it (float32).  mean / std: 3 host floats each.
+ */
+int ds_preprocess_bicubic(ds_ctx *ctx, const void *images, void *out, int batch, int in_h, int in_w, int out_h, int out_w,
+                          int flip_channels, const float *mean, const float *std, int dtype, void *stream);
 
 /*
  * ds_residual_layernorm -- the element-wise part of a transformer block between two GEMMs, fused:

@@ -171,6 +171,105 @@ DS_API int ds_upsample_bilinear_nhwc(ds_ctx *ctx, const void *in, void *out, int
 }
 
 // ------------------------------------------------------------------------------------------------------------------------
+// ds_preprocess_bicubic: the image -> network-input chain of estimatemidas / estimatedepthanything_v2 in ONE pass
+// (src/depthmap_generation.py:381 `cvtColor(BGR2RGB) / 255`, :457-476 Resize(INTER_CUBIC) -> NormalizeImage -> PrepareForNet;
+// ddepth_anything_v2/depth_anything_v2/dpt.py:196-221): uint8 [B, H, W, 3] in, [B, 3, h, w] in channels_last memory out,
+//     out[b][c][y][x] = (bicubic(in[b][:, :, flip ? 2 - c : c] / 255)(y, x) - mean[c]) / std[c].
+// The host used to run it as six torch kernels over the float32 image (flip, permute + convert, / 255, bicubic, normalise,
+// cast: 0.9 ms per 32 x 1024^2, a third of it the float32 resize); here every image byte is read once.  The resampling is
+// torch's upsample_bicubic2d (align_corners=False, no antialias: the cubic convolution kernel with A = -0.75 on half-pixel
+// centres, border replicated, float32 accumulation) -- the stand-in the product has used for cv2.INTER_CUBIC since round 1
+// (same kernel and centres; OpenCV's own arithmetic is unpinned), so the network input is the same to float32 rounding.
+// One lane per output pixel (three channels): 16 pixel reads that hit L1 / L2 (neighbouring lanes share them).
+struct PreParams {
+    const uint8_t *in;
+    void *out;
+    int B, ih, iw, oh, ow, flip;
+    float sy, sx;                // in / out
+    float mean[3], istd[3];      // per OUTPUT channel
+    long long total;
+};
+
+__device__ __forceinline__ void pre_cubic(float t, float *c)
+{
+    const float A = -0.75f;
+    const float x0 = t + 1.0f, x3 = 2.0f - t, x2 = 1.0f - t;
+    c[0] = ((A * x0 - 5.0f * A) * x0 + 8.0f * A) * x0 - 4.0f * A;
+    c[1] = ((A + 2.0f) * t - (A + 3.0f)) * t * t + 1.0f;
+    c[2] = ((A + 2.0f) * x2 - (A + 3.0f)) * x2 * x2 + 1.0f;
+    c[3] = ((A * x3 - 5.0f * A) * x3 + 8.0f * A) * x3 - 4.0f * A;
+}
+
+template <int DT>      // 0 f16, 1 bf16, 2 f32
+__global__ __launch_bounds__(256) void k_preprocess_bicubic(PreParams P)
+{
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= P.total) return;
+    const int ox = (int)(idx % P.ow);
+    long long r = idx / P.ow;
+    const int oy = (int)(r % P.oh);
+    const int b = (int)(r / P.oh);
+    const float fy = P.sy * ((float)oy + 0.5f) - 0.5f, fx = P.sx * ((float)ox + 0.5f) - 0.5f;
+    const float fy0 = floorf(fy), fx0 = floorf(fx);
+    float cy[4], cx[4];
+    pre_cubic(fy - fy0, cy);
+    pre_cubic(fx - fx0, cx);
+    const int iy = (int)fy0, ix = (int)fx0;
+    const uint8_t *img = P.in + (size_t)b * P.ih * P.iw * 3;
+    float acc[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ky = 0; ky < 4; ky++) {
+        const int y = min(max(iy - 1 + ky, 0), P.ih - 1);
+        const uint8_t *row = img + (size_t)y * P.iw * 3;
+        float h[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kx = 0; kx < 4; kx++) {
+            const int x = min(max(ix - 1 + kx, 0), P.iw - 1);
+            const uint8_t *px = row + (size_t)x * 3;
+#pragma unroll
+            for (int c = 0; c < 3; c++) h[c] += cx[kx] * ((float)px[c] / 255.0f);
+        }
+#pragma unroll
+        for (int c = 0; c < 3; c++) acc[c] += cy[ky] * h[c];
+    }
+    float o[3];
+#pragma unroll
+    for (int c = 0; c < 3; c++) o[c] = (acc[P.flip ? 2 - c : c] - P.mean[c]) * P.istd[c];
+    if (DT == 2) {
+        float *q = (float *)P.out + (size_t)idx * 3;
+        q[0] = o[0]; q[1] = o[1]; q[2] = o[2];
+    } else {
+        typedef typename eo_traits<DT == 1 ? 1 : 0>::T T;
+        T *q = (T *)P.out + (size_t)idx * 3;
+        q[0] = (T)o[0]; q[1] = (T)o[1]; q[2] = (T)o[2];
+    }
+}
+
+DS_API int ds_preprocess_bicubic(ds_ctx *ctx, const void *images, void *out, int batch, int in_h, int in_w, int out_h, int out_w,
+                                 int flip_channels, const float *mean, const float *std, int dtype, void *stream)
+{
+    DS_REQUIRE(ctx && images && out && mean && std, DS_EINVAL, "ds_preprocess_bicubic: null argument");
+    DS_REQUIRE(batch > 0 && in_h > 0 && in_w > 0 && out_h > 0 && out_w > 0, DS_EINVAL, "ds_preprocess_bicubic: bad shape");
+    DS_REQUIRE(dtype == DS_DTYPE_F16 || dtype == DS_DTYPE_BF16 || dtype == DS_DTYPE_F32, DS_EINVAL, "ds_preprocess_bicubic: dtype must be f16, bf16 or f32");
+    DS_REQUIRE(std[0] != 0.f && std[1] != 0.f && std[2] != 0.f, DS_EINVAL, "ds_preprocess_bicubic: std must be non-zero");
+    DS_HIP_CHECK(hipSetDevice(ctx->device));
+    PreParams P;
+    P.in = (const uint8_t *)images; P.out = out;
+    P.B = batch; P.ih = in_h; P.iw = in_w; P.oh = out_h; P.ow = out_w; P.flip = flip_channels ? 1 : 0;
+    P.sy = (float)in_h / (float)out_h; P.sx = (float)in_w / (float)out_w;
+    for (int c = 0; c < 3; c++) { P.mean[c] = mean[c]; P.istd[c] = 1.0f / std[c]; }
+    P.total = (long long)batch * out_h * out_w;
+    DS_REQUIRE((P.total + 255) / 256 < (1ll << 31), DS_EUNSUPPORTED, "ds_preprocess_bicubic: tensor too large");
+    dim3 grid((unsigned)((P.total + 255) / 256));
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == DS_DTYPE_F16) hipLaunchKernelGGL((k_preprocess_bicubic<0>), grid, dim3(256), 0, st, P);
+    else if (dtype == DS_DTYPE_BF16) hipLaunchKernelGGL((k_preprocess_bicubic<1>), grid, dim3(256), 0, st, P);
+    else hipLaunchKernelGGL((k_preprocess_bicubic<2>), grid, dim3(256), 0, st, P);
+    DS_HIP_CHECK(hipGetLastError());
+    return DS_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
 // ds_dpt_head_tail: the tail of the DPT depth heads, fused:
 //     bilinear upsample (align_corners=True) -> conv3x3 128->32 (pad 1) -> ReLU -> conv1x1 32->1 -> ReLU
 // (dmidas/dpt_depth.py:150-158: scratch.output_conv[1:6]; ddepth_anything_v2/.../dpt.py:146-147 + output_conv2, :105-111).

@@ -139,6 +139,11 @@ class DepthAnythingV2(nn.Module):
         cv2 itself is not available in this environment: parity of the resize is unpinned."""
         b, h, w, _ = images_u8.shape
         nw, nh = lower_bound_size(w, h, input_size)
+        if images_u8.is_cuda:
+            # one pass over the image bytes (ds_preprocess_bicubic), already in the network's dtype
+            from src import _native
+            dtype = self.pretrained.blocks[0].norm1.weight.dtype
+            return _native.preprocess_bicubic(images_u8, (nh, nw), vm.IMAGENET_MEAN, vm.IMAGENET_STD, flip=True, dtype=dtype), (h, w)
         x = images_u8.flip(-1).permute(0, 3, 1, 2).float() / 255.0
         x = F.interpolate(x, size=(nh, nw), mode="bicubic", align_corners=False)
         mean = vm.device_constant(vm.IMAGENET_MEAN, x.device).view(1, 3, 1, 1)

@@ -165,16 +165,21 @@ class DPTDepthModel(DPT):
         return super().forward(x, features).squeeze(dim=1)
 
     @staticmethod
-    def preprocess(images_u8, net_size=512, net_h=None, resize_mode="minimal", mean=0.5, std=0.5):
+    def preprocess(images_u8, net_size=512, net_h=None, resize_mode="minimal", mean=0.5, std=0.5, dtype=None):
         """The transform chain of estimatemidas (src/depthmap_generation.py:457-476: Resize(keep_aspect_ratio, multiple of 32,
         INTER_CUBIC) -> NormalizeImage -> PrepareForNet) after get_raw_prediction's channel swap and /255 (:381), as tensor ops:
         uint8 [B,H,W,3] (RGB) -> float32 [B,3,nh,nw].  Pinned against the reference's own transform classes run with a numpy
         stand-in for cv2.resize (tests/golden/make_golden_transforms.py); cv2's arithmetic itself stays unpinned."""
         b, h, w, _ = images_u8.shape
         nw, nh = midas_net_size(w, h, int(net_size), int(net_size if net_h is None else net_h), resize_mode)
+        if images_u8.is_cuda:
+            # one pass over the image bytes (ds_preprocess_bicubic): flip, / 255, bicubic, normalise, cast, channels_last
+            from src import _native
+            return _native.preprocess_bicubic(images_u8, (nh, nw), mean, std, flip=True, dtype=dtype)
         x = images_u8.flip(-1).permute(0, 3, 1, 2).float() / 255.0
         x = F.interpolate(x, size=(nh, nw), mode="bicubic", align_corners=False)
-        return (x - mean) / std
+        x = (x - mean) / std
+        return x if dtype is None else x.to(dtype)
 
     # ---- device-resident pre/post of estimatemidas (src/depthmap_generation.py:455-499; SURVEY.md 8f-1) ------------------
     @torch.no_grad()
@@ -186,11 +191,10 @@ class DPTDepthModel(DPT):
         order -- reproduced.  cv2.INTER_CUBIC resize -> torch bicubic (same kernel a=-0.75, half-pixel centres; cv2 is
         not available here: unpinned); prediction upsampled with torch bicubic align_corners=False exactly as :484-489."""
         b, h, w, _ = images_u8.shape
-        x = self.preprocess(images_u8, net_size, net_h, resize_mode, mean, std)
         dtype = self.scratch.layer1_rn.weight.dtype
-        x = x.to(dtype)
+        x = self.preprocess(images_u8, net_size, net_h, resize_mode, mean, std, dtype=dtype)
         if x.is_cuda:
-            x = x.contiguous(memory_format=torch.channels_last)
+            x = x.contiguous(memory_format=torch.channels_last)      # (already so: the fused kernel writes channels_last)
         pred = self.forward(x)
         pred = F.interpolate(pred.unsqueeze(1), size=(h, w), mode="bicubic", align_corners=False).squeeze(1)
         return pred.float()

@@ -20,7 +20,7 @@ FILL_IDS = {"none": 0, "naive": 1, "naive_interpolating": 2, "polylines_soft": 3
 EXPORTS = [
     "ds_version", "ds_last_error", "ds_normalmap_f64", "ds_reassemble_readout", "ds_bias_act_nhwc", "ds_linear", "ds_linear_residual", "ds_linear_vt", "ds_conv3x3_nhwc", "ds_ctx_create", "ds_ctx_destroy", "ds_stereo_warp", "ds_depth_minmax",
     "ds_stereo_last_exact_rows", "ds_copy_view", "ds_overlap_red_cyan", "ds_normalmap", "ds_depth_to_u16",
-    "ds_convert_to_i16", "ds_profile_enable", "ds_profile_last_ms", "ds_stereo_last_stats", "ds_attention_fwd", "ds_attention_bias_pack", "ds_colorize_u16", "ds_residual_layernorm", "ds_boost_blend", "ds_upsample_bilinear_nhwc", "ds_dpt_head_tail",
+    "ds_convert_to_i16", "ds_profile_enable", "ds_profile_last_ms", "ds_stereo_last_stats", "ds_attention_fwd", "ds_attention_bias_pack", "ds_colorize_u16", "ds_residual_layernorm", "ds_boost_blend", "ds_upsample_bilinear_nhwc", "ds_dpt_head_tail", "ds_preprocess_bicubic",
 ]
 
 
@@ -69,6 +69,8 @@ def lib():
             L.ds_boost_blend.argtypes = [vp, vp, i64, ci, ci, vp, ci, vp, ci, vp, ci, vp]
             L.ds_upsample_bilinear_nhwc.argtypes = [vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, vp]
             L.ds_dpt_head_tail.argtypes = [vp, vp, ci, ci, ci, ci, ci, vp, vp, vp, ctypes.c_float, ci, vp, ci, vp]
+            L.ds_preprocess_bicubic.argtypes = [vp, vp, vp, ci, ci, ci, ci, ci, ci, ctypes.POINTER(ctypes.c_float),
+                                                ctypes.POINTER(ctypes.c_float), ci, vp]
             L.ds_reassemble_readout.argtypes = [vp, vp, vp, vp, ci, ci, ci, ci, vp]
             L.ds_bias_act_nhwc.argtypes = [vp, vp, vp, vp, vp, vp, i64, ci, ci, ci, vp]
             L.ds_linear.argtypes = [vp, vp, vp, vp, vp, i64, i64, i64, i64, ci, ci, vp]
@@ -499,6 +501,24 @@ def boost_blend(dst, rects, coefs, preds, mask_template):
                                 buf.data_ptr(), n, preds.data_ptr(), preds.shape[1], mask_template.data_ptr(),
                                 mask_template.shape[0], _stream(dst)))
     return dst
+
+
+def preprocess_bicubic(images_u8, size_hw, mean, std, flip=True, dtype=None):
+    """uint8 [B,H,W,3] CUDA -> normalised network input [B,3,h,w] (channels_last memory) in one pass
+    (include/depthstereo.h: ds_preprocess_bicubic): channel flip, / 255, bicubic resize, (x - mean) / std, cast."""
+    torch = require_gpu()
+    assert images_u8.is_cuda and images_u8.dtype == torch.uint8 and images_u8.dim() == 4 and images_u8.shape[3] == 3
+    dtype = torch.float32 if dtype is None else dtype
+    code = {torch.float16: 1, torch.bfloat16: 2, torch.float32: 3}[dtype]
+    x = images_u8.contiguous()
+    b, h, w, _ = x.shape
+    oh, ow = int(size_hw[0]), int(size_hw[1])
+    out = torch.empty((b, 3, oh, ow), dtype=dtype, device=x.device, memory_format=torch.channels_last)
+    m = (ctypes.c_float * 3)(*[float(v) for v in (mean if hasattr(mean, "__len__") else (mean,) * 3)])
+    s = (ctypes.c_float * 3)(*[float(v) for v in (std if hasattr(std, "__len__") else (std,) * 3)])
+    _check(lib().ds_preprocess_bicubic(ctx_for(_dev_index(x)), x.data_ptr(), out.data_ptr(), b, h, w, oh, ow, 1 if flip else 0, m, s, code,
+                                       _stream(x)))
+    return out
 
 
 def upsample_bilinear(x, size=None, scale_factor=None, align_corners=True):

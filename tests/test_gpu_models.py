@@ -927,3 +927,36 @@ def test_linear_vt_and_fused_fc2_at_benchmark_shapes(gpu):
         worst = max(worst, (got[r0:r0 + 4352].float() - want).abs().max().item() / (1 + want.abs().max().item()))
     assert worst < 1.5e-3, worst
     assert torch.equal(_native.linear_residual(a, w2, b2, gam, res), got)
+
+
+def test_preprocess_bicubic_kernel_vs_torch_chain(gpu):
+    """ds_preprocess_bicubic (uint8 image -> normalised network input in one pass) against the torch chain it replaces -- flip,
+    permute, float / 255, F.interpolate(bicubic, align_corners=False), (x - mean) / std -- for down-, up- and identity scaling,
+    non-square shapes, scalar and per-channel mean / std, f32 / f16 / bf16 outputs; then against the reference's own transform
+    chain (tests/golden/make_golden_transforms.py: Resize(INTER_CUBIC) / NormalizeImage / PrepareForNet on a numpy cubic stand-in)."""
+    import torch.nn.functional as F
+    import make_golden_transforms as mgt
+    from src import _native
+    from src import vit_mi355x as vm
+    g = torch.Generator().manual_seed(3)
+    for (b, h, w, oh, ow, mean, std) in [(2, 64, 96, 32, 48, 0.5, 0.5), (1, 50, 70, 96, 128, vm.IMAGENET_MEAN, vm.IMAGENET_STD),
+                                        (3, 33, 41, 33, 41, 0.5, 0.5), (1, 1024, 1024, 512, 512, 0.5, 0.5), (2, 135, 240, 266, 476, vm.IMAGENET_MEAN, vm.IMAGENET_STD)]:
+        img = torch.randint(0, 256, (b, h, w, 3), generator=g, dtype=torch.uint8).cuda()
+        x = img.flip(-1).permute(0, 3, 1, 2).float() / 255.0
+        x = F.interpolate(x, size=(oh, ow), mode="bicubic", align_corners=False)
+        m = torch.tensor(mean if isinstance(mean, tuple) else (mean,) * 3, device="cuda").view(1, 3, 1, 1)
+        s = torch.tensor(std if isinstance(std, tuple) else (std,) * 3, device="cuda").view(1, 3, 1, 1)
+        want = (x - m) / s
+        got = _native.preprocess_bicubic(img, (oh, ow), mean, std, flip=True, dtype=torch.float32)
+        assert got.shape == want.shape and got.is_contiguous(memory_format=torch.channels_last)
+        assert (got - want).abs().max().item() < 5e-6 * (1 + want.abs().max().item()), (b, h, w, oh, ow)
+        for dt, tol in ((torch.float16, 2e-3), (torch.bfloat16, 1.6e-2)):
+            gh = _native.preprocess_bicubic(img, (oh, ow), mean, std, flip=True, dtype=dt)
+            assert gh.dtype == dt and (gh.float() - want).abs().max().item() < tol * (1 + want.abs().max().item())
+        nf = _native.preprocess_bicubic(img, (oh, ow), mean, std, flip=False, dtype=torch.float32)
+        assert (nf - want.flip(1) * s.flip(1) / s - (m.flip(1) - m) / s).abs().max().item() < 1e-4      # same pixels, channels not swapped
+    z = np.load(os.path.join(os.path.dirname(GOLD), "transform_cases.npz"))
+    from dmidas.dpt_depth import DPTDepthModel
+    for name, h, w, nw, nh, method, seed in mgt.CASES:
+        x = DPTDepthModel.preprocess(torch.from_numpy(mgt.image(h, w, seed))[None].cuda(), nw, nh, method, 0.5, 0.5)[0].cpu().numpy()
+        assert x.shape == z[name].shape and np.abs(x - z[name]).max() < 5e-5, (name, float(np.abs(x - z[name]).max()))
