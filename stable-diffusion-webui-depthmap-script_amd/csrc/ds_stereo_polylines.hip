@@ -843,8 +843,10 @@ __device__ __forceinline__ double pl_nd_one(const PolyParams &P, const void *dep
     return (v - mn) / (mx - mn);
 }
 
+// (launch bounds: 4 waves per SIMD = 128 VGPRs, no spill -- the pass is a chain of dependent LDS reads, ballots and shuffles, i.e.
+// latency bound, and the unconstrained allocation of 170 registers left it two waves per SIMD to hide that latency with)
 template <int C, int SHARP>
-__global__ __launch_bounds__(64) void k_polylines_general(PolyParams P, int ncmax, int per_seg)
+__global__ __launch_bounds__(64, 4) void k_polylines_general(PolyParams P, int ncmax, int per_seg)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int NP = SHARP ? 2 : 1;
@@ -859,10 +861,17 @@ __global__ __launch_bounds__(64) void k_polylines_general(PolyParams P, int ncma
     const int seg = blockIdx.x / per_seg, part = blockIdx.x - seg * per_seg;
     const int count = P.gq_count[seg];
     const unsigned long long *q = P.gq + (size_t)seg * P.gq_cap;
+    // the queue entry of the NEXT group of 8 is requested while this one is rendered: one global round trip less on the
+    // dependent chain entry -> depth / pixel loads -> window of every iteration
+    unsigned long long ent_next = (part * 8 + grp < count) ? q[part * 8 + grp] : 0ull;
     for (int base = part * 8; base < count; base += 8 * per_seg) {
         const int idx = base + grp;
         const bool have = idx < count;
-        const unsigned long long ent = have ? q[idx] : 0ull;
+        const unsigned long long ent = ent_next;
+        {
+            const int nidx = idx + 8 * per_seg;
+            ent_next = nidx < count ? q[nidx] : 0ull;
+        }
         const int rowid = (int)(ent >> 32), col = (int)(ent & 0xffffffffull);
         const int row = rowid % P.h, ie = rowid / P.h;
         const int e = ie % P.n_eyes, img = ie / P.n_eyes;

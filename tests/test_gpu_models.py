@@ -949,7 +949,9 @@ def test_preprocess_bicubic_kernel_vs_torch_chain(gpu):
         want = (x - m) / s
         got = _native.preprocess_bicubic(img, (oh, ow), mean, std, flip=True, dtype=torch.float32)
         assert got.shape == want.shape and got.is_contiguous(memory_format=torch.channels_last)
-        assert (got - want).abs().max().item() < 5e-6 * (1 + want.abs().max().item()), (b, h, w, oh, ow)
+        # (white-noise images and a non-integer scale are the worst case: torch's build contracts scale * (dst + 0.5) - 0.5 into
+        # an FMA, this library is built with -ffp-contract=off -- one ulp of the source coordinate times a pixel step of 255)
+        assert (got - want).abs().max().item() < 3e-5 * (1 + want.abs().max().item()), (b, h, w, oh, ow)
         for dt, tol in ((torch.float16, 2e-3), (torch.bfloat16, 1.6e-2)):
             gh = _native.preprocess_bicubic(img, (oh, ow), mean, std, flip=True, dtype=dt)
             assert gh.dtype == dt and (gh.float() - want).abs().max().item() < tol * (1 + want.abs().max().item())
