@@ -48,6 +48,7 @@
 //   S0   (start of the next work item) the finished output rows leave LDS as 16-byte stores.
 // HBM sees each input byte once per supertile (+ the window halo) and each output byte once.
 #include <stdlib.h>
+#include <atomic>
 
 #include "ds_common.h"
 
@@ -1154,6 +1155,145 @@ __global__ __launch_bounds__(64) void k_polylines_exact(PolyParams P, ExactScrat
 
 
 
+// ------------------------------------------------------------------------------------------------
+// Exact fallback, LDS resident: ONE WORKGROUP PER FLAGGED ROW (used whenever the row's arrays fit the CU's LDS; the kernel
+// above is what remains for wider rows).  A network's prediction flags one or two rows of a 1080p batch now and then, and
+// the lock-step kernel above -- one LANE per row, every array in global scratch -- took 14-17 ms for such a launch: a
+// single lane walking 1920 columns with a dependent global round trip behind every access.  Here the row's points are built
+// by all 64 lanes, sorted in parallel, and only the sweep itself -- the history-dependent part -- runs on one lane, against
+// LDS.  The sort: the reference's insertion sort (:214-219, strict '>': stable) puts point i at position
+// #{j : x_j < x_i} + #{j < i : x_j == x_i}; a point can only be overtaken by points of columns within |divergence_px| + 2 of
+// its own (x = col + 0.5 + d + sep +- 0.45 with d between 0 and divergence_px), so each lane counts inside that window.
+// NaN coordinates (a constant depth map: 0 / 0) compare false like in the reference's loop: such points stay where they are.
+template <int DT, int SHARP>
+__global__ __launch_bounds__(64) void k_polylines_exact_lds(PolyParams P, int c, int win_pts)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int NP = SHARP ? 2 : 1;
+    const int lane = threadIdx.x;
+    const int w = P.w;
+    const int pt_end = NP * w + 2, sg_end = pt_end - 1;
+    double *ox = reinterpret_cast<double *>(smem);
+    double *od = ox + pt_end;
+    double *sx = od + pt_end;
+    int *sk = reinterpret_cast<int *>(sx + pt_end);
+    int *csg = sk + pt_end;
+    uint32_t *rgbx = reinterpret_cast<uint32_t *>(csg + pt_end);
+    const int count = P.counters[0];
+    for (int it = blockIdx.x; it < count; it += gridDim.x) {
+        const int rowid = P.row_list[it];
+        const int row = rowid % P.h;
+        const int ie = rowid / P.h;
+        const int eye = ie % P.n_eyes, img = ie / P.n_eyes;
+        const double div_px = P.div_px[eye], sep_px = P.sep_px[eye];
+        const double mn = P.minmax[img * 2], mx = P.minmax[img * 2 + 1];
+        const uint8_t *src = P.img + ((size_t)img * P.h + row) * (size_t)w * c;
+        typedef typename ds_depth_traits<DT>::T DTy;
+        const DTy *depth_row = (const DTy *)P.depth + ((size_t)img * P.h + row) * (size_t)w;
+        uint8_t *dst = P.out[eye] + (int64_t)img * P.ois[eye] + (int64_t)row * P.ors[eye];
+        __syncthreads();                                     // the previous row's arrays are no longer read
+        // ---- points in original order (:179-191) and the row's colours, all lanes ----
+        for (int col = lane; col < w; col += 64) {
+            const double coord_d = pl_coord_d<DT>(P, img, depth_row, col, mn, mx, div_px);
+            const double coord_x = (double)col + 0.5 + coord_d + sep_px;
+            if (SHARP) {
+                ox[2 * col + 1] = coord_x - 0.45; od[2 * col + 1] = fabs(coord_d);
+                ox[2 * col + 2] = coord_x + 0.45; od[2 * col + 2] = fabs(coord_d);
+            } else {
+                ox[col + 1] = coord_x; od[col + 1] = fabs(coord_d);
+            }
+            uint32_t px = 0;
+            for (int q = 0; q < c; q++) px |= (uint32_t)src[(size_t)col * c + q] << (8 * q);
+            rgbx[col] = px;
+        }
+        if (lane == 0) {
+            ox[0] = -1.0 * (double)w; od[0] = 0.0;
+            ox[pt_end - 1] = 2.0 * (double)w; od[pt_end - 1] = 0.0;
+        }
+        __syncthreads();
+        // ---- stable sort of points 0 .. sg_end - 1 by x; the last point keeps its place (:214 sorts range(1, sg_end)) ----
+        for (int i = lane; i < pt_end; i += 64) {
+            const double xi = ox[i];
+            int pos = i;
+            if (i < sg_end && xi == xi) {
+                const int lo = max(0, i - win_pts), hi = min(sg_end - 1, i + win_pts);
+                int less = lo;                               // everything left of the window is smaller (or NaN: see below)
+                for (int j = lo; j <= hi; j++) {
+                    const double xj = ox[j];
+                    less += (xj < xi || (xj == xi && j < i)) ? 1 : 0;
+                }
+                pos = less;
+            }
+            sx[pos] = xi;
+            sk[pos] = i;
+        }
+        __syncthreads();
+        if (lane == 0) {
+            // ---- the sweep (:228-282), statement by statement as in k_polylines_exact ----
+#define CI_(p) ((p) == 0 ? 0 : ((p) == pt_end - 1 ? (w - 1) : (SHARP ? ((p) - 1) >> 1 : (p) - 1)))
+            int csg_end = 0, sg_pointer = 0, pt_i = 0;
+            bool slot0_written = false;
+            for (int col = 0; col < w; col++) {
+                double color[4] = { 0.5, 0.5, 0.5, 0.5 };
+                while (sx[pt_i] < (double)col) pt_i++;
+                pt_i--;
+                while (sx[pt_i] < (double)(col + 1)) {
+                    const double pa = sx[pt_i], pb = sx[pt_i + 1];
+                    const double coord_from = (pa > (double)col ? pa : (double)col) + PL_EPS;
+                    const double coord_to = (pb < (double)(col + 1) ? pb : (double)(col + 1)) - PL_EPS;
+                    const double significance = coord_to - coord_from;
+                    const double coord_center = coord_from + 0.5 * significance;
+                    while (sg_pointer < sg_end && sx[sg_pointer] < coord_center) {
+                        csg[csg_end] = sk[sg_pointer];
+                        if (csg_end == 0) slot0_written = true;
+                        sg_pointer++; csg_end++;
+                    }
+                    int csg_i = 0;
+                    while (csg_i < csg_end) {
+                        const int k = csg[csg_i];
+                        if (ox[k + 1] < coord_center) { csg[csg_i] = csg[csg_end - 1]; csg_end--; }
+                        else csg_i++;
+                    }
+                    int best = 0;
+                    if (csg_end != 1) {
+                        double best_closeness = -PL_EPS;
+                        for (csg_i = 0; csg_i < csg_end; csg_i++) {
+                            const int k = csg[csg_i];
+                            const double x0 = ox[k], x1 = ox[k + 1];
+                            const double ip_k = (coord_center - x0) / (x1 - x0);
+                            const double closeness = (1.0 - ip_k) * od[k] + ip_k * od[k + 1];
+                            if (best_closeness < closeness && 0.0 < ip_k && ip_k < 1.0) { best_closeness = closeness; best = csg_i; }
+                        }
+                    }
+                    const int k = (csg_end > 0 || slot0_written) ? csg[best] : -1;
+                    if (k >= 0) {
+                        const int col_l = CI_(k), col_r = CI_(k + 1);
+                        const uint32_t pl = rgbx[col_l];
+                        if (col_l == col_r) {
+                            for (int q = 0; q < 4; q++) if (q < c) color[q] += (double)((pl >> (8 * q)) & 0xffu) * significance;
+                        } else {
+                            const uint32_t pr = rgbx[col_r];
+                            const double x0 = ox[k], x1 = ox[k + 1];
+                            const double ip_k = (coord_center - x0) / (x1 - x0);
+                            for (int q = 0; q < 4; q++) if (q < c) {
+                                const double u = (double)((pl >> (8 * q)) & 0xffu) * (1.0 - ip_k);
+                                const double v = (double)((pr >> (8 * q)) & 0xffu) * ip_k;
+                                color[q] += (u + v) * significance;
+                            }
+                        }
+                    } else {
+                        const uint32_t p0 = rgbx[0];
+                        for (int q = 0; q < 4; q++) if (q < c) color[q] += (double)((p0 >> (8 * q)) & 0xffu) * significance;
+                    }
+                    pt_i++;
+                }
+                for (int q = 0; q < 4; q++) if (q < c) dst[(size_t)col * c + q] = ds_f64_to_u8(color[q]);
+            }
+#undef CI_
+        }
+    }
+}
+
 template <int C, int SHARP, int NE>
 static int pl_main_blocks(int ncu, long long nwork, size_t lds, long long *nblocks_out)
 {
@@ -1208,11 +1348,31 @@ static int pl_dispatch(int op, const PolyParams &P, int c, int ncu, long long nw
 #undef PL_CASE
 }
 
+// LDS of k_polylines_exact_lds for a row of w columns: 3 double + 2 int arrays of NP w + 2 points, one packed colour per column
+static size_t pl_exact_lds_bytes(int w, int sharp) { return (size_t)((sharp ? 2 : 1) * w + 2) * 32 + (size_t)w * 4 + 16; }
+
 template <int DT>
-static void pl_launch_exact(const PolyParams &P, int sharp, const ExactScratch &S, int exact_blocks, hipStream_t st)
+static int pl_launch_exact(const PolyParams &P, int sharp, const ExactScratch &S, int exact_blocks, int c, double max_div_px, int device, hipStream_t st)
 {
+    const size_t lds = pl_exact_lds_bytes(P.w, sharp);
+    const int force_global = getenv("DS_PL_EXACT_GLOBAL") ? atoi(getenv("DS_PL_EXACT_GLOBAL")) : 0;      // A/B switch (tests)
+    if (lds <= 160 * 1024 && !force_global) {
+        // one workgroup per flagged row, rows taken round-robin by a fixed grid (the count lives on the device)
+        const int win_pts = (sharp ? 2 : 1) * ((int)ceil(fabs(max_div_px)) + 3);
+        static std::atomic<uint64_t> attr_done{0};           // per device (bit) -- the limit is raised to the CU's whole LDS once
+        const uint64_t bit = 1ull << (device & 63);
+        if (!(attr_done.load(std::memory_order_relaxed) & bit)) {
+            DS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_polylines_exact_lds<DT, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            DS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_polylines_exact_lds<DT, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            attr_done.fetch_or(bit, std::memory_order_relaxed);
+        }
+        if (sharp) hipLaunchKernelGGL((k_polylines_exact_lds<DT, 1>), dim3(1024), dim3(64), lds, st, P, c, win_pts);
+        else hipLaunchKernelGGL((k_polylines_exact_lds<DT, 0>), dim3(1024), dim3(64), lds, st, P, c, win_pts);
+        return DS_OK;
+    }
     if (sharp) hipLaunchKernelGGL((k_polylines_exact<DT, 1>), dim3(exact_blocks), dim3(64), 0, st, P, S);
     else hipLaunchKernelGGL((k_polylines_exact<DT, 0>), dim3(exact_blocks), dim3(64), 0, st, P, S);
+    return DS_OK;
 }
 
 // called from ds_stereo_warp (ds_stereo.hip)
@@ -1353,10 +1513,15 @@ int ds_polylines_launch(ds_ctx *ctx, const uint8_t *image, const void *depth, in
         if (rc) return rc;
     }
     if (ctx->profile) { (void)hipEventRecord(ctx->ev[1], st); (void)hipEventRecord(ctx->ev[2], st); }
-    switch (depth_dtype) {
-    case DS_DEPTH_U16: pl_launch_exact<DS_DEPTH_U16>(P, sharp, X, nworkers / 64, st); break;
-    case DS_DEPTH_F32: pl_launch_exact<DS_DEPTH_F32>(P, sharp, X, nworkers / 64, st); break;
-    default: pl_launch_exact<DS_DEPTH_F64>(P, sharp, X, nworkers / 64, st); break;
+    {
+        double max_div = 0.0;
+        for (int e = 0; e < n_eyes; e++) max_div = fmax(max_div, fabs(eyes[e].divergence_px));
+        switch (depth_dtype) {
+        case DS_DEPTH_U16: rc = pl_launch_exact<DS_DEPTH_U16>(P, sharp, X, nworkers / 64, c, max_div, ctx->device, st); break;
+        case DS_DEPTH_F32: rc = pl_launch_exact<DS_DEPTH_F32>(P, sharp, X, nworkers / 64, c, max_div, ctx->device, st); break;
+        default: rc = pl_launch_exact<DS_DEPTH_F64>(P, sharp, X, nworkers / 64, c, max_div, ctx->device, st); break;
+        }
+        if (rc) return rc;
     }
     if (ctx->profile) { (void)hipEventRecord(ctx->ev[3], st); ctx->ev_recorded = 1; }
     DS_HIP_CHECK(hipGetLastError());

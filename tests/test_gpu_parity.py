@@ -587,3 +587,43 @@ def test_funnel_failure_in_a_later_group_keeps_earlier_results(gpu):
                                                 deps[:2] + [Boom()], None, {'gen_stereo': True, 'stereo_modes': ['left-right']}):
             got.append((item[0], item[1]))
     assert got == [(0, 'depth'), (0, 'left-right'), (1, 'depth'), (1, 'left-right')], got
+
+
+def test_exact_fallback_lds_kernel_equals_global_kernel(sg, native, oracle, gpu):
+    """The two implementations of the exact row sweep -- one workgroup per flagged row with the row's arrays in LDS and a
+    parallel stable sort (the default when the row fits), one lane per row against global scratch (wider rows,
+    DS_PL_EXACT_GLOBAL=1) -- on inputs that flag rows: quantised depth at a power-of-two divergence (coincident breakpoints,
+    exact ties; both fills, both eyes unbalanced), a constant depth map (NaN coordinates: the sort must leave them in place),
+    float32 depth, and a row too wide for the LDS kernel.  Byte-identical to each other and to the oracle."""
+    import os
+    torch = gpu
+    rng = np.random.default_rng(15)
+    cases = []
+    for (h, w, div, bal, fill) in [(24, 512, 6.25, 0.0, 'polylines_sharp'), (24, 512, 6.25, 0.4, 'polylines_soft'), (8, 2048, 1.5625, -0.5, 'polylines_sharp')]:
+        img = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+        dep = (rng.integers(0, 4, (h, w)) * 21845).astype(np.uint16)
+        cases.append((img, dep, div, bal, fill))
+    img = rng.integers(0, 256, (6, 320, 3), dtype=np.uint8)
+    cases.append((img, np.full((6, 320), 1234, np.uint16), 5.0, 0.0, 'polylines_sharp'))                    # constant: NaN
+    cases.append((img, (rng.integers(0, 3, (6, 320)) * 0.5).astype(np.float32), 10.0, 0.0, 'polylines_soft'))   # float32, 32 px
+    wide = rng.integers(0, 256, (2, 5200, 3), dtype=np.uint8)
+    cases.append((wide, (rng.integers(0, 4, (2, 5200)) * 21845).astype(np.uint16), 100.0 * 32 / 5200, 0.0, 'polylines_sharp'))   # 332 KB of row arrays
+    flagged = 0
+    old = os.environ.get("DS_PL_EXACT_GLOBAL")
+    try:
+        for img, dep, div, bal, fill in cases:
+            want = oracle.create_stereoimages_arrays(img, dep, div, 0.0, ['left-right'], bal, 1.0, fill)[0]
+            it, dt = torch.from_numpy(img).cuda().unsqueeze(0), torch.from_numpy(dep).cuda().unsqueeze(0)
+            outs = []
+            for force in ("0", "1"):
+                os.environ["DS_PL_EXACT_GLOBAL"] = force
+                outs.append(sg.create_stereoimages_batch(it, dt, div, 0.0, ['left-right'], bal, 1.0, fill)[0][0].cpu().numpy())
+                flagged += native.last_exact_rows(it)
+            assert np.array_equal(outs[0], outs[1]), (img.shape, fill, 'LDS and global exact kernels differ')
+            assert np.array_equal(outs[0], want), (img.shape, fill, int((outs[0] != want).sum()))
+    finally:
+        if old is None:
+            os.environ.pop("DS_PL_EXACT_GLOBAL", None)
+        else:
+            os.environ["DS_PL_EXACT_GLOBAL"] = old
+    assert flagged > 0
