@@ -270,7 +270,11 @@ def main():
 
     import torch
     import torch.distributed as dist
-    if os.environ.get("DS_CUDNN_BENCHMARK"):                  # A/B switch: let MIOpen time its solvers per convolution shape
+    # MIOpen's search over its solvers for the ~15 library convolution shapes of a forward (the 256 -> 128 head convolution gets a
+    # CK kernel at 880 us instead of the heuristic's 2.0 ms igemm): +2.4-3 % on the step, ~40 s of the untimed priming pass on a
+    # fresh box (measured: 9 s -> 49 s wall for the whole command).  DS_CUDNN_BENCHMARK=0 leaves the heuristic choice.
+    miopen_find = os.environ.get("DS_CUDNN_BENCHMARK", "1") != "0"
+    if miopen_find:
         torch.backends.cudnn.benchmark = True
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -528,6 +532,7 @@ def main():
                        "network_precision_vs_reference": "fp16 = the reference's GPU default; held to 2e-2 of its float32 output "
                                                          "(float32 path: 1e-4), tests/test_gpu_models.py",
                        "forward_launch": ("hipGraph replay" if (fwd is not None and fwd.graphs) else "eager"),
+                       "library_convolutions": "MIOpen, solver search on (torch.backends.cudnn.benchmark)" if miopen_find else "MIOpen, heuristic solver choice",
                        "overlap": "per-pixel kernels of step k on a second stream beside the forward of step k+1" if post is not None else "single stream",
                        "parallelism": f"units sharded over {world} GPU(s), no data-path collective"
                                       + (", ONE RCCL gather of the collated outputs (stereo pair + uint16 depth"
