@@ -846,8 +846,10 @@ __device__ __forceinline__ double pl_nd_one(const PolyParams &P, const void *dep
 
 // (launch bounds: 4 waves per SIMD = 128 VGPRs, no spill -- the pass is a chain of dependent LDS reads, ballots and shuffles, i.e.
 // latency bound, and the unconstrained allocation of 170 registers left it two waves per SIMD to hide that latency with)
-template <int C, int SHARP>
-__global__ __launch_bounds__(64, 4) void k_polylines_general(PolyParams P, int ncmax, int per_seg)
+// WPE = waves per SIMD the register allocation is bounded for: 4 is the default; 6 (80 VGPRs, a few spills) exists for A/B runs
+// (DS_PL_GEN_WPE=6)
+template <int C, int SHARP, int WPE = 4>
+__global__ __launch_bounds__(64, WPE) void k_polylines_general(PolyParams P, int ncmax, int per_seg)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int NP = SHARP ? 2 : 1;
@@ -1326,6 +1328,12 @@ static int pl_dispatch(int op, const PolyParams &P, int c, int ncu, long long nw
     do {                                                                                                                \
         if (op == 0) return pl_main_blocks<C_, SHARP, NE_>(ncu, nwork, lds, nblocks);                                   \
         if (op == 1) return pl_launch_main<C_, SHARP, NE_>(P, *nblocks, lds, st);                                       \
+        if (getenv("DS_PL_GEN_WPE") && atoi(getenv("DS_PL_GEN_WPE")) == 6) {                                            \
+            DS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_polylines_general<C_, SHARP, 6>),         \
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)glds));                   \
+            hipLaunchKernelGGL((k_polylines_general<C_, SHARP, 6>), dim3((unsigned)(P.gq_segments * per_seg)), dim3(64), glds, st, P, ncmax, per_seg); \
+            return DS_OK;                                                                                               \
+        }                                                                                                               \
         DS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_polylines_general<C_, SHARP>),                \
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)glds));                       \
         hipLaunchKernelGGL((k_polylines_general<C_, SHARP>), dim3((unsigned)(P.gq_segments * per_seg)), dim3(64), glds, st, P, ncmax, per_seg); \
