@@ -290,6 +290,7 @@ def main():
     import src._native as nat
     import src.normalmap_generation as nmg
     import src.stereoimage_generation as sg
+    from src import multigpu
     from src import vit_mi355x as vm
 
     img_np, pred_np = synth_batch(batch, seed=1000 + rank)
@@ -359,8 +360,7 @@ def main():
             sbs = sg.create_stereoimages_batch(img, d16, 2.5, 0.0, ['left-right'], 0.0, 1.0, args.fill)[0]
             nmap = nmg.create_normalmap_batch(d16) if normalmap else None
             if gather_ok:
-                parts = [sbs.view(batch, -1), d16.view(torch.uint8).view(batch, -1)] + ([nmap.view(batch, -1)] if normalmap else [])
-                packed = torch.cat(parts, dim=1)
+                packed, _ = multigpu.pack_collated([sbs, d16] + ([nmap] if normalmap else []))
                 ev = torch.cuda.Event()
                 ev.record()
                 with torch.cuda.stream(side):

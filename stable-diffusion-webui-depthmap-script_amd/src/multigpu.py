@@ -77,3 +77,28 @@ def render_sharded(images, depth, render_fn, group=None, dst=0):
     s, e = my_shard(n, rank, world)
     local = render_fn(images[s:e], depth[s:e])
     return gather_units(local, n, group=group, dst=dst)
+
+
+def pack_collated(parts):
+    """The collated output of a shard of units -- e.g. [stereo pairs uint8 [n,H,2W,3], depth uint16 [n,H,W], normal maps uint8
+    [n,H,W,3]] -- as ONE byte buffer [n, bytes per unit], so that a single gather moves all of it (north_star: "a single RCCL
+    gather over xGMI for the collated output").  Returns (packed, layout); `unpack_collated(buf, layout)` restores the tensors."""
+    import torch
+    n = parts[0].shape[0]
+    flat, layout = [], []
+    for t in parts:
+        assert t.shape[0] == n and t.is_contiguous()
+        b = t.view(torch.uint8) if t.dtype != torch.uint8 else t
+        flat.append(b.reshape(n, -1))
+        layout.append((tuple(t.shape[1:]), t.dtype, flat[-1].shape[1]))
+    return torch.cat(flat, dim=1), layout
+
+
+def unpack_collated(buf, layout):
+    out, o = [], 0
+    n = buf.shape[0]
+    for shape, dtype, nbytes in layout:
+        piece = buf[:, o:o + nbytes].contiguous()
+        out.append(piece.view(dtype).reshape((n,) + shape))
+        o += nbytes
+    return out

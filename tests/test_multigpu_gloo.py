@@ -318,3 +318,43 @@ def test_local_percentiles_issue_no_collective_inside_a_process_group(tmp_path):
     path = str(tmp_path / "local.npy")
     mp.spawn(_local_only_worker, args=(2, _free_port(), path), nprocs=2, join=True)
     assert np.array_equal(np.load(path), want)
+
+
+def _packed_gather_worker(rank, world, port, result_path):
+    for p in (conftest.ROOT, conftest.PKG):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from src import multigpu
+    g = torch.Generator().manual_seed(100 + rank)
+    n, h, w = 3, 6, 10                                            # what bench.py gathers per step: every rank renders its own batch
+    sbs = torch.randint(0, 256, (n, h, 2 * w, 3), generator=g, dtype=torch.uint8)
+    d16 = torch.randint(0, 65536, (n, h, w), generator=g, dtype=torch.int32).to(torch.uint16)
+    nm = torch.randint(0, 256, (n, h, w, 3), generator=g, dtype=torch.uint8)
+    packed, layout = multigpu.pack_collated([sbs, d16, nm])
+    assert packed.shape == (n, h * 2 * w * 3 + h * w * 2 + h * w * 3) and packed.dtype == torch.uint8
+    back = multigpu.unpack_collated(packed, layout)
+    assert torch.equal(back[0], sbs) and torch.equal(back[1].view(torch.int16), d16.view(torch.int16)) and torch.equal(back[2], nm)
+    bufs = [torch.empty_like(packed) for _ in range(world)] if rank == 0 else None
+    dist.gather(packed, bufs, dst=0)                              # the ONE collective of a bench step
+    if rank == 0:
+        got = [multigpu.unpack_collated(b, layout) for b in bufs]
+        np.save(result_path, np.stack([g_[0].numpy() for g_ in got]))
+        assert torch.equal(got[0][0], sbs)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_packed_gather_of_collated_outputs(tmp_path):
+    """bench.py's multi-GPU step gathers ONE packed byte buffer per rank (stereo pair + uint16 depth + normal map of every unit):
+    pack / unpack round-trip and the gather itself on a world of 2 (gloo)."""
+    path = str(tmp_path / "packed.npy")
+    mp.spawn(_packed_gather_worker, args=(2, _free_port(), path), nprocs=2, join=True)
+    got = np.load(path)
+    assert got.shape == (2, 3, 6, 20, 3)
+    for r in range(2):
+        g = torch.Generator().manual_seed(100 + r)
+        want = torch.randint(0, 256, (3, 6, 20, 3), generator=g, dtype=torch.uint8).numpy()
+        assert np.array_equal(got[r], want)
