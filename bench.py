@@ -680,7 +680,11 @@ def funnel_leg(model, model_name, img_np, net_size, net_h, normalmap):
     n_out = sum(1 for _ in core.core_generation_funnel(None, list(pils), None, None, opts))
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    st = dict(core.FUNNEL_STATS)
     return {"value": len(pils) / dt, "unit": "pairs/s", "results": n_out, "seconds": dt,
+            "host_seconds": {"enqueue (decode + stage + launch)": st.get("launch"), "blocked on device results": st.get("wait"),
+                             "groups": st.get("groups"), "rest (PIL conversion, generator overhead)":
+                             None if not st else st.get("total", dt) - (st.get("launch") or 0.0) - (st.get("wait") or 0.0)},
             "what": "core_generation_funnel: PIL in -> uint16 depth, left-right pair" + (", normal map" if normalmap else "")
                     + " as PIL out (host<->device copies and PIL conversion included)"}
 

@@ -282,7 +282,7 @@ class BeitBackbone(nn.Module):
             y = post[0](tap)                                   # ProjectReadout: [B, N-1, C]
             y = y.reshape(y.shape[0], grid[0], grid[1], y.shape[2]).permute(0, 3, 1, 2)     # NHWC view, no copy
             for layer in list(post)[3:]:
-                y = layer(y)
+                y = vm.conv_module(layer, y)                    # library convolution + in-tree bias pass
             outs.append(y)
         return outs
 

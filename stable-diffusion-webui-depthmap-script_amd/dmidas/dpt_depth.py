@@ -42,7 +42,7 @@ class FeatureFusionBlock_custom(nn.Module):
             output = vm.residual_conv_unit(self.resConfUnit1.conv1, self.resConfUnit1.conv2, xs[1], skip=output)
         output = self.resConfUnit2(output)
         # 1x1 out_conv and bilinear interpolation commute (linear, weights sum to one): conv first, on 4x fewer pixels
-        output = self.out_conv(output)
+        output = vm.conv_module(self.out_conv, output)
         if size is None:
             return vm.interpolate_bilinear(output, scale_factor=2, align_corners=True)
         return vm.interpolate_bilinear(output, size=tuple(size), align_corners=True)
@@ -102,7 +102,7 @@ class DPT(nn.Module):
                 and head[2].padding_mode == 'zeros'):          # TILING_MODE makes the convolutions circular: library path
             # upsample x2 -> conv3x3 128->32 -> ReLU -> conv1x1 -> ReLU in one MFMA kernel (ds_dpt_head_tail)
             from src import _native
-            y = head[0](path_1)
+            y = vm.conv_module(head[0], path_1)
             size = (int(y.shape[2] * head[1].scale_factor), int(y.shape[3] * head[1].scale_factor))
             return _native.dpt_head_tail(y, size, head[2], head[4], relu_out=isinstance(head[5], nn.ReLU))
         return head(path_1)

@@ -106,6 +106,7 @@ def _custom_depth_to_float(dp, image):
 
 
 import os as _os
+import time as _time
 
 # device batch of the funnel: up to this many pixels (16 x 1024^2 by default), at most 64 images.  Measured on 32 x 1024^2
 # through dpt_beit_large_512: one group of 32 -> 176 pairs/s, two pipelined groups of 16 -> 289 pairs/s (the PIL conversion
@@ -307,6 +308,9 @@ def _launch_group(gen, idxs, inputimages, inputdepthmaps, inp, device):
 _pool = None
 _pil_tuned = False
 _copy_streams = {}
+# DS_FUNNEL_STATS=1: wall-clock seconds the host spent per stage of the last funnel call (bench.py's funnel leg reports them):
+# 'launch' = decoding + staging + enqueueing the groups, 'wait' = blocked on a group's results, 'convert' = results -> PIL
+FUNNEL_STATS = {}
 
 
 def _copy_stream(device):
@@ -361,7 +365,10 @@ def _emit_group(g, outpath, inp, device):
     torch = _native._torch()
     if g.get("skip"):
         return
+    _t0 = _time.perf_counter()
     g["done"].synchronize()
+    if True:
+        FUNNEL_STATS["wait"] = FUNNEL_STATS.get("wait", 0.0) + (_time.perf_counter() - _t0)
     host = {k: v.numpy() for k, v in g["host"].items()}
     pred_host = None if g["pred_host"] is None else g["pred_host"].numpy()
 
@@ -440,6 +447,8 @@ def core_generation_funnel(outpath, inputimages, inputdepthmaps, inputnames, inp
     torch = _native.require_gpu()        # the hot path has no CPU implementation, whatever COMPUTE_DEVICE says
     device = torch.device('cuda', torch.cuda.current_device())
     _tune_pil_allocator()
+    FUNNEL_STATS.clear()
+    _t_start = _time.perf_counter()
 
     try:
         if not inputdepthmaps_complete:
@@ -456,7 +465,9 @@ def core_generation_funnel(outpath, inputimages, inputdepthmaps, inputnames, inp
             # while enqueueing it (a bad image, out of memory) must not swallow the finished results of group k: the
             # reference's per-image loop (:133-329) would have yielded them before reaching the failing image
             try:
+                _t0 = _time.perf_counter()
                 launched, failure = _launch_group(gi & 1, idxs, inputimages, inputdepthmaps, inp, device), None
+                FUNNEL_STATS["launch"] = FUNNEL_STATS.get("launch", 0.0) + (_time.perf_counter() - _t0)
             except Exception as e:          # noqa: BLE001 -- re-raised below, after the results that precede it
                 launched, failure = None, e
             if pending is not None:
@@ -466,6 +477,8 @@ def core_generation_funnel(outpath, inputimages, inputdepthmaps, inputnames, inp
             pending = launched
         if pending is not None:
             yield from _emit_group(pending, outpath, inp, device)
+        FUNNEL_STATS["total"] = _time.perf_counter() - _t_start
+        FUNNEL_STATS["groups"] = len(groups)
     except Exception as e:
         if 'out of memory' in str(e).lower():                                                  # :308-326
             suggestion = "out of GPU memory, could not generate depthmap! " \

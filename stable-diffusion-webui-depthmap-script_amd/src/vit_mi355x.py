@@ -304,6 +304,26 @@ def conv2d(conv, x):
     return conv(x)
 
 
+def conv_module(layer, x):
+    """layer(x) for the library convolutions of the decoders (1x1, strided 3x3, ConvTranspose2d with a bias).  torch adds a
+    convolution's bias with a separate strided broadcast kernel on ROCm; for half-precision channels_last activations the
+    convolution runs WITHOUT its bias and ds_bias_act_nhwc adds it in place (a vectorised pass at HBM rate).  Everything else
+    -- float32, CPU, no bias, circular padding, other modules -- is the plain call."""
+    if (x.is_cuda and x.dtype in (torch.float16, torch.bfloat16) and x.dim() == 4 and getattr(layer, "bias", None) is not None
+            and layer.out_channels % 8 == 0 and getattr(layer, "padding_mode", "zeros") == "zeros"):
+        if type(layer) is nn.Conv2d:
+            y = layer._conv_forward(x, layer.weight, None)
+        elif type(layer) is nn.ConvTranspose2d:
+            y = F.conv_transpose2d(x, layer.weight, None, layer.stride, layer.padding, layer.output_padding, layer.groups, layer.dilation)
+        else:
+            return layer(x)
+        if y.is_contiguous(memory_format=torch.channels_last):
+            from . import _native
+            return _native.bias_act(y, layer.bias, relu=False)
+        return y + layer.bias.view(1, -1, 1, 1)
+    return layer(x)
+
+
 def residual_conv_unit(conv1, conv2, x, skip=None):
     """[skip +] ( conv2(relu(conv1(relu(x)))) + x ): ResidualConvUnit_custom (dmidas/blocks.py:352-377) / ResidualConvUnit
     (ddepth_anything_v2/.../util/blocks.py:56-85) and, with `skip`, the add of the fusion block around it (:427 / :135).
