@@ -212,12 +212,16 @@ def _launch_group(gen, idxs, inputimages, inputdepthmaps, inp, device):
         return st.to(device, non_blocking=True)
 
     img_t = None
-    if want_stereo and np.asarray(images[0]).ndim != 3:                                          # :252 np.array(image)
+    ndim0 = 3 if len(images[0].getbands()) > 1 else 2                                            # np.array(image).ndim
+    if want_stereo and ndim0 != 3:                                                               # :252 np.array(image)
         # a single-channel image fails in the reference's stereo step (:55 `h, w, c = original_image.shape`), i.e. AFTER the
         # image's depth outputs were yielded: the group is rendered without stereo and _emit_group raises at that point
-        g["stereo_error"] = ValueError('not enough values to unpack (expected 3, got %d)' % np.asarray(images[0]).ndim)
+        g["stereo_error"] = ValueError('not enough values to unpack (expected 3, got %d)' % ndim0)
         want_stereo = False
     if want_stereo:
+        # (Pillow >= 11.2 can export an image's pixel store without a copy through the Arrow interface, which would replace
+        # np.asarray's ~3 interpreter-locked passes per image by one memcpy -- but the export SEGFAULTS on images that map
+        # foreign memory (Image.fromarray of an L / RGBA array, Pillow 12.2): not something a drop-in library may risk)
         img_t = upload_pixels("img", lambda im: np.asarray(im, dtype=np.uint8))
     mesh_source = None
     if custom:
