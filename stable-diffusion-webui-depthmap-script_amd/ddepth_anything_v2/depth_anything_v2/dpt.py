@@ -139,7 +139,7 @@ class DepthAnythingV2(nn.Module):
         cv2 itself is not available in this environment: parity of the resize is unpinned."""
         b, h, w, _ = images_u8.shape
         nw, nh = lower_bound_size(w, h, input_size)
-        if images_u8.is_cuda:
+        if images_u8.is_cuda and vm.PREPROCESS_HIP:
             # one pass over the image bytes (ds_preprocess_bicubic), already in the network's dtype
             from src import _native
             dtype = self.pretrained.blocks[0].norm1.weight.dtype

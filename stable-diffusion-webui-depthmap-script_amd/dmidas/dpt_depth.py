@@ -172,7 +172,7 @@ class DPTDepthModel(DPT):
         stand-in for cv2.resize (tests/golden/make_golden_transforms.py); cv2's arithmetic itself stays unpinned."""
         b, h, w, _ = images_u8.shape
         nw, nh = midas_net_size(w, h, int(net_size), int(net_size if net_h is None else net_h), resize_mode)
-        if images_u8.is_cuda:
+        if images_u8.is_cuda and vm.PREPROCESS_HIP:
             # one pass over the image bytes (ds_preprocess_bicubic): flip, / 255, bicubic, normalise, cast, channels_last
             from src import _native
             return _native.preprocess_bicubic(images_u8, (nh, nw), mean, std, flip=True, dtype=dtype)

@@ -304,12 +304,16 @@ def conv2d(conv, x):
     return conv(x)
 
 
+CONV_BIAS_HIP = os.environ.get("DS_CONV_BIAS", "1") != "0"          # A/B switch
+PREPROCESS_HIP = os.environ.get("DS_PREPROCESS", "1") != "0"      # A/B switch: ds_preprocess_bicubic vs the torch chain
+
+
 def conv_module(layer, x):
     """layer(x) for the library convolutions of the decoders (1x1, strided 3x3, ConvTranspose2d with a bias).  torch adds a
     convolution's bias with a separate strided broadcast kernel on ROCm; for half-precision channels_last activations the
     convolution runs WITHOUT its bias and ds_bias_act_nhwc adds it in place (a vectorised pass at HBM rate).  Everything else
     -- float32, CPU, no bias, circular padding, other modules -- is the plain call."""
-    if (x.is_cuda and x.dtype in (torch.float16, torch.bfloat16) and x.dim() == 4 and getattr(layer, "bias", None) is not None
+    if (CONV_BIAS_HIP and x.is_cuda and x.dtype in (torch.float16, torch.bfloat16) and x.dim() == 4 and getattr(layer, "bias", None) is not None
             and layer.out_channels % 8 == 0 and getattr(layer, "padding_mode", "zeros") == "zeros"):
         if type(layer) is nn.Conv2d:
             y = layer._conv_forward(x, layer.weight, None)
