@@ -5,6 +5,7 @@
 // is read once (x, branch), written once (x, h).  One wave per token row, float32 statistics on the ROUNDED residual
 // stream (so h is exactly LayerNorm of the x that is stored), two-pass variance in registers.
 #include <stdlib.h>
+#include <string.h>
 
 #include <algorithm>
 
@@ -492,6 +493,256 @@ __global__ __launch_bounds__(512) void k_dpt_head_tail_p(HeadTailParams P, int t
     }
 }
 
+// Streaming variant (DS_HEAD_MODE=stream).  The persistent kernel above still spends 2 LDS fragment reads per MFMA (every wave
+// re-reads the weights for its single output row: 256 B per cycle and CU wanted, 128 available) and runs the gather of the
+// upsampled tile and the convolution one after the other.  Here a workgroup owns a 32-pixel-wide column strip and walks DOWN it:
+//   * waves 4-7 are PRODUCERS: four new upsampled rows (34 pixels x 128 channels) per step into a ring of 12 rows in LDS
+//     (global loads of the next batch of items in flight while the current one is interpolated);
+//   * waves 0-3 are CONSUMERS: wave (kh, rp) = half of the input channels x two output rows.  Its 9 x 4 weight fragments live
+//     in REGISTERS for the whole launch (144 VGPRs), an activation fragment read serves up to three taps (the three rows it
+//     is a neighbour of): 48 fragment reads per 72 MFMAs.  The two channel halves exchange one accumulator each through
+//     LDS (16 KB per step) and each finishes ONE row (bias, ReLU, 1x1 convolution, ReLU) at the start of the next step;
+//   * ONE barrier per step of four output rows; both roles run between the same two barriers on different rows of the ring
+//     (step t reads rows 4t-1 .. 4t+4 while rows 4t+7 .. 4t+10 are produced), so the vector work of the upsample sits beside
+//     the matrix work instead of in front of it, and the halo in y disappears.
+#define HTS_RING 12
+#define HTS_PIXB 272              // bytes per pixel in the ring: 256 + 16, so that consecutive pixels start one 16-byte slot apart and
+                                  // the fragment reads (32 consecutive pixels, one chunk) are conflict-free WITHOUT an address swizzle:
+                                  // every read of a step is  row base + immediate(dx * 272 + chunk * 16)
+#define HTS_ROWB (HT_PW * HTS_PIXB)
+#define HTS_ACT_BYTES (HTS_RING * HTS_ROWB)
+#define HTS_PART_BYTES (4 * 4 * 64 * 16)
+#define HTS_LDS_BYTES (HTS_ACT_BYTES + 2 * HTS_PART_BYTES + 256)
+#define HTS_NIT 9                 // producer items per thread and step: columns (pl >> 2) + 4 k, k = 0 .. 8, of ONE row (pl & 3)
+
+__device__ __forceinline__ void hts_barrier()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
+// what a producer thread knows about its 9 columns of the strip (constant while the workgroup walks down the strip)
+struct HtsCols {
+    uint32_t xo0[HTS_NIT], xo1[HTS_NIT];        // byte offsets of the two source columns (+ the thread's 16-byte channel chunk)
+    float wx0[HTS_NIT], wx1[HTS_NIT];           // their weights; both 0 outside the image (the convolution's zero padding) and for the idle 9th item
+};
+
+// out = w00 a + w01 b + w10 c + w11 d for the 8 halves of four 16-byte vectors, float32 accumulation, ONE rounding (what
+// torch's upsample does on half tensors).  f16: v_fma_mix_f32 / v_fma_mixlo_f16 / v_fma_mixhi_f16 read the halves in place.
+template <int BF16>
+__device__ __forceinline__ uint4 hts_lerp4(const uint4 &a, const uint4 &b, const uint4 &c, const uint4 &d, float w00, float w01, float w10, float w11)
+{
+    uint4 o;
+    if (BF16) {
+        typedef typename eo_traits<BF16>::T T;
+        union { uint4 q; T h[8]; } A, B, C, D, O;
+        A.q = a; B.q = b; C.q = c; D.q = d;
+#pragma unroll
+        for (int k = 0; k < 8; k++)
+            O.h[k] = (T)__builtin_fmaf(w11, (float)D.h[k], __builtin_fmaf(w10, (float)C.h[k], __builtin_fmaf(w01, (float)B.h[k], w00 * (float)A.h[k])));
+        o = O.q;
+    } else {
+        const uint32_t av[4] = { a.x, a.y, a.z, a.w }, bv[4] = { b.x, b.y, b.z, b.w }, cv[4] = { c.x, c.y, c.z, c.w }, dv[4] = { d.x, d.y, d.z, d.w };
+        uint32_t ov[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            float lo, hi2;
+            uint32_t r = 0;
+            asm("v_fma_mix_f32 %0, %1, %2, 0 op_sel_hi:[1,0,0]" : "=v"(lo) : "v"(av[k]), "v"(w00));
+            asm("v_fma_mix_f32 %0, %1, %2, 0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(hi2) : "v"(av[k]), "v"(w00));
+            asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel_hi:[1,0,0]" : "+v"(lo) : "v"(bv[k]), "v"(w01));
+            asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(hi2) : "v"(bv[k]), "v"(w01));
+            asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel_hi:[1,0,0]" : "+v"(lo) : "v"(cv[k]), "v"(w10));
+            asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(hi2) : "v"(cv[k]), "v"(w10));
+            asm("v_fma_mixlo_f16 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "+v"(r) : "v"(dv[k]), "v"(w11), "v"(lo));
+            asm("v_fma_mixhi_f16 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(r) : "v"(dv[k]), "v"(w11), "v"(hi2));
+            ov[k] = r;
+        }
+        o = make_uint4(ov[0], ov[1], ov[2], ov[3]);
+    }
+    return o;
+}
+
+// producer: rows jfirst .. jfirst + 3 (relative to the segment's first output row; -1 = the halo row above it) of the strip's
+// upsampled activations -> ring slots (j + 1) % HTS_RING.  gt = 0 .. 255: chunk = gt & 15 (16 bytes = 8 channels), pl = gt >> 4:
+// the thread owns row jfirst + (pl & 3) and the columns (pl >> 2) + 4 k of it.  The loads of the next three items are in flight
+// while three are interpolated.
+template <int BF16>
+__device__ __forceinline__ void hts_gather(const HeadTailParams &P, const unsigned char *xb, unsigned char *s_act, const HtsCols &X,
+                                           int gt, int y0seg, int jfirst)
+{
+    constexpr int NB = 3, NBATCH = HTS_NIT / NB;
+    const int chunk = gt & 15, pl = gt >> 4, rr = pl & 3, c0 = pl >> 2;
+    const int oy = y0seg + jfirst + rr;
+    const bool inside_y = oy >= 0 && oy < P.oh;
+    const float fy = P.sy * max(oy, 0);
+    const int y0 = min((int)fy, P.ih - 1), y1 = min(y0 + 1, P.ih - 1);
+    const float ty = fy - y0;
+    const float wy0 = inside_y ? 1.f - ty : 0.f, wy1 = inside_y ? ty : 0.f;
+    const uint32_t yo0 = (uint32_t)(y0 * P.iw) * 256u, yo1 = (uint32_t)(y1 * P.iw) * 256u;
+    const int slot = (jfirst + 1 + rr) % HTS_RING;
+    const int pix0 = slot * HT_PW + c0;
+    uint4 va[2][NB], vb[2][NB], vc[2][NB], vd[2][NB];
+#define HTS_ISSUE(bi, buf)                                                                                    \
+    _Pragma("unroll") for (int u = 0; u < NB; u++) {                                                          \
+        const int k = (bi) * NB + u;                                                                          \
+        va[buf][u] = *reinterpret_cast<const uint4 *>(xb + (yo0 + X.xo0[k]));                                 \
+        vb[buf][u] = *reinterpret_cast<const uint4 *>(xb + (yo0 + X.xo1[k]));                                 \
+        vc[buf][u] = *reinterpret_cast<const uint4 *>(xb + (yo1 + X.xo0[k]));                                 \
+        vd[buf][u] = *reinterpret_cast<const uint4 *>(xb + (yo1 + X.xo1[k]));                                 \
+    }
+    HTS_ISSUE(0, 0)
+#pragma unroll
+    for (int bi = 0; bi < NBATCH; bi++) {
+        const int buf = bi & 1;
+        if (bi + 1 < NBATCH) { HTS_ISSUE(bi + 1, (bi + 1) & 1) }
+#pragma unroll
+        for (int u = 0; u < NB; u++) {
+            const int k = bi * NB + u;
+            const int c = c0 + 4 * k;
+            if (c < HT_PW) {
+                const uint4 o = hts_lerp4<BF16>(va[buf][u], vb[buf][u], vc[buf][u], vd[buf][u],
+                                                wy0 * X.wx0[k], wy0 * X.wx1[k], wy1 * X.wx0[k], wy1 * X.wx1[k]);
+                *reinterpret_cast<uint4 *>(s_act + (pix0 + 4 * k) * HTS_PIXB + chunk * 16) = o;
+            }
+        }
+    }
+#undef HTS_ISSUE
+}
+
+template <int BF16>
+__global__ __launch_bounds__(512) void k_dpt_head_tail_s(HeadTailParams P, int strips_x, int nseg, int seg_rows, int nitems)
+{
+    typedef typename eo_traits<BF16>::T T;
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_all[];
+    unsigned char *s_act = s_all;                                        // ring: [HTS_RING rows][34 pixels][HTS_PIXB bytes: 16 chunks of 16 B + 16 B of padding]
+    unsigned char *s_part = s_all + HTS_ACT_BYTES;                       // [2][wave 4][quad 4][lane 64] 16 B: the accumulator a wave hands to its partner
+    float *s_cst = reinterpret_cast<float *>(s_all + HTS_ACT_BYTES + 2 * HTS_PART_BYTES);   // b2[32], w3[32]
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, hi = lane >> 5, l31 = lane & 31;
+    if (tid < 32) { s_cst[tid] = P.b2[tid]; s_cst[32 + tid] = P.w3[tid]; }           // visible after the first barrier
+    const int per_img = strips_x * nseg;
+
+    if (wave >= 4) {                                                     // ---------------- producers ----------------
+        const int gt = tid - 256;
+        for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
+            const int b = item / per_img, rem = item - b * per_img, sxi = rem / nseg, seg = rem - sxi * nseg;
+            const int y0seg = seg * seg_rows, tx0 = sxi * HT_TW;
+            const int nsteps = (min(seg_rows, P.oh - y0seg) + 3) >> 2;
+            const unsigned char *xb = (const unsigned char *)P.x + (size_t)b * P.ih * P.iw * 256;
+            HtsCols X;
+#pragma unroll
+            for (int k = 0; k < HTS_NIT; k++) {
+                const int c = (gt >> 6) + 4 * k;                        // (gt >> 4) >> 2
+                const int ox = tx0 - 1 + c;
+                const bool inside_x = c < HT_PW && ox >= 0 && ox < P.ow;
+                const float fx = P.sx * max(ox, 0);
+                const int x0 = min((int)fx, P.iw - 1), x1 = min(x0 + 1, P.iw - 1);
+                const float tx = fx - x0;
+                X.xo0[k] = (uint32_t)x0 * 256u + (uint32_t)(gt & 15) * 16u;
+                X.xo1[k] = (uint32_t)x1 * 256u + (uint32_t)(gt & 15) * 16u;
+                X.wx0[k] = inside_x ? 1.f - tx : 0.f;
+                X.wx1[k] = inside_x ? tx : 0.f;
+            }
+            // gather g fills rows 4g - 1 .. 4g + 2; step t reads rows 4t - 1 .. 4t + 4 = gathers t and t + 1
+            hts_gather<BF16>(P, xb, s_act, X, gt, y0seg, -1);
+            hts_gather<BF16>(P, xb, s_act, X, gt, y0seg, 3);
+            hts_barrier();
+            for (int t = 0; t < nsteps; t++) {
+                if (t + 2 <= nsteps) hts_gather<BF16>(P, xb, s_act, X, gt, y0seg, 4 * (t + 2) - 1);
+                hts_barrier();
+            }
+        }
+        return;
+    }
+
+    // ---------------- consumers: wave (kh, rp): input channels [64 kh, 64 kh + 64), output rows 2 rp, 2 rp + 1 of a step ----------------
+    const int kh = wave & 1, rp = wave >> 1;
+    uint4 wreg[9][4];
+#pragma unroll
+    for (int tap = 0; tap < 9; tap++)
+#pragma unroll
+        for (int s = 0; s < 4; s++)
+            wreg[tap][s] = reinterpret_cast<const uint4 *>(P.wfrag)[((size_t)(tap * 8 + 4 * kh + s) * 2 + hi) * 32 + l31];
+    ht_f32x16 acc0, acc1;
+    for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
+        const int b = item / per_img, rem = item - b * per_img, sxi = rem / nseg, seg = rem - sxi * nseg;
+        const int y0seg = seg * seg_rows, tx0 = sxi * HT_TW;
+        const int yend = min(y0seg + seg_rows, P.oh);
+        const int nsteps = (yend - y0seg + 3) >> 2;
+        hts_barrier();                                                   // the producers' rows -1 .. 6 are in the ring
+        for (int t = 0; t <= nsteps; t++) {
+            if (t > 0) {
+                // finish row 2 rp + kh of step t - 1: own accumulator + the partner's (the other channel half)
+                const unsigned char *pp = s_part + ((t - 1) & 1) * HTS_PART_BYTES + (size_t)((wave ^ 1) * 4) * 1024 + lane * 16;
+                ht_f32x16 fin = kh ? acc1 : acc0;
+                float part = 0.f;
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const float4 o = *reinterpret_cast<const float4 *>(pp + q * 1024);
+                    const float4 bb = *reinterpret_cast<const float4 *>(s_cst + 8 * q + 4 * hi);        // channels (r & 3) + 8 (r >> 2) + 4 hi
+                    const float4 ww = *reinterpret_cast<const float4 *>(s_cst + 32 + 8 * q + 4 * hi);
+                    part = __builtin_fmaf(ww.x, fmaxf(fin[4 * q + 0] + o.x + bb.x, 0.f), part);
+                    part = __builtin_fmaf(ww.y, fmaxf(fin[4 * q + 1] + o.y + bb.y, 0.f), part);
+                    part = __builtin_fmaf(ww.z, fmaxf(fin[4 * q + 2] + o.z + bb.z, 0.f), part);
+                    part = __builtin_fmaf(ww.w, fmaxf(fin[4 * q + 3] + o.w + bb.w, 0.f), part);
+                }
+                part += __shfl_xor(part, 32, 64);
+                float res = part + P.b3;
+                if (P.relu_out) res = fmaxf(res, 0.f);
+                const int oy = y0seg + 4 * (t - 1) + 2 * rp + kh, ox = tx0 + l31;
+                if (hi == 0 && oy < yend && ox < P.ow) ((T *)P.out)[((size_t)b * P.oh + oy) * P.ow + ox] = (T)res;
+                if (t == nsteps) break;
+            }
+#pragma unroll
+            for (int r = 0; r < 16; r++) { acc0[r] = 0.f; acc1[r] = 0.f; }
+            // activation rows 4t - 1 + 2 rp + i, i = 0 .. 3, live in ring slots (4t + 2 rp + i) % HTS_RING
+            const int sb = (4 * t + 2 * rp) % HTS_RING;
+            const unsigned char *rowp[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                int sl = sb + i; sl = sl >= HTS_RING ? sl - HTS_RING : sl;
+                rowp[i] = s_act + (sl * HT_PW + l31) * HTS_PIXB + (8 * kh + hi) * 16;       // chunk 2 (4 kh + s) + hi = (8 kh + hi) + 2 s
+            }
+#define HTS_MFMA(ACC, TAP, S, BQ) do {                                                                                  \
+                if (BF16) { union { uint4 u; ht_bf16x8 v; } wa, ab; wa.u = wreg[TAP][S]; ab.u = BQ;                          \
+                            ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa.v, ab.v, ACC, 0, 0, 0); }                        \
+                else { union { uint4 u; ht_f16x8 v; } wa, ab; wa.u = wreg[TAP][S]; ab.u = BQ;                                 \
+                       ACC = __builtin_amdgcn_mfma_f32_32x32x16_f16(wa.v, ab.v, ACC, 0, 0, 0); }                              \
+            } while (0)
+            // 12 groups (dx, s) of 4 fragment reads + 6 MFMAs; the reads of group g + 1 are issued before the MFMAs of group g
+            uint4 bq[2][4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) bq[0][i] = *reinterpret_cast<const uint4 *>(rowp[i]);
+#pragma unroll
+            for (int g = 0; g < 12; g++) {
+                const int dx = g >> 2, s4 = g & 3, cur = g & 1;
+                if (g + 1 < 12) {
+                    const int off = ((g + 1) >> 2) * HTS_PIXB + ((g + 1) & 3) * 32;
+#pragma unroll
+                    for (int i = 0; i < 4; i++) bq[cur ^ 1][i] = *reinterpret_cast<const uint4 *>(rowp[i] + off);
+                }
+                HTS_MFMA(acc0, 0 * 3 + dx, s4, bq[cur][0]);          // output row 2 rp:     taps dy = 0, 1, 2 on activation rows i = 0, 1, 2
+                HTS_MFMA(acc1, 0 * 3 + dx, s4, bq[cur][1]);          // output row 2 rp + 1: taps dy = 0, 1, 2 on activation rows i = 1, 2, 3
+                HTS_MFMA(acc0, 1 * 3 + dx, s4, bq[cur][1]);
+                HTS_MFMA(acc1, 1 * 3 + dx, s4, bq[cur][2]);
+                HTS_MFMA(acc0, 2 * 3 + dx, s4, bq[cur][2]);
+                HTS_MFMA(acc1, 2 * 3 + dx, s4, bq[cur][3]);
+            }
+#undef HTS_MFMA
+            // hand the accumulator of the row this wave does NOT finish to its partner
+            {
+                unsigned char *pw = s_part + (t & 1) * HTS_PART_BYTES + (size_t)(wave * 4) * 1024 + lane * 16;
+                const ht_f32x16 give = kh ? acc0 : acc1;
+#pragma unroll
+                for (int q = 0; q < 4; q++)
+                    *reinterpret_cast<float4 *>(pw + q * 1024) = make_float4(give[4 * q], give[4 * q + 1], give[4 * q + 2], give[4 * q + 3]);
+            }
+            hts_barrier();
+        }
+    }
+}
+
 DS_API int ds_dpt_head_tail(ds_ctx *ctx, const void *x, int batch, int in_h, int in_w, int out_h, int out_w,
                             const void *conv3_wfrag, const float *conv3_bias, const float *conv1_weight, float conv1_bias,
                             int relu_out, void *out, int dtype, void *stream)
@@ -509,9 +760,34 @@ DS_API int ds_dpt_head_tail(ds_ctx *ctx, const void *x, int batch, int in_h, int
     // the persistent variant (weights resident in LDS, one workgroup per CU) is the default since round 3: value-tested on
     // hardware, 1.90 -> 1.67 ms at 32 x 256^2 -> 512^2 (profiles/round3_head_tail_ab.txt); DS_HEAD_PERSIST=0 selects the
     // tile-per-workgroup kernel (A/B runs)
-    static int s_persist = -1;
-    if (s_persist < 0) { const char *e = getenv("DS_HEAD_PERSIST"); s_persist = (e && atoi(e) == 0) ? 0 : 1; }
-    if (s_persist) {
+    // DS_HEAD_MODE=stream: the streaming kernel (column strips, producer / consumer waves).  The switches are read per call.
+    int mode = 1;
+    { const char *e = getenv("DS_HEAD_PERSIST"); if (e && atoi(e) == 0) mode = 0; }
+    { const char *e = getenv("DS_HEAD_MODE"); if (e) mode = !strcmp(e, "stream") ? 2 : (!strcmp(e, "tile") ? 0 : (!strcmp(e, "persist") ? 1 : mode)); }
+    if (mode == 2) {
+        int ncu = 0, dev = 0;
+        DS_HIP_CHECK(hipGetDevice(&dev));
+        DS_HIP_CHECK(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev));
+        const int strips_x = (out_w + HT_TW - 1) / HT_TW;
+        // segments of a strip: as long as possible (1.5 producer steps of lead-in each), but at least ~4 work items per CU
+        int seg_rows = (out_h + 3) & ~3;
+        while ((long long)strips_x * batch * ((out_h + seg_rows - 1) / seg_rows) < 4ll * ncu && seg_rows > 16) seg_rows = ((seg_rows / 2) + 3) & ~3;
+        { const char *e = getenv("DS_HEAD_SEG"); if (e && atoi(e) >= 4) seg_rows = (atoi(e) + 3) & ~3; }
+        const int nseg = (out_h + seg_rows - 1) / seg_rows;
+        const long long nitems = (long long)strips_x * nseg * batch;
+        DS_REQUIRE(nitems < (1ll << 30), DS_EUNSUPPORTED, "ds_dpt_head_tail: too many work items");
+        const int grid = (int)std::min<long long>(ncu, nitems);
+        if (dtype == DS_DTYPE_F16) {
+            DS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_dpt_head_tail_s<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)HTS_LDS_BYTES));
+            hipLaunchKernelGGL((k_dpt_head_tail_s<0>), dim3(grid), dim3(512), HTS_LDS_BYTES, (hipStream_t)stream, P, strips_x, nseg, seg_rows, (int)nitems);
+        } else {
+            DS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_dpt_head_tail_s<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)HTS_LDS_BYTES));
+            hipLaunchKernelGGL((k_dpt_head_tail_s<1>), dim3(grid), dim3(512), HTS_LDS_BYTES, (hipStream_t)stream, P, strips_x, nseg, seg_rows, (int)nitems);
+        }
+        DS_HIP_CHECK(hipGetLastError());
+        return DS_OK;
+    }
+    if (mode == 1) {
         const int tiles_x = (out_w + HT_TW - 1) / HT_TW, tiles_y = (out_h + HTP_TH - 1) / HTP_TH;
         const long long nt = (long long)tiles_x * tiles_y * batch;
         DS_REQUIRE(nt < (1ll << 30), DS_EUNSUPPORTED, "ds_dpt_head_tail: too many tiles");

@@ -287,6 +287,41 @@ def test_dpt_head_tail_kernel(gpu, dtype, tol):
         assert err < tol * (1 + want.abs().max().item()), (b, ih, iw, oh, ow, err)
 
 
+@pytest.mark.parametrize("dtype,tol", [(torch.float16, 4e-3), (torch.bfloat16, 3e-2)])
+def test_dpt_head_tail_stream_kernel(gpu, dtype, tol, monkeypatch):
+    """The streaming variant of ds_dpt_head_tail (DS_HEAD_MODE=stream: column strips, producer / consumer waves, a ring of
+    upsampled rows in LDS) against the float32 torch sequence, on shapes with one and several segments per strip, several work
+    items per workgroup (forced with DS_HEAD_SEG), ragged right / bottom edges, and the benchmark's own 256^2 -> 512^2."""
+    from src import _native
+    import torch.nn as nn
+    import torch.nn.functional as F
+    torch.manual_seed(4)
+    conv3 = nn.Conv2d(128, 32, 3, padding=1).cuda()
+    conv1 = nn.Conv2d(32, 1, 1).cuda()
+    with torch.no_grad():
+        conv1.bias.fill_(0.05)
+    monkeypatch.setenv("DS_HEAD_MODE", "stream")
+    for (b, ih, iw, oh, ow, relu, seg) in [(2, 9, 13, 18, 26, True, None), (1, 37, 37, 518 // 7, 518 // 7, True, None), (3, 16, 16, 32, 32, False, 8),
+                                           (1, 20, 31, 33, 70, True, None), (2, 64, 64, 128, 128, True, 16), (1, 37, 66, 518, 924, True, None),
+                                           (40, 48, 40, 97, 80, True, 12), (2, 256, 256, 512, 512, True, None)]:
+        if seg is None:
+            monkeypatch.delenv("DS_HEAD_SEG", raising=False)
+        else:
+            monkeypatch.setenv("DS_HEAD_SEG", str(seg))
+        x = torch.randn((b, 128, ih, iw), device='cuda')
+        with torch.no_grad():
+            up = F.interpolate(x.to(dtype).float(), size=(oh, ow), mode="bilinear", align_corners=True)
+            y = conv1(F.relu(conv3(up)))
+            want = F.relu(y) if relu else y
+            got = _native.dpt_head_tail(x.to(dtype).contiguous(memory_format=torch.channels_last), (oh, ow),
+                                        conv3.to(dtype), conv1.to(dtype), relu_out=relu).float()
+        conv3.float(); conv1.float()
+        assert got.shape == want.shape
+        assert torch.isfinite(got).all(), (b, ih, iw, oh, ow)
+        err = (got - want).abs().max().item()
+        assert err < tol * (1 + want.abs().max().item()), (b, ih, iw, oh, ow, err)
+
+
 def test_video_two_pass_pipeline_single_rank(gpu, oracle):
     """gen_frames_sharded on one rank: network -> global normalisation -> uint16 -> stereo, against the same steps done by
     hand (process_predicitons on the host, the stereo oracle)."""

@@ -60,8 +60,16 @@ def main():
         conv3 = nn.Conv2d(128, 32, 3, padding=1).to(dev).half()
         conv1 = nn.Conv2d(32, 1, 1).to(dev).half()
         x = torch.randn(B, 128, 256, 256, device=dev, dtype=torch.float16).contiguous(memory_format=torch.channels_last)
-        ms = timeit(lambda: nat.dpt_head_tail(x, (512, 512), conv3, conv1, True))
-        print(f"dpt_head_tail 256^2 -> 512^2 x{B}: {ms:.3f} ms  {2.0 * 9 * 128 * 32 * 512 * 512 * B / ms / 1e9:.1f} TF/s")
+        import os
+        ref = None
+        for mode in ("tile", "persist", "stream"):
+            os.environ["DS_HEAD_MODE"] = mode
+            out = nat.dpt_head_tail(x, (512, 512), conv3, conv1, True).float()
+            ref = out if ref is None else ref
+            ms = timeit(lambda: nat.dpt_head_tail(x, (512, 512), conv3, conv1, True))
+            print(f"dpt_head_tail [{mode}] 256^2 -> 512^2 x{B}: {ms:.3f} ms  {2.0 * 9 * 128 * 32 * 512 * 512 * B / ms / 1e9:.1f} TF/s"
+                  f"  max|diff to tile| {(out - ref).abs().max().item():.2e}")
+        os.environ.pop("DS_HEAD_MODE", None)
     if "rln" in which:
         x = torch.randn(B * 1088, 1024, device=dev, dtype=torch.float16)
         o = torch.randn_like(x)
