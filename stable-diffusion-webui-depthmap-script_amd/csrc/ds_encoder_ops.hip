@@ -496,24 +496,34 @@ __global__ __launch_bounds__(512) void k_dpt_head_tail_p(HeadTailParams P, int t
 // Streaming variant (DS_HEAD_MODE=stream).  The persistent kernel above still spends 2 LDS fragment reads per MFMA (every wave
 // re-reads the weights for its single output row: 256 B per cycle and CU wanted, 128 available) and runs the gather of the
 // upsampled tile and the convolution one after the other.  Here a workgroup owns a 32-pixel-wide column strip and walks DOWN it:
-//   * waves 4-7 are PRODUCERS: four new upsampled rows (34 pixels x 128 channels) per step into a ring of 12 rows in LDS
-//     (global loads of the next batch of items in flight while the current one is interpolated);
+//   * waves 4-7 are PRODUCERS: four new upsampled rows (34 pixels x 128 channels) per step into a ring of 10 rows in LDS.
+//     Producer wave w owns ~9 of the 34 columns: it copies the 4 x 7 source pixels under them into a private staging tile in
+//     LDS ONCE (7 global loads per lane, issued one step ahead) and interpolates out of that tile -- the first version loaded
+//     the four neighbours of every upsampled pixel straight from memory, 36 16-byte loads per lane and step = 144 KB per step
+//     through a 64 B / clock vector L1: 0.81 ms per launch, the L1 port alone cost as much as all the MFMAs;
 //   * waves 0-3 are CONSUMERS: wave (kh, rp) = half of the input channels x two output rows.  Its 9 x 4 weight fragments live
 //     in REGISTERS for the whole launch (144 VGPRs), an activation fragment read serves up to three taps (the three rows it
-//     is a neighbour of): 48 fragment reads per 72 MFMAs.  The two channel halves exchange one accumulator each through
-//     LDS (16 KB per step) and each finishes ONE row (bias, ReLU, 1x1 convolution, ReLU) at the start of the next step;
+//     is a neighbour of): 48 fragment reads per 72 MFMAs, every one of them  row base + immediate.  The two channel halves
+//     exchange one accumulator each through LDS (16 KB per step) and each finishes ONE row (bias, ReLU, 1x1 convolution,
+//     ReLU) at the start of the next step;
 //   * ONE barrier per step of four output rows; both roles run between the same two barriers on different rows of the ring
-//     (step t reads rows 4t-1 .. 4t+4 while rows 4t+7 .. 4t+10 are produced), so the vector work of the upsample sits beside
+//     (step t reads rows 4t-1 .. 4t+4 while rows 4t+5 .. 4t+8 are produced), so the vector work of the upsample sits beside
 //     the matrix work instead of in front of it, and the halo in y disappears.
-#define HTS_RING 12
+// Needs an upsample by at least ~1.6 (3 sy < 2, 8 sx < 5: the source pixels under 4 rows x 9 columns fit the 4 x 7 staging tile);
+// anything else takes the persistent kernel.
+#define HTS_RING 10
 #define HTS_PIXB 272              // bytes per pixel in the ring: 256 + 16, so that consecutive pixels start one 16-byte slot apart and
                                   // the fragment reads (32 consecutive pixels, one chunk) are conflict-free WITHOUT an address swizzle:
                                   // every read of a step is  row base + immediate(dx * 272 + chunk * 16)
 #define HTS_ROWB (HT_PW * HTS_PIXB)
 #define HTS_ACT_BYTES (HTS_RING * HTS_ROWB)
 #define HTS_PART_BYTES (4 * 4 * 64 * 16)
-#define HTS_LDS_BYTES (HTS_ACT_BYTES + 2 * HTS_PART_BYTES + 256)
-#define HTS_NIT 9                 // producer items per thread and step: columns (pl >> 2) + 4 k, k = 0 .. 8, of ONE row (pl & 3)
+#define HTS_SRC_ROWS 4
+#define HTS_SRC_COLS 7
+#define HTS_SRC_LOADS (HTS_SRC_ROWS * HTS_SRC_COLS * 16 / 64)          // 16-byte loads per lane for one staging tile
+#define HTS_STAGE_BYTES (HTS_SRC_ROWS * HTS_SRC_COLS * 256)
+#define HTS_LDS_BYTES (HTS_ACT_BYTES + 2 * HTS_PART_BYTES + 256 + 4 * HTS_STAGE_BYTES)
+#define HTS_NIT 9                 // columns per producer wave (9, 9, 8, 8)
 
 __device__ __forceinline__ void hts_barrier()
 {
@@ -522,10 +532,11 @@ __device__ __forceinline__ void hts_barrier()
     asm volatile("" ::: "memory");
 }
 
-// what a producer thread knows about its 9 columns of the strip (constant while the workgroup walks down the strip)
+// what a producer wave knows about its columns of the strip (constant while the workgroup walks down the strip; wave-uniform)
 struct HtsCols {
-    uint32_t xo0[HTS_NIT], xo1[HTS_NIT];        // byte offsets of the two source columns (+ the thread's 16-byte channel chunk)
-    float wx0[HTS_NIT], wx1[HTS_NIT];           // their weights; both 0 outside the image (the convolution's zero padding) and for the idle 9th item
+    int cx0[HTS_NIT], cx1[HTS_NIT];             // byte offsets (256 x column) of the two source columns inside the staging tile
+    float wx0[HTS_NIT], wx1[HTS_NIT];           // their weights; both 0 outside the image (the convolution's zero padding)
+    int xlo;                                    // first source column of the staging tile
 };
 
 // out = w00 a + w01 b + w10 c + w11 d for the 8 halves of four 16-byte vectors, float32 accumulation, ONE rounding (what
@@ -564,55 +575,75 @@ __device__ __forceinline__ uint4 hts_lerp4(const uint4 &a, const uint4 &b, const
     return o;
 }
 
-// producer: rows jfirst .. jfirst + 3 (relative to the segment's first output row; -1 = the halo row above it) of the strip's
-// upsampled activations -> ring slots (j + 1) % HTS_RING.  gt = 0 .. 255: chunk = gt & 15 (16 bytes = 8 channels), pl = gt >> 4:
-// the thread owns row jfirst + (pl & 3) and the columns (pl >> 2) + 4 k of it.  The loads of the next three items are in flight
-// while three are interpolated.
-template <int BF16>
-__device__ __forceinline__ void hts_gather(const HeadTailParams &P, const unsigned char *xb, unsigned char *s_act, const HtsCols &X,
-                                           int gt, int y0seg, int jfirst)
+// first source row under the gather whose first output row is jfirst (relative to the segment's first output row)
+__device__ __forceinline__ int hts_ylo(const HeadTailParams &P, int y0seg, int jfirst)
 {
-    constexpr int NB = 3, NBATCH = HTS_NIT / NB;
-    const int chunk = gt & 15, pl = gt >> 4, rr = pl & 3, c0 = pl >> 2;
-    const int oy = y0seg + jfirst + rr;
+    return min((int)(P.sy * max(y0seg + jfirst, 0)), P.ih - 1);
+}
+
+// the 4 x 7 source pixels under a producer wave's part of a gather -> registers: load m of a lane is 16-byte slot lane + 64 m of
+// the staging tile [row][column][16 chunks].  (Seven named registers, not an array: carried across the step loop and its
+// barriers an array stays in scratch memory.)
+struct HtsSrc { uint4 r0, r1, r2, r3, r4, r5, r6; };
+__device__ __forceinline__ uint4 hts_src_load1(const HeadTailParams &P, const unsigned char *xb, int lane, int ylo, int xlo, int m)
+{
+    const int id = lane + 64 * m, chunk = id & 15, pixel = id >> 4;
+    const int r = pixel / HTS_SRC_COLS, cx = pixel - r * HTS_SRC_COLS;
+    const int y = min(ylo + r, P.ih - 1), x = min(xlo + cx, P.iw - 1);
+    return *reinterpret_cast<const uint4 *>(xb + ((uint32_t)(y * P.iw + x) * 256u + (uint32_t)chunk * 16u));
+}
+__device__ __forceinline__ HtsSrc hts_src_load(const HeadTailParams &P, const unsigned char *xb, int lane, int ylo, int xlo)
+{
+    HtsSrc R;
+    R.r0 = hts_src_load1(P, xb, lane, ylo, xlo, 0); R.r1 = hts_src_load1(P, xb, lane, ylo, xlo, 1);
+    R.r2 = hts_src_load1(P, xb, lane, ylo, xlo, 2); R.r3 = hts_src_load1(P, xb, lane, ylo, xlo, 3);
+    R.r4 = hts_src_load1(P, xb, lane, ylo, xlo, 4); R.r5 = hts_src_load1(P, xb, lane, ylo, xlo, 5);
+    R.r6 = hts_src_load1(P, xb, lane, ylo, xlo, 6);
+    return R;
+}
+
+// producer wave: rows jfirst .. jfirst + nrows - 1 (nrows = 4, or 2 for the segment's first two rows; -1 = the halo row above the
+// segment), columns cb .. cb + ncols - 1 of the strip's upsampled activations -> ring slots (j + 1) % HTS_RING.  R holds the
+// source tile of THIS gather (hts_src_load, issued a step ago); it goes to the wave's staging tile, the loads of the NEXT
+// gather (first row jnext) are issued into R, and the 16 lanes x 4 rows interpolate out of LDS:
+// lane = 16 q + chunk owns row jfirst + q and the 16-byte channel chunk.  LDS operations of one wave execute in order, so the
+// tile needs no barrier: only this wave touches it.
+template <int BF16>
+__device__ __forceinline__ void hts_produce(const HeadTailParams &P, const unsigned char *xb, unsigned char *s_act, unsigned char *s_stage,
+                                            const HtsCols &X, int lane, int y0seg, int jfirst, int nrows, int cb, int ncols,
+                                            HtsSrc &R, int jnext)
+{
+    static_assert(HTS_SRC_LOADS == 7, "HtsSrc holds seven loads");
+    uint4 *st = reinterpret_cast<uint4 *>(s_stage) + lane;
+    st[0] = R.r0; st[64] = R.r1; st[128] = R.r2; st[192] = R.r3; st[256] = R.r4; st[320] = R.r5; st[384] = R.r6;
+    const int ylo = hts_ylo(P, y0seg, jfirst);
+    R = hts_src_load(P, xb, lane, hts_ylo(P, y0seg, jnext), X.xlo);         // unconditional: the addresses are clamped
+    const int chunk = lane & 15, q = lane >> 4;
+    const int oy = y0seg + jfirst + q;
     const bool inside_y = oy >= 0 && oy < P.oh;
     const float fy = P.sy * max(oy, 0);
     const int y0 = min((int)fy, P.ih - 1), y1 = min(y0 + 1, P.ih - 1);
     const float ty = fy - y0;
     const float wy0 = inside_y ? 1.f - ty : 0.f, wy1 = inside_y ? ty : 0.f;
-    const uint32_t yo0 = (uint32_t)(y0 * P.iw) * 256u, yo1 = (uint32_t)(y1 * P.iw) * 256u;
-    const int slot = (jfirst + 1 + rr) % HTS_RING;
-    const int pix0 = slot * HT_PW + c0;
-    uint4 va[2][NB], vb[2][NB], vc[2][NB], vd[2][NB];
-#define HTS_ISSUE(bi, buf)                                                                                    \
-    _Pragma("unroll") for (int u = 0; u < NB; u++) {                                                          \
-        const int k = (bi) * NB + u;                                                                          \
-        va[buf][u] = *reinterpret_cast<const uint4 *>(xb + (yo0 + X.xo0[k]));                                 \
-        vb[buf][u] = *reinterpret_cast<const uint4 *>(xb + (yo0 + X.xo1[k]));                                 \
-        vc[buf][u] = *reinterpret_cast<const uint4 *>(xb + (yo1 + X.xo0[k]));                                 \
-        vd[buf][u] = *reinterpret_cast<const uint4 *>(xb + (yo1 + X.xo1[k]));                                 \
-    }
-    HTS_ISSUE(0, 0)
+    const unsigned char *s0 = s_stage + (y0 - ylo) * (HTS_SRC_COLS * 256) + chunk * 16;
+    const unsigned char *s1 = s_stage + (y1 - ylo) * (HTS_SRC_COLS * 256) + chunk * 16;
+    const int slot = (jfirst + 1 + q) % HTS_RING;
+    unsigned char *dst = s_act + (slot * HT_PW + cb) * HTS_PIXB + chunk * 16;
+    if (q < nrows) {
 #pragma unroll
-    for (int bi = 0; bi < NBATCH; bi++) {
-        const int buf = bi & 1;
-        if (bi + 1 < NBATCH) { HTS_ISSUE(bi + 1, (bi + 1) & 1) }
-#pragma unroll
-        for (int u = 0; u < NB; u++) {
-            const int k = bi * NB + u;
-            const int c = c0 + 4 * k;
-            if (c < HT_PW) {
-                const uint4 o = hts_lerp4<BF16>(va[buf][u], vb[buf][u], vc[buf][u], vd[buf][u],
-                                                wy0 * X.wx0[k], wy0 * X.wx1[k], wy1 * X.wx0[k], wy1 * X.wx1[k]);
-                *reinterpret_cast<uint4 *>(s_act + (pix0 + 4 * k) * HTS_PIXB + chunk * 16) = o;
+        for (int k = 0; k < HTS_NIT; k++) {
+            if (k < ncols) {
+                const uint4 a = *reinterpret_cast<const uint4 *>(s0 + X.cx0[k]), b = *reinterpret_cast<const uint4 *>(s0 + X.cx1[k]);
+                const uint4 c = *reinterpret_cast<const uint4 *>(s1 + X.cx0[k]), d = *reinterpret_cast<const uint4 *>(s1 + X.cx1[k]);
+                *reinterpret_cast<uint4 *>(dst + k * HTS_PIXB) =
+                    hts_lerp4<BF16>(a, b, c, d, wy0 * X.wx0[k], wy0 * X.wx1[k], wy1 * X.wx0[k], wy1 * X.wx1[k]);
             }
         }
     }
-#undef HTS_ISSUE
 }
 
 template <int BF16>
-__global__ __launch_bounds__(512) void k_dpt_head_tail_s(HeadTailParams P, int strips_x, int nseg, int seg_rows, int nitems)
+__global__ __launch_bounds__(512) void k_dpt_head_tail_s(HeadTailParams P, int strips_x, int nseg, int seg_rows, int nitems, int dbg)
 {
     typedef typename eo_traits<BF16>::T T;
     extern __shared__ __attribute__((aligned(16))) unsigned char s_all[];
@@ -624,32 +655,36 @@ __global__ __launch_bounds__(512) void k_dpt_head_tail_s(HeadTailParams P, int s
     const int per_img = strips_x * nseg;
 
     if (wave >= 4) {                                                     // ---------------- producers ----------------
-        const int gt = tid - 256;
+        const int w4 = wave - 4;
+        const int cb = w4 == 0 ? 0 : (w4 == 1 ? 9 : (w4 == 2 ? 18 : 26)), ncols = w4 < 2 ? 9 : 8;
+        unsigned char *s_stage = s_all + HTS_ACT_BYTES + 2 * HTS_PART_BYTES + 256 + w4 * HTS_STAGE_BYTES;
+        HtsSrc R;
         for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
             const int b = item / per_img, rem = item - b * per_img, sxi = rem / nseg, seg = rem - sxi * nseg;
             const int y0seg = seg * seg_rows, tx0 = sxi * HT_TW;
             const int nsteps = (min(seg_rows, P.oh - y0seg) + 3) >> 2;
             const unsigned char *xb = (const unsigned char *)P.x + (size_t)b * P.ih * P.iw * 256;
             HtsCols X;
+            X.xlo = min((int)(P.sx * max(tx0 - 1 + cb, 0)), P.iw - 1);
 #pragma unroll
             for (int k = 0; k < HTS_NIT; k++) {
-                const int c = (gt >> 6) + 4 * k;                        // (gt >> 4) >> 2
-                const int ox = tx0 - 1 + c;
-                const bool inside_x = c < HT_PW && ox >= 0 && ox < P.ow;
+                const int ox = tx0 - 1 + cb + k;
+                const bool inside_x = k < ncols && ox >= 0 && ox < P.ow;
                 const float fx = P.sx * max(ox, 0);
                 const int x0 = min((int)fx, P.iw - 1), x1 = min(x0 + 1, P.iw - 1);
                 const float tx = fx - x0;
-                X.xo0[k] = (uint32_t)x0 * 256u + (uint32_t)(gt & 15) * 16u;
-                X.xo1[k] = (uint32_t)x1 * 256u + (uint32_t)(gt & 15) * 16u;
+                X.cx0[k] = (x0 - X.xlo) * 256;
+                X.cx1[k] = (x1 - X.xlo) * 256;
                 X.wx0[k] = inside_x ? 1.f - tx : 0.f;
                 X.wx1[k] = inside_x ? tx : 0.f;
             }
-            // gather g fills rows 4g - 1 .. 4g + 2; step t reads rows 4t - 1 .. 4t + 4 = gathers t and t + 1
-            hts_gather<BF16>(P, xb, s_act, X, gt, y0seg, -1);
-            hts_gather<BF16>(P, xb, s_act, X, gt, y0seg, 3);
+            // step t reads rows 4t - 1 .. 4t + 4; rows -1, 0 and 1 .. 4 before the first step, rows 4t + 5 .. 4t + 8 during step t
+            R = hts_src_load(P, xb, lane, hts_ylo(P, y0seg, -1), X.xlo);
+            hts_produce<BF16>(P, xb, s_act, s_stage, X, lane, y0seg, -1, 2, cb, ncols, R, 1);
+            hts_produce<BF16>(P, xb, s_act, s_stage, X, lane, y0seg, 1, 4, cb, ncols, R, 5);
             hts_barrier();
             for (int t = 0; t < nsteps; t++) {
-                if (t + 2 <= nsteps) hts_gather<BF16>(P, xb, s_act, X, gt, y0seg, 4 * (t + 2) - 1);
+                if (t + 1 < nsteps && !(dbg & 1)) hts_produce<BF16>(P, xb, s_act, s_stage, X, lane, y0seg, 4 * t + 5, 4, cb, ncols, R, 4 * t + 9);
                 hts_barrier();
             }
         }
@@ -670,7 +705,7 @@ __global__ __launch_bounds__(512) void k_dpt_head_tail_s(HeadTailParams P, int s
         const int y0seg = seg * seg_rows, tx0 = sxi * HT_TW;
         const int yend = min(y0seg + seg_rows, P.oh);
         const int nsteps = (yend - y0seg + 3) >> 2;
-        hts_barrier();                                                   // the producers' rows -1 .. 6 are in the ring
+        hts_barrier();                                                   // the producers' rows -1 .. 4 are in the ring
         for (int t = 0; t <= nsteps; t++) {
             if (t > 0) {
                 // finish row 2 rp + kh of step t - 1: own accumulator + the partner's (the other channel half)
@@ -716,6 +751,7 @@ __global__ __launch_bounds__(512) void k_dpt_head_tail_s(HeadTailParams P, int s
             for (int i = 0; i < 4; i++) bq[0][i] = *reinterpret_cast<const uint4 *>(rowp[i]);
 #pragma unroll
             for (int g = 0; g < 12; g++) {
+                if (dbg & 2) break;
                 const int dx = g >> 2, s4 = g & 3, cur = g & 1;
                 if (g + 1 < 12) {
                     const int off = ((g + 1) >> 2) * HTS_PIXB + ((g + 1) & 3) * 32;
@@ -764,6 +800,7 @@ DS_API int ds_dpt_head_tail(ds_ctx *ctx, const void *x, int batch, int in_h, int
     int mode = 1;
     { const char *e = getenv("DS_HEAD_PERSIST"); if (e && atoi(e) == 0) mode = 0; }
     { const char *e = getenv("DS_HEAD_MODE"); if (e) mode = !strcmp(e, "stream") ? 2 : (!strcmp(e, "tile") ? 0 : (!strcmp(e, "persist") ? 1 : mode)); }
+    if (mode == 2 && !(3.f * P.sy < 1.99f && 8.f * P.sx < 4.99f)) mode = 1;      // the staging tile of the streaming kernel: 4 x 7 source pixels
     if (mode == 2) {
         int ncu = 0, dev = 0;
         DS_HIP_CHECK(hipGetDevice(&dev));
@@ -776,13 +813,17 @@ DS_API int ds_dpt_head_tail(ds_ctx *ctx, const void *x, int batch, int in_h, int
         const int nseg = (out_h + seg_rows - 1) / seg_rows;
         const long long nitems = (long long)strips_x * nseg * batch;
         DS_REQUIRE(nitems < (1ll << 30), DS_EUNSUPPORTED, "ds_dpt_head_tail: too many work items");
+        int dbg = 0;                                        // timing ablations (WRONG results): -DDS_EXPERIMENTS builds only
+#ifdef DS_EXPERIMENTS
+        { const char *e = getenv("DS_HEAD_ABLATE"); if (e) dbg = atoi(e); }        // 1: no steady-state producer work, 2: no MFMAs
+#endif
         const int grid = (int)std::min<long long>(ncu, nitems);
         if (dtype == DS_DTYPE_F16) {
             DS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_dpt_head_tail_s<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)HTS_LDS_BYTES));
-            hipLaunchKernelGGL((k_dpt_head_tail_s<0>), dim3(grid), dim3(512), HTS_LDS_BYTES, (hipStream_t)stream, P, strips_x, nseg, seg_rows, (int)nitems);
+            hipLaunchKernelGGL((k_dpt_head_tail_s<0>), dim3(grid), dim3(512), HTS_LDS_BYTES, (hipStream_t)stream, P, strips_x, nseg, seg_rows, (int)nitems, dbg);
         } else {
             DS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_dpt_head_tail_s<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)HTS_LDS_BYTES));
-            hipLaunchKernelGGL((k_dpt_head_tail_s<1>), dim3(grid), dim3(512), HTS_LDS_BYTES, (hipStream_t)stream, P, strips_x, nseg, seg_rows, (int)nitems);
+            hipLaunchKernelGGL((k_dpt_head_tail_s<1>), dim3(grid), dim3(512), HTS_LDS_BYTES, (hipStream_t)stream, P, strips_x, nseg, seg_rows, (int)nitems, dbg);
         }
         DS_HIP_CHECK(hipGetLastError());
         return DS_OK;

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Lane-level numpy model of k_dpt_head_tail_s (csrc/ds_encoder_ops.hip): the index arithmetic of the streaming head-tail
-kernel -- ring slots, the producers' thread -> (row, column, chunk) map, the consumers' fragment addresses, the MFMA operand
+kernel -- ring slots, the producers' staging tiles and lane -> (row, chunk) map, the consumers' fragment addresses, the MFMA operand
 and accumulator layouts, the exchange of partial accumulators between the two channel halves, the segment / strip walk --
 restated one to one and checked against the torch definition on the CPU.  It exists because the build container has no GPU:
 the kernel's bookkeeping can be debugged here, and only its transcription to HIP remains to be checked on hardware
@@ -15,8 +15,9 @@ import numpy as np
 import torch
 import torch.nn.functional as F
 
-TW, PW, RING, PIXB = 32, 34, 12, 272
-NIT = 9
+TW, PW, RING, PIXB = 32, 34, 10, 272
+NIT, SRC_ROWS, SRC_COLS = 9, 4, 7
+CB, NCOLS = (0, 9, 18, 26), (9, 9, 8, 8)
 f32 = np.float32
 
 
@@ -57,51 +58,67 @@ class Model:
         self.producers_first = producers_first
 
     # ---- producers -------------------------------------------------------------------------------------------------------
-    def cols(self, tx0):
-        gt = np.arange(256)
-        X = {k: np.zeros((256, NIT), dt) for k, dt in (("x0", np.int64), ("x1", np.int64), ("wx0", f32), ("wx1", f32))}
+    def ylo(self, y0seg, jfirst):
+        return min(int(f32(self.sy * f32(max(y0seg + jfirst, 0)))), self.ih - 1)
+
+    def cols(self, tx0, w4):
+        cb, ncols = CB[w4], NCOLS[w4]
+        X = dict(cx0=[0] * NIT, cx1=[0] * NIT, wx0=[f32(0)] * NIT, wx1=[f32(0)] * NIT)
+        X["xlo"] = min(int(f32(self.sx * f32(max(tx0 - 1 + cb, 0)))), self.iw - 1)
         for k in range(NIT):
-            c = (gt >> 6) + 4 * k
-            ox = tx0 - 1 + c
-            inside = (c < PW) & (ox >= 0) & (ox < self.ow)
-            fx = (self.sx * np.maximum(ox, 0).astype(f32)).astype(f32)
-            x0 = np.minimum(fx.astype(np.int64), self.iw - 1)
-            x1 = np.minimum(x0 + 1, self.iw - 1)
-            tx = (fx - x0.astype(f32)).astype(f32)
-            X["x0"][:, k], X["x1"][:, k] = x0, x1
-            X["wx0"][:, k] = np.where(inside, f32(1) - tx, f32(0))
-            X["wx1"][:, k] = np.where(inside, tx, f32(0))
+            ox = tx0 - 1 + cb + k
+            inside = k < ncols and 0 <= ox < self.ow
+            fx = f32(self.sx * f32(max(ox, 0)))
+            x0 = min(int(fx), self.iw - 1)
+            x1 = min(x0 + 1, self.iw - 1)
+            tx = f32(fx - f32(x0))
+            X["cx0"][k], X["cx1"][k] = x0 - X["xlo"], x1 - X["xlo"]
+            X["wx0"][k] = f32(1) - tx if inside else f32(0)
+            X["wx1"][k] = tx if inside else f32(0)
+            if k < ncols:
+                assert 0 <= X["cx0"][k] < SRC_COLS and 0 <= X["cx1"][k] < SRC_COLS, "staging tile too narrow"
         return X
 
-    def gather(self, b, X, y0seg, jfirst):
-        gt = np.arange(256)
-        chunk, pl = gt & 15, gt >> 4
-        rr, c0 = pl & 3, pl >> 2
-        oy = y0seg + jfirst + rr
-        inside_y = (oy >= 0) & (oy < self.oh)
-        fy = (self.sy * np.maximum(oy, 0).astype(f32)).astype(f32)
-        y0 = np.minimum(fy.astype(np.int64), self.ih - 1)
-        y1 = np.minimum(y0 + 1, self.ih - 1)
-        ty = (fy - y0.astype(f32)).astype(f32)
-        wy0 = np.where(inside_y, f32(1) - ty, f32(0))
-        wy1 = np.where(inside_y, ty, f32(0))
-        slot = (jfirst + 1 + rr) % RING
-        pix0 = slot * PW + c0
-        xb = self.x[b]
-        for k in range(NIT):
-            c = c0 + 4 * k
-            for th in range(256):
-                if c[th] >= PW:
-                    continue
-                ch = slice(chunk[th] * 8, chunk[th] * 8 + 8)
-                a = xb[y0[th], X["x0"][th, k], ch].astype(np.float64)
-                bq = xb[y0[th], X["x1"][th, k], ch].astype(np.float64)
-                cq = xb[y1[th], X["x0"][th, k], ch].astype(np.float64)
-                d = xb[y1[th], X["x1"][th, k], ch].astype(np.float64)
-                w00, w01 = f32(wy0[th] * X["wx0"][th, k]), f32(wy0[th] * X["wx1"][th, k])
-                w10, w11 = f32(wy1[th] * X["wx0"][th, k]), f32(wy1[th] * X["wx1"][th, k])
-                o = f32(f32(f32(f32(w00 * a) + w01 * bq) + w10 * cq) + w11 * d) if False else (w00 * a + w01 * bq + w10 * cq + w11 * d)
-                addr = (pix0[th] + 4 * k) * PIXB + chunk[th] * 16
+    def src_load(self, b, ylo, xlo):
+        """registers of one producer wave: [7 loads][64 lanes][8 halves]"""
+        R = np.zeros((SRC_ROWS * SRC_COLS * 16 // 64, 64, 8), np.float16)
+        for m in range(R.shape[0]):
+            for lane in range(64):
+                idx = lane + 64 * m
+                chunk, pixel = idx & 15, idx >> 4
+                r, cx = divmod(pixel, SRC_COLS)
+                y, x = min(ylo + r, self.ih - 1), min(xlo + cx, self.iw - 1)
+                R[m, lane] = self.x[b, y, x, chunk * 8:chunk * 8 + 8]
+        return R
+
+    def produce(self, b, w4, X, y0seg, jfirst, nrows, R):
+        cb, ncols = CB[w4], NCOLS[w4]
+        stage = self.s_stage[w4]                                    # [28 pixels * 16 chunks][8 halves]
+        for m in range(R.shape[0]):
+            for lane in range(64):
+                stage[lane + 64 * m] = R[m, lane]
+        ylo = self.ylo(y0seg, jfirst)
+        for lane in range(64):
+            chunk, q = lane & 15, lane >> 4
+            if q >= nrows:
+                continue
+            oy = y0seg + jfirst + q
+            inside_y = 0 <= oy < self.oh
+            fy = f32(self.sy * f32(max(oy, 0)))
+            y0 = min(int(fy), self.ih - 1)
+            y1 = min(y0 + 1, self.ih - 1)
+            ty = f32(fy - f32(y0))
+            wy0 = f32(1) - ty if inside_y else f32(0)
+            wy1 = ty if inside_y else f32(0)
+            assert 0 <= y0 - ylo < SRC_ROWS and 0 <= y1 - ylo < SRC_ROWS, "staging tile too short"
+            slot = (jfirst + 1 + q) % RING
+            for k in range(ncols):
+                def rd(ry, cx):
+                    return stage[(ry * SRC_COLS + cx) * 16 + chunk].astype(np.float64)
+                a, bq = rd(y0 - ylo, X["cx0"][k]), rd(y0 - ylo, X["cx1"][k])
+                cq, d = rd(y1 - ylo, X["cx0"][k]), rd(y1 - ylo, X["cx1"][k])
+                o = f32(wy0 * X["wx0"][k]) * a + f32(wy0 * X["wx1"][k]) * bq + f32(wy1 * X["wx0"][k]) * cq + f32(wy1 * X["wx1"][k]) * d
+                addr = (slot * PW + cb + k) * PIXB + chunk * 16
                 self.s_act[addr // 2:addr // 2 + 8] = o.astype(f32).astype(np.float16)
 
     # ---- consumers -------------------------------------------------------------------------------------------------------
@@ -164,6 +181,7 @@ class Model:
         for wg in range(self.grid):
             self.s_act = np.full(RING * PW * PIXB // 2, np.nan, np.float16)
             self.s_part = np.full((2, 4, 4, 64, 4), np.nan, f32)
+            self.s_stage = np.full((4, SRC_ROWS * SRC_COLS * 16, 8), np.nan, np.float16)
             acc = [(np.zeros((64, 16), f32), np.zeros((64, 16), f32)) for _ in range(4)]
             for item in range(wg, self.nitems, self.grid):
                 b, rem = divmod(item, per_img)
@@ -171,9 +189,13 @@ class Model:
                 y0seg, tx0 = seg * self.seg_rows, sxi * TW
                 yend = min(y0seg + self.seg_rows, self.oh)
                 nsteps = (yend - y0seg + 3) >> 2
-                X = self.cols(tx0)
-                self.gather(b, X, y0seg, -1)
-                self.gather(b, X, y0seg, 3)
+                X = [self.cols(tx0, w4) for w4 in range(4)]
+                R = [self.src_load(b, self.ylo(y0seg, -1), X[w4]["xlo"]) for w4 in range(4)]
+                for w4 in range(4):                                  # rows -1, 0, then rows 1 .. 4; the next tile is loaded in between
+                    self.produce(b, w4, X[w4], y0seg, -1, 2, R[w4])
+                    R[w4] = self.src_load(b, self.ylo(y0seg, 1), X[w4]["xlo"])
+                    self.produce(b, w4, X[w4], y0seg, 1, 4, R[w4])
+                    R[w4] = self.src_load(b, self.ylo(y0seg, 5), X[w4]["xlo"])
                 for t in range(nsteps + 1):
                     def consumers():
                         if t > 0:
@@ -186,8 +208,10 @@ class Model:
                                 self.give(w, t, acc[w][0], acc[w][1])
 
                     def producers():
-                        if t < nsteps and t + 2 <= nsteps:
-                            self.gather(b, X, y0seg, 4 * (t + 2) - 1)
+                        if t + 1 < nsteps:
+                            for w4 in range(4):
+                                self.produce(b, w4, X[w4], y0seg, 4 * t + 5, 4, R[w4])
+                                R[w4] = self.src_load(b, self.ylo(y0seg, 4 * t + 9), X[w4]["xlo"])
                     if self.producers_first:
                         producers(); consumers()
                     else:
