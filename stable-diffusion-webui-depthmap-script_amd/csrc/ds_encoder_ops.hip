@@ -559,14 +559,14 @@ __device__ __forceinline__ uint4 hts_lerp4(const uint4 &a, const uint4 &b, const
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             float lo, hi2;
-            uint32_t r = 0;
+            uint32_t r;
             asm("v_fma_mix_f32 %0, %1, %2, 0 op_sel_hi:[1,0,0]" : "=v"(lo) : "v"(av[k]), "v"(w00));
             asm("v_fma_mix_f32 %0, %1, %2, 0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(hi2) : "v"(av[k]), "v"(w00));
             asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel_hi:[1,0,0]" : "+v"(lo) : "v"(bv[k]), "v"(w01));
             asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(hi2) : "v"(bv[k]), "v"(w01));
             asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel_hi:[1,0,0]" : "+v"(lo) : "v"(cv[k]), "v"(w10));
             asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(hi2) : "v"(cv[k]), "v"(w10));
-            asm("v_fma_mixlo_f16 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "+v"(r) : "v"(dv[k]), "v"(w11), "v"(lo));
+            asm("v_fma_mixlo_f16 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(r) : "v"(dv[k]), "v"(w11), "v"(lo));      // (the high half is written next)
             asm("v_fma_mixhi_f16 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(r) : "v"(dv[k]), "v"(w11), "v"(hi2));
             ov[k] = r;
         }
@@ -630,15 +630,22 @@ __device__ __forceinline__ void hts_produce(const HeadTailParams &P, const unsig
     const int slot = (jfirst + 1 + q) % HTS_RING;
     unsigned char *dst = s_act + (slot * HT_PW + cb) * HTS_PIXB + chunk * 16;
     if (q < nrows) {
+        // the four source reads of item k + 3 are issued before item k is interpolated: a producer wave is alone on its SIMD
+        // for vector work, so nothing else hides the LDS latency (the consumers keep the LDS busy)
+        constexpr int DEPTH = 3;
+        uint4 ra[DEPTH], rb[DEPTH], rc[DEPTH], rd[DEPTH];
+#define HTS_RD(k) do { ra[(k) % DEPTH] = *reinterpret_cast<const uint4 *>(s0 + X.cx0[k]); rb[(k) % DEPTH] = *reinterpret_cast<const uint4 *>(s0 + X.cx1[k]);   \
+                       rc[(k) % DEPTH] = *reinterpret_cast<const uint4 *>(s1 + X.cx0[k]); rd[(k) % DEPTH] = *reinterpret_cast<const uint4 *>(s1 + X.cx1[k]); } while (0)
+#pragma unroll
+        for (int k = 0; k < DEPTH; k++) HTS_RD(k);
 #pragma unroll
         for (int k = 0; k < HTS_NIT; k++) {
-            if (k < ncols) {
-                const uint4 a = *reinterpret_cast<const uint4 *>(s0 + X.cx0[k]), b = *reinterpret_cast<const uint4 *>(s0 + X.cx1[k]);
-                const uint4 c = *reinterpret_cast<const uint4 *>(s1 + X.cx0[k]), d = *reinterpret_cast<const uint4 *>(s1 + X.cx1[k]);
-                *reinterpret_cast<uint4 *>(dst + k * HTS_PIXB) =
-                    hts_lerp4<BF16>(a, b, c, d, wy0 * X.wx0[k], wy0 * X.wx1[k], wy1 * X.wx0[k], wy1 * X.wx1[k]);
-            }
+            const uint4 o = hts_lerp4<BF16>(ra[k % DEPTH], rb[k % DEPTH], rc[k % DEPTH], rd[k % DEPTH],
+                                            wy0 * X.wx0[k], wy0 * X.wx1[k], wy1 * X.wx0[k], wy1 * X.wx1[k]);
+            if (k + DEPTH < HTS_NIT) HTS_RD(k + DEPTH);
+            if (k < ncols) *reinterpret_cast<uint4 *>(dst + k * HTS_PIXB) = o;
         }
+#undef HTS_RD
     }
 }
 
@@ -673,8 +680,8 @@ __global__ __launch_bounds__(512) void k_dpt_head_tail_s(HeadTailParams P, int s
                 const float fx = P.sx * max(ox, 0);
                 const int x0 = min((int)fx, P.iw - 1), x1 = min(x0 + 1, P.iw - 1);
                 const float tx = fx - x0;
-                X.cx0[k] = (x0 - X.xlo) * 256;
-                X.cx1[k] = (x1 - X.xlo) * 256;
+                X.cx0[k] = k < ncols ? (x0 - X.xlo) * 256 : 0;           // (item 8 of the 8-column waves is read, then dropped)
+                X.cx1[k] = k < ncols ? (x1 - X.xlo) * 256 : 0;
                 X.wx0[k] = inside_x ? 1.f - tx : 0.f;
                 X.wx1[k] = inside_x ? tx : 0.f;
             }
@@ -700,35 +707,22 @@ __global__ __launch_bounds__(512) void k_dpt_head_tail_s(HeadTailParams P, int s
         for (int s = 0; s < 4; s++)
             wreg[tap][s] = reinterpret_cast<const uint4 *>(P.wfrag)[((size_t)(tap * 8 + 4 * kh + s) * 2 + hi) * 32 + l31];
     ht_f32x16 acc0, acc1;
+#pragma unroll
+    for (int r = 0; r < 16; r++) { acc0[r] = 0.f; acc1[r] = 0.f; }
     for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
         const int b = item / per_img, rem = item - b * per_img, sxi = rem / nseg, seg = rem - sxi * nseg;
         const int y0seg = seg * seg_rows, tx0 = sxi * HT_TW;
         const int yend = min(y0seg + seg_rows, P.oh);
         const int nsteps = (yend - y0seg + 3) >> 2;
         hts_barrier();                                                   // the producers' rows -1 .. 4 are in the ring
-        for (int t = 0; t <= nsteps; t++) {
-            if (t > 0) {
-                // finish row 2 rp + kh of step t - 1: own accumulator + the partner's (the other channel half)
-                const unsigned char *pp = s_part + ((t - 1) & 1) * HTS_PART_BYTES + (size_t)((wave ^ 1) * 4) * 1024 + lane * 16;
-                ht_f32x16 fin = kh ? acc1 : acc0;
-                float part = 0.f;
-#pragma unroll
-                for (int q = 0; q < 4; q++) {
-                    const float4 o = *reinterpret_cast<const float4 *>(pp + q * 1024);
-                    const float4 bb = *reinterpret_cast<const float4 *>(s_cst + 8 * q + 4 * hi);        // channels (r & 3) + 8 (r >> 2) + 4 hi
-                    const float4 ww = *reinterpret_cast<const float4 *>(s_cst + 32 + 8 * q + 4 * hi);
-                    part = __builtin_fmaf(ww.x, fmaxf(fin[4 * q + 0] + o.x + bb.x, 0.f), part);
-                    part = __builtin_fmaf(ww.y, fmaxf(fin[4 * q + 1] + o.y + bb.y, 0.f), part);
-                    part = __builtin_fmaf(ww.z, fmaxf(fin[4 * q + 2] + o.z + bb.z, 0.f), part);
-                    part = __builtin_fmaf(ww.w, fmaxf(fin[4 * q + 3] + o.w + bb.w, 0.f), part);
-                }
-                part += __shfl_xor(part, 32, 64);
-                float res = part + P.b3;
-                if (P.relu_out) res = fmaxf(res, 0.f);
-                const int oy = y0seg + 4 * (t - 1) + 2 * rp + kh, ox = tx0 + l31;
-                if (hi == 0 && oy < yend && ox < P.ow) ((T *)P.out)[((size_t)b * P.oh + oy) * P.ow + ox] = (T)res;
-                if (t == nsteps) break;
-            }
+        const int ox = tx0 + l31;
+        for (int t = 0; t < nsteps; t++) {
+            // Row 2 rp + kh of step t - 1 is finished UNDER this step's MFMAs: the own accumulator is copied out, the partner's
+            // (the other channel half, written before the last barrier) is read quad by quad between the MFMA groups.  At t = 0
+            // the same code runs on stale values and its store is switched off: no branch inside the MFMA stream.
+            const ht_f32x16 fin = kh ? acc1 : acc0;
+            const unsigned char *pp = s_part + ((t + 1) & 1) * HTS_PART_BYTES + (size_t)((wave ^ 1) * 4) * 1024 + lane * 16;   // (t - 1) & 1
+            float part = 0.f;
 #pragma unroll
             for (int r = 0; r < 16; r++) { acc0[r] = 0.f; acc1[r] = 0.f; }
             // activation rows 4t - 1 + 2 rp + i, i = 0 .. 3, live in ring slots (4t + 2 rp + i) % HTS_RING
@@ -764,8 +758,25 @@ __global__ __launch_bounds__(512) void k_dpt_head_tail_s(HeadTailParams P, int s
                 HTS_MFMA(acc1, 1 * 3 + dx, s4, bq[cur][2]);
                 HTS_MFMA(acc0, 2 * 3 + dx, s4, bq[cur][2]);
                 HTS_MFMA(acc1, 2 * 3 + dx, s4, bq[cur][3]);
+                if ((g & 1) && g < 8) {                              // quad g >> 1 of the previous step's row
+                    const int q = g >> 1;
+                    const float4 o = *reinterpret_cast<const float4 *>(pp + q * 1024);
+                    const float4 bb = *reinterpret_cast<const float4 *>(s_cst + 8 * q + 4 * hi);        // channels (r & 3) + 8 (r >> 2) + 4 hi
+                    const float4 ww = *reinterpret_cast<const float4 *>(s_cst + 32 + 8 * q + 4 * hi);
+                    part = __builtin_fmaf(ww.x, fmaxf(fin[4 * q + 0] + o.x + bb.x, 0.f), part);
+                    part = __builtin_fmaf(ww.y, fmaxf(fin[4 * q + 1] + o.y + bb.y, 0.f), part);
+                    part = __builtin_fmaf(ww.z, fmaxf(fin[4 * q + 2] + o.z + bb.z, 0.f), part);
+                    part = __builtin_fmaf(ww.w, fmaxf(fin[4 * q + 3] + o.w + bb.w, 0.f), part);
+                }
             }
 #undef HTS_MFMA
+            {
+                part += __shfl_xor(part, 32, 64);
+                float res = part + P.b3;
+                if (P.relu_out) res = fmaxf(res, 0.f);
+                const int oy = y0seg + 4 * (t - 1) + 2 * rp + kh;
+                if (t > 0 && hi == 0 && oy < yend && ox < P.ow) ((T *)P.out)[((size_t)b * P.oh + oy) * P.ow + ox] = (T)res;
+            }
             // hand the accumulator of the row this wave does NOT finish to its partner
             {
                 unsigned char *pw = s_part + (t & 1) * HTS_PART_BYTES + (size_t)(wave * 4) * 1024 + lane * 16;
@@ -775,6 +786,26 @@ __global__ __launch_bounds__(512) void k_dpt_head_tail_s(HeadTailParams P, int s
                     *reinterpret_cast<float4 *>(pw + q * 1024) = make_float4(give[4 * q], give[4 * q + 1], give[4 * q + 2], give[4 * q + 3]);
             }
             hts_barrier();
+        }
+        {   // the last step's row: nothing left to hide it under
+            const ht_f32x16 fin = kh ? acc1 : acc0;
+            const unsigned char *pp = s_part + ((nsteps - 1) & 1) * HTS_PART_BYTES + (size_t)((wave ^ 1) * 4) * 1024 + lane * 16;
+            float part = 0.f;
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const float4 o = *reinterpret_cast<const float4 *>(pp + q * 1024);
+                const float4 bb = *reinterpret_cast<const float4 *>(s_cst + 8 * q + 4 * hi);
+                const float4 ww = *reinterpret_cast<const float4 *>(s_cst + 32 + 8 * q + 4 * hi);
+                part = __builtin_fmaf(ww.x, fmaxf(fin[4 * q + 0] + o.x + bb.x, 0.f), part);
+                part = __builtin_fmaf(ww.y, fmaxf(fin[4 * q + 1] + o.y + bb.y, 0.f), part);
+                part = __builtin_fmaf(ww.z, fmaxf(fin[4 * q + 2] + o.z + bb.z, 0.f), part);
+                part = __builtin_fmaf(ww.w, fmaxf(fin[4 * q + 3] + o.w + bb.w, 0.f), part);
+            }
+            part += __shfl_xor(part, 32, 64);
+            float res = part + P.b3;
+            if (P.relu_out) res = fmaxf(res, 0.f);
+            const int oy = y0seg + 4 * (nsteps - 1) + 2 * rp + kh;
+            if (hi == 0 && oy < yend && ox < P.ow) ((T *)P.out)[((size_t)b * P.oh + oy) * P.ow + ox] = (T)res;
         }
     }
 }
