@@ -649,7 +649,9 @@ __device__ __forceinline__ void hts_produce(const HeadTailParams &P, const unsig
     }
 }
 
-template <int BF16>
+// VARIANT 1: the previous step's row is finished between the MFMA groups (own accumulator copied out: 16 registers), fragment reads one
+// group ahead, the order pinned with sched_barrier.  VARIANT 0: the same stream without the pins (the compiler's own order).
+template <int BF16, int VARIANT>
 __global__ __launch_bounds__(512) void k_dpt_head_tail_s(HeadTailParams P, int strips_x, int nseg, int seg_rows, int nitems, int dbg)
 {
     typedef typename eo_traits<BF16>::T T;
@@ -716,15 +718,25 @@ __global__ __launch_bounds__(512) void k_dpt_head_tail_s(HeadTailParams P, int s
         const int nsteps = (yend - y0seg + 3) >> 2;
         hts_barrier();                                                   // the producers' rows -1 .. 4 are in the ring
         const int ox = tx0 + l31;
+#define HTS_MFMA(ACC, TAP, S, BQ) do {                                                                                  \
+            if (BF16) { union { uint4 u; ht_bf16x8 v; } wa, ab; wa.u = wreg[TAP][S]; ab.u = BQ;                          \
+                        ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa.v, ab.v, ACC, 0, 0, 0); }                        \
+            else { union { uint4 u; ht_f16x8 v; } wa, ab; wa.u = wreg[TAP][S]; ab.u = BQ;                                 \
+                   ACC = __builtin_amdgcn_mfma_f32_32x32x16_f16(wa.v, ab.v, ACC, 0, 0, 0); }                              \
+        } while (0)
+#define HTS_FIN_QUAD(ACC, q) do {               /* channels (r & 3) + 8 (r >> 2) + 4 hi; the bias went in with the accumulator's initial value */ \
+            const float4 o = *reinterpret_cast<const float4 *>(pp + (q) * 1024);                                            \
+            const float4 ww = *reinterpret_cast<const float4 *>(s_cst + 32 + 8 * (q) + 4 * hi);                             \
+            part = __builtin_fmaf(ww.x, fmaxf(ACC[4 * (q) + 0] + o.x, 0.f), part);                                         \
+            part = __builtin_fmaf(ww.y, fmaxf(ACC[4 * (q) + 1] + o.y, 0.f), part);                                         \
+            part = __builtin_fmaf(ww.z, fmaxf(ACC[4 * (q) + 2] + o.z, 0.f), part);                                         \
+            part = __builtin_fmaf(ww.w, fmaxf(ACC[4 * (q) + 3] + o.w, 0.f), part);                                         \
+        } while (0)
         for (int t = 0; t < nsteps; t++) {
-            // Row 2 rp + kh of step t - 1 is finished UNDER this step's MFMAs: the own accumulator is copied out, the partner's
-            // (the other channel half, written before the last barrier) is read quad by quad between the MFMA groups.  At t = 0
-            // the same code runs on stale values and its store is switched off: no branch inside the MFMA stream.
-            const ht_f32x16 fin = kh ? acc1 : acc0;
+            // Row 2 rp + kh of step t - 1: own accumulator + the partner's (the other channel half, written before the last
+            // barrier).  At t = 0 the same code runs on stale values and its store is switched off: no branch in the stream.
             const unsigned char *pp = s_part + ((t + 1) & 1) * HTS_PART_BYTES + (size_t)((wave ^ 1) * 4) * 1024 + lane * 16;   // (t - 1) & 1
             float part = 0.f;
-#pragma unroll
-            for (int r = 0; r < 16; r++) { acc0[r] = 0.f; acc1[r] = 0.f; }
             // activation rows 4t - 1 + 2 rp + i, i = 0 .. 3, live in ring slots (4t + 2 rp + i) % HTS_RING
             const int sb = (4 * t + 2 * rp) % HTS_RING;
             const unsigned char *rowp[4];
@@ -733,43 +745,38 @@ __global__ __launch_bounds__(512) void k_dpt_head_tail_s(HeadTailParams P, int s
                 int sl = sb + i; sl = sl >= HTS_RING ? sl - HTS_RING : sl;
                 rowp[i] = s_act + (sl * HT_PW + l31) * HTS_PIXB + (8 * kh + hi) * 16;       // chunk 2 (4 kh + s) + hi = (8 kh + hi) + 2 s
             }
-#define HTS_MFMA(ACC, TAP, S, BQ) do {                                                                                  \
-                if (BF16) { union { uint4 u; ht_bf16x8 v; } wa, ab; wa.u = wreg[TAP][S]; ab.u = BQ;                          \
-                            ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa.v, ab.v, ACC, 0, 0, 0); }                        \
-                else { union { uint4 u; ht_f16x8 v; } wa, ab; wa.u = wreg[TAP][S]; ab.u = BQ;                                 \
-                       ACC = __builtin_amdgcn_mfma_f32_32x32x16_f16(wa.v, ab.v, ACC, 0, 0, 0); }                              \
-            } while (0)
-            // 12 groups (dx, s) of 4 fragment reads + 6 MFMAs; the reads of group g + 1 are issued before the MFMAs of group g
-            uint4 bq[2][4];
+            // 12 groups g = (dx, s) of 4 fragment reads + 6 MFMAs; byte offset of group g: (g >> 2) * HTS_PIXB + (g & 3) * 32
+            constexpr int NBUF = 2;              // (three buffers = reads two groups ahead does not fit: the weights start to spill)
+            uint4 bq[NBUF][4];
+            ht_f32x16 fin;
+            fin = kh ? acc1 : acc0;
 #pragma unroll
             for (int i = 0; i < 4; i++) bq[0][i] = *reinterpret_cast<const uint4 *>(rowp[i]);
+            // the accumulator of the row this wave finishes starts at the 3x3 convolution's bias, the other one at zero
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const float4 bv = *reinterpret_cast<const float4 *>(s_cst + 8 * q + 4 * hi);
+                acc0[4 * q + 0] = kh ? 0.f : bv.x; acc0[4 * q + 1] = kh ? 0.f : bv.y; acc0[4 * q + 2] = kh ? 0.f : bv.z; acc0[4 * q + 3] = kh ? 0.f : bv.w;
+                acc1[4 * q + 0] = kh ? bv.x : 0.f; acc1[4 * q + 1] = kh ? bv.y : 0.f; acc1[4 * q + 2] = kh ? bv.z : 0.f; acc1[4 * q + 3] = kh ? bv.w : 0.f;
+            }
 #pragma unroll
             for (int g = 0; g < 12; g++) {
                 if (dbg & 2) break;
-                const int dx = g >> 2, s4 = g & 3, cur = g & 1;
-                if (g + 1 < 12) {
-                    const int off = ((g + 1) >> 2) * HTS_PIXB + ((g + 1) & 3) * 32;
+                const int dx = g >> 2, s4 = g & 3, cur = g % NBUF, gn = g + NBUF - 1;
+                if (gn < 12) {
 #pragma unroll
-                    for (int i = 0; i < 4; i++) bq[cur ^ 1][i] = *reinterpret_cast<const uint4 *>(rowp[i] + off);
+                    for (int i = 0; i < 4; i++) bq[gn % NBUF][i] = *reinterpret_cast<const uint4 *>(rowp[i] + (gn >> 2) * HTS_PIXB + (gn & 3) * 32);
                 }
+                if (VARIANT == 1) __builtin_amdgcn_sched_barrier(0);
                 HTS_MFMA(acc0, 0 * 3 + dx, s4, bq[cur][0]);          // output row 2 rp:     taps dy = 0, 1, 2 on activation rows i = 0, 1, 2
                 HTS_MFMA(acc1, 0 * 3 + dx, s4, bq[cur][1]);          // output row 2 rp + 1: taps dy = 0, 1, 2 on activation rows i = 1, 2, 3
                 HTS_MFMA(acc0, 1 * 3 + dx, s4, bq[cur][1]);
                 HTS_MFMA(acc1, 1 * 3 + dx, s4, bq[cur][2]);
                 HTS_MFMA(acc0, 2 * 3 + dx, s4, bq[cur][2]);
                 HTS_MFMA(acc1, 2 * 3 + dx, s4, bq[cur][3]);
-                if ((g & 1) && g < 8) {                              // quad g >> 1 of the previous step's row
-                    const int q = g >> 1;
-                    const float4 o = *reinterpret_cast<const float4 *>(pp + q * 1024);
-                    const float4 bb = *reinterpret_cast<const float4 *>(s_cst + 8 * q + 4 * hi);        // channels (r & 3) + 8 (r >> 2) + 4 hi
-                    const float4 ww = *reinterpret_cast<const float4 *>(s_cst + 32 + 8 * q + 4 * hi);
-                    part = __builtin_fmaf(ww.x, fmaxf(fin[4 * q + 0] + o.x + bb.x, 0.f), part);
-                    part = __builtin_fmaf(ww.y, fmaxf(fin[4 * q + 1] + o.y + bb.y, 0.f), part);
-                    part = __builtin_fmaf(ww.z, fmaxf(fin[4 * q + 2] + o.z + bb.z, 0.f), part);
-                    part = __builtin_fmaf(ww.w, fmaxf(fin[4 * q + 3] + o.w + bb.w, 0.f), part);
-                }
+                if ((g & 1) && g < 8) HTS_FIN_QUAD(fin, g >> 1);
+                if (VARIANT == 1) __builtin_amdgcn_sched_barrier(0);
             }
-#undef HTS_MFMA
             {
                 part += __shfl_xor(part, 32, 64);
                 float res = part + P.b3;
@@ -787,26 +794,19 @@ __global__ __launch_bounds__(512) void k_dpt_head_tail_s(HeadTailParams P, int s
             }
             hts_barrier();
         }
-        {   // the last step's row: nothing left to hide it under
+        {   // the last step's row
             const ht_f32x16 fin = kh ? acc1 : acc0;
             const unsigned char *pp = s_part + ((nsteps - 1) & 1) * HTS_PART_BYTES + (size_t)((wave ^ 1) * 4) * 1024 + lane * 16;
             float part = 0.f;
-#pragma unroll
-            for (int q = 0; q < 4; q++) {
-                const float4 o = *reinterpret_cast<const float4 *>(pp + q * 1024);
-                const float4 bb = *reinterpret_cast<const float4 *>(s_cst + 8 * q + 4 * hi);
-                const float4 ww = *reinterpret_cast<const float4 *>(s_cst + 32 + 8 * q + 4 * hi);
-                part = __builtin_fmaf(ww.x, fmaxf(fin[4 * q + 0] + o.x + bb.x, 0.f), part);
-                part = __builtin_fmaf(ww.y, fmaxf(fin[4 * q + 1] + o.y + bb.y, 0.f), part);
-                part = __builtin_fmaf(ww.z, fmaxf(fin[4 * q + 2] + o.z + bb.z, 0.f), part);
-                part = __builtin_fmaf(ww.w, fmaxf(fin[4 * q + 3] + o.w + bb.w, 0.f), part);
-            }
+            HTS_FIN_QUAD(fin, 0); HTS_FIN_QUAD(fin, 1); HTS_FIN_QUAD(fin, 2); HTS_FIN_QUAD(fin, 3);
             part += __shfl_xor(part, 32, 64);
             float res = part + P.b3;
             if (P.relu_out) res = fmaxf(res, 0.f);
             const int oy = y0seg + 4 * (nsteps - 1) + 2 * rp + kh;
             if (hi == 0 && oy < yend && ox < P.ow) ((T *)P.out)[((size_t)b * P.oh + oy) * P.ow + ox] = (T)res;
         }
+#undef HTS_MFMA
+#undef HTS_FIN_QUAD
     }
 }
 
@@ -849,13 +849,15 @@ DS_API int ds_dpt_head_tail(ds_ctx *ctx, const void *x, int batch, int in_h, int
         { const char *e = getenv("DS_HEAD_ABLATE"); if (e) dbg = atoi(e); }        // 1: no steady-state producer work, 2: no MFMAs
 #endif
         const int grid = (int)std::min<long long>(ncu, nitems);
-        if (dtype == DS_DTYPE_F16) {
-            DS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_dpt_head_tail_s<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)HTS_LDS_BYTES));
-            hipLaunchKernelGGL((k_dpt_head_tail_s<0>), dim3(grid), dim3(512), HTS_LDS_BYTES, (hipStream_t)stream, P, strips_x, nseg, seg_rows, (int)nitems, dbg);
-        } else {
-            DS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_dpt_head_tail_s<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)HTS_LDS_BYTES));
-            hipLaunchKernelGGL((k_dpt_head_tail_s<1>), dim3(grid), dim3(512), HTS_LDS_BYTES, (hipStream_t)stream, P, strips_x, nseg, seg_rows, (int)nitems, dbg);
-        }
+        int variant = 0;
+        { const char *e = getenv("DS_HEAD_VARIANT"); if (e) variant = atoi(e) == 1 ? 1 : 0; }        // A/B switch, read per call
+#define HTS_LAUNCH(BF, V) do {                                                                                                                              \
+            DS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_dpt_head_tail_s<BF, V>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)HTS_LDS_BYTES)); \
+            hipLaunchKernelGGL((k_dpt_head_tail_s<BF, V>), dim3(grid), dim3(512), HTS_LDS_BYTES, (hipStream_t)stream, P, strips_x, nseg, seg_rows, (int)nitems, dbg);    \
+        } while (0)
+        if (dtype == DS_DTYPE_F16) { if (variant) HTS_LAUNCH(0, 1); else HTS_LAUNCH(0, 0); }
+        else { if (variant) HTS_LAUNCH(1, 1); else HTS_LAUNCH(1, 0); }
+#undef HTS_LAUNCH
         DS_HIP_CHECK(hipGetLastError());
         return DS_OK;
     }

@@ -131,6 +131,9 @@ class Model:
         hi, l31 = self.lanes()
         acc0[:] = 0
         acc1[:] = 0
+        own = acc1 if kh else acc0                                   # the row this wave finishes starts at the 3x3 bias
+        for r in range(16):
+            own[:, r] = self.b2[(r & 3) + 8 * (r >> 2) + 4 * hi]
         sb = (4 * t + 2 * rp) % RING
         rowp = []
         for i in range(4):
@@ -162,7 +165,7 @@ class Model:
         for q in range(4):
             for j in range(4):
                 ch = 8 * q + 4 * hi + j
-                v = np.maximum(fin[:, 4 * q + j] + pp[q, :, j] + self.b2[ch], f32(0))
+                v = np.maximum(fin[:, 4 * q + j] + pp[q, :, j], f32(0))
                 part = (part + self.w3[ch] * v).astype(f32)
         part = part + part[np.arange(64) ^ 32]
         res = part + self.b3
