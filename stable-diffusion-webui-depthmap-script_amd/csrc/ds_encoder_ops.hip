@@ -824,11 +824,10 @@ DS_API int ds_dpt_head_tail(ds_ctx *ctx, const void *x, int batch, int in_h, int
     P.B = batch; P.ih = in_h; P.iw = in_w; P.oh = out_h; P.ow = out_w; P.relu_out = relu_out;
     P.sy = out_h > 1 ? (float)(in_h - 1) / (float)(out_h - 1) : 0.f;
     P.sx = out_w > 1 ? (float)(in_w - 1) / (float)(out_w - 1) : 0.f;
-    // the persistent variant (weights resident in LDS, one workgroup per CU) is the default since round 3: value-tested on
-    // hardware, 1.90 -> 1.67 ms at 32 x 256^2 -> 512^2 (profiles/round3_head_tail_ab.txt); DS_HEAD_PERSIST=0 selects the
-    // tile-per-workgroup kernel (A/B runs)
-    // DS_HEAD_MODE=stream: the streaming kernel (column strips, producer / consumer waves).  The switches are read per call.
-    int mode = 1;
+    // The streaming kernel (column strips, producer / consumer waves) is the default since round 3: 1.69 -> 0.72 ms at 32 x 256^2 ->
+    // 512^2 (profiles/round3_head_tail_ab.txt).  DS_HEAD_MODE=persist / tile select the older kernels (A/B runs; persist is also what
+    // an upsample by less than ~1.6 gets); DS_HEAD_PERSIST=0 is the round-2 spelling of tile.  The switches are read per call.
+    int mode = 2;
     { const char *e = getenv("DS_HEAD_PERSIST"); if (e && atoi(e) == 0) mode = 0; }
     { const char *e = getenv("DS_HEAD_MODE"); if (e) mode = !strcmp(e, "stream") ? 2 : (!strcmp(e, "tile") ? 0 : (!strcmp(e, "persist") ? 1 : mode)); }
     if (mode == 2 && !(3.f * P.sy < 1.99f && 8.f * P.sx < 4.99f)) mode = 1;      // the staging tile of the streaming kernel: 4 x 7 source pixels
@@ -849,8 +848,8 @@ DS_API int ds_dpt_head_tail(ds_ctx *ctx, const void *x, int batch, int in_h, int
         { const char *e = getenv("DS_HEAD_ABLATE"); if (e) dbg = atoi(e); }        // 1: no steady-state producer work, 2: no MFMAs
 #endif
         const int grid = (int)std::min<long long>(ncu, nitems);
-        int variant = 0;
-        { const char *e = getenv("DS_HEAD_VARIANT"); if (e) variant = atoi(e) == 1 ? 1 : 0; }        // A/B switch, read per call
+        int variant = 1;                                    // pinned consumer order: consumers alone 0.51 vs 0.58 ms, the whole kernel 0.725 vs 0.732
+        { const char *e = getenv("DS_HEAD_VARIANT"); if (e) variant = atoi(e) == 0 ? 0 : 1; }        // A/B switch, read per call
 #define HTS_LAUNCH(BF, V) do {                                                                                                                              \
             DS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_dpt_head_tail_s<BF, V>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)HTS_LDS_BYTES)); \
             hipLaunchKernelGGL((k_dpt_head_tail_s<BF, V>), dim3(grid), dim3(512), HTS_LDS_BYTES, (hipStream_t)stream, P, strips_x, nseg, seg_rows, (int)nitems, dbg);    \

@@ -261,10 +261,14 @@ def test_upsample_bilinear_nhwc_kernel(gpu, dtype):
         assert (got.float() - want).abs().max().item() < tol * (1 + want.abs().max().item())
 
 
+@pytest.mark.parametrize("mode", ["persist", "tile"])
 @pytest.mark.parametrize("dtype,tol", [(torch.float16, 4e-3), (torch.bfloat16, 3e-2)])
-def test_dpt_head_tail_kernel(gpu, dtype, tol):
-    """ds_dpt_head_tail against the torch sequence upsample -> conv3x3 -> ReLU -> conv1x1 -> ReLU in float32."""
+def test_dpt_head_tail_kernel(gpu, dtype, tol, mode, monkeypatch):
+    """ds_dpt_head_tail against the torch sequence upsample -> conv3x3 -> ReLU -> conv1x1 -> ReLU in float32: the two older
+    kernels (DS_HEAD_MODE=persist is also the fallback of the default for upsamples below ~1.6; the streaming default has its
+    own test below)."""
     from src import _native
+    monkeypatch.setenv("DS_HEAD_MODE", mode)
     import torch.nn as nn
     import torch.nn.functional as F
     torch.manual_seed(4)
@@ -289,9 +293,10 @@ def test_dpt_head_tail_kernel(gpu, dtype, tol):
 
 @pytest.mark.parametrize("dtype,tol", [(torch.float16, 4e-3), (torch.bfloat16, 3e-2)])
 def test_dpt_head_tail_stream_kernel(gpu, dtype, tol, monkeypatch):
-    """The streaming variant of ds_dpt_head_tail (DS_HEAD_MODE=stream: column strips, producer / consumer waves, a ring of
-    upsampled rows in LDS) against the float32 torch sequence, on shapes with one and several segments per strip, several work
-    items per workgroup (forced with DS_HEAD_SEG), ragged right / bottom edges, and the benchmark's own 256^2 -> 512^2."""
+    """The streaming kernel of ds_dpt_head_tail (the default: column strips, producer / consumer waves, a ring of upsampled
+    rows in LDS) against the float32 torch sequence, on shapes with one and several segments per strip, several work items
+    per workgroup (forced with DS_HEAD_SEG), ragged right / bottom edges, the two production shapes (256^2 -> 512^2 of DPT,
+    296 x 528 -> 518 x 924 of Depth-Anything-V2 at 1080p), both consumer schedules, and one shape that takes the fallback."""
     from src import _native
     import torch.nn as nn
     import torch.nn.functional as F
@@ -300,10 +305,12 @@ def test_dpt_head_tail_stream_kernel(gpu, dtype, tol, monkeypatch):
     conv1 = nn.Conv2d(32, 1, 1).cuda()
     with torch.no_grad():
         conv1.bias.fill_(0.05)
-    monkeypatch.setenv("DS_HEAD_MODE", "stream")
-    for (b, ih, iw, oh, ow, relu, seg) in [(2, 9, 13, 18, 26, True, None), (1, 37, 37, 518 // 7, 518 // 7, True, None), (3, 16, 16, 32, 32, False, 8),
+    monkeypatch.delenv("DS_HEAD_MODE", raising=False)
+    for ci, (b, ih, iw, oh, ow, relu, seg) in enumerate([(2, 9, 13, 18, 26, True, None), (1, 37, 37, 518 // 7, 518 // 7, True, None), (3, 16, 16, 32, 32, False, 8),
                                            (1, 20, 31, 33, 70, True, None), (2, 64, 64, 128, 128, True, 16), (1, 37, 66, 518, 924, True, None),
-                                           (40, 48, 40, 97, 80, True, 12), (2, 256, 256, 512, 512, True, None)]:
+                                           (40, 48, 40, 97, 80, True, 12), (2, 256, 256, 512, 512, True, None), (1, 296, 528, 518, 924, True, None),
+                                           (1, 100, 100, 150, 161, True, None)]):
+        monkeypatch.setenv("DS_HEAD_VARIANT", str(ci & 1))
         if seg is None:
             monkeypatch.delenv("DS_HEAD_SEG", raising=False)
         else:
