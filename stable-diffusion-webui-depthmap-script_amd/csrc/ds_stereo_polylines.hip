@@ -805,7 +805,8 @@ __global__ __launch_bounds__(PL_THREADS, 4) void k_polylines(PolyParams P)
 // ------------------------------------------------------------------------------------------------
 // GENERAL pixels, second pass.  k_polylines queued them (row id, column) in HBM; here they are rendered densely packed,
 // EIGHT LANES PER PIXEL, 8 pixels per wave, one wave per workgroup (no workgroup barrier is ever shared with idle waves).
-// A group first rebuilds the pixel's own source window in LDS -- the <= offU - offL + 2 columns that can reach it: normalised
+// A group first rebuilds the pixel's own source window in LDS (since round 3: ONE window per wave when its 8 pixels sit in one
+// row, see the kernel) -- the <= offU - offL + 2 columns that can reach it: normalised
 // depth, points, packed colours, with the arithmetic of phase P01, so every value is bit-identical to what the main kernel
 // staged -- then the 8 lanes test the candidate segments together (8 per step) and share two bit masks (forward segments
 // overlapping the strip, points inside the pixel); lane u takes the u-th point, the group ranks its points (the reference's
@@ -849,7 +850,7 @@ __device__ __forceinline__ double pl_nd_one(const PolyParams &P, const void *dep
 // WPE = waves per SIMD the register allocation is bounded for: 4 is the default; 6 (80 VGPRs, a few spills) exists for A/B runs
 // (DS_PL_GEN_WPE=6)
 template <int C, int SHARP, int WPE = 4>
-__global__ __launch_bounds__(64, WPE) void k_polylines_general(PolyParams P, int ncmax, int per_seg)
+__global__ __launch_bounds__(64, WPE) void k_polylines_general(PolyParams P, int ncmax, int per_seg, int one_window)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int NP = SHARP ? 2 : 1;
@@ -860,6 +861,17 @@ __global__ __launch_bounds__(64, WPE) void k_polylines_general(PolyParams P, int
     double *g_nd = reinterpret_cast<double *>(gbase) + G.ptn + 1;            // g_nd[-1] exists
     uint32_t *g_rgbx = reinterpret_cast<uint32_t *>(gbase + (G.ptn + G.ndn) * 8) + 1;   // g_rgbx[-1] exists
     const int w = P.w;
+    // ONE window for the whole wave when its pixels sit in one row (they almost always do: the main kernel queues a row's
+    // general pixels in column order, folds come in clusters, and a wave takes 8 consecutive entries): the 8 private windows
+    // overlap almost completely, and building them costs every lane ~4 columns of dependent global loads.  The shared window
+    // (columns cmin + offL - 1 .. cmax + offU, the same LDS bytes, laid out as ONE window of up to `cap` columns) costs a lane
+    // one column; a group then works on its own slice of it through the same PlWin view (V.pt = s_pt + NP * (j0 - js0), ...):
+    // every value and every index a group reads is what its private window would have held.
+    const int cap = (8 * G.stride - 176) / (8 * NP + 12);
+    const PlGenLds S = pl_gen_layout(cap, NP);
+    double *s_pt = reinterpret_cast<double *>(smem);
+    double *s_nd = reinterpret_cast<double *>(smem) + S.ptn + 1;
+    uint32_t *s_rgbx = reinterpret_cast<uint32_t *>(smem + (S.ptn + S.ndn) * 8) + 1;
     // workgroup (seg, part): entries part*8, part*8 + 8*per_seg, ... of queue segment seg
     const int seg = blockIdx.x / per_seg, part = blockIdx.x - seg * per_seg;
     const int count = P.gq_count[seg];
@@ -889,39 +901,69 @@ __global__ __launch_bounds__(64, WPE) void k_polylines_general(PolyParams P, int
         const int j1 = max(j0, min(w - 1, col + P.offU[e]));
         const int ncols = have ? j1 - j0 + 1 : 1;
         const bool head = j0 == 0, tail = j1 == w - 1;
+        // all pixels of this wave in one row?  (group 0 always has an entry here; its row id is the reference)
+        const int rowid0 = __builtin_amdgcn_readfirstlane(rowid);
+        int cmin = have ? col : 0x7fffffff, cmax = have ? col : -1;
+#pragma unroll
+        for (int sft = 8; sft < 64; sft <<= 1) { cmin = min(cmin, __shfl_xor(cmin, sft, 64)); cmax = max(cmax, __shfl_xor(cmax, sft, 64)); }
+        const int e0 = (rowid0 / P.h) % P.n_eyes;
+        const int js0 = max(0, cmin + P.offL[e0] - 1);
+        const int js1 = max(js0, min(w - 1, cmax + P.offU[e0]));
+        const int ncs = js1 - js0 + 1;
+        const bool shared = one_window != 0 && ncs <= cap && __all(!have || rowid == rowid0);
         __syncthreads();                                    // the previous pixel's window is no longer read
         const double b16 = (double)(((uint32_t)mx - ((uint32_t)mn & 0xffffu)) & 0xffffu), y16 = 1.0 / b16;   // uint16 path only
-        if (have) {
-            for (int i = u - 1; i < ncols; i += 8) {        // i = -1: the column before the window (point 0, colour -1)
-                const int j = j0 + i;
-                double nd = 0.0;
-                uint32_t px = 0;
-                if (j >= 0) {
-                    nd = pl_nd_one(P, depth_row, j, mn, mx, lut, b16, y16);
-#pragma unroll
-                    for (int k = 0; k < C; k++) px |= (uint32_t)src_row[(size_t)j * C + k] << (8 * k);
-                }
-                g_nd[i] = nd;
-                g_rgbx[i] = px;
-                const double coord_d = nd * div_px;                                             // :182
-                const double coord_x = ((double)j + 0.5) + coord_d + sep_px;                    // :183
-                if (i < 0) {
-                    g_pt[0] = head ? -1.0 * (double)w : (SHARP ? coord_x + 0.45 : coord_x);   // :179 / the previous point
-                } else if (SHARP) {
-                    g_pt[2 * i + 1] = coord_x - 0.45;                                           // :188
-                    g_pt[2 * i + 2] = coord_x + 0.45;                                           // :189
-                } else {
-                    g_pt[i + 1] = coord_x;                                                      // :185
-                }
+        // column i of a window that starts at column jw (i = -1: the column before it: point 0, colour -1)
+#define PL_GEN_COLUMN(PT, ND, RGBX, jw, i, hd, srow, drow, mn_, mx_, lut_, b_, y_, div_, sep_) do {                      \
+            const int j = (jw) + (i);                                                                                     \
+            double nd = 0.0;                                                                                              \
+            uint32_t px = 0;                                                                                              \
+            if (j >= 0) {                                                                                                 \
+                nd = pl_nd_one(P, drow, j, mn_, mx_, lut_, b_, y_);                                                       \
+                _Pragma("unroll") for (int k = 0; k < C; k++) px |= (uint32_t)(srow)[(size_t)j * C + k] << (8 * k);       \
+            }                                                                                                             \
+            (ND)[i] = nd;                                                                                                 \
+            (RGBX)[i] = px;                                                                                               \
+            const double coord_d = nd * (div_);                                                 /* :182 */                \
+            const double coord_x = ((double)j + 0.5) + coord_d + (sep_);                        /* :183 */                \
+            if ((i) < 0) {                                                                                                \
+                (PT)[0] = (hd) ? -1.0 * (double)w : (SHARP ? coord_x + 0.45 : coord_x);       /* :179 / the previous point */ \
+            } else if (SHARP) {                                                                                           \
+                (PT)[2 * (i) + 1] = coord_x - 0.45;                                             /* :188 */                \
+                (PT)[2 * (i) + 2] = coord_x + 0.45;                                             /* :189 */                \
+            } else {                                                                                                      \
+                (PT)[(i) + 1] = coord_x;                                                        /* :185 */                \
+            }                                                                                                             \
+        } while (0)
+        if (shared) {
+            // the row's constants from group 0's entry (every group that has an entry agrees; the others must not be used)
+            const int row0 = rowid0 % P.h, ie0 = rowid0 / P.h, img0 = ie0 / P.n_eyes;
+            const double div0 = P.div_px[e0], sep0 = P.sep_px[e0];
+            const double mn0 = P.minmax[img0 * 2], mx0 = P.minmax[img0 * 2 + 1];
+            const uint8_t *srow0 = P.img + ((size_t)img0 * P.h + row0) * (size_t)w * C;
+            const void *drow0 = (const char *)P.depth + ((size_t)img0 * P.h + row0) * (size_t)w * esz;
+            const double *lut0 = (P.lut != nullptr && P.depth_dtype == DS_DEPTH_U16) ? P.lut + (size_t)img0 * 65536 : nullptr;
+            const double b0 = (double)(((uint32_t)mx0 - ((uint32_t)mn0 & 0xffffu)) & 0xffffu), y0 = 1.0 / b0;
+            const bool heads = js0 == 0;
+            for (int i = lane - 1; i < ncs; i += 64)
+                PL_GEN_COLUMN(s_pt, s_nd, s_rgbx, js0, i, heads, srow0, drow0, mn0, mx0, lut0, b0, y0, div0, sep0);
+            if (lane == 0) {
+                const int qT = NP * ncs + 1;
+                for (int k = 0; k < PL_PT_PAD - 1; k++) s_pt[qT + k] = 2.0 * (double)w;         // :191 (or harmless padding)
             }
+        } else if (have) {
+            for (int i = u - 1; i < ncols; i += 8)
+                PL_GEN_COLUMN(g_pt, g_nd, g_rgbx, j0, i, head, src_row, depth_row, mn, mx, lut, b16, y16, div_px, sep_px);
             if (u == 0) {
                 const int qT = NP * ncols + 1;
                 for (int k = 0; k < PL_PT_PAD - 1; k++) g_pt[qT + k] = 2.0 * (double)w;         // :191 (or harmless padding)
             }
         }
+#undef PL_GEN_COLUMN
         __syncthreads();
         PlWin V;
-        V.pt = g_pt; V.nd = g_nd; V.rgbx = g_rgbx; V.ncols = ncols; V.head = head; V.tail = tail; V.div_px = div_px;
+        const int woff = have ? j0 - js0 : 0;              // this group's slice of the shared window (groups without an entry read nothing)
+        V.pt = shared ? s_pt + NP * woff : g_pt; V.nd = shared ? s_nd + woff : g_nd; V.rgbx = shared ? s_rgbx + woff : g_rgbx; V.ncols = ncols; V.head = head; V.tail = tail; V.div_px = div_px;
         const int qlo = 1;
         const int qhi = !have ? 0 : (tail ? NP * ncols + 1 : NP * ncols);
         const double fq = (double)col, fq1 = (double)(col + 1);
@@ -1328,15 +1370,16 @@ static int pl_dispatch(int op, const PolyParams &P, int c, int ncu, long long nw
     do {                                                                                                                \
         if (op == 0) return pl_main_blocks<C_, SHARP, NE_>(ncu, nwork, lds, nblocks);                                   \
         if (op == 1) return pl_launch_main<C_, SHARP, NE_>(P, *nblocks, lds, st);                                       \
+        const int one_window = !(getenv("DS_PL_GEN_SHARED") && atoi(getenv("DS_PL_GEN_SHARED")) == 0);   /* A/B switch, read per call */ \
         if (getenv("DS_PL_GEN_WPE") && atoi(getenv("DS_PL_GEN_WPE")) == 6) {                                            \
             DS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_polylines_general<C_, SHARP, 6>),         \
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)glds));                   \
-            hipLaunchKernelGGL((k_polylines_general<C_, SHARP, 6>), dim3((unsigned)(P.gq_segments * per_seg)), dim3(64), glds, st, P, ncmax, per_seg); \
+            hipLaunchKernelGGL((k_polylines_general<C_, SHARP, 6>), dim3((unsigned)(P.gq_segments * per_seg)), dim3(64), glds, st, P, ncmax, per_seg, one_window); \
             return DS_OK;                                                                                               \
         }                                                                                                               \
         DS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_polylines_general<C_, SHARP>),                \
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)glds));                       \
-        hipLaunchKernelGGL((k_polylines_general<C_, SHARP>), dim3((unsigned)(P.gq_segments * per_seg)), dim3(64), glds, st, P, ncmax, per_seg); \
+        hipLaunchKernelGGL((k_polylines_general<C_, SHARP>), dim3((unsigned)(P.gq_segments * per_seg)), dim3(64), glds, st, P, ncmax, per_seg, one_window); \
         return DS_OK;                                                                                                   \
     } while (0)
     if (P.n_eyes == 2) {

@@ -627,3 +627,36 @@ def test_exact_fallback_lds_kernel_equals_global_kernel(sg, native, oracle, gpu)
         else:
             os.environ["DS_PL_EXACT_GLOBAL"] = old
     assert flagged > 0
+
+
+def test_general_pixels_one_window_per_wave_equals_private_windows(sg, native, oracle, gpu, monkeypatch):
+    """The second pass renders 8 queued general pixels per wave; when they sit in one row it builds ONE source window for
+    all of them (the default) instead of eight private ones (DS_PL_GEN_SHARED=0).  Both must give the same bytes, and the
+    oracle's: noisy depth (general pixels everywhere, waves inside one row), narrow images (a wave's 8 entries straddle
+    rows: the private-window path inside the default), both fills, unbalanced eyes, float32 depth, an image border in
+    every window (w = 40), and a wide divergence (four 64-segment candidate words)."""
+    torch = gpu
+    rng = np.random.default_rng(91)
+    cases = []
+    for (n, h, w, div, bal, fill, dt) in [(2, 96, 768, 4.0, 0.0, 'polylines_sharp', np.uint16), (2, 64, 640, 3.0, 0.35, 'polylines_soft', np.uint16),
+                                          (3, 200, 40, 12.0, 0.0, 'polylines_sharp', np.uint16), (2, 120, 72, 9.0, -0.4, 'polylines_soft', np.float32),
+                                          (1, 48, 1920, 2.5, 0.0, 'polylines_sharp', np.uint16), (1, 16, 2048, 9.0, 0.0, 'polylines_sharp', np.uint16)]:
+        img = rng.integers(0, 256, (n, h, w, 3), dtype=np.uint8)
+        base = rng.integers(0, 65536, (n, h, w))
+        smooth = (np.linspace(0, 50000, w)[None, None, :] + rng.integers(0, 9000, (n, h, w))).clip(0, 65535)
+        dep = np.where(rng.random((n, h, w)) < 0.5, base, smooth)
+        dep = dep.astype(np.uint16) if dt is np.uint16 else (dep / 65535.0).astype(np.float32)
+        cases.append((img, dep, div, bal, fill))
+    total_general = 0
+    for img, dep, div, bal, fill in cases:
+        it, dt = torch.from_numpy(img).cuda(), torch.from_numpy(dep).cuda()
+        outs = []
+        for sw in ("1", "0"):
+            monkeypatch.setenv("DS_PL_GEN_SHARED", sw)
+            outs.append(sg.create_stereoimages_batch(it, dt, div, 0.0, ['left-right'], bal, 1.0, fill)[0].cpu().numpy())
+            total_general += native.last_stats(it)[1]
+        assert np.array_equal(outs[0], outs[1]), (img.shape, fill, 'shared and private windows differ', int((outs[0] != outs[1]).sum()))
+        for i in range(img.shape[0]):
+            want = oracle.create_stereoimages_arrays(img[i], dep[i], div, 0.0, ['left-right'], bal, 1.0, fill)[0]
+            assert np.array_equal(outs[0][i], want), (img.shape, fill, i, int((outs[0][i] != want).sum()))
+    assert total_general > 10000
