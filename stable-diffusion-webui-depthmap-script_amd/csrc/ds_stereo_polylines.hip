@@ -1035,48 +1035,27 @@ __global__ __launch_bounds__(64, WPE) void k_polylines_general(PolyParams P, int
             int count_a = 0, first = -1, win = -1;
             double best = -PL_EPS;                                                       // :261
             bool hv = false;
-            // The candidates are visited in index order, PL_CB at a time: their end points and closenesses are requested together
-            // (up to 4 PL_CB dependent-free LDS reads in flight) before any of them is looked at -- one candidate at a time the
-            // loop was a chain of two exposed LDS round trips per candidate, and with a network's noisy depth a pixel strip
-            // is overlapped by dozens of forward segments: that chain was the second pass.
-            constexpr int PL_CB = 4;
 #pragma nounroll
             for (;;) {
-                int qv[PL_CB];
+                int qq = -1;                                 // next forward candidate: lowest set bit of the multi-word mask
 #pragma unroll
-                for (int bb = 0; bb < PL_CB; bb++) {         // next forward candidates: lowest set bits of the multi-word mask
-                    int qq = -1;
-#pragma unroll
-                    for (int k = 0; k < PL_KMAX; k++) {
-                        if (qq < 0 && fm[k] != 0ull) {
-                            qq = qlo + 64 * k + __ffsll((long long)fm[k]) - 1;
-                            fm[k] &= fm[k] - 1ull;
-                        }
+                for (int k = 0; k < PL_KMAX; k++) {
+                    if (qq < 0 && fm[k] != 0ull) {
+                        qq = qlo + 64 * k + __ffsll((long long)fm[k]) - 1;
+                        fm[k] &= fm[k] - 1ull;
                     }
-                    qv[bb] = qq;
                 }
-                if (qv[0] < 0) break;
-                double X0[PL_CB], X1[PL_CB], D0[PL_CB], D1[PL_CB];
-#pragma unroll
-                for (int bb = 0; bb < PL_CB; bb++) {
-                    const int qq = qv[bb] < 0 ? qv[0] : qv[bb];
-                    X0[bb] = V.pt[qq - 1]; X1[bb] = V.pt[qq];
-                    D0[bb] = pl_dd_of<NP>(V, qq - 1); D1[bb] = pl_dd_of<NP>(V, qq);
-                }
-#pragma unroll
-                for (int bb = 0; bb < PL_CB; bb++) {
-                    const int qq = qv[bb];
-                    const double x0 = X0[bb], x1 = X1[bb];
-                    if (qq >= 0 && x0 < sb.coord_center && !(x1 < sb.coord_center)) {   // :242-253
-                        if (count_a == 0) first = qq;
-                        count_a++;
-                        const double d0 = D0[bb], d1 = D1[bb];
-                        const double ip_k = (sb.coord_center - x0) / (x1 - x0);         // :263
-                        const double closeness = (1.0 - ip_k) * d0 + ip_k * d1;         // :265
-                        const bool valid = 0.0 < ip_k && ip_k < 1.0;
-                        if (valid && hv && closeness == best) flag = 1;                 // exact tie: csg order decides
-                        if (best < closeness && valid) { best = closeness; win = qq; hv = true; }   // :266
-                    }
+                if (qq < 0) break;
+                const double x0 = V.pt[qq - 1], x1 = V.pt[qq];
+                if (x0 < sb.coord_center && !(x1 < sb.coord_center)) {                  // :242-253
+                    if (count_a == 0) first = qq;
+                    count_a++;
+                    const double d0 = pl_dd_of<NP>(V, qq - 1), d1 = pl_dd_of<NP>(V, qq);
+                    const double ip_k = (sb.coord_center - x0) / (x1 - x0);             // :263
+                    const double closeness = (1.0 - ip_k) * d0 + ip_k * d1;             // :265
+                    const bool valid = 0.0 < ip_k && ip_k < 1.0;
+                    if (valid && hv && closeness == best) flag = 1;                     // exact tie: csg order decides
+                    if (best < closeness && valid) { best = closeness; win = qq; hv = true; }   // :266
                 }
             }
             if (count_a == 1) win = first;                                               // :259
