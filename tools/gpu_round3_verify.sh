@@ -23,6 +23,14 @@ cd $R
 python tools/pmc_summary.py $O/pmc_* --set=round=3 --set=batch=32 "--set=command=DS_CUDNN_BENCHMARK=0 rocprofv3 --pmc <one counter group per pass> -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-funnel" > $O/pmc_summary.json 2>&1; rm -rf $O/pmc_*/; head -c 300 $O/pmc_summary.json
 timeout 200 python bench.py --config c2 --no-cpu-baseline --steps 20 --funnel > $O/bench_c2.json 2> $O/bench_c2.err; cut -c1-160 $O/bench_c2.json
 timeout 200 python bench.py --config c5 --no-cpu-baseline --steps 5 > $O/bench_c5.json 2> $O/bench_c5.err; cut -c1-160 $O/bench_c5.json
+# the general-pixel pass of the polylines kernel on a network's noisy depth (c5: 27 % general pixels): where do its cycles go?
+cd /tmp
+for c in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_SALU" "SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_RD SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_WAVES"; do
+  n=$(echo $c | tr ' ' '_' | cut -c1-24)
+  DS_CUDNN_BENCHMARK=0 timeout 200 rocprofv3 --pmc $c -d $O/pmcc5_$n -o a -- python $R/bench.py --config c5 --steps 2 --warmup 1 --no-cpu-baseline > $O/pmcc5_$n.log 2>&1
+done
+cd $R
+python tools/pmc_summary.py $O/pmcc5_* --match polylines --set=round=3 "--set=command=DS_CUDNN_BENCHMARK=0 rocprofv3 --pmc <group> -- python bench.py --config c5 --steps 2 --warmup 1 --no-cpu-baseline" > $O/pmc_c5_polylines.json 2>&1; rm -rf $O/pmcc5_*/; head -c 200 $O/pmc_c5_polylines.json
 timeout 200 python bench.py --config c3match --no-cpu-baseline --steps 5 > $O/bench_c3match.json 2> $O/bench_c3match.err; cut -c1-160 $O/bench_c3match.json
 timeout 100 python bench.py --model none --no-cpu-baseline > $O/bench_n1_stereo_only.json 2> $O/bench_none.err; cut -c1-160 $O/bench_n1_stereo_only.json
 timeout 300 python tools/microbench.py gemms 2>&1 | grep -E "^gemm|residual_layernorm" | tee $O/microbench_gemms.txt | cut -c1-200
