@@ -342,7 +342,7 @@ __device__ __forceinline__ void pl_piece(const PlWin &V, int q, double x0, doubl
 // GENERAL pixel.  fm/bm: bit t of word k <=> segment / point q = qlo + 64k + t is a forward segment overlapping the
 // closed strip [fq, fq1] / a point inside [fq, fq1).  Sub-intervals are visited in (x, original index) order of the
 // points -- the order of the reference's stable insertion sort (:214-219).
-template <int C, int NP>
+template <int C, int NP, int KW = PL_KMAX>
 __device__ __forceinline__ void pl_general_pixel_lds(const PlWin &V, int qlo, int K, const unsigned long long *fm, unsigned long long *bm,
                                                   double fq, double fq1, double *color, int &flag)
 {
@@ -352,7 +352,7 @@ __device__ __forceinline__ void pl_general_pixel_lds(const PlWin &V, int qlo, in
         double b = fq1;
         int bk = -1, bt = 0;
 #pragma unroll
-        for (int k = 0; k < PL_KMAX; k++) {
+        for (int k = 0; k < KW; k++) {
             if (k < K) {
                 unsigned long long m = bm[k];
                 while (m != 0ull) {
@@ -366,7 +366,7 @@ __device__ __forceinline__ void pl_general_pixel_lds(const PlWin &V, int qlo, in
         const bool more = bk >= 0;
         if (more) {
 #pragma unroll
-            for (int k = 0; k < PL_KMAX; k++) if (k == bk) bm[k] &= ~(1ull << bt);
+            for (int k = 0; k < KW; k++) if (k == bk) bm[k] &= ~(1ull << bt);
         } else {
             b = fq1;
         }
@@ -378,7 +378,7 @@ __device__ __forceinline__ void pl_general_pixel_lds(const PlWin &V, int qlo, in
         double best = -PL_EPS;                                                       // :261
         bool have = false;
 #pragma unroll
-        for (int k = 0; k < PL_KMAX; k++) {
+        for (int k = 0; k < KW; k++) {
             if (k < K) {
                 unsigned long long m = fm[k];
                 while (m != 0ull) {
@@ -849,7 +849,10 @@ __device__ __forceinline__ double pl_nd_one(const PolyParams &P, const void *dep
 // latency bound, and the unconstrained allocation of 170 registers left it two waves per SIMD to hide that latency with)
 // WPE = waves per SIMD the register allocation is bounded for: 4 is the default; 6 (80 VGPRs, a few spills) exists for A/B runs
 // (DS_PL_GEN_WPE=6)
-template <int C, int SHARP, int WPE = 4>
+// KW = 64-segment words of the candidate masks the kernel is compiled for: 1 when P.K == 1 (windows of up to 64 segments: every
+// default-parameter launch) -- popping the next candidate out of a four-word mask cost ~40 vector instructions per candidate,
+// and the pass is bound by vector-instruction issue (profiles/round3_pmc_c5_polylines.json) -- PL_KMAX otherwise.
+template <int C, int SHARP, int WPE = 4, int KW = PL_KMAX>
 __global__ __launch_bounds__(64, WPE) void k_polylines_general(PolyParams P, int ncmax, int per_seg, int one_window)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -967,11 +970,11 @@ __global__ __launch_bounds__(64, WPE) void k_polylines_general(PolyParams P, int
         const int qlo = 1;
         const int qhi = !have ? 0 : (tail ? NP * ncols + 1 : NP * ncols);
         const double fq = (double)col, fq1 = (double)(col + 1);
-        unsigned long long fm[PL_KMAX], bm[PL_KMAX];
+        unsigned long long fm[KW], bm[KW];
 #pragma unroll
-        for (int k = 0; k < PL_KMAX; k++) { fm[k] = 0ull; bm[k] = 0ull; }
+        for (int k = 0; k < KW; k++) { fm[k] = 0ull; bm[k] = 0ull; }
 #pragma unroll
-        for (int k = 0; k < PL_KMAX; k++) {
+        for (int k = 0; k < KW; k++) {
             if (k < P.K) {
                 for (int st = 0; st < 8 && 64 * k + 8 * st < P.nseg; st++) {
                     const int qq = qlo + 64 * k + 8 * st + u;
@@ -986,7 +989,7 @@ __global__ __launch_bounds__(64, WPE) void k_polylines_general(PolyParams P, int
         }
         int nb = 0;
 #pragma unroll
-        for (int k = 0; k < PL_KMAX; k++) nb += __popcll(bm[k]);
+        for (int k = 0; k < KW; k++) nb += __popcll(bm[k]);
         const bool ovf = nb > 7;                             // more than 8 sub-intervals: one lane walks them all
         const bool par = have && !ovf;
         // lane u's point, its rank among the group's points, the sorted sequence
@@ -995,7 +998,7 @@ __global__ __launch_bounds__(64, WPE) void k_polylines_general(PolyParams P, int
         {
             int n = u, qb = -1;
 #pragma unroll
-            for (int k = 0; k < PL_KMAX; k++) {
+            for (int k = 0; k < KW; k++) {
                 const int c = __popcll(bm[k]);
                 if (qb < 0 && n < c) {
                     unsigned long long mm = bm[k];
@@ -1039,7 +1042,7 @@ __global__ __launch_bounds__(64, WPE) void k_polylines_general(PolyParams P, int
             for (;;) {
                 int qq = -1;                                 // next forward candidate: lowest set bit of the multi-word mask
 #pragma unroll
-                for (int k = 0; k < PL_KMAX; k++) {
+                for (int k = 0; k < KW; k++) {
                     if (qq < 0 && fm[k] != 0ull) {
                         qq = qlo + 64 * k + __ffsll((long long)fm[k]) - 1;
                         fm[k] &= fm[k] - 1ull;
@@ -1069,7 +1072,7 @@ __global__ __launch_bounds__(64, WPE) void k_polylines_general(PolyParams P, int
 #pragma unroll
             for (int k = 0; k < C; k++) color[k] += __shfl(term[k], (lane & ~7) | (t & 7), 64);   // lanes past nb hold 0.0
         }
-        if (have && ovf && u == 0) pl_general_pixel_lds<C, NP>(V, qlo, P.K, fm, bm, fq, fq1, color, flag);
+        if (have && ovf && u == 0) pl_general_pixel_lds<C, NP, KW>(V, qlo, P.K, fm, bm, fq, fq1, color, flag);
         if (have && u == 0) {
             uint8_t *o = P.out[e] + (int64_t)img * P.ois[e] + (int64_t)row * P.ors[e] + (size_t)col * C;
 #pragma unroll
@@ -1375,6 +1378,12 @@ static int pl_dispatch(int op, const PolyParams &P, int c, int ncu, long long nw
             DS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_polylines_general<C_, SHARP, 6>),         \
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)glds));                   \
             hipLaunchKernelGGL((k_polylines_general<C_, SHARP, 6>), dim3((unsigned)(P.gq_segments * per_seg)), dim3(64), glds, st, P, ncmax, per_seg, one_window); \
+            return DS_OK;                                                                                               \
+        }                                                                                                               \
+        if (P.K == 1 && !(getenv("DS_PL_GEN_KW") && atoi(getenv("DS_PL_GEN_KW")) != 1)) {                              \
+            DS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_polylines_general<C_, SHARP, 4, 1>),      \
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)glds));                   \
+            hipLaunchKernelGGL((k_polylines_general<C_, SHARP, 4, 1>), dim3((unsigned)(P.gq_segments * per_seg)), dim3(64), glds, st, P, ncmax, per_seg, one_window); \
             return DS_OK;                                                                                               \
         }                                                                                                               \
         DS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_polylines_general<C_, SHARP>),                \

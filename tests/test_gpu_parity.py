@@ -634,7 +634,8 @@ def test_general_pixels_one_window_per_wave_equals_private_windows(sg, native, o
     all of them (the default) instead of eight private ones (DS_PL_GEN_SHARED=0).  Both must give the same bytes, and the
     oracle's: noisy depth (general pixels everywhere, waves inside one row), narrow images (a wave's 8 entries straddle
     rows: the private-window path inside the default), both fills, unbalanced eyes, float32 depth, an image border in
-    every window (w = 40), and a wide divergence (four 64-segment candidate words)."""
+    every window (w = 40), and a wide divergence (four 64-segment candidate words); the kernel specialised for one-word
+    candidate masks (the default wherever the window has at most 64 segments) against the general one."""
     torch = gpu
     rng = np.random.default_rng(91)
     cases = []
@@ -651,11 +652,13 @@ def test_general_pixels_one_window_per_wave_equals_private_windows(sg, native, o
     for img, dep, div, bal, fill in cases:
         it, dt = torch.from_numpy(img).cuda(), torch.from_numpy(dep).cuda()
         outs = []
-        for sw in ("1", "0"):
+        for sw, kw in (("1", "1"), ("0", "1"), ("1", "4")):      # DS_PL_GEN_KW=4: the four-word candidate masks even where one word holds them
             monkeypatch.setenv("DS_PL_GEN_SHARED", sw)
+            monkeypatch.setenv("DS_PL_GEN_KW", kw)
             outs.append(sg.create_stereoimages_batch(it, dt, div, 0.0, ['left-right'], bal, 1.0, fill)[0].cpu().numpy())
             total_general += native.last_stats(it)[1]
         assert np.array_equal(outs[0], outs[1]), (img.shape, fill, 'shared and private windows differ', int((outs[0] != outs[1]).sum()))
+        assert np.array_equal(outs[0], outs[2]), (img.shape, fill, 'one-word and four-word candidate masks differ', int((outs[0] != outs[2]).sum()))
         for i in range(img.shape[0]):
             want = oracle.create_stereoimages_arrays(img[i], dep[i], div, 0.0, ['left-right'], bal, 1.0, fill)[0]
             assert np.array_equal(outs[0][i], want), (img.shape, fill, i, int((outs[0][i] != want).sum()))

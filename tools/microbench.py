@@ -60,7 +60,6 @@ def main():
         conv3 = nn.Conv2d(128, 32, 3, padding=1).to(dev).half()
         conv1 = nn.Conv2d(32, 1, 1).to(dev).half()
         x = torch.randn(B, 128, 256, 256, device=dev, dtype=torch.float16).contiguous(memory_format=torch.channels_last)
-        import os
         ref = None
         for mode in ("tile", "persist", "stream"):
             os.environ["DS_HEAD_MODE"] = mode
