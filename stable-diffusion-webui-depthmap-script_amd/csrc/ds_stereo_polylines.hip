@@ -850,7 +850,7 @@ __device__ __forceinline__ double pl_nd_one(const PolyParams &P, const void *dep
 // WPE = waves per SIMD the register allocation is bounded for: 4 is the default; 6 (80 VGPRs, a few spills) exists for A/B runs
 // (DS_PL_GEN_WPE=6)
 // KW = 64-segment words of the candidate masks the kernel is compiled for: 1 when P.K == 1 (windows of up to 64 segments: every
-// default-parameter launch) -- popping the next candidate out of a four-word mask cost ~40 vector instructions per candidate,
+// default-parameter launch at 1024 columns), 2 when P.K == 2 (1080p) -- popping the next candidate out of a four-word mask cost ~40 vector instructions per candidate,
 // and the pass is bound by vector-instruction issue (profiles/round3_pmc_c5_polylines.json) -- PL_KMAX otherwise.
 template <int C, int SHARP, int WPE = 4, int KW = PL_KMAX>
 __global__ __launch_bounds__(64, WPE) void k_polylines_general(PolyParams P, int ncmax, int per_seg, int one_window)
@@ -1380,10 +1380,17 @@ static int pl_dispatch(int op, const PolyParams &P, int c, int ncu, long long nw
             hipLaunchKernelGGL((k_polylines_general<C_, SHARP, 6>), dim3((unsigned)(P.gq_segments * per_seg)), dim3(64), glds, st, P, ncmax, per_seg, one_window); \
             return DS_OK;                                                                                               \
         }                                                                                                               \
-        if (P.K == 1 && !(getenv("DS_PL_GEN_KW") && atoi(getenv("DS_PL_GEN_KW")) != 1)) {                              \
+        const bool kw_auto = !(getenv("DS_PL_GEN_KW") && atoi(getenv("DS_PL_GEN_KW")) == 4);   /* DS_PL_GEN_KW=4: always the four-word kernel */ \
+        if (P.K == 1 && kw_auto) {                                                                                      \
             DS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_polylines_general<C_, SHARP, 4, 1>),      \
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)glds));                   \
             hipLaunchKernelGGL((k_polylines_general<C_, SHARP, 4, 1>), dim3((unsigned)(P.gq_segments * per_seg)), dim3(64), glds, st, P, ncmax, per_seg, one_window); \
+            return DS_OK;                                                                                               \
+        }                                                                                                               \
+        if (P.K == 2 && kw_auto) {                                                                                      \
+            DS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_polylines_general<C_, SHARP, 4, 2>),      \
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)glds));                   \
+            hipLaunchKernelGGL((k_polylines_general<C_, SHARP, 4, 2>), dim3((unsigned)(P.gq_segments * per_seg)), dim3(64), glds, st, P, ncmax, per_seg, one_window); \
             return DS_OK;                                                                                               \
         }                                                                                                               \
         DS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_polylines_general<C_, SHARP>),                \
