@@ -490,6 +490,28 @@ def main():
         del cv, xc
     torch.cuda.synchronize()
 
+    # ---- route_check (untimed): the forward the step runs -- every block GEMM and the decoder's 3x3 convolutions in-tree, which
+    # needs the batch -- against the SAME network on the same images with every GEMM / 3x3 convolution sent to the ROCm
+    # libraries (vm.library_routing), plus how often the fused entry points were reached in one forward of the step
+    route = None
+    if model is not None:
+        names = ("ds_linear", "ds_linear_residual", "ds_linear_vt", "ds_conv3x3_nhwc", "ds_attention_fwd", "ds_residual_layernorm",
+                 "ds_dpt_head_tail", "ds_preprocess_bicubic")
+        before = dict(nat.CALLS)
+        with torch.no_grad():
+            p_hip = run_forward(model, model_name, img, net_size, net_h).float()
+        calls = {n: nat.CALLS[n] - before.get(n, 0) for n in names}
+        nlib = min(batch, 4)
+        with torch.no_grad(), vm.library_routing():
+            p_lib = run_forward(model, model_name, img[:nlib], net_size, net_h).float()
+        span = (p_lib.flatten(1).max(1).values - p_lib.flatten(1).min(1).values).clamp_min(1e-12)
+        err = (p_hip[:nlib] - p_lib).abs().flatten(1).max(1).values / span
+        route = {"max_abs_diff_over_prediction_range": float(err.max().item()), "units_compared": nlib,
+                 "what": "prediction of the timed forward (in-tree GEMM / convolution routing at the step's batch) vs the same network on "
+                         "the same images with every token GEMM and 3x3 convolution through hipBLASLt / MIOpen; fp16 both sides",
+                 "c_abi_calls_per_forward": calls}
+        del p_hip, p_lib
+
     funnel = None
     want_funnel = args.funnel or (args.config == "c3" and world == 1 and args.model is None and args.batch is None)
     if want_funnel and not args.no_funnel and rank == 0 and model is not None:
@@ -565,6 +587,8 @@ def main():
                                          "unit": "GB/s", "frac": a / HBM_PEAK_GBPS, "traffic": None,
                                          "algorithmic_bytes_per_launch": batch * algo_bytes_normalmap(),
                                          "avg_kernel_ms": float(np.mean(nm_ms))}
+        if route is not None:
+            out["route_check"] = route
         if funnel is not None:
             out["funnel"] = funnel
         if not args.no_cpu_baseline and world == 1:

@@ -318,6 +318,35 @@ def depth_postprocess(raw_prediction, invert=False, clipdepth=False, clipdepth_m
     return (d - lo) / (hi - lo)
 
 
+def depth_postprocess_f16_numpy1(raw_prediction_f16, invert=False, clipdepth=False, far=0.0, near=1.0):
+    """core.py:189-211 for a FLOAT16 prediction -- what estimatemidas hands over on the reference's default GPU path
+    (src/depthmap_generation.py:484-497: `.half()` network, the bicubic upsample in half, `.cpu().numpy()`) -- under the
+    promotion rules of NumPy 1.x, the NumPy the reference was written for, spelled out with explicit casts so that the result
+    does not depend on the NumPy that runs this file:
+      * `out - out.min()`, `out.max() - out.min()` and their quotient are float16 operations (array and numpy-scalar operands
+        of one dtype; each correctly rounded -- NumPy computes them in float32 and rounds, which is the same thing for + - /
+        at 24 >= 2 * 11 + 2 bits);  np.clip(float16, python floats in [0, 1]) ('Range') stays float16;
+      * `arr * 65536 + 0.0001` (convert_to_i16, :44-50): value-based casting makes the python int 65536 a uint32, and
+        promote_types(float16, uint32) = float64, so the product, the sum and the clip are float64, truncated to uint16.
+    I.e. the depth map is quantised to float16's ~2 k levels per octave and then scaled exactly.  Under NumPy >= 2 (NEP 50) the
+    same reference code multiplies in float16 by float16(65536) = inf and stores zeros (and NaNs for a zero) -- see
+    tests/test_host_logic.py::test_float16_prediction_corner.  Returns the uint16 depth map."""
+    raw = np.asarray(raw_prediction_f16)
+    assert raw.dtype == np.float16
+    with np.errstate(over='ignore', invalid='ignore'):
+        if not abs(raw.max() - raw.min()) > np.finfo("float").eps:
+            return np.zeros(raw.shape, np.uint16)
+        d = (-raw if invert else raw.copy())
+        if clipdepth:                                                     # 'Range' (:197-198)
+            lo, hi = d.min(), d.max()
+            d = ((d - lo).astype(np.float16) / np.float16(hi - lo)).astype(np.float16)
+            d = np.clip(d, np.float16(far), np.float16(near)).astype(np.float16)
+        lo, hi = d.min(), d.max()
+        norm = ((d - lo).astype(np.float16) / np.float16(hi - lo)).astype(np.float16)
+        out = np.clip(norm.astype(np.float64) * 65536.0 + 0.0001, 0, 65536 - 0.1)
+    return out.astype(np.uint16)
+
+
 def colorize_u16(depth, lut_rgba, lo=2.0, hi=85.0):
     """dzoedepth/utils/misc.py:97-150 (colorize with default arguments, as src/core.py:271-274 calls it) on a uint16
     depth; lut_rgba = the colormap's bytes=True table [N, 4].  Percentile normalisation (:121-127) in float64, then

@@ -4,6 +4,7 @@ PyTorch is plumbing here: it owns device memory and streams; every per-pixel ope
 hand-written HIP kernel reached through the C ABI.  There is NO CPU fallback: if the shared library is
 missing, or no MI355X is visible, the calls raise.
 """
+import collections
 import ctypes
 import math
 import os
@@ -35,6 +36,10 @@ class ds_eye(ctypes.Structure):
 
 _lib = None
 _lib_lock = threading.Lock()
+
+# How often each C-ABI entry point was reached through this binding (tests and bench.py's route_check assert that a forward
+# really took the in-tree kernels it claims: a routing threshold that silently sends a shape to the library shows up here).
+CALLS = collections.Counter()
 
 
 def lib():
@@ -144,6 +149,7 @@ def depth_minmax(depth):
     torch = require_gpu()
     n, h, w = depth.shape
     out = torch.empty((n, 2), dtype=torch.float64, device=depth.device)
+    CALLS["ds_depth_minmax"] += 1
     _check(lib().ds_depth_minmax(ctx_for(_dev_index(depth)), depth.data_ptr(), _depth_dtype_id(depth), n, h, w,
                                  out.data_ptr(), _stream(depth)))
     return out
@@ -182,6 +188,7 @@ def stereo_warp(image, depth, eyes, fill, exponent=1.0, pow_lut=None):
         arr[i].out = ptr
         arr[i].out_row_stride = int(rs)
         arr[i].out_img_stride = int(is_)
+    CALLS["ds_stereo_warp"] += 1
     _check(lib().ds_stereo_warp(ctx_for(_dev_index(image)), image.data_ptr(), depth.data_ptr(), _depth_dtype_id(depth),
                                 n, h, w, c, float(exponent), pow_lut.data_ptr() if pow_lut is not None else None,
                                 FILL_IDS[fill], arr, len(eyes), _stream(image)))
@@ -212,11 +219,13 @@ def profile_last_ms(device_index):
 
 
 def copy_view(src_ptr, src_rs, src_is, dst_ptr, dst_rs, dst_is, n, h, row_bytes, like):
+    CALLS["ds_copy_view"] += 1
     _check(lib().ds_copy_view(ctx_for(_dev_index(like)), src_ptr, src_rs, src_is, dst_ptr, dst_rs, dst_is, n, h, row_bytes,
                               _stream(like)))
 
 
 def overlap_red_cyan(im1_ptr, r1, i1, im2_ptr, r2, i2, n, h, w, c, out):
+    CALLS["ds_overlap_red_cyan"] += 1
     _check(lib().ds_overlap_red_cyan(ctx_for(_dev_index(out)), im1_ptr, r1, i1, im2_ptr, r2, i2, n, h, w, c, out.data_ptr(),
                                      _stream(out)))
 
@@ -228,6 +237,7 @@ def normalmap(depth, pre_blur, sobel_ksize, post_blur, invert):
     assert depth.dtype in (torch.uint16, torch.float64) and depth.is_contiguous()
     out = torch.empty((n, h, w, 3), dtype=torch.uint8, device=depth.device)
     fn = lib().ds_normalmap if depth.dtype == torch.uint16 else lib().ds_normalmap_f64
+    CALLS["ds_normalmap" if depth.dtype == torch.uint16 else "ds_normalmap_f64"] += 1
     _check(fn(ctx_for(_dev_index(depth)), depth.data_ptr(), n, h, w, int(pre_blur), int(sobel_ksize),
               int(post_blur), 1 if invert else 0, out.data_ptr(), _stream(depth)))
     return out
@@ -238,6 +248,7 @@ def depth_to_u16(pred_f32, invert=False, want_norm=False):
     n, h, w = pred_f32.shape
     out = torch.empty((n, h, w), dtype=torch.uint16, device=pred_f32.device)
     norm = torch.empty((n, h, w), dtype=torch.float32, device=pred_f32.device) if want_norm else None
+    CALLS["ds_depth_to_u16"] += 1
     _check(lib().ds_depth_to_u16(ctx_for(_dev_index(pred_f32)), pred_f32.data_ptr(), n, h, w, 1 if invert else 0,
                                  out.data_ptr(), norm.data_ptr() if want_norm else None, _stream(pred_f32)))
     return (out, norm) if want_norm else out
@@ -247,6 +258,7 @@ def convert_to_i16(arr):
     torch = require_gpu()
     assert arr.dtype in (torch.float32, torch.float64) and arr.is_contiguous()
     out = torch.empty(arr.shape, dtype=torch.uint16, device=arr.device)
+    CALLS["ds_convert_to_i16"] += 1
     _check(lib().ds_convert_to_i16(ctx_for(_dev_index(arr)), arr.data_ptr(), 1 if arr.dtype == torch.float64 else 0,
                                    arr.numel(), out.data_ptr(), _stream(arr)))
     return out
@@ -262,6 +274,7 @@ def colorize_u16(depth, vmin_vmax, lut_rgba):
     lut = lut_rgba.to(device=depth.device, dtype=torch.uint8).contiguous()
     assert tuple(vmm.shape) == (n, 2) and lut.dim() == 2 and lut.shape[1] == 4
     out = torch.empty((n, h, w, 4), dtype=torch.uint8, device=depth.device)
+    CALLS["ds_colorize_u16"] += 1
     _check(lib().ds_colorize_u16(ctx_for(_dev_index(depth)), depth.data_ptr(), n, h, w, vmm.data_ptr(), lut.data_ptr(),
                                  int(lut.shape[0]), out.data_ptr(), _stream(depth)))
     return out
@@ -286,6 +299,7 @@ def attention_bias_pack(bias, npad, dtype):
     h, n = int(bias.shape[0]), int(bias.shape[1])
     src = bias.detach().float().contiguous()
     out = torch.empty((h * npad * npad,), dtype=dtype, device=bias.device)
+    CALLS["ds_attention_bias_pack"] += 1
     _check(lib().ds_attention_bias_pack(ctx_for(_dev_index(src)), src.data_ptr(), h, n, int(npad),
                                         1 if dtype == torch.float16 else 2, out.data_ptr(), _stream(src)))
     return PackedAttentionBias(out, h, n, int(npad))
@@ -306,6 +320,7 @@ def attention_fwd(qk, vt, n_valid, scale, bias=None):
         assert (bias.heads, bias.npad, bias.dtype) == (h, npad, qk.dtype) and bias.data.device == qk.device
     out = torch.empty((b, npad, h * 64), dtype=qk.dtype, device=qk.device)
     dt = 1 if qk.dtype == torch.float16 else 2
+    CALLS["ds_attention_fwd"] += 1
     _check(lib().ds_attention_fwd(ctx_for(_dev_index(qk)), qk.data_ptr(), vt.data_ptr(),
                                   bias.data.data_ptr() if bias is not None else None, out.data_ptr(),
                                   b, npad, h, int(n_valid), float(scale), dt, _stream(qk)))
@@ -331,6 +346,7 @@ def residual_layernorm(x, branch, gamma, ln_weight, ln_bias, eps=1e-6):
         bp = branch.data_ptr()
     g = None if gamma is None else gamma.to(x.dtype).contiguous()
     w, b = ln_weight.to(x.dtype).contiguous(), ln_bias.to(x.dtype).contiguous()
+    CALLS["ds_residual_layernorm"] += 1
     _check(lib().ds_residual_layernorm(ctx_for(_dev_index(x)), x.data_ptr(), bp, None if g is None else g.data_ptr(),
                                        w.data_ptr(), b.data_ptr(), None if branch is None else x_out.data_ptr(), h.data_ptr(),
                                        rows, c, float(eps), dt, _stream(x)))
@@ -346,6 +362,7 @@ def reassemble_readout(proj, clsvec):
     proj, clsvec = proj.contiguous(), clsvec.contiguous()
     assert tuple(clsvec.shape) == (b, c)
     out = torch.empty((b, n - 1, c), dtype=proj.dtype, device=proj.device)
+    CALLS["ds_reassemble_readout"] += 1
     _check(lib().ds_reassemble_readout(ctx_for(_dev_index(proj)), proj.data_ptr(), clsvec.data_ptr(), out.data_ptr(), b, n, c,
                                        1 if proj.dtype == torch.float16 else 2, _stream(proj)))
     return out
@@ -377,6 +394,7 @@ def linear(x, weight, bias=None, gelu=False):
         b = bias.detach()
         b = b if (b.dtype == x.dtype and b.is_contiguous()) else b.to(x.dtype).contiguous()
     out = torch.empty((x2.shape[0], n), dtype=x.dtype, device=x.device)
+    CALLS["ds_linear"] += 1
     _check(lib().ds_linear(ctx_for(_dev_index(x)), x2.data_ptr(), w.data_ptr(), None if b is None else b.data_ptr(),
                            out.data_ptr(), x2.shape[0], n, k, n, 1 if gelu else 0,
                            1 if x.dtype == torch.float16 else 2, _stream(x)))
@@ -400,6 +418,7 @@ def linear_residual(x, weight, bias, gamma, residual):
         return t if (t.dtype == x.dtype and t.is_contiguous()) else t.to(x.dtype).contiguous()
     w, b, g = prep(weight), prep(bias), prep(gamma)
     out = torch.empty_like(r2)
+    CALLS["ds_linear_residual"] += 1
     _check(lib().ds_linear_residual(ctx_for(_dev_index(x)), x2.data_ptr(), w.data_ptr(), None if b is None else b.data_ptr(),
                                     None if g is None else g.data_ptr(), r2.data_ptr(), out.data_ptr(), x2.shape[0], n, k,
                                     1 if x.dtype == torch.float16 else 2, _stream(x)))
@@ -424,6 +443,7 @@ def linear_vt(w_v, h):
     w = w_v.detach()
     w = w if (w.dtype == h.dtype and w.is_contiguous()) else w.to(h.dtype).contiguous()
     out = torch.empty((b, c, npad), dtype=h.dtype, device=h.device)
+    CALLS["ds_linear_vt"] += 1
     _check(lib().ds_linear_vt(ctx_for(_dev_index(h)), w.data_ptr(), h2.data_ptr(), out.data_ptr(), c, b, npad, k,
                               1 if h.dtype == torch.float16 else 2, _stream(h)))
     return out
@@ -457,6 +477,7 @@ def conv3x3(conv, x, relu=False, res1=None, res2=None):
     out = torch.empty((b, conv.out_channels, h, w), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
     for r in (res1, res2):
         assert r is None or (r.shape == out.shape and r.dtype == x.dtype and r.is_contiguous(memory_format=torch.channels_last))
+    CALLS["ds_conv3x3_nhwc"] += 1
     _check(lib().ds_conv3x3_nhwc(ctx_for(_dev_index(x)), x.data_ptr(), wk.data_ptr(), None if bk is None else bk.data_ptr(),
                                  None if res1 is None else res1.data_ptr(), None if res2 is None else res2.data_ptr(),
                                  out.data_ptr(), b, h, w, c, conv.out_channels, 2 if relu else 0,
@@ -474,6 +495,7 @@ def bias_act(x, bias, relu=False, res1=None, res2=None, inplace=True):
         assert r is None or (r.shape == x.shape and r.dtype == x.dtype and r.is_contiguous(memory_format=torch.channels_last))
     out = x if inplace else torch.empty_like(x)
     b = bias.detach().to(x.dtype).contiguous()
+    CALLS["ds_bias_act_nhwc"] += 1
     _check(lib().ds_bias_act_nhwc(ctx_for(_dev_index(x)), x.data_ptr(), b.data_ptr(), None if res1 is None else res1.data_ptr(),
                                   None if res2 is None else res2.data_ptr(), out.data_ptr(), x.numel(), x.shape[1], 1 if relu else 0,
                                   1 if x.dtype == torch.float16 else 2, _stream(x)))
@@ -497,6 +519,7 @@ def boost_blend(dst, rects, coefs, preds, mask_template):
     for i, (r, c) in enumerate(zip(rects, coefs)):
         rec[i] = (int(r[0]), int(r[1]), int(r[2]), int(r[3]), float(c[0]), float(c[1]))
     buf = torch.from_numpy(rec.view(np.uint8).copy()).to(dst.device)
+    CALLS["ds_boost_blend"] += 1
     _check(lib().ds_boost_blend(ctx_for(_dev_index(dst)), dst.data_ptr(), dst.stride(0), dst.shape[0], dst.shape[1],
                                 buf.data_ptr(), n, preds.data_ptr(), preds.shape[1], mask_template.data_ptr(),
                                 mask_template.shape[0], _stream(dst)))
@@ -516,6 +539,7 @@ def preprocess_bicubic(images_u8, size_hw, mean, std, flip=True, dtype=None):
     out = torch.empty((b, 3, oh, ow), dtype=dtype, device=x.device, memory_format=torch.channels_last)
     m = (ctypes.c_float * 3)(*[float(v) for v in (mean if hasattr(mean, "__len__") else (mean,) * 3)])
     s = (ctypes.c_float * 3)(*[float(v) for v in (std if hasattr(std, "__len__") else (std,) * 3)])
+    CALLS["ds_preprocess_bicubic"] += 1
     _check(lib().ds_preprocess_bicubic(ctx_for(_dev_index(x)), x.data_ptr(), out.data_ptr(), b, h, w, oh, ow, 1 if flip else 0, m, s, code,
                                        _stream(x)))
     return out
@@ -532,6 +556,7 @@ def upsample_bilinear(x, size=None, scale_factor=None, align_corners=True):
     assert x.is_cuda and x.dtype in (torch.float16, torch.bfloat16) and c % 8 == 0
     xin = x.contiguous(memory_format=torch.channels_last)
     out = torch.empty((b, c, oh, ow), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+    CALLS["ds_upsample_bilinear_nhwc"] += 1
     _check(lib().ds_upsample_bilinear_nhwc(ctx_for(_dev_index(x)), xin.data_ptr(), out.data_ptr(), b, c, ih, iw, oh, ow,
                                            1 if align_corners else 0, 1 if x.dtype == torch.float16 else 2, _stream(x)))
     return out
@@ -562,6 +587,7 @@ def dpt_head_tail(x, size, conv3, conv1, relu_out=True):
     _, wf, b2, w3, b3 = hit
     oh, ow = int(size[0]), int(size[1])
     out = torch.empty((b, 1, oh, ow), dtype=x.dtype, device=x.device)
+    CALLS["ds_dpt_head_tail"] += 1
     _check(lib().ds_dpt_head_tail(ctx_for(_dev_index(x)), xin.data_ptr(), b, ih, iw, oh, ow, wf.data_ptr(), b2.data_ptr(),
                                   w3.data_ptr(), b3, 1 if relu_out else 0, out.data_ptr(),
                                   1 if x.dtype == torch.float16 else 2, _stream(x)))

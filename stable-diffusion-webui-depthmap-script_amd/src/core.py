@@ -146,6 +146,53 @@ def _postprocess_batch(pred, invert, inp):
     return out, prediction_copy, broken
 
 
+def _wants_reference_f16():
+    """`reference_f16_postproc` (ops / ModelHolder.update_settings; DS_REFERENCE_F16_POSTPROC=1): reproduce the reference's
+    float16 depth post-processing for the networks whose prediction it receives as a float16 array (MiDaS ids 1-4 in half
+    precision: src/depthmap_generation.py:268-275, :484-497).  DEFAULT OFF -- a defined corner, see DESIGN.md: by default a
+    half-precision network's prediction is post-processed in float32 here (65 536 depth levels instead of float16's ~2 k per
+    octave)."""
+    want = getattr(model_holder, "reference_f16_postproc", None)
+    if want is None:
+        want = _os.environ.get("DS_REFERENCE_F16_POSTPROC", "0") != "0"
+    if not want:
+        return False
+    dm = model_holder.depth_model
+    if model_holder.pix2pix_model is not None:               # Boost never runs the base network in half (:271)
+        return False
+    if getattr(dm, "returns_f16", False):                    # a registered predictor that says so
+        return True
+    return getattr(dm, "model_type", None) in (1, 2, 3, 4) and not getattr(dm, "no_half", True)
+
+
+def _postprocess_f16(pred, invert, inp):
+    """src/core.py:189-211 on a float16 prediction with NumPy 1.x's promotion (defined corners, states the
+    rules): min / max / subtract / divide as float16 operations (torch computes half arithmetic in float32 and rounds once:
+    the correctly rounded float16 result), then convert_to_i16 in float64.  pred: float32 [B,H,W] holding float16 values.
+    Returns (uint16 [B,H,W], broken)."""
+    torch = _native._torch()
+    if inp[go.CLIPDEPTH] and inp[go.CLIPDEPTH_MODE] != 'Range':
+        raise NotImplementedError("reference_f16_postproc reproduces the float16 path for CLIPDEPTH off and 'Range' only "
+                                  "(np.percentile of a float16 array is not restated)")
+    out = pred.to(torch.float16)
+    flat = out.flatten(1)
+    pmin, pmax = flat.min(1).values, flat.max(1).values
+    broken = [not bool(v) for v in ((pmax - pmin).abs().double() > np.finfo("float").eps).cpu().tolist()]      # :190
+    if invert:
+        out = -out
+
+    def norm01(t):
+        lo = t.flatten(1).min(1).values.view(-1, 1, 1)
+        hi = t.flatten(1).max(1).values.view(-1, 1, 1)
+        return (t - lo) / (hi - lo)
+    if inp[go.CLIPDEPTH]:
+        far = torch.tensor(float(inp[go.CLIPDEPTH_FAR]), dtype=torch.float16, device=out.device)
+        near = torch.tensor(float(inp[go.CLIPDEPTH_NEAR]), dtype=torch.float16, device=out.device)
+        out = torch.minimum(torch.maximum(norm01(out), far), near)
+    d16 = _native.convert_to_i16(norm01(out).double().contiguous())
+    return d16, broken
+
+
 class _HostStaging:
     """Pinned host buffers of the funnel, two generations (the results of group k are converted to PIL while group k+1
     runs on the device).  A buffer is (re)allocated only when a larger one is needed."""
@@ -244,7 +291,16 @@ def _launch_group(gen, idxs, inputimages, inputdepthmaps, inp, device):
             return g
         pred = pred.to(device=device, dtype=torch.float32)
         mesh_source = pred
-        if not inp[go.CLIPDEPTH] and not inp[go.DO_OUTPUT_DEPTH_PREDICTION]:
+        if _wants_reference_f16():
+            d16, broken = _postprocess_f16(pred, invert, inp)
+            g["broken"] = broken
+            if inp[go.DO_OUTPUT_DEPTH_PREDICTION]:            # the reference yields its float16 array (:194-195)
+                pc = (pred * -1 if invert else pred).to(torch.float16)
+                g["pred_host"] = (pc, _staging.get(gen, "pred16", tuple(pc.shape), torch.float16))
+            if any(broken):
+                keep = torch.tensor([0 if x else 1 for x in broken], device=device, dtype=torch.int16).view(-1, 1, 1)
+                d16 = (d16.view(torch.int16) * keep).view(torch.uint16)
+        elif not inp[go.CLIPDEPTH] and not inp[go.DO_OUTPUT_DEPTH_PREDICTION]:
             d16 = _native.depth_to_u16(pred, invert)         # fused: per-image min/max -> normalise -> uint16 (:189-211)
         else:
             out_t, prediction_copy, broken = _postprocess_batch(pred, invert, inp)
@@ -310,10 +366,10 @@ def _launch_group(gen, idxs, inputimages, inputdepthmaps, inp, device):
 
 
 _pool = None
-_pil_tuned = False
 _copy_streams = {}
-# DS_FUNNEL_STATS=1: wall-clock seconds the host spent per stage of the last funnel call (bench.py's funnel leg reports them):
-# 'launch' = decoding + staging + enqueueing the groups, 'wait' = blocked on a group's results, 'convert' = results -> PIL
+# wall-clock seconds the host spent per stage of the last FINISHED funnel call (bench.py's funnel leg reports them): 'launch' =
+# decoding + staging + enqueueing the groups, 'wait' = blocked on a group's results.  Every call accumulates into a dict of its
+# own and publishes it here when its generator finishes, so interleaved generators cannot mix their numbers.
 FUNNEL_STATS = {}
 
 
@@ -330,17 +386,27 @@ def _tune_pil_allocator():
     """Pillow allocates every image from fresh 16 MB blocks and returns them to the OS on release (blocks_max = 0): each of the
     funnel's results (8 MB for a 1024 x 2048 pair) then pays a first-touch page fault per 4 KB page, serialised on the process's
     memory-map lock however many threads convert -- measured here 9.9 ms -> 4.1 ms per unit (depth + pair + normal map) once
-    freed blocks are kept for reuse.  DS_PIL_BLOCKS_MAX blocks (default 64 = at most 1 GB retained; 0 leaves Pillow alone)."""
-    global _pil_tuned
-    if _pil_tuned:
-        return
-    _pil_tuned = True
+    freed blocks are kept for reuse.  The setting is process wide, so it is SCOPED to the funnel call: raised to
+    DS_PIL_BLOCKS_MAX blocks (default 64 = at most 1 GB retained while the call runs; 0 leaves Pillow alone) on entry, and
+    the caller's value is put back -- which also releases the retained blocks -- when the generator finishes or is closed
+    (INTEGRATION.md section 4).  Returns the value to restore, or None when nothing was changed."""
     try:
         want = int(_os.environ.get("DS_PIL_BLOCKS_MAX", 64))
-        if want > 0 and Image.core.get_blocks_max() < want:
+        before = Image.core.get_blocks_max()
+        if want > 0 and before < want:
             Image.core.set_blocks_max(want)
+            return before
     except Exception:           # an older Pillow without the arena controls: nothing to tune
         pass
+    return None
+
+
+def _restore_pil_allocator(before):
+    if before is not None:
+        try:
+            Image.core.set_blocks_max(before)
+        except Exception:
+            pass
 
 
 def _host_pool():
@@ -362,7 +428,7 @@ def _to_pil(a):
     return Image.fromarray(a.copy())
 
 
-def _emit_group(g, outpath, inp, device):
+def _emit_group(g, outpath, inp, device, stats):
     """Yield a finished group's results image by image in the reference's order (:208-306).  The pinned buffers are reused
     two groups later, so every result is copied out of them (PIL owns its pixels); the copies of a group run on a small
     thread pool while the generator hands out what is already done."""
@@ -371,8 +437,7 @@ def _emit_group(g, outpath, inp, device):
         return
     _t0 = _time.perf_counter()
     g["done"].synchronize()
-    if True:
-        FUNNEL_STATS["wait"] = FUNNEL_STATS.get("wait", 0.0) + (_time.perf_counter() - _t0)
+    stats["wait"] = stats.get("wait", 0.0) + (_time.perf_counter() - _t0)
     host = {k: v.numpy() for k, v in g["host"].items()}
     pred_host = None if g["pred_host"] is None else g["pred_host"].numpy()
 
@@ -450,8 +515,8 @@ def core_generation_funnel(outpath, inputimages, inputdepthmaps, inputnames, inp
 
     torch = _native.require_gpu()        # the hot path has no CPU implementation, whatever COMPUTE_DEVICE says
     device = torch.device('cuda', torch.cuda.current_device())
-    _tune_pil_allocator()
-    FUNNEL_STATS.clear()
+    pil_blocks_before = _tune_pil_allocator()
+    stats = {}
     _t_start = _time.perf_counter()
 
     try:
@@ -471,18 +536,20 @@ def core_generation_funnel(outpath, inputimages, inputdepthmaps, inputnames, inp
             try:
                 _t0 = _time.perf_counter()
                 launched, failure = _launch_group(gi & 1, idxs, inputimages, inputdepthmaps, inp, device), None
-                FUNNEL_STATS["launch"] = FUNNEL_STATS.get("launch", 0.0) + (_time.perf_counter() - _t0)
+                stats["launch"] = stats.get("launch", 0.0) + (_time.perf_counter() - _t0)
             except Exception as e:          # noqa: BLE001 -- re-raised below, after the results that precede it
                 launched, failure = None, e
             if pending is not None:
-                yield from _emit_group(pending, outpath, inp, device)
+                yield from _emit_group(pending, outpath, inp, device, stats)
             if failure is not None:
                 raise failure
             pending = launched
         if pending is not None:
-            yield from _emit_group(pending, outpath, inp, device)
-        FUNNEL_STATS["total"] = _time.perf_counter() - _t_start
-        FUNNEL_STATS["groups"] = len(groups)
+            yield from _emit_group(pending, outpath, inp, device, stats)
+        stats["total"] = _time.perf_counter() - _t_start
+        stats["groups"] = len(groups)
+        FUNNEL_STATS.clear()
+        FUNNEL_STATS.update(stats)
     except Exception as e:
         if 'out of memory' in str(e).lower():                                                  # :308-326
             suggestion = "out of GPU memory, could not generate depthmap! " \
@@ -494,6 +561,7 @@ def core_generation_funnel(outpath, inputimages, inputdepthmaps, inputnames, inp
             raise Exception(suggestion)
         raise e
     finally:
+        _restore_pil_allocator(pil_blocks_before)
         if ops.get('keepmodels', True):
             model_holder.offload()
         else:

@@ -20,6 +20,7 @@ float32 tensors take ``attention_reference`` (plain torch arithmetic, the defini
 and what the CPU parity tests against the reference's own modules run); float16 / bfloat16 tensors on a GPU take the HIP
 kernel and raise if the library is missing -- there is no silent fallback.
 """
+import contextlib
 import math
 import os
 
@@ -161,7 +162,23 @@ LINEAR_HIP_MIN_TILES = int(os.environ.get("DS_LINEAR_MIN_TILES", 96))
 
 
 def hip_gemm_ok(rows, out_features):
-    return ((rows + 255) // 256) * (out_features // 256) >= LINEAR_HIP_MIN_TILES
+    # (rows >= 256 whatever the threshold says: the fused entry points -- ds_linear_residual, ds_linear_vt -- take whole tiles)
+    return rows >= 256 and ((rows + 255) // 256) * (out_features // 256) >= LINEAR_HIP_MIN_TILES
+
+
+@contextlib.contextmanager
+def library_routing():
+    """Inside the block every token GEMM and every 3x3 convolution of the networks goes through the ROCm libraries behind
+    torch (what DS_LINEAR=0 DS_CONV=0 select at import time); the fused attention, LayerNorm and element-wise kernels stay.
+    The reference point of the route checks (tests/test_gpu_models.py, bench.py's route_check): the SAME network, the same
+    input, the other GEMM / convolution implementation."""
+    global LINEAR_HIP, CONV_HIP
+    saved = LINEAR_HIP, CONV_HIP
+    LINEAR_HIP, CONV_HIP = "0", False
+    try:
+        yield
+    finally:
+        LINEAR_HIP, CONV_HIP = saved
 
 
 def linear(x, weight, bias=None, gelu=False):

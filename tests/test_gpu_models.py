@@ -1004,3 +1004,89 @@ def test_preprocess_bicubic_kernel_vs_torch_chain(gpu):
     for name, h, w, nw, nh, method, seed in mgt.CASES:
         x = DPTDepthModel.preprocess(torch.from_numpy(mgt.image(h, w, seed))[None].cuda(), nw, nh, method, 0.5, 0.5)[0].cpu().numpy()
         assert x.shape == z[name].shape and np.abs(x - z[name]).max() < 5e-5, (name, float(np.abs(x - z[name]).max()))
+
+
+# ---- the route the benchmark runs: every block GEMM and the decoder's 3x3 convolutions in-tree ---------------------------
+def _variants(x, count):
+    """`count` inputs out of ONE golden image: the image itself first, then flips / rolls of it (distinct units, same
+    statistics: a routing bug that mixes batch elements or drops rows cannot cancel)."""
+    outs = [x]
+    ops = [lambda t: t.flip(-1), lambda t: t.flip(-2), lambda t: t.roll(37, -1), lambda t: t.roll(-53, -2),
+           lambda t: t.flip(-1).roll(91, -2), lambda t: t.flip(-2).roll(-17, -1), lambda t: t.roll(11, -1).roll(5, -2)]
+    for i in range(count - 1):
+        outs.append(ops[i % len(ops)](x))
+    return torch.cat(outs, 0)
+
+
+def _route_calls(before, names):
+    from src import _native
+    return {n: _native.CALLS[n] - before.get(n, 0) for n in names}
+
+
+def test_dpt_beit_large_512_batch8_takes_the_benchmarked_route(gpu):
+    """The route bench.py times (dmidas/backbones/beit.py:94-107 + dmidas/blocks.py:352-377 of the reference as in-tree
+    kernels: qk / V^T / proj + LayerScale + residual / fc1 + GELU / fc2 + LayerScale + residual through k_linear256, the
+    residual convolution units through the implicit-GEMM convolution) needs >= 96 GEMM tiles and >= 128 convolution tiles,
+    i.e. a batch: dpt_beit_large_512 at 512^2, batch 8, float16.  Unit 0 is the golden image: 2e-2 against the float32
+    output of the reference's own dmidas code.  ALL units: against the same network with every GEMM / 3x3 convolution
+    sent to the ROCm libraries (vm.library_routing) at float16 noise level.  The counters of the ctypes binding prove
+    that the fused entry points were really reached."""
+    from dmidas.dpt_depth import DPTDepthModel
+    from src import _native
+    from src import vit_mi355x as vm
+    gold = np.load(GOLD_LARGE)
+    m = DPTDepthModel(path=None, backbone="beitl16_512", non_negative=True).eval()
+    m.load_state_dict(mw.fill_state_dict_beit(m.state_dict()), strict=True)
+    m = m.cuda().half()
+    x = _variants(mw.synthetic_image((1, 3, 512, 512), seed=31), 8).cuda().half().contiguous(memory_format=torch.channels_last)
+    names = ("ds_linear", "ds_linear_residual", "ds_linear_vt", "ds_conv3x3_nhwc", "ds_attention_fwd")
+    before = dict(_native.CALLS)
+    with torch.no_grad():
+        y = m(x).float()
+    calls = _route_calls(before, names)
+    # 24 blocks: qk + fc1 through ds_linear, proj + fc2 through ds_linear_residual, V^T through ds_linear_vt
+    assert calls["ds_linear"] >= 48 and calls["ds_linear_residual"] == 48 and calls["ds_linear_vt"] == 24, calls
+    assert calls["ds_conv3x3_nhwc"] >= 4 and calls["ds_attention_fwd"] == 24, calls
+    before = dict(_native.CALLS)
+    with torch.no_grad(), vm.library_routing():
+        y_lib = m(x).float()
+    calls_lib = _route_calls(before, names)
+    assert calls_lib["ds_linear"] == calls_lib["ds_linear_residual"] == calls_lib["ds_linear_vt"] == calls_lib["ds_conv3x3_nhwc"] == 0, calls_lib
+    ref = gold["dpt_beitl512_512x512_out_s2"]
+    scale = float(np.abs(ref).max())
+    e0 = np.abs(y[0:1, ::2, ::2].cpu().numpy() - ref).max() / scale
+    assert e0 < 2e-2, e0
+    e_lib = ((y - y_lib).abs().flatten(1).max(1).values / y_lib.abs().flatten(1).max(1).values).max().item()
+    assert e_lib < 1e-2, e_lib
+    # the units are distinct images: their outputs must differ (a route that broadcast unit 0 would pass the checks above)
+    assert (y[1] - y[0]).abs().max().item() > 1e-3 * scale
+
+
+def test_dav2_vitl_1080p_batch4_takes_the_benchmarked_route(gpu):
+    """Depth-Anything-V2 ViT-L at 518 x 924 (2443 tokens, BASELINE config 5), batch 4, float16: the block route of
+    ddepth_anything_v2/depth_anything_v2/dinov2_layers/block.py:82-107 as in-tree GEMMs (156 tiles at 1024 columns).
+    Unit 0 against the reference's own float32 output (2e-2), every unit against library routing."""
+    from ddepth_anything_v2 import DepthAnythingV2
+    from src import _native
+    from src import vit_mi355x as vm
+    gold = np.load(GOLD_LARGE)
+    m = DepthAnythingV2('vitl', features=256, out_channels=[256, 512, 1024, 1024]).eval()
+    m.load_state_dict(mw.fill_state_dict(m.state_dict()), strict=True)
+    m = m.cuda().half()
+    x = _variants(mw.synthetic_image((1, 3, 518, 924), seed=32), 4).cuda().half()
+    names = ("ds_linear", "ds_linear_residual", "ds_linear_vt", "ds_conv3x3_nhwc", "ds_attention_fwd")
+    before = dict(_native.CALLS)
+    with torch.no_grad():
+        y = m(x).float()
+    calls = _route_calls(before, names)
+    assert calls["ds_linear"] >= 48 and calls["ds_linear_residual"] == 48 and calls["ds_linear_vt"] == 24, calls
+    assert calls["ds_attention_fwd"] == 24, calls
+    with torch.no_grad(), vm.library_routing():
+        y_lib = m(x).float()
+    ref = gold["dav2_vitl_518x924_out_s2"]
+    scale = float(np.abs(ref).max())
+    e0 = np.abs(y[0:1, ::2, ::2].cpu().numpy() - ref).max() / scale
+    assert e0 < 2e-2, e0
+    e_lib = ((y - y_lib).abs().flatten(1).max(1).values / y_lib.abs().flatten(1).max(1).values).max().item()
+    assert e_lib < 1e-2, e_lib
+    assert (y[1] - y[0]).abs().max().item() > 1e-3 * scale

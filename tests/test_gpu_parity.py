@@ -663,3 +663,53 @@ def test_general_pixels_one_window_per_wave_equals_private_windows(sg, native, o
             want = oracle.create_stereoimages_arrays(img[i], dep[i], div, 0.0, ['left-right'], bal, 1.0, fill)[0]
             assert np.array_equal(outs[0][i], want), (img.shape, fill, i, int((outs[0][i] != want).sum()))
     assert total_general > 10000
+
+
+def test_funnel_reference_f16_postproc(gpu, oracle):
+    """`reference_f16_postproc` (defined corners): the funnel's depth map of a float16 prediction under the
+    reference's NumPy-1.x promotion rules (src/core.py:189-211, :44-50 fed by src/depthmap_generation.py:484-497), bit for
+    bit against oracle.depth_postprocess_f16_numpy1 -- plain, inverted, 'Range' clip, a flat (broken) prediction in the batch,
+    and the depth_prediction result (a float16 array, like the reference's).  Off (the default): float32 post-processing."""
+    import torch
+    from PIL import Image
+    import src.core as core
+    rng = np.random.default_rng(11)
+    imgs = [rng.integers(0, 256, (48, 72, 3), dtype=np.uint8) for _ in range(3)]
+    preds = [(util.smooth_depth(48, 72, 6 + i) * 41.0 + 2.0).astype(np.float16) for i in range(3)]
+    preds[1][:] = np.float16(3.5)                                   # a flat prediction: zeros (:203-206)
+    pils = [Image.fromarray(a) for a in imgs]
+    lookup = {id(p): a for p, a in zip(pils, preds)}
+
+    class Pred:
+        returns_f16 = True
+
+        def __call__(self, pil, nw, nh, dev):
+            return self.batch([pil], nw, nh, dev)[0]
+
+        def batch(self, plist, nw, nh, dev):
+            return torch.stack([torch.from_numpy(lookup[id(p)].astype(np.float32)) for p in plist]).to(dev)
+
+    for mt, inv in ((4, False), (0, True)):
+        core.model_holder.register_predictor(mt, Pred())
+        for opts in ({}, {'clipdepth': True, 'clipdepth_mode': 'Range', 'clipdepth_far': 0.1, 'clipdepth_near': 0.8},
+                     {'do_output_depth_prediction': True}):
+            o = dict(opts, model_type=mt)
+            got = list(core.core_generation_funnel(None, list(pils), None, None, o, {'reference_f16_postproc': True}))
+            depth = [np.asarray(r) for _, k, r in got if k == 'depth']
+            assert len(depth) == 3
+            for j in range(3):
+                want = oracle.depth_postprocess_f16_numpy1(preds[j], inv, bool(opts.get('clipdepth')), opts.get('clipdepth_far', 0.0),
+                                                           opts.get('clipdepth_near', 1.0))
+                assert np.array_equal(depth[j], want), (mt, opts, j)
+            if 'do_output_depth_prediction' in opts:
+                pp = [(i, r) for i, k, r in got if k == 'depth_prediction']
+                assert [i for i, _ in pp] == [0, 2] and all(r.dtype == np.float16 for _, r in pp)
+                assert np.array_equal(pp[0][1], -preds[0] if inv else preds[0])
+            # default (switch off): float32 post-processing of the same values
+            got32 = list(core.core_generation_funnel(None, [pils[0]], None, None, o, {'reference_f16_postproc': False}))
+            d32 = [np.asarray(r) for _, k, r in got32 if k == 'depth'][0]
+            p32 = preds[0].astype(np.float32)
+            want32 = oracle.convert_to_i16(oracle.depth_postprocess(p32, inv, True, 'Range', opts['clipdepth_far'], opts['clipdepth_near'])
+                                           if opts.get('clipdepth') else oracle.depth_normalize01(p32, inv))
+            assert np.array_equal(d32, want32), (mt, opts)
+    core.model_holder.update_settings(reference_f16_postproc=None)

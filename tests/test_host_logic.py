@@ -289,3 +289,38 @@ def test_linear_and_conv_dispatch_rules_host_side():
     xr, sk = torch.randn((2, 16, 9, 11), generator=g), torch.randn((2, 16, 9, 11), generator=g)
     want = sk + (c2(F.relu(c1(F.relu(xr)))) + xr)
     assert torch.allclose(vm.residual_conv_unit(c1, c2, xr, skip=sk), want)
+
+
+def test_float16_prediction_corner():
+    """DESIGN.md 'defined corners': the reference's default GPU path hands core.py a FLOAT16 prediction
+    (src/depthmap_generation.py:484-497) and post-processes it with whatever promotion rules its NumPy has (src/core.py:189-211,
+    :44-50).  Pinned here: (a) NumPy 1.x semantics, restated with explicit casts (oracle.depth_postprocess_f16_numpy1): float16
+    normalisation, float64 scaling -- promote_types(float16, uint32) is float64 in every NumPy, which is what value-based
+    casting made of `arr * 65536`; (b) what the SAME reference statements do under NumPy >= 2 (this image): the python int
+    becomes float16(inf) and the depth map is zeros; (c) the product's default, float32 post-processing, differs from (a) by
+    float16's quantisation only."""
+    from oracle import oracle as orc
+    rng = np.random.default_rng(5)
+    pred = (rng.random((48, 64)) * 37.0 + 3.0).astype(np.float16)
+    assert np.promote_types(np.float16, np.uint32) == np.float64
+    want = orc.depth_postprocess_f16_numpy1(pred)
+    # (a) spelled differently: the reference's statements with the NumPy-1.x result dtypes forced
+    out = pred.copy()
+    out = ((out - out.min()) / (out.max() - out.min()))
+    assert out.dtype == np.float16                       # array (op) numpy-scalar of one dtype: float16 in every NumPy
+    a = np.clip(out.astype(np.float64) * np.uint32(65536) + 0.0001, 0, 65536 - 0.1).astype("uint16")
+    assert np.array_equal(a, want)
+    assert len(np.unique(want)) < 3000 and want.max() == 65535 and want.min() == 0      # float16's levels, full range
+    # (b) the reference's convert_to_i16 verbatim on the float16 array under this NumPy
+    if int(np.__version__.split(".")[0]) >= 2:
+        import warnings
+        with np.errstate(all='ignore'), warnings.catch_warnings():
+            warnings.simplefilter('ignore')
+            b = np.clip(out * (2 ** 16) + 0.0001, 0, (2 ** 16) - 0.1).astype("uint16")
+        assert int(b.max()) == 0
+    # (c) the default here: float32 throughout
+    c = orc.convert_to_i16(orc.depth_normalize01(pred.astype(np.float32)))
+    assert np.abs(c.astype(np.int64) - want.astype(np.int64)).max() <= 64      # half a float16 ulp at the top octave x 65536
+    # inverted models and the 'Range' clip
+    w2 = orc.depth_postprocess_f16_numpy1(pred, invert=True, clipdepth=True, far=0.25, near=0.75)
+    assert w2.dtype == np.uint16 and w2.min() == 0 and w2.max() == 65535
