@@ -285,6 +285,14 @@ int ds_linear_vt(ds_ctx *ctx, const void *w_v, const void *h, void *vt, int64_t 
                  int64_t in_features, int dtype, void *stream);
 
 /*
+ * ds_linear_reload_env -- the GEMM path (ds_linear, ds_linear_residual, ds_linear_vt, ds_conv3x3_nhwc) reads its A/B switches
+ * (DS_LIN_KERNEL, DS_LIN_EARLY, DS_LIN_GRID, DS_LIN_RAGGED, DS_LIN_RAGGED_DEN, DS_LIN_RAGGED_RING; none changes a result) from
+ * the environment ONCE per process, not per launch; this re-reads them (tests and A/B runs that flip a switch in-process).
+ * No counterpart in the reference.
+ */
+int ds_linear_reload_env(void);
+
+/*
  * ds_conv3x3_nhwc -- y = act(conv3x3(x, W) + bias [+ res1] [+ res2]), stride 1, zero padding 1, as the implicit GEMM of
  * csrc/ds_linear.hip (same 256 x 256 MFMA tiles; a K-tile is 64 channels of one tap, fetched by LDS-DMA from the shifted
  * pixel or from a zero line for the padding ring): the 3x3 convolutions of the DPT decoders with their element-wise tails

@@ -21,7 +21,7 @@ FILL_IDS = {"none": 0, "naive": 1, "naive_interpolating": 2, "polylines_soft": 3
 EXPORTS = [
     "ds_version", "ds_last_error", "ds_normalmap_f64", "ds_reassemble_readout", "ds_bias_act_nhwc", "ds_linear", "ds_linear_residual", "ds_linear_vt", "ds_conv3x3_nhwc", "ds_ctx_create", "ds_ctx_destroy", "ds_stereo_warp", "ds_depth_minmax",
     "ds_stereo_last_exact_rows", "ds_copy_view", "ds_overlap_red_cyan", "ds_normalmap", "ds_depth_to_u16",
-    "ds_convert_to_i16", "ds_profile_enable", "ds_profile_last_ms", "ds_stereo_last_stats", "ds_attention_fwd", "ds_attention_bias_pack", "ds_colorize_u16", "ds_residual_layernorm", "ds_boost_blend", "ds_upsample_bilinear_nhwc", "ds_dpt_head_tail", "ds_preprocess_bicubic",
+    "ds_convert_to_i16", "ds_profile_enable", "ds_profile_last_ms", "ds_stereo_last_stats", "ds_attention_fwd", "ds_attention_bias_pack", "ds_colorize_u16", "ds_residual_layernorm", "ds_boost_blend", "ds_upsample_bilinear_nhwc", "ds_dpt_head_tail", "ds_preprocess_bicubic", "ds_linear_reload_env",
 ]
 
 
@@ -366,6 +366,18 @@ def reassemble_readout(proj, clsvec):
     _check(lib().ds_reassemble_readout(ctx_for(_dev_index(proj)), proj.data_ptr(), clsvec.data_ptr(), out.data_ptr(), b, n, c,
                                        1 if proj.dtype == torch.float16 else 2, _stream(proj)))
     return out
+
+
+def linear_env(**switches):
+    """Set (a value) or remove (None) DS_LIN_* switches of the GEMM path in os.environ and make the library re-read them
+    (include/depthstereo.h: ds_linear_reload_env -- the library reads them once, not per launch).  Tests and A/B runs only."""
+    for k, v in switches.items():
+        assert k.startswith("DS_LIN_")
+        if v is None:
+            os.environ.pop(k, None)
+        else:
+            os.environ[k] = str(v)
+    _check(lib().ds_linear_reload_env())
 
 
 def linear_supported(x, weight):
