@@ -286,7 +286,7 @@ int ds_linear_vt(ds_ctx *ctx, const void *w_v, const void *h, void *vt, int64_t 
 
 /*
  * ds_linear_reload_env -- the GEMM path (ds_linear, ds_linear_residual, ds_linear_vt, ds_conv3x3_nhwc) reads its A/B switches
- * (DS_LIN_KERNEL, DS_LIN_EARLY, DS_LIN_GRID, DS_LIN_RAGGED, DS_LIN_RAGGED_DEN, DS_LIN_RAGGED_RING; none changes a result) from
+ * (DS_LIN_EARLY, DS_LIN_GRID, DS_LIN_RAGGED, DS_LIN_RAGGED_DEN, DS_LIN_RAGGED_RING; none changes a result) from
  * the environment ONCE per process, not per launch; this re-reads them (tests and A/B runs that flip a switch in-process).
  * No counterpart in the reference.
  */

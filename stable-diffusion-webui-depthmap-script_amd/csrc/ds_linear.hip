@@ -543,272 +543,15 @@ __global__ __launch_bounds__(LN_THREADS) void k_linear256(LinParams P)
 
 
 
-// ---- k_linear256s: the same tile, operands, LDS image and epilogue on a STREAMED K loop (round 4) --------------------------------
-// k_linear256 above alternates its two wave-rows between a memory part and an MFMA part, barrier by barrier: 16 barriers per
-// K-tile of 64, and every barrier-to-barrier segment costs its 256 cycles of MFMA issue plus ~130 cycles of rendezvous (the
-// K loop runs at 63 % of the MFMA rate).  Here every wave runs the same software-pipelined stream and the
-// workgroup meets ONCE per K-tile:
-//   * K-tile t lives in LDS buffer t & 1 (the same four half-tiles, the same swizzle).  Its DMAs are issued right after the
-//     barrier of K-tile t-1 -- a whole K-tile (32 MFMAs per wave, ~2 k cycles per SIMD) ahead of their first read -- and the
-//     stream does not stop at the end of an output tile: the last K-tile of a tile stages K-tile 0 of the workgroup's NEXT tile.
-//   * inside a K-tile a wave walks the four k-steps of 16: the fragments of step ks+1 (4 x-blocks + 2 W-blocks = 6
-//     ds_read_b128 = 24 VGPRs, two register sets) are requested while the 8 MFMAs of step ks issue, and the last step's MFMAs
-//     are issued AFTER the next barrier, beside the first reads of the new K-tile: the matrix pipe always has work from both
-//     waves of a SIMD, and the barrier costs its round trip only.
-//   * barrier of K-tile t:  every wave has waited for ITS DMAs of K-tile t (issued a K-tile ago; nothing younger is in flight
-//     except the epilogue's stores at a tile boundary, see below) and for its own LDS reads (lgkmcnt(0): the reads of step 3 of
-//     K-tile t-1 were issued before the barrier and feed MFMAs after it) -> after the barrier K-tile t is readable by every
-//     wave and buffer (t+1) & 1 -- K-tile t-1 -- is dead: the DMAs of K-tile t+1 go there.
-// Register budget: 128 accumulators + 48 fragment registers (k_linear256: + 96), so the epilogue has room to breathe.
-// vmcnt at a tile boundary: in this wave's queue behind the DMAs of the next tile's K-tile 0 are the bias / residual loads of
-// the epilogue (consumed there, i.e. retired, and with them everything older: the counter is in order) and its 16 stores.
-#define LS_READ(set, ks, s)                                                                                              \
-    do {                                                                                                                 \
-        _Pragma("unroll") for (int ha_ = 0; ha_ < 2; ++ha_) _Pragma("unroll") for (int rb_ = 0; rb_ < 2; ++rb_)          \
-            ga[set][ha_][rb_] = *(const V8 *)(lds + offA[ks] + (ha_ * 2 * LN_HALF + (s) * LN_HALF + rb_ * 4096));        \
-        _Pragma("unroll") for (int hb_ = 0; hb_ < 2; ++hb_)                                                              \
-            gb[set][hb_] = *(const V8 *)(lds + offB[ks] + (hb_ * 2 * LN_HALF + (s) * LN_HALF));                           \
-    } while (0)
-// the 8 MFMAs of one k-step as four pairs (ha, rb): PAIR(set, ha, rb) = both W halves against one x block
-#define LS_PAIR(set, ha, rb)                                                                                             \
-    do {                                                                                                                 \
-        acc[ha][rb][0] = TR::mfma(gb[set][0], ga[set][ha][rb], acc[ha][rb][0]);                                          \
-        acc[ha][rb][1] = TR::mfma(gb[set][1], ga[set][ha][rb], acc[ha][rb][1]);                                          \
-    } while (0)
-#define LS_MMA(set)                                                                                                      \
-    do { LS_PAIR(set, 0, 0); LS_PAIR(set, 0, 1); LS_PAIR(set, 1, 0); LS_PAIR(set, 1, 1); } while (0)
-// first k-step of an output tile: the accumulators start from the MFMA's zero C operand, not from 128 v_mov
-#define LS_PAIR_Z(set, ha, rb)                                                                                           \
-    do {                                                                                                                 \
-        acc[ha][rb][0] = TR::mfma(gb[set][0], ga[set][ha][rb], zero16);                                                  \
-        acc[ha][rb][1] = TR::mfma(gb[set][1], ga[set][ha][rb], zero16);                                                  \
-    } while (0)
-#define LS_FENCE() __builtin_amdgcn_sched_barrier(0)
-
-template <int BF16, int EPI, int CONV, int RES, int VT = 0>
-__global__ __launch_bounds__(LN_THREADS) void k_linear256s(LinParams P)
-{
-    typedef ln_traits<BF16> TR;
-    typedef typename TR::T T;
-    typedef typename TR::V8 V8;
-    extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wr = wid >> 2, wc = wid & 3;
-    const int nwg = P.n_main;
-    const int K = P.K;
-    const int rowbytes = (CONV ? P.C : K) * (int)sizeof(T);
-
-    // staging addresses: exactly k_linear256's (LN_STAGE is shared)
-    unsigned srcA[2], srcB[2];
-    int rowA[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int c = 2 * wid + i;
-        const int j = 8 * c + (lane >> 3);
-        const int slot = (lane & 7) ^ ((j >> 1) & 7);
-        rowA[i] = (j >> 6) * 128 + (j & 63);
-        srcA[i] = (unsigned)rowA[i] * (unsigned)rowbytes + slot * 16;
-        const int col = (j >> 5) * 64 + (j & 31);
-        srcB[i] = (unsigned)col * (unsigned)K * (unsigned)sizeof(T) + slot * 16;
-    }
-    const unsigned a_half = 64u * (unsigned)rowbytes;
-    const unsigned b_half = 32u * (unsigned)K * (unsigned)sizeof(T);
-    const unsigned lds_stage = (unsigned)(size_t)(__attribute__((address_space(3))) void *)lds + (unsigned)(2 * wid) * 1024u;
-
-    int bm0 = 0, bn0 = 0;
-    const unsigned char *xb = nullptr, *wb = nullptr;
-    unsigned okA = 0;
-    auto set_tile = [&](const int orig) {
-        const int xcd = orig & 7, q8 = nwg >> 3, r8 = nwg & 7;
-        const int tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (orig >> 3);
-        ln_tile_origin(P, tile, bm0, bn0);
-        xb = (const unsigned char *)P.x + (size_t)bm0 * rowbytes;
-        wb = (const unsigned char *)P.w + (size_t)bn0 * K * sizeof(T);
-        if (CONV) {
-            okA = 0;
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    const unsigned pix = (unsigned)(bm0 + rowA[i] + 64 * h) % (unsigned)(P.H * P.W);
-                    const int py = (int)(pix / (unsigned)P.W), px = (int)(pix % (unsigned)P.W);
-                    const unsigned bits = (py > 0 ? 1u : 0u) | 2u | (py < P.H - 1 ? 4u : 0u) | (px > 0 ? 8u : 0u) | 16u | (px < P.W - 1 ? 32u : 0u);
-                    okA |= bits << (6 * (2 * h + i));
-                }
-        }
-    };
-
-    unsigned offA[4], offB[4];
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-        const unsigned sl = (unsigned)((2 * ks + (lane >> 5)) ^ ((lane >> 1) & 7)) << 4;
-        offA[ks] = (unsigned)(wr * 64 + (lane & 31)) * 128u + sl;
-        offB[ks] = LN_B_BASE + (unsigned)(wc * 32 + (lane & 31)) * 128u + sl;
-    }
-    V8 ga[2][2][2];      // [register set][x half][row block]
-    V8 gb[2][2];         // [register set][W half]
-    V8 bv[2][2];         // bias of this wave's columns, [W half][k]
-    lf32x16 acc[2][2][2];
-    lf32x16 zero16;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) zero16[r] = 0.f;
-
-    const int nt = K >> 6;            // even (K is a multiple of 128)
-    const bool counted = P.early != 0;
-    bool stores_ahead = false;
-    int cur = blockIdx.x;
-    int next = cur + (int)gridDim.x;
-    int cbm0 = 0, cbn0 = 0;
-
-    // KIND 2: first K-tile of an output tile (no MFMAs pending from the previous K-tile); 1: last K-tile (stages K-tile 0 of the
-    // next output tile and requests the bias); 0: in between.  S = LDS buffer of this K-tile (t & 1).
-    auto ktile = [&](const int t, auto kind_c, auto s_c) {
-        constexpr int KIND = decltype(kind_c)::value;
-        constexpr int S = decltype(s_c)::value;
-        if constexpr (KIND == 2) {
-            // behind the DMAs of this K-tile: the previous tile's epilogue (its loads retired, its 16 stores maybe not)
-            if (counted && stores_ahead) LN_WAIT_VM(16); else LN_WAIT_VM(0);
-        } else {
-            LN_WAIT_VM(0);
-        }
-        LN_WAIT_LGKM0();
-        LN_BARRIER();
-        asm volatile("" ::: "memory");
-        // step 0: fragments of (t, 0) into set 0 | the pending MFMAs of (t-1, 3) from set 1 | DMAs of the next K-tile
-        LS_READ(0, 0, S);
-        LS_FENCE();
-        if constexpr (KIND == 1) {
-            // K-tile 0 of the workgroup's next tile (after the last tile: of this tile again -- a harmless load into the dead
-            // buffer that keeps the stream branch-free; the kernel waits for it before it exits)
-            set_tile(next < nwg ? next : cur);
-            LS_PAIR(1, 0, 0); LS_FENCE(); LN_STAGE(0, 0, 0); LS_FENCE();
-            LS_PAIR(1, 0, 1); LS_FENCE(); LN_STAGE(2, 0, 0); LS_FENCE();
-            LS_PAIR(1, 1, 0); LS_FENCE(); LN_STAGE(3, 0, 0); LS_FENCE();
-            LS_PAIR(1, 1, 1); LS_FENCE(); LN_STAGE(1, 0, 0); LS_FENCE();
-            // the bias vectors of THIS tile, consumed by its epilogue (younger than every DMA in flight)
-            if (P.bias) {
-#pragma unroll
-                for (int hb_ = 0; hb_ < 2; ++hb_)
-#pragma unroll
-                    for (int k_ = 0; k_ < 2; ++k_)
-                        bv[hb_][k_] = *(const V8 *)((const T *)P.bias + (cbn0 + wc * 64 + hb_ * 32 + 8 * (lane >> 5) + 16 * k_));
-            }
-        } else {
-            if constexpr (KIND == 0) { LS_PAIR(1, 0, 0); LS_FENCE(); }
-            LN_STAGE(0, t + 1, S ^ 1); LS_FENCE();
-            if constexpr (KIND == 0) { LS_PAIR(1, 0, 1); LS_FENCE(); }
-            LN_STAGE(2, t + 1, S ^ 1); LS_FENCE();
-            if constexpr (KIND == 0) { LS_PAIR(1, 1, 0); LS_FENCE(); }
-            LN_STAGE(3, t + 1, S ^ 1); LS_FENCE();
-            if constexpr (KIND == 0) { LS_PAIR(1, 1, 1); LS_FENCE(); }
-            LN_STAGE(1, t + 1, S ^ 1); LS_FENCE();
-        }
-        LS_FENCE();
-        // steps 1 .. 3
-        LS_READ(1, 1, S);
-        if constexpr (KIND == 2) { LS_PAIR_Z(0, 0, 0); LS_PAIR_Z(0, 0, 1); LS_PAIR_Z(0, 1, 0); LS_PAIR_Z(0, 1, 1); }
-        else LS_MMA(0);
-        LS_FENCE();
-        LS_READ(0, 2, S);
-        LS_MMA(1);
-        LS_FENCE();
-        LS_READ(1, 3, S);
-        LS_MMA(0);
-        LS_FENCE();
-    };
-
-    set_tile(cur);
-    LN_STAGE(0, 0, 0); LN_STAGE(2, 0, 0); LN_STAGE(3, 0, 0); LN_STAGE(1, 0, 0);
-    for (;;) {
-        cbm0 = bm0; cbn0 = bn0;              // this tile's origin: set_tile(next) moves bm0 / bn0 in the last K-tile
-        ktile(0, std::integral_constant<int, 2>(), std::integral_constant<int, 0>());
-        for (int t = 1; t < nt - 1; t += 2) {
-            ktile(t, std::integral_constant<int, 0>(), std::integral_constant<int, 1>());
-            ktile(t + 1, std::integral_constant<int, 0>(), std::integral_constant<int, 0>());
-        }
-        ktile(nt - 1, std::integral_constant<int, 1>(), std::integral_constant<int, 1>());
-        LS_MMA(1);                           // (nt-1, 3)
-        LS_FENCE();
-
-        // ---- epilogue: k_linear256's (register r of a 32 x 32 block = column (r & 3) + 8 (r >> 2) + 4 (lane >> 5) of row lane & 31;
-        // one v_permlane32_swap per register pair gives a lane 8 consecutive columns; ONE 16-byte store per (ha, rb, hb, k)) -------
-        const int hi8 = 8 * (lane >> 5);
-        if (!P.bias) {
-#pragma unroll
-            for (int hb = 0; hb < 2; ++hb)
-#pragma unroll
-                for (int k = 0; k < 2; ++k)
-#pragma unroll
-                    for (int t_ = 0; t_ < 8; ++t_) bv[hb][k][t_] = (T)0.f;
-        }
-        T *yb = (T *)P.y;
-        const T *r1 = (const T *)P.res1, *r2 = (const T *)P.res2;
-        V8 gv[2][2];
-        if (EPI == 3) {
-#pragma unroll
-            for (int hb = 0; hb < 2; ++hb)
-#pragma unroll
-                for (int k = 0; k < 2; ++k) gv[hb][k] = *(const V8 *)((const T *)P.gamma + cbn0 + wc * 64 + hb * 32 + hi8 + 16 * k);
-        }
-#pragma unroll
-        for (int ha = 0; ha < 2; ++ha)
-#pragma unroll
-            for (int rb = 0; rb < 2; ++rb) {
-                const int rl = ha * 64 + rb * 32 + (lane & 31);
-                const size_t o0 = (size_t)(cbm0 + wr * 128 + rl) * P.ldy + cbn0 + wc * 64 + hi8;
-                auto out_off = [&](const int hb_, const int k_) -> size_t {
-                    return VT ? ln_out_off<VT>(P, cbm0 + wr * 128 + rl, cbn0 + wc * 64 + hi8 + hb_ * 32 + 16 * k_) : o0 + hb_ * 32 + 16 * k_;
-                };
-                V8 ra[2][2], rb2[2][2];
-#pragma unroll
-                for (int hb = 0; hb < 2; ++hb)
-#pragma unroll
-                    for (int k = 0; k < 2; ++k) {
-                        if (RES >= 1) ra[hb][k] = *(const V8 *)(r1 + o0 + hb * 32 + 16 * k);
-                        if (RES >= 2) rb2[hb][k] = *(const V8 *)(r2 + o0 + hb * 32 + 16 * k);
-                    }
-#pragma unroll
-                for (int hb = 0; hb < 2; ++hb)
-#pragma unroll
-                    for (int k = 0; k < 2; ++k) {
-                        float v[8];
-#pragma unroll
-                        for (int t_ = 0; t_ < 4; ++t_) {
-                            const float fa_ = acc[ha][rb][hb][8 * k + t_], fb_ = acc[ha][rb][hb][8 * k + 4 + t_];
-                            const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(fa_), __float_as_uint(fb_), false, false);
-                            v[t_] = __uint_as_float(sw[0]);
-                            v[4 + t_] = __uint_as_float(sw[1]);
-                        }
-                        V8 o;
-#pragma unroll
-                        for (int t_ = 0; t_ < 8; t_ += 2) {
-                            lf32x2 u = {v[t_] + (float)bv[hb][k][t_], v[t_ + 1] + (float)bv[hb][k][t_ + 1]};
-                            if (EPI == 3) u *= (lf32x2){(float)gv[hb][k][t_], (float)gv[hb][k][t_ + 1]};
-                            if (RES >= 1) u += (lf32x2){(float)ra[hb][k][t_], (float)ra[hb][k][t_ + 1]};
-                            if (RES >= 2) u += (lf32x2){(float)rb2[hb][k][t_], (float)rb2[hb][k][t_ + 1]};
-                            if (EPI == 1) u = ln_gelu2(u);
-                            if (EPI == 2) u = (lf32x2){fmaxf(u[0], 0.f), fmaxf(u[1], 0.f)};
-                            o[t_] = (T)u[0];
-                            o[t_ + 1] = (T)u[1];
-                        }
-                        *(V8 *)(yb + out_off(hb, k)) = o;
-                    }
-            }
-        if (next >= nwg) break;
-        cur = next;
-        next = cur + (int)gridDim.x;
-        stores_ahead = true;
-    }
-    LN_WAIT_VM(0);                           // the trailing re-load: nothing may still be writing LDS at exit
-}
-#undef LS_READ
-#undef LS_PAIR
-#undef LS_MMA
-#undef LS_PAIR_Z
-#undef LS_FENCE
+// (Round 4 built and measured a second K-loop generation here, k_linear256s: every wave runs ONE software-pipelined stream --
+// fragment reads one k-step ahead in two register sets, the last step's MFMAs issued behind the next barrier, the DMA stream
+// continuing across output tiles, ONE barrier per K-tile instead of sixteen, 192-245 VGPRs without a spill.  Bit-identical to
+// k_linear256 on first run, and not faster: 30.7 vs 30.9 us per round of 256 tiles at K = 1024, 115 vs 106 us at K = 4096
+// (profiles/round4_gemm_streamed_experiment.txt).  The ablations taken with it say why neither schedule matters at this
+// point: on ZERO operands this kernel runs 1870 TF/s against 1296 on random ones, and on half the chip (128 workgroups) 1958
+// TF/s-equivalent per CU -- the full chip on random float16 data is POWER limited (the clock drops), at about 1600 TF/s for the
+// MFMA stream alone (no DMA, no fragment reads) and 1300 with its operand traffic.  The kernel is in the history: commit
+// "k_linear256s: streamed K loop".)
 
 // ---- the ragged round ----------------------------------------------------------------------------------------------------
 // A persistent launch of T tiles on G workgroups costs ceil(T / G) rounds; the token GEMMs of an encoder block at batch 32 are
@@ -956,19 +699,16 @@ __global__ __launch_bounds__(LN_THREADS, S == 3 ? 4 : 2) void k_linear_ragged(Li
 // ---- C ABI -------------------------------------------------------------------------------------------------------------
 // A/B switches of the GEMM path, read from the environment ONCE (hundreds of launches per forward; ds_linear_reload_env re-reads
 // them: the tests flip them inside one process).  None of them changes a result.
-//   DS_LIN_KERNEL   2 (default) k_linear256s, the streamed K loop; 1 k_linear256, the two-barriers-per-phase schedule of rounds 2-3
-//   DS_LIN_EARLY    k_linear256: 1 (default) next tile's prologue before the epilogue; k_linear256s: 1 counted waits at a tile
-//                   boundary, 0 vmcnt(0)
+//   DS_LIN_EARLY    1 (default) the next tile's prologue DMAs are issued before the epilogue, 0 after it
 //   DS_LIN_GRID     number of persistent workgroups (default: one per CU)
 //   DS_LIN_RAGGED / DS_LIN_RAGGED_DEN / DS_LIN_RAGGED_RING   the ragged round: on / "at most 1/DEN full" / ring depth 3 or 6
-struct LinOptions { int kernel, early, grid, ragged, ragged_den, ragged_ring; };
+struct LinOptions { int early, grid, ragged, ragged_den, ragged_ring; };
 static LinOptions g_lin_options;
 static std::atomic<int> g_lin_options_state{0};
 static void ln_read_options()
 {
     auto geti = [](const char *name, int dflt) { const char *e = getenv(name); return e ? atoi(e) : dflt; };
     LinOptions o;
-    o.kernel = geti("DS_LIN_KERNEL", 2) == 1 ? 1 : 2;
     o.early = geti("DS_LIN_EARLY", 1);
     o.grid = geti("DS_LIN_GRID", 0);
     o.ragged = geti("DS_LIN_RAGGED", 1);
@@ -996,12 +736,10 @@ static int ln_launch(ds_ctx *ctx, const LinParams &P0, hipStream_t stream)
     // so the bit mask needs no lock.
     static std::atomic<uint64_t> attr_done{0};
     auto fn = k_linear256<BF16, EPI, CONV, RES, VT>;
-    auto fns = k_linear256s<BF16, EPI, CONV, RES, VT>;
     DS_HIP_CHECK(hipSetDevice(ctx->device));
     const uint64_t bit = 1ull << (ctx->device & 63);
     if (!(attr_done.load(std::memory_order_relaxed) & bit)) {
         DS_HIP_CHECK(hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, LN_LDS_BYTES));
-        DS_HIP_CHECK(hipFuncSetAttribute((const void *)fns, hipFuncAttributeMaxDynamicSharedMemorySize, LN_LDS_BYTES));
         if constexpr (CONV == 0) {
             DS_HIP_CHECK(hipFuncSetAttribute((const void *)k_linear_ragged<BF16, EPI, RES, VT, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * RG_SLOT));
             DS_HIP_CHECK(hipFuncSetAttribute((const void *)k_linear_ragged<BF16, EPI, RES, VT, 6>, hipFuncAttributeMaxDynamicSharedMemorySize, 6 * RG_SLOT));
@@ -1017,7 +755,7 @@ static int ln_launch(ds_ctx *ctx, const LinParams &P0, hipStream_t stream)
     int grid = ctx->ncu;
     if (O.grid >= 8) grid = O.grid / 8 * 8;             // tests: a small grid makes every workgroup walk many tiles
     LinParams P = P0;
-    P.early = O.early;                                   // k_linear256: prologue order; k_linear256s: counted waits.  Same values either way
+    P.early = O.early;                                   // A/B switch (both orders give the same values)
 #ifdef DS_EXPERIMENTS
     if (P.ablate) P.early = 0;               // the no-store ablation changes the store count the early mode's waits rely on
 #endif
@@ -1030,8 +768,7 @@ static int ln_launch(ds_ctx *ctx, const LinParams &P0, hipStream_t stream)
         if (O.ragged && r > 0 && O.ragged_den > 0 && O.ragged_den * r <= grid) ragged = r;
     }
     P.n_main = ntiles - ragged;
-    if (O.kernel == 1) hipLaunchKernelGGL(fn, dim3(P.n_main < grid ? P.n_main : grid), dim3(LN_THREADS), LN_LDS_BYTES, stream, P);
-    else hipLaunchKernelGGL(fns, dim3(P.n_main < grid ? P.n_main : grid), dim3(LN_THREADS), LN_LDS_BYTES, stream, P);
+    hipLaunchKernelGGL(fn, dim3(P.n_main < grid ? P.n_main : grid), dim3(LN_THREADS), LN_LDS_BYTES, stream, P);
     if constexpr (CONV == 0) {
         const int deep = O.ragged_ring ? O.ragged_ring == 6 : 8 * ragged <= grid;
         if (ragged && deep) hipLaunchKernelGGL((k_linear_ragged<BF16, EPI, RES, VT, 6>), dim3(8 * ragged), dim3(LN_THREADS), 6 * RG_SLOT, stream, P);

@@ -13,16 +13,6 @@ pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "model_cases.npz")
 
 
-@pytest.fixture(params=[2, 1], ids=["streamed", "phased"])
-def lin_kernel(request):
-    """Both K-loop generations of csrc/ds_linear.hip behind the same entry points: k_linear256s (streamed, the default) and
-    k_linear256 (the two-barriers-per-phase schedule of rounds 2-3, DS_LIN_KERNEL=1)."""
-    from src import _native
-    _native.linear_env(DS_LIN_KERNEL=request.param)
-    yield request.param
-    _native.linear_env(DS_LIN_KERNEL=None)
-
-
 def _case(b, n_valid, h, dtype, seed, with_bias):
     from src import vit_mi355x as vm
     g = torch.Generator().manual_seed(seed)
@@ -651,7 +641,7 @@ def test_hip_graph_replay_equals_eager_forward(gpu):
 
 
 @pytest.mark.parametrize("dtype,tol", [(torch.float16, 1.5e-3), (torch.bfloat16, 1.2e-2)])
-def test_linear_kernel_matches_float32_and_is_race_free(gpu, dtype, tol, lin_kernel):
+def test_linear_kernel_matches_float32_and_is_race_free(gpu, dtype, tol):
     """ds_linear (csrc/ds_linear.hip: 256x256 MFMA tiles, LDS-DMA staging, 8-phase K loop, fused bias / erf-GELU) against
     x @ W.T + b [-> GELU] in float32 on the SAME rounded operands.  Shapes cover: one K iteration (K = 128), odd numbers
     of iterations, a ragged last row panel, rows < 256, no bias, several column panels, and the encoder shapes of
@@ -727,7 +717,7 @@ def test_linear_gelu_polynomial_against_erf_everywhere(gpu):
 
 
 @pytest.mark.parametrize("dtype,tol", [(torch.float16, 2e-3), (torch.bfloat16, 1.6e-2)])
-def test_conv3x3_kernel_matches_float32_convolution(gpu, dtype, tol, lin_kernel):
+def test_conv3x3_kernel_matches_float32_convolution(gpu, dtype, tol):
     """ds_conv3x3_nhwc (the implicit GEMM of csrc/ds_linear.hip) against F.conv2d in float32 on the same rounded operands:
     image borders inside and across 256-pixel tiles, several images per tile, ragged last tile, 128 / 256 / 512 input
     channels, no bias (scratch.layerN_rn), bias + ReLU (first half of a residual unit), bias + residual + skip (second
@@ -788,7 +778,7 @@ def test_conv3x3_kernel_matches_float32_convolution(gpu, dtype, tol, lin_kernel)
 
 @pytest.mark.parametrize("m,n,k,gelu", [(34816, 4096, 1024, True), (34816, 1024, 4096, False), (34816, 2048, 1024, False),
                                         (34816, 1024, 1024, False)])
-def test_linear_kernel_at_benchmark_shapes(gpu, m, n, k, gelu, lin_kernel):
+def test_linear_kernel_at_benchmark_shapes(gpu, m, n, k, gelu):
     """ds_linear at the shapes ONE encoder block of dpt_beit_large_512 launches at batch 32 (the bench's step): 34 816
     rows = 136 row panels, i.e. the whole XCD-aware tile list of ~2 000 tiles over all 256 persistent workgroups (the
     smaller tests walk at most 17 panels).  Every element against a float32 GEMM of the same rounded operands."""
@@ -811,7 +801,7 @@ def test_linear_kernel_at_benchmark_shapes(gpu, m, n, k, gelu, lin_kernel):
     assert torch.equal(_native.linear(x, w, b, gelu), got), "run-to-run difference at the benchmark shape"
 
 
-def test_conv3x3_kernel_at_benchmark_shape(gpu, lin_kernel):
+def test_conv3x3_kernel_at_benchmark_shape(gpu):
     """ds_conv3x3_nhwc at refinenet1's shape in the bench's step: 32 x 128 x 128, 256 -> 256, bias + residual
     (2 048 tiles), every output against F.conv2d in float32 on the same rounded operands."""
     import torch.nn as nn
@@ -888,7 +878,7 @@ def _lin_ref(x, w, b=None, gamma=None, res=None, gelu=False):
 
 
 @pytest.mark.parametrize("dtype,tol", [(torch.float16, 1.5e-3), (torch.bfloat16, 1.2e-2)])
-def test_linear_ragged_round_vt_and_fused_residual(gpu, dtype, tol, lin_kernel):
+def test_linear_ragged_round_vt_and_fused_residual(gpu, dtype, tol):
     """The pieces of csrc/ds_linear.hip added in round 3, at small sizes with a small persistent grid (DS_LIN_GRID) so that
     every path is taken: k_linear_ragged (the last, nearly empty round of tiles rendered as 128 x 64 pieces with K split over
     the 8 waves and summed through LDS) behind plain / GELU / LayerScale + residual epilogues, a shifted last row panel,
@@ -951,7 +941,7 @@ def test_linear_ragged_round_vt_and_fused_residual(gpu, dtype, tol, lin_kernel):
             _native.linear_env(**{k_: v})
 
 
-def test_linear_vt_and_fused_fc2_at_benchmark_shapes(gpu, lin_kernel):
+def test_linear_vt_and_fused_fc2_at_benchmark_shapes(gpu):
     """ds_linear_vt and ds_linear_residual at the shapes of ONE encoder block of dpt_beit_large_512 at batch 32 (544 tiles:
     two full rounds on 256 CUs + a ragged round of 32 tiles), every element against float32 on the same rounded operands."""
     from src import _native

@@ -196,67 +196,6 @@ def linear_ab():
     print(f"residual_layernorm 34816x1024: with branch {t2 * 1e3:.1f} us, LayerNorm only {t1 * 1e3:.1f} us")
 
 
-def linear_kernels():
-    """Round 4: the two K-loop generations (DS_LIN_KERNEL=2 streamed / 1 phased) on the GEMMs of one dpt_beit_large_512 block at
-    batch 32, the decoder's 3x3 convolution and a K sweep -- interleaved rounds in one process, values cross-checked."""
-    import torch.nn.functional as F
-    dev = torch.device("cuda")
-    dt = torch.float16
-    g = torch.Generator(device="cpu").manual_seed(5)
-    m = 34816
-    x = torch.randn(m, 1024, generator=g).to(dev, dt)
-    x4 = torch.randn(m, 4096, generator=g).to(dev, dt)
-    res = torch.randn(m, 1024, generator=g).to(dev, dt)
-    gam = torch.randn(1024, generator=g).to(dev, dt)
-
-    def w_(n, k):
-        return (torch.randn(n, k, generator=g) * k ** -0.5).to(dev, dt)
-    w_qk, w_v, w_p, w_1, w_2 = w_(2048, 1024), w_(1024, 1024), w_(1024, 1024), w_(4096, 1024), w_(1024, 4096)
-    b_qk, b_p, b_1, b_2 = (torch.randn(n, generator=g).to(dev, dt) for n in (2048, 1024, 4096, 1024))
-    h3 = x.view(32, 1088, 1024)
-    conv = nn.Conv2d(256, 256, 3, padding=1).to(dev, dt)
-    xc = torch.randn(32, 256, 128, 128, device=dev, dtype=dt).contiguous(memory_format=torch.channels_last)
-    cases = [
-        ("qk       34816x2048x1024", 2.0 * m * 2048 * 1024, lambda: nat.linear(x, w_qk, b_qk, False)),
-        ("v^T      1024x34816x1024", 2.0 * m * 1024 * 1024, lambda: nat.linear_vt(w_v, h3)),
-        ("proj+res 34816x1024x1024", 2.0 * m * 1024 * 1024, lambda: nat.linear_residual(x, w_p, b_p, gam, res)),
-        ("fc1+gelu 34816x4096x1024", 2.0 * m * 4096 * 1024, lambda: nat.linear(x, w_1, b_1, True)),
-        ("fc2+res  34816x1024x4096", 2.0 * m * 1024 * 4096, lambda: nat.linear_residual(x4, w_2, b_2, gam, res)),
-        ("conv3x3  32x128x128 256->256 +relu", 2.0 * 32 * 128 * 128 * 256 * 2304, lambda: nat.conv3x3(conv, xc, relu=True)),
-    ]
-    variants = [("streamed", dict(DS_LIN_KERNEL=2, DS_LIN_EARLY=1)), ("streamed vmcnt(0)", dict(DS_LIN_KERNEL=2, DS_LIN_EARLY=0)),
-                ("phased", dict(DS_LIN_KERNEL=1, DS_LIN_EARLY=1))]
-    total = {v: 0.0 for v, _ in variants}
-    for name, fl, fn in cases:
-        outs, t = {}, {v: [] for v, _ in variants}
-        for _ in range(3):
-            for v, env in variants:
-                nat.linear_env(**env)
-                t[v].append(timeit(fn, reps=10, warm=2))
-                if v not in outs:
-                    outs[v] = fn().float()
-                    same = all(torch.equal(fn().float(), outs[v]) for _ in range(3))
-                    assert same, f"{name} [{v}]: run-to-run difference"
-        d = max((outs[v] - outs["phased"]).abs().max().item() for v in outs)
-        msg = " | ".join(f"{v} {min(t[v]) * 1e3:7.1f} us {fl / min(t[v]) / 1e9:6.0f} TF" for v, _ in variants)
-        for v, _ in variants:
-            total[v] += min(t[v])
-        print(f"gemm {name}: {msg} | max|diff between kernels| {d:.2e}", flush=True)
-    print("block total (5 GEMMs + conv): " + " | ".join(f"{v} {total[v] * 1e3:7.1f} us" for v, _ in variants), flush=True)
-    for k in (256, 1024, 4096, 8192):
-        mm = 256 * 16 * 8
-        xs = torch.randn(mm, k, device=dev, dtype=dt)
-        ws = torch.randn(4096, k, device=dev, dtype=dt) * k ** -0.5
-        bs = torch.randn(4096, device=dev, dtype=dt)
-        row = []
-        for v, env in variants:
-            nat.linear_env(**env)
-            t0 = min(timeit(lambda: nat.linear(xs, ws, bs, False), reps=10, warm=2) for _ in range(3))
-            row.append(f"{v} {t0 * 1e3 / 8:7.2f} us/round {2.0 * mm * 4096 * k / t0 / 1e9:6.0f} TF")
-        print(f"sweep K={k:5d} (8 rounds of 256 tiles, plain): " + " | ".join(row), flush=True)
-    nat.linear_env(DS_LIN_KERNEL=None, DS_LIN_EARLY=None)
-
-
 def single_shapes(which):
     """One shape per kernel instantiation, a few launches each: what the hardware-counter passes profile."""
     dev = torch.device("cuda")
@@ -332,9 +271,6 @@ if __name__ == "__main__":
         sys.exit(0)
     if "linear" in sys.argv[1:]:
         linear_bench()
-        sys.exit(0)
-    if "kernels" in sys.argv[1:]:
-        linear_kernels()
         sys.exit(0)
     if "gemms" in sys.argv[1:]:
         linear_ab()
