@@ -413,7 +413,7 @@ def main():
     attn = None
     if model is not None:
         n_tok = minfo["tokens"]
-        npad = vm.pad_len(n_tok)
+        npad = vm.pad_len(n_tok, batch)
         qk = torch.randn(batch, npad, 2, minfo["heads"], 64, device=dev, dtype=torch.float16)
         vt = torch.randn(batch, minfo["heads"] * 64, npad, device=dev, dtype=torch.float16)
         bias = None
@@ -442,7 +442,7 @@ def main():
     # 3x3 convolution of the decoder's last residual units (256 -> 256 at net/4 resolution), random operands
     lin = conv_roof = None
     if model is not None and vm.LINEAR_HIP != "0":
-        m_rows, dim = batch * vm.pad_len(minfo["tokens"]), minfo["dim"]
+        m_rows, dim = batch * vm.pad_len(minfo["tokens"], batch), minfo["dim"]
         xw = torch.randn(m_rows, dim, device=dev, dtype=torch.float16)
         ww = torch.randn(4 * dim, dim, device=dev, dtype=torch.float16) * dim ** -0.5
         bw = torch.randn(4 * dim, device=dev, dtype=torch.float16)

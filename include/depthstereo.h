@@ -176,10 +176,13 @@ int ds_convert_to_i16(ds_ctx *ctx, const void *arr, int is_f64, int64_t count, u
  * :65-82) and of dmidas/backbones/beit.py:65-91 (attention_forward with relative position bias); head_dim = 64.
  *   qk      [B, Np, 2, H, 64]  Q (index 0) and K (index 1), token major, as the projection GEMM writes them
  *   vt      [B, H*64, Np]      V transposed (key index contiguous)
- *   bias_packed  NULL, or the operand made by ds_attention_bias_pack for this (H, Np) in the same dtype
+ *   bias_packed  NULL, or the operand made by ds_attention_bias_pack for this H and Np ROUNDED UP to a multiple of 64, same dtype
  *   out     [B, Np, H*64]
- * Np is a multiple of 64 (the padded token count); keys >= n_valid are masked; query rows >= n_valid are computed
- * like any other row (they stay finite) and are never read as keys.  scale multiplies q.k before the bias is added.
+ * Np is the token stride of the operands, a multiple of 8 (the padded token count: a tight pad keeps the token GEMMs around
+ * the kernel close to whole rounds of tiles -- 32 x 1032 rows are 129 row panels, 32 x 1088 are 136); the kernel walks whole
+ * 64-key tiles, rows in [Np, roundup(Np, 64)) read as pad keys and are not stored.  Keys >= n_valid are masked; query rows >=
+ * n_valid are computed like any other row (they stay finite) and are never read as keys.  scale multiplies q.k before the bias
+ * is added.
  */
 int ds_attention_fwd(ds_ctx *ctx, const void *qk, const void *vt, const void *bias_packed, void *out,
                      int B, int Np, int H, int n_valid, float scale, int dtype, void *stream);

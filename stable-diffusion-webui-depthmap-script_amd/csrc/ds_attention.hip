@@ -10,7 +10,7 @@
 //   bias optional: the operand made by ds_attention_bias_pack (this file) from the [H, n, n] table -- x log2(e), zero
 //        padded, stored in the register order of the logits tile, so a wave loads its 32 x 64 tile straight into registers
 //   out  [B, Np, H*64]      f16/bf16
-// Np is a multiple of 64; keys >= n_valid are masked (pad rows of the padded token sequence).
+// Np (the token stride) is a multiple of 8; keys >= n_valid are masked (pad rows of the padded token sequence).
 //
 // Mapping: workgroup = 4 waves = 128 query rows of one (batch, head); each wave owns 32 query rows.  Per 64-key tile:
 //   S^T = K . Q^T   "swapped" so that a lane holds logits of ONE query (column lane&31) for 32 of the 64 keys: the
@@ -377,7 +377,12 @@ __global__ __launch_bounds__(AT_THREADS, NQB == 2 ? 2 : ((ABL & 4096) ? 4 : 3)) 
     if (P.flags & 2) { b = L % P.B; qblk = (L / P.B) % P.nq; h = L / (P.B * P.nq); }
     else { qblk = L % P.nq; b = (L / P.nq) % P.B; h = L / (P.nq * P.B); }
     const int q0 = qblk * (128 * NQB) + wave * (32 * NQB);
+    // Np = token STRIDE of the operands (rows that exist per batch element, a multiple of 8); the key tiles and the packed
+    // bias run on Np64, the stride rounded up to whole 64-key tiles.  Rows in [Np, Np64) do not exist: K rows there read as
+    // zeros (the buffer descriptor ends at the batch element), V^T columns there alias the next row -- both are pad keys
+    // (>= n_valid), whose probabilities are exactly 0 -- and query rows there are neither loaded nor stored.
     const int Np = P.Np, H = P.H;
+    const int Np64 = (Np + 63) & ~63;
     const size_t tok_stride = (size_t)2 * H * AT_D;
     const T *qk = (const T *)P.qk + (size_t)b * Np * tok_stride;
     const T *q_base = qk + (size_t)h * AT_D;
@@ -449,10 +454,10 @@ __global__ __launch_bounds__(AT_THREADS, NQB == 2 ? 2 : ((ABL & 4096) ? 4 : 3)) 
     // Bias: [head][32-query block][64-key tile][chunk c = 2 kb + s][64 lanes][8]: lane (hi, l31) of chunk c holds
     // bias[query 16 s + 8 hi + t][key 32 kb + l31] / scale, t = 0..7 -- the A fragment of the MFMA that adds it.
     u32x4 breg[2][4];                                           // (unused, and eliminated, without a bias)
-    const int n_kt = Np / AT_KB;
+    const int n_kt = Np64 / AT_KB;
     const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc(
-        (void *)(HAS_BIAS ? (const T *)P.bias + (size_t)h * Np * (size_t)Np : (const T *)P.qk), 0,
-        (int)((size_t)Np * Np * sizeof(T)), 0x00020000);
+        (void *)(HAS_BIAS ? (const T *)P.bias + (size_t)h * Np64 * (size_t)Np64 : (const T *)P.qk), 0,
+        (int)((size_t)Np64 * Np64 * sizeof(T)), 0x00020000);
     const int vo_b = (int)((((size_t)(q0 / 32) * n_kt) * 2048 + (size_t)lane * 8) * sizeof(T));
     const int so_bq = (int)((size_t)n_kt * 2048 * sizeof(T));                               // next 32-query block
 #define A2_FETCH_BIAS(kt_) do {                                                                                        \
@@ -739,7 +744,8 @@ DS_API int ds_attention_fwd(ds_ctx *ctx, const void *qk, const void *vt, const v
 {
     DS_REQUIRE(ctx && qk && vt && out, DS_EINVAL, "ds_attention_fwd: null argument");
     const void *bias = bias_packed;
-    DS_REQUIRE(B > 0 && H > 0 && Np > 0 && (Np % 64) == 0, DS_EINVAL, "ds_attention_fwd: Np must be a positive multiple of 64 (got %d)", Np);
+    DS_REQUIRE(B > 0 && H > 0 && Np > 0 && (Np % 8) == 0, DS_EINVAL, "ds_attention_fwd: Np must be a positive multiple of 8 (got %d)", Np);
+    DS_REQUIRE(at_version() == 2 || (Np % 64) == 0, DS_EINVAL, "ds_attention_fwd: the first kernel generation needs Np to be a multiple of 64");
     DS_REQUIRE(n_valid > 0 && n_valid <= Np, DS_EINVAL, "ds_attention_fwd: n_valid %d outside 1..%d", n_valid, Np);
     DS_REQUIRE(dtype == DS_DTYPE_F16 || dtype == DS_DTYPE_BF16, DS_EINVAL, "ds_attention_fwd: dtype must be f16 or bf16");
     DS_REQUIRE((long long)B * H * ((Np + AT_QB - 1) / AT_QB) < (1ll << 30), DS_EUNSUPPORTED, "ds_attention_fwd: batch x heads too large for the grid");

@@ -93,7 +93,7 @@ __device__ __forceinline__ void ln_tile_origin(const LinParams &P, const int til
 
 // element offset of output (row, col .. col + 7), col a multiple of 8.  VT: the GEMM computes W_v . h^T with the TOKENS as its
 // columns, and the result is stored per batch element as [channels][tokens] -- V transposed, the operand layout of the
-// attention kernel's P.V product (a group of 8 columns never straddles two batch elements: vt_np is a multiple of 64)
+// attention kernel's P.V product (a group of 8 columns never straddles two batch elements: vt_np is a multiple of 8)
 template <int VT>
 __device__ __forceinline__ size_t ln_out_off(const LinParams &P, const int row, const int col)
 {
@@ -900,8 +900,8 @@ DS_API int ds_linear_vt(ds_ctx *ctx, const void *w_v, const void *h, void *vt, i
 {
     DS_REQUIRE(ctx && w_v && h && vt, DS_EINVAL, "ds_linear_vt: null argument");
     DS_REQUIRE(channels >= 256, DS_EINVAL, "ds_linear_vt: channels must be >= 256 (one tile)");
-    DS_REQUIRE(batch > 0 && tokens > 0 && tokens % 64 == 0 && (batch * tokens) % 256 == 0 && batch * tokens < (1ll << 31) - 256, DS_EINVAL,
-               "ds_linear_vt: tokens must be a multiple of 64 and batch * tokens a multiple of 256");
+    DS_REQUIRE(batch > 0 && tokens > 0 && tokens % 8 == 0 && (batch * tokens) % 256 == 0 && batch * tokens < (1ll << 31) - 256, DS_EINVAL,
+               "ds_linear_vt: tokens must be a multiple of 8 and batch * tokens a multiple of 256");
     DS_REQUIRE(batch * tokens * tokens < (1ll << 32), DS_EUNSUPPORTED, "ds_linear_vt: batch * tokens^2 must stay below 2^32");
     DS_REQUIRE(in_features >= 128 && in_features % 128 == 0 && in_features <= 16384, DS_EINVAL,
                "ds_linear_vt: in_features must be a multiple of 128 (<= 16384)");

@@ -125,7 +125,7 @@ class DinoVisionTransformer(nn.Module):
         token split off.  The sequence is padded once and the pad rows are dropped when a tap is taken."""
         tokens = self.prepare_tokens(x)
         n_valid = tokens.shape[1]
-        tokens = vm.pad_tokens(tokens, vm.pad_len(n_valid))
+        tokens = vm.pad_tokens(tokens, vm.pad_len(n_valid, tokens.shape[0]))
         take = sorted(set(range(len(self.blocks) - n, len(self.blocks))) if isinstance(n, int) else set(n))
         _, taps = vm.run_blocks(self.blocks, tokens, n_valid, None, set(take))
         outs = [taps[i] for i in take]

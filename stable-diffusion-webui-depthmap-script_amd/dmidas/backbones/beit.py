@@ -119,6 +119,8 @@ class Block(vm.EncoderBlock):
         per block, 155 GB for the 24 blocks): the block then hands out a _LazyBias that gathers per query tile from the
         resized table, like the reference, which builds the bias transiently in every block (beit.py:29-62)."""
         a = self.attn
+        if not (dtype == torch.float32 or device.type != 'cuda'):
+            n_pad = (n_pad + 63) // 64 * 64            # the packed operand of the HIP kernel lives on whole 64-key tiles
         key = (tuple(grid_hw), n_pad, dtype, device, a.relative_position_bias_table._version)
         hit = self._bias_cache.get(key)
         if hit is not None:
@@ -207,7 +209,7 @@ class Beit(nn.Module):
         t = self.patch_embed(x)
         t = torch.cat((self.cls_token.expand(t.shape[0], -1, -1).to(t.dtype), t), dim=1)
         n_valid = t.shape[1]
-        t = vm.pad_tokens(t, vm.pad_len(n_valid))
+        t = vm.pad_tokens(t, vm.pad_len(n_valid, t.shape[0]))
         _, taps = vm.run_blocks(self.blocks, t, n_valid, grid, set(hooks))
         return [taps[i] for i in hooks], grid
 

@@ -232,7 +232,7 @@ class VisionTransformer(nn.Module):
         t = torch.cat((self.cls_token.expand(b, -1, -1).to(t.dtype), t), dim=1)
         t = t + self.resized_pos_embed(grid[0], grid[1], t.dtype)
         n_valid = t.shape[1]
-        t = vm.pad_tokens(t, vm.pad_len(n_valid))
+        t = vm.pad_tokens(t, vm.pad_len(n_valid, t.shape[0]))
         block_hooks = list(hooks[n_stage_taps:])
         _, taps = vm.run_blocks(self.blocks, t, n_valid, grid, set(block_hooks))
         return stage_outs, [taps[i] for i in block_hooks], grid

@@ -292,9 +292,10 @@ class PackedAttentionBias:
 
 
 def attention_bias_pack(bias, npad, dtype):
-    """bias [H, n, n] (CUDA tensor, any float dtype, natural units) -> PackedAttentionBias for sequences padded to npad
-    (include/depthstereo.h: ds_attention_bias_pack)."""
+    """bias [H, n, n] (CUDA tensor, any float dtype, natural units) -> PackedAttentionBias for sequences whose token stride is
+    npad (include/depthstereo.h: ds_attention_bias_pack; the operand itself is laid out on npad rounded up to 64)."""
     torch = require_gpu()
+    npad = (int(npad) + 63) // 64 * 64
     assert bias.is_cuda and bias.dim() == 3 and bias.shape[1] == bias.shape[2] and dtype in (torch.float16, torch.bfloat16)
     h, n = int(bias.shape[0]), int(bias.shape[1])
     src = bias.detach().float().contiguous()
@@ -312,12 +313,12 @@ def attention_fwd(qk, vt, n_valid, scale, bias=None):
     torch = require_gpu()
     assert qk.is_cuda and vt.is_cuda and qk.dtype == vt.dtype and qk.dtype in (torch.float16, torch.bfloat16)
     b, npad, two, h, d = qk.shape
-    assert two == 2 and d == 64 and npad % 64 == 0 and tuple(vt.shape) == (b, h * 64, npad), (qk.shape, vt.shape)
+    assert two == 2 and d == 64 and npad % 8 == 0 and tuple(vt.shape) == (b, h * 64, npad), (qk.shape, vt.shape)
     qk = qk.contiguous()
     vt = vt.contiguous()
     if bias is not None:
         assert isinstance(bias, PackedAttentionBias), "bias must come from attention_bias_pack"
-        assert (bias.heads, bias.npad, bias.dtype) == (h, npad, qk.dtype) and bias.data.device == qk.device
+        assert (bias.heads, bias.npad, bias.dtype) == (h, (npad + 63) // 64 * 64, qk.dtype) and bias.data.device == qk.device
     out = torch.empty((b, npad, h * 64), dtype=qk.dtype, device=qk.device)
     dt = 1 if qk.dtype == torch.float16 else 2
     CALLS["ds_attention_fwd"] += 1
@@ -438,8 +439,8 @@ def linear_residual(x, weight, bias, gamma, residual):
 
 
 def linear_vt_supported(w_v, h):
-    """Shapes ds_linear_vt takes: h [B, Np, K] with Np % 64 == 0 and (B * Np) % 256 == 0, w_v [C >= 256, K], K % 128 == 0."""
-    return (h.dim() == 3 and h.shape[1] % 64 == 0 and (h.shape[0] * h.shape[1]) % 256 == 0 and w_v.shape[0] >= 256
+    """Shapes ds_linear_vt takes: h [B, Np, K] with Np % 8 == 0 and (B * Np) % 256 == 0, w_v [C >= 256, K], K % 128 == 0."""
+    return (h.dim() == 3 and h.shape[1] % 8 == 0 and (h.shape[0] * h.shape[1]) % 256 == 0 and w_v.shape[0] >= 256
             and w_v.shape[1] == h.shape[2] and h.shape[2] % 128 == 0 and 128 <= h.shape[2] <= 16384
             and h.shape[0] * h.shape[1] * h.shape[1] < (1 << 32))
 

@@ -105,6 +105,7 @@ def _custom_depth_to_float(dp, image):
     return out
 
 
+import ctypes as _ctypes
 import os as _os
 import time as _time
 
@@ -112,6 +113,50 @@ import time as _time
 # through dpt_beit_large_512: one group of 32 -> 176 pairs/s, two pipelined groups of 16 -> 289 pairs/s (the PIL conversion
 # of a group overlaps the next group's device work)
 FUNNEL_BATCH_PIXELS = int(_os.environ.get("DS_FUNNEL_BATCH_PIXELS", 16 << 20))
+
+
+# ---- PIL -> pinned staging without the interpreter lock ----------------------------------------------------------------------
+# np.asarray(PIL image) is Image.tobytes(): Pillow's "raw" encoder packs the image's 32-bit pixel store (RGBX) to 3 bytes per
+# pixel in 64 KB pieces under the GIL, the pieces are joined (a second copy) and then copied into the staging buffer (a third):
+# ~2.5 ms per 1024^2 image, and a thread pool cannot share it -- 80 of the 105 ms a 32-image call took in round 3.  Pillow >= 11.2
+# exports an image's pixel store through the Arrow C data interface (a stable C ABI: struct ArrowArray) without a copy; the
+# funnel takes the pointer, copies the 4-byte pixels into pinned memory with memmove (which releases the GIL, so the host pool
+# really runs in parallel), uploads them as they are and drops the fourth byte on the device.
+# The export is only SAFE for images that own their pixel store: Pillow 12.2 crashes the process when asked to export an image
+# that maps foreign memory (Image.fromarray of an L / RGBA / I;16 array, Image.frombuffer: `readonly` is set).  Mode "RGB" can
+# never be mapped (the packed 3-byte layout is not Pillow's storage layout: Image._MAPMODES), so RGB and not readonly it is;
+# an image stored in several blocks (larger than Pillow's 16 MB block) refuses the export with a ValueError; everything else --
+# other modes, older Pillow -- takes np.asarray as before.  DS_FUNNEL_ARROW=0 switches the path off.
+class _ArrowArray(_ctypes.Structure):
+    pass
+
+
+_ArrowArray._fields_ = [("length", _ctypes.c_int64), ("null_count", _ctypes.c_int64), ("offset", _ctypes.c_int64),
+                        ("n_buffers", _ctypes.c_int64), ("n_children", _ctypes.c_int64), ("buffers", _ctypes.POINTER(_ctypes.c_void_p)),
+                        ("children", _ctypes.POINTER(_ctypes.POINTER(_ArrowArray))), ("dictionary", _ctypes.c_void_p),
+                        ("release", _ctypes.c_void_p), ("private_data", _ctypes.c_void_p)]
+_capsule_pointer = _ctypes.pythonapi.PyCapsule_GetPointer
+_capsule_pointer.restype = _ctypes.c_void_p
+_capsule_pointer.argtypes = [_ctypes.py_object, _ctypes.c_char_p]
+FUNNEL_ARROW = _os.environ.get("DS_FUNNEL_ARROW", "1") != "0"
+
+
+def _rgbx_pixels(im):
+    """(address of the image's H*W 4-byte RGBX pixels, keep-alive object) for an RGB image that owns its pixel store, else None.
+    The address is valid while the keep-alive object (the Arrow capsules, which hold the image's blocks) is referenced."""
+    if not FUNNEL_ARROW or im.mode != "RGB" or getattr(im, "readonly", 1) or not hasattr(im, "__arrow_c_array__"):
+        return None
+    try:
+        capsules = im.__arrow_c_array__()
+        arr = _ArrowArray.from_address(_capsule_pointer(capsules[1], b"arrow_array"))
+        if arr.n_children != 1 or arr.length != im.width * im.height or arr.offset != 0:
+            return None
+        pix = arr.children[0].contents                         # fixed_size_list<uint8>[4]: the child holds the bytes
+        if pix.n_buffers != 2 or pix.length != 4 * arr.length or pix.offset != 0 or not pix.buffers[1]:
+            return None
+        return int(pix.buffers[1]), capsules
+    except Exception:           # multi-block images (ValueError), a Pillow whose export differs: the ordinary path
+        return None
 
 
 def _postprocess_batch(pred, invert, inp):
@@ -248,8 +293,20 @@ def _launch_group(gen, idxs, inputimages, inputdepthmaps, inp, device):
             np.copyto(stn[j], a)
         return st.to(device, non_blocking=True)
 
-    def upload_pixels(tag, to_array):
-        """PIL -> uint8 array -> pinned staging (decoded and copied on the host thread pool) -> device."""
+    def upload_pixels(tag, to_array, rgb=False):
+        """PIL -> uint8 array -> pinned staging (decoded and copied on the host thread pool) -> device.
+        rgb: the result is the images' RGB pixels [b,h,w,3]; RGB images that own their pixel store go through _rgbx_pixels."""
+        if rgb:
+            srcs = [_rgbx_pixels(im) for im in images]
+            if all(x is not None for x in srcs):
+                st = _staging.get(gen, tag + "x", (b, h, w, 4), torch.uint8)
+                base, nbytes = st.data_ptr(), h * w * 4
+                if b > 1:
+                    list(_host_pool().map(lambda j: _ctypes.memmove(base + j * nbytes, srcs[j][0], nbytes), range(b)))
+                else:
+                    _ctypes.memmove(base, srcs[0][0], nbytes)
+                del srcs
+                return st.to(device, non_blocking=True)[..., :3].contiguous()
         first = to_array(images[0])
         st = _staging.get(gen, tag, (b,) + first.shape, torch.uint8)
         stn = st.numpy()
@@ -269,7 +326,7 @@ def _launch_group(gen, idxs, inputimages, inputdepthmaps, inp, device):
         # (Pillow >= 11.2 can export an image's pixel store without a copy through the Arrow interface, which would replace
         # np.asarray's ~3 interpreter-locked passes per image by one memcpy -- but the export SEGFAULTS on images that map
         # foreign memory (Image.fromarray of an L / RGBA array, Pillow 12.2): not something a drop-in library may risk)
-        img_t = upload_pixels("img", lambda im: np.asarray(im, dtype=np.uint8))
+        img_t = upload_pixels("img", lambda im: np.asarray(im, dtype=np.uint8), rgb=images[0].mode == "RGB")
     mesh_source = None
     if custom:
         outs = [_custom_depth_to_float(inputdepthmaps[i], inputimages[i]) for i in idxs]         # :145-174 (host: PIL)
@@ -284,7 +341,7 @@ def _launch_group(gen, idxs, inputimages, inputdepthmaps, inp, device):
         if images[0].mode == "RGB" and img_t is not None:
             rgb_t = img_t
         else:
-            rgb_t = upload_pixels("rgb", lambda im: np.asarray(im.convert("RGB"), dtype=np.uint8))
+            rgb_t = upload_pixels("rgb", lambda im: np.asarray(im.convert("RGB"), dtype=np.uint8), rgb=images[0].mode == "RGB")
         pred, invert = model_holder.get_raw_prediction_batch(images, rgb_t, net_width, net_height)
         if pred is None:                 # Boost sharded over ranks (ModelHolder.boost_group): only the group's rank 0 renders
             g["skip"] = True

@@ -70,7 +70,20 @@ IMAGENET_MEAN = (0.485, 0.456, 0.406)
 IMAGENET_STD = (0.229, 0.224, 0.225)
 
 
-def pad_len(n):
+TIGHT_PAD = os.environ.get("DS_TIGHT_PAD", "1") != "0"      # A/B switch: 0 = pad every sequence to a multiple of 64 (rounds 1-3)
+
+
+def pad_len(n, batch=None):
+    """Token stride of a sequence of n tokens.  Without a batch size: n rounded up to 64 (one key tile of the attention
+    kernel).  With one: the TIGHTEST pad (a multiple of 8, 16 or 32 instead of 64) whose batch * stride rows are whole
+    256-row panels -- the unit of the token GEMMs and what ds_linear_vt needs for its columns: 32 x 1025 tokens pad to 1032
+    (129 row panels; 1088 would be 136, and fc1's 2176 tiles a ninth, half-empty round on 256 CUs), 8 x 2443 to 2464.  The
+    attention kernel takes any stride that is a multiple of 8; when no tight pad fits, 64."""
+    if batch and TIGHT_PAD:
+        for a in (8, 16, 32):
+            s = (n + a - 1) // a * a
+            if (batch * s) % 256 == 0:
+                return s
     return (n + SEQ_ALIGN - 1) // SEQ_ALIGN * SEQ_ALIGN
 
 

@@ -13,10 +13,10 @@ pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "model_cases.npz")
 
 
-def _case(b, n_valid, h, dtype, seed, with_bias):
+def _case(b, n_valid, h, dtype, seed, with_bias, stride=None):
     from src import vit_mi355x as vm
     g = torch.Generator().manual_seed(seed)
-    npad = vm.pad_len(n_valid)
+    npad = vm.pad_len(n_valid) if stride is None else stride
     qk = (torch.randn((b, npad, 2, h, 64), generator=g) * 1.5).to(dtype).cuda()
     vt = torch.randn((b, h * 64, npad), generator=g).to(dtype).cuda()
     # the bias is defined on the valid tokens only ([H, n, n], natural units), like the reference's relative position bias
@@ -67,6 +67,41 @@ def test_attention_kernel_matches_definition(gpu, dtype, with_bias):
         tol = (2e-3 if dtype == torch.float16 else 1.6e-2) if bias is None else (5e-3 if dtype == torch.float16 else 8e-2)
         assert err < tol, (dtype, with_bias, b, n_valid, h, err)
         assert torch.isfinite(got.float()).all()               # pad query rows must stay finite
+
+
+@pytest.mark.parametrize("b,n_valid,h,with_bias,stride", [
+    (32, 1025, 16, True, 1032),       # dpt_beit_large_512 at batch 32 with the tight pad vm.pad_len(1025, 32): 129 row panels
+    (8, 2443, 16, False, 2464),       # Depth-Anything-V2 ViT-L, 1080p, batch 8
+    (3, 131, 2, True, 136), (2, 577, 12, False, 584), (2, 60, 1, True, 64), (1, 200, 3, True, 200),
+])
+def test_attention_tight_token_stride(gpu, b, n_valid, h, with_bias, stride):
+    """The token stride of the operands only has to be a multiple of 8: the kernel walks whole 64-key tiles, rows between the
+    stride and the next multiple of 64 do not exist (K reads end at the batch element, V^T columns alias the next row, both
+    masked; query rows there are neither loaded nor stored).  Against the float32 definition on the same strided operands;
+    the neighbouring batch elements are poisoned where a stray read or store would show."""
+    from src import vit_mi355x as vm
+    from src import _native
+    assert stride % 8 == 0 and stride >= n_valid
+    dtype = torch.float16
+    qk, vt, bias, npad = _case(b, n_valid, h, dtype, 4000 + n_valid, with_bias, stride=stride)
+    packed, padded = None, None
+    if bias is not None:
+        packed = _native.attention_bias_pack(bias, npad, dtype)
+        assert packed.npad == (npad + 63) // 64 * 64
+        padded = torch.zeros((h, npad, npad), device='cuda')
+        padded[:, :n_valid, :n_valid] = bias
+    # pad rows of every batch element carry large finite junk in K and V (a real pad row holds whatever the GEMM wrote)
+    if npad > n_valid:
+        qk[:, n_valid:, 1] = 300.0
+        vt[:, :, n_valid:] = -250.0
+    got = _native.attention_fwd(qk, vt, n_valid, 0.125, packed)
+    tol = 2e-3 if bias is None else 1e-2
+    worst = 0.0
+    for b0 in range(0, b, 4):
+        want = vm.attention_reference(qk[b0:b0 + 4].float(), vt[b0:b0 + 4].float(), n_valid, 0.125, padded)
+        worst = max(worst, (got[b0:b0 + 4].float()[:, :n_valid] - want[:, :n_valid]).abs().max().item())
+    assert worst < tol, (b, n_valid, stride, worst)
+    assert got.shape == (b, npad, h * 64) and torch.isfinite(got.float()).all()
 
 
 def test_attention_masks_pad_keys(gpu):
@@ -776,12 +811,13 @@ def test_conv3x3_kernel_matches_float32_convolution(gpu, dtype, tol):
     assert (got.float() - want).abs().max().item() < 4 * tol * (1 + want.abs().max().item())
 
 
-@pytest.mark.parametrize("m,n,k,gelu", [(34816, 4096, 1024, True), (34816, 1024, 4096, False), (34816, 2048, 1024, False),
-                                        (34816, 1024, 1024, False)])
+@pytest.mark.parametrize("m,n,k,gelu", [(33024, 4096, 1024, True), (33024, 1024, 4096, False), (33024, 2048, 1024, False),
+                                        (33024, 1024, 1024, False), (34816, 4096, 1024, True), (34816, 2048, 1024, False)])
 def test_linear_kernel_at_benchmark_shapes(gpu, m, n, k, gelu):
-    """ds_linear at the shapes ONE encoder block of dpt_beit_large_512 launches at batch 32 (the bench's step): 34 816
-    rows = 136 row panels, i.e. the whole XCD-aware tile list of ~2 000 tiles over all 256 persistent workgroups (the
-    smaller tests walk at most 17 panels).  Every element against a float32 GEMM of the same rounded operands."""
+    """ds_linear at the shapes ONE encoder block of dpt_beit_large_512 launches at batch 32 (the bench's step): 33 024 rows
+    = 32 x 1032 = 129 row panels with the tight token pad (round 4; rounds 1-3 padded to 1088: 34 816 rows = 136 panels),
+    i.e. the whole XCD-aware tile list of ~2 000 tiles over all 256 persistent workgroups (the smaller tests walk at most
+    17 panels).  Every element against a float32 GEMM of the same rounded operands."""
     import torch.nn.functional as F
     from src import _native
     g = torch.Generator().manual_seed(m + n + k)
@@ -941,12 +977,15 @@ def test_linear_ragged_round_vt_and_fused_residual(gpu, dtype, tol):
             _native.linear_env(**{k_: v})
 
 
-def test_linear_vt_and_fused_fc2_at_benchmark_shapes(gpu):
-    """ds_linear_vt and ds_linear_residual at the shapes of ONE encoder block of dpt_beit_large_512 at batch 32 (544 tiles:
-    two full rounds on 256 CUs + a ragged round of 32 tiles), every element against float32 on the same rounded operands."""
+@pytest.mark.parametrize("npad", [1032, 1088])
+def test_linear_vt_and_fused_fc2_at_benchmark_shapes(gpu, npad):
+    """ds_linear_vt and ds_linear_residual at the shapes of ONE encoder block of dpt_beit_large_512 at batch 32 -- token stride
+    1032 (round 4's tight pad: 516 tiles = two full rounds on 256 CUs + a ragged round of 4 tiles) and 1088 (544 tiles: + 32)
+    -- every element against float32 on the same rounded operands."""
     from src import _native
     g = torch.Generator().manual_seed(91)
-    h = torch.randn((32, 1088, 1024), generator=g).half().cuda()
+    rows = 32 * npad
+    h = torch.randn((32, npad, 1024), generator=g).half().cuda()
     wv = (torch.randn((1024, 1024), generator=g) / 32).half().cuda()
     got = _native.linear_vt(wv, h)
     worst = 0.0
@@ -955,13 +994,13 @@ def test_linear_vt_and_fused_fc2_at_benchmark_shapes(gpu):
         worst = max(worst, (got[b].float() - want).abs().max().item() / (1 + want.abs().max().item()))
     assert worst < 1.5e-3, worst
     assert torch.equal(_native.linear_vt(wv, h), got)
-    a = torch.randn((34816, 4096), generator=g).half().cuda()
+    a = torch.randn((rows, 4096), generator=g).half().cuda()
     w2 = (torch.randn((1024, 4096), generator=g) / 64).half().cuda()
     b2, gam = torch.randn(1024, generator=g).half().cuda(), torch.randn(1024, generator=g).half().cuda()
-    res = torch.randn((34816, 1024), generator=g).half().cuda()
+    res = torch.randn((rows, 1024), generator=g).half().cuda()
     got = _native.linear_residual(a, w2, b2, gam, res)
     worst = 0.0
-    for r0 in range(0, 34816, 4352):
+    for r0 in range(0, rows, 4352):
         want = (a[r0:r0 + 4352].float() @ w2.float().T + b2.float()) * gam.float() + res[r0:r0 + 4352].float()
         worst = max(worst, (got[r0:r0 + 4352].float() - want).abs().max().item() / (1 + want.abs().max().item()))
     assert worst < 1.5e-3, worst

@@ -324,3 +324,31 @@ def test_float16_prediction_corner():
     # inverted models and the 'Range' clip
     w2 = orc.depth_postprocess_f16_numpy1(pred, invert=True, clipdepth=True, far=0.25, near=0.75)
     assert w2.dtype == np.uint16 and w2.min() == 0 and w2.max() == 65535
+
+
+def test_funnel_rgbx_pixel_export_is_only_taken_where_it_is_safe():
+    """core._rgbx_pixels (the GIL-free PIL -> pinned staging path of the funnel): for RGB images that own their pixel store the
+    exported 4-byte pixels equal np.asarray's RGB; images that map foreign memory (readonly: Image.fromarray of L / RGBA / I;16,
+    where Pillow 12.2's export crashes the process), other modes and multi-block images are refused -> the np.asarray path."""
+    import ctypes
+    from PIL import Image
+    import src.core as core
+    rng = np.random.default_rng(3)
+    rgb = rng.integers(0, 256, (37, 53, 3), dtype=np.uint8)
+    cases = [Image.fromarray(rgb), Image.fromarray(rgb).crop((1, 2, 40, 30)), Image.new("RGB", (9, 5), (1, 2, 3)),
+             Image.frombuffer("RGB", (53, 37), rgb.tobytes(), "raw", "RGB", 0, 1), Image.fromarray(rgb).convert("L").convert("RGB")]
+    if not hasattr(cases[0], "__arrow_c_array__"):
+        assert all(core._rgbx_pixels(im) is None for im in cases)          # an older Pillow: the ordinary path everywhere
+        return
+    for im in cases:
+        got = core._rgbx_pixels(im)
+        assert got is not None, im
+        addr, keep = got
+        px = np.frombuffer((ctypes.c_uint8 * (im.width * im.height * 4)).from_address(addr), np.uint8).reshape(im.height, im.width, 4)
+        assert np.array_equal(px[:, :, :3], np.asarray(im))
+        del px, keep
+    refused = [Image.fromarray(rgb[:, :, 0].copy()), Image.fromarray(np.dstack([rgb, rgb[:, :, :1]])),
+               Image.fromarray(rng.integers(0, 65536, (8, 8), dtype=np.uint16)), Image.new("L", (4, 4)), Image.new("RGBA", (4, 4)),
+               Image.new("RGB", (3000, 2000))]                             # 24 MB of pixels: more than one 16 MB block
+    for im in refused:
+        assert core._rgbx_pixels(im) is None, (im.mode, im.size)
