@@ -695,7 +695,17 @@ def funnel_leg(model, model_name, img_np, net_size, net_h, normalmap):
 
         def batch(self, pils, nw, nh, device):
             t = torch.from_numpy(np.stack([np.asarray(p.convert("RGB")) for p in pils])).to(device)
+            return self.batch_tensor(t)
+
+        def batch_tensor(self, t, nw=None, nh=None):   # what the funnel calls with the pixels it has already uploaded (like the
+            if graphed is not None:                        # product's own _NetPredictor.predict_batch)
+                return graphed(t)
             return run_forward(model, model_name, t, net_size, net_h)
+
+    graphed = None
+    if os.environ.get("DS_FUNNEL_GRAPH", "0") != "0":        # the group's forward as ONE hipGraph replay (src/hip_graph.py)
+        from src.hip_graph import GraphedForward
+        graphed = GraphedForward(lambda x: run_forward(model, model_name, x, net_size, net_h))
 
     core.model_holder.register_predictor(mt, _Pred())
     pils = [Image.fromarray(a) for a in img_np]
@@ -710,7 +720,9 @@ def funnel_leg(model, model_name, img_np, net_size, net_h, normalmap):
     dt = time.perf_counter() - t0
     st = dict(core.FUNNEL_STATS)
     return {"value": len(pils) / dt, "unit": "pairs/s", "results": n_out, "seconds": dt,
-            "host_seconds": {"enqueue (decode + stage + launch)": st.get("launch"), "blocked on device results": st.get("wait"),
+            "host_seconds": {"enqueue (decode + stage + launch)": st.get("launch"), "enqueue: decode + upload": st.get("launch_decode"),
+                             "enqueue: network forward": st.get("launch_forward"), "enqueue: post-processing + downloads": st.get("launch_post"),
+                             "blocked on device results": st.get("wait"),
                              "groups": st.get("groups"), "rest (PIL conversion, generator overhead)":
                              None if not st else st.get("total", dt) - (st.get("launch") or 0.0) - (st.get("wait") or 0.0)},
             "what": "core_generation_funnel: PIL in -> uint16 depth, left-right pair" + (", normal map" if normalmap else "")

@@ -274,7 +274,7 @@ def _plan_groups(inputimages, inputdepthmaps, batchable):
     return groups
 
 
-def _launch_group(gen, idxs, inputimages, inputdepthmaps, inp, device):
+def _launch_group(gen, idxs, inputimages, inputdepthmaps, inp, device, stats=None):
     """Enqueue everything a group needs on the current stream -- H2D, network, post-processing, stereo, normal map, heat
     map, D2H into pinned buffers -- and return the handles; nothing here waits for the device except the post-processing
     branches that must know which predictions are flat (one sync per batch) and the percentile bisection of 'Outliers'."""
@@ -283,6 +283,13 @@ def _launch_group(gen, idxs, inputimages, inputdepthmaps, inp, device):
     images = [inputimages[i] for i in idxs]
     w, h = images[0].size
     g = {"idxs": idxs, "images": images, "host": {}, "pred_host": None, "broken": [False] * b}
+    _tm = [_time.perf_counter()]
+
+    def lap(name):               # host seconds of this stage of the enqueue path (decode / forward / post), per funnel call
+        if stats is not None:
+            now = _time.perf_counter()
+            stats[name] = stats.get(name, 0.0) + (now - _tm[0])
+            _tm[0] = now
     custom = inputdepthmaps[idxs[0]] is not None
     want_stereo = inp[go.GEN_STEREO]
 
@@ -342,7 +349,9 @@ def _launch_group(gen, idxs, inputimages, inputdepthmaps, inp, device):
             rgb_t = img_t
         else:
             rgb_t = upload_pixels("rgb", lambda im: np.asarray(im.convert("RGB"), dtype=np.uint8), rgb=images[0].mode == "RGB")
+        lap("launch_decode")
         pred, invert = model_holder.get_raw_prediction_batch(images, rgb_t, net_width, net_height)
+        lap("launch_forward")
         if pred is None:                 # Boost sharded over ranks (ModelHolder.boost_group): only the group's rank 0 renders
             g["skip"] = True
             return g
@@ -419,6 +428,7 @@ def _launch_group(gen, idxs, inputimages, inputdepthmaps, inp, device):
             g["host"][tag] = hbuf
         g["done"] = torch.cuda.Event()
         g["done"].record()
+    lap("launch_post")
     return g
 
 
@@ -592,7 +602,7 @@ def core_generation_funnel(outpath, inputimages, inputdepthmaps, inputnames, inp
             # reference's per-image loop (:133-329) would have yielded them before reaching the failing image
             try:
                 _t0 = _time.perf_counter()
-                launched, failure = _launch_group(gi & 1, idxs, inputimages, inputdepthmaps, inp, device), None
+                launched, failure = _launch_group(gi & 1, idxs, inputimages, inputdepthmaps, inp, device, stats), None
                 stats["launch"] = stats.get("launch", 0.0) + (_time.perf_counter() - _t0)
             except Exception as e:          # noqa: BLE001 -- re-raised below, after the results that precede it
                 launched, failure = None, e

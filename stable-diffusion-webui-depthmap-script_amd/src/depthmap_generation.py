@@ -244,7 +244,8 @@ class ModelHolder:
         """get_raw_prediction for a device batch of same-size images (the funnel's unit of work on an MI355X).
         pil_images: the PIL inputs; rgb_u8: the same pixels as a uint8 [B,H,W,3] tensor on the device.
         -> (float32 [B,H,W] on the device, invert?).  A built network runs ONE forward for the batch; a registered predictor
-        is called through its optional ``batch(pils, net_width, net_height, device)`` or image by image; Boost renders image
+        is called through its optional ``batch_tensor(rgb_u8, net_width, net_height)`` (the pixels the funnel has already
+        uploaded), its optional ``batch(pils, net_width, net_height, device)``, or image by image; Boost renders image
         by image (estimateboost batches its own patches)."""
         import torch
         invert = self.depth_model_type in INVERTED_MODEL_IDS
@@ -260,6 +261,8 @@ class ModelHolder:
             return torch.stack([torch.as_tensor(o) for o in outs]), invert
         if isinstance(self.depth_model, _NetPredictor):
             return self.depth_model.predict_batch(rgb_u8, net_width, net_height), invert
+        if hasattr(self.depth_model, "batch_tensor"):          # a registered predictor that takes the uploaded pixels, like _NetPredictor
+            return torch.as_tensor(self.depth_model.batch_tensor(rgb_u8, net_width, net_height)), invert
         if hasattr(self.depth_model, "batch"):
             return torch.as_tensor(self.depth_model.batch(pil_images, net_width, net_height, self.device)), invert
         outs = []
