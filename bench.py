@@ -48,9 +48,10 @@ import numpy as np  # noqa: E402
 
 H = W = 1024
 HBM_PEAK_GBPS = 8000.0            # MI355X HBM3E spec peak (guides/MI355X_MICROARCH.md)
+HBM_COPY_GBPS = 6290.0            # what a float4 copy kernel reaches on this chip (same guide: 79 % of the spec peak)
 MFMA_PEAK_TFLOPS = 2500.0         # dense f16/bf16 MFMA peak (same guide)
-PMC_SUMMARY = "profiles/round3_pmc_summary.json"      # tools/pmc_summary.py over rocprofv3 --pmc passes of THIS command
-KERNEL_STATS = "profiles/round3_kernel_stats.csv"     # rocprofv3 --kernel-trace --stats of THIS command
+PMC_SUMMARY = "profiles/round4_pmc_summary.json"      # tools/pmc_summary.py over rocprofv3 --pmc passes of THIS command
+KERNEL_STATS = "profiles/round4_kernel_stats.csv"     # rocprofv3 --kernel-trace --stats of THIS command
 
 DEPTH_KIND = "steps"
 
@@ -119,6 +120,13 @@ def net_grid(model_name, net_size, net_h=None):
 
 
 def run_forward(model, model_name, img, net_size, net_h=None):
+    # (Round 4 tried the batch as 2 / 4 micro-batches on as many streams, GEMMs on half the CUs, so that one micro-batch's
+    # attention / LayerNorm / decoder kernels run beside another's GEMMs: 792.6 / 778.5 / 688.2 pairs/s against 791.6 on the same
+    # box -- the chip is power limited during the GEMMs, concurrency moves work around without adding any; removed.)
+    return _forward_one(model, model_name, img, net_size, net_h)
+
+
+def _forward_one(model, model_name, img, net_size, net_h=None):
     if model_name == "dav2_vitl":
         return model.infer_batch(img, net_size)
     return model.infer_batch(img, net_size=net_size, resize_mode="minimal", net_h=net_h)
@@ -585,8 +593,20 @@ def main():
             a = batch * algo_bytes_normalmap() / (float(np.mean(nm_ms)) * 1e-3) / 1e9
             out["roofline_normalmap"] = {"bound": "hbm", "kernel": "k_normalmap_fused", "achieved": a, "peak": HBM_PEAK_GBPS,
                                          "unit": "GB/s", "frac": a / HBM_PEAK_GBPS, "traffic": None,
+                                         "traffic_from_profile": traffic_from_profile("k_normalmap_fused4", batch) if (H, W) == (1024, 1024) else None,
                                          "algorithmic_bytes_per_launch": batch * algo_bytes_normalmap(),
                                          "avg_kernel_ms": float(np.mean(nm_ms))}
+        # `traffic`: HBM bytes per launch from the PMC counters.  bench.py cannot read counters itself; the figure comes from the
+        # committed rocprofv3 --pmc passes of THIS command (profiles/, FETCH_SIZE doubled as the guide prescribes for gfx950),
+        # and stays null when that profile was taken at another batch size or lacks the kernel.  HBM-bound kernels also carry
+        # their fraction of what a copy kernel reaches on this chip (6.29 TB/s), next to the fraction of the 8 TB/s spec peak.
+        for key, r in out.items():
+            if key.startswith("roofline") and isinstance(r, dict):
+                tp = r.get("traffic_from_profile")
+                if tp:
+                    r["traffic"] = tp["hbm_bytes_per_launch"]
+                if r.get("bound") == "hbm":
+                    r["frac_of_measured_copy_peak"] = r["achieved"] / HBM_COPY_GBPS
         if route is not None:
             out["route_check"] = route
         if funnel is not None:

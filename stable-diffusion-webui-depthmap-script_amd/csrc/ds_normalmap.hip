@@ -20,19 +20,28 @@ __device__ __forceinline__ int nm_reflect101(int i, int n)
 }
 
 // normal = (zx, -zy, 1)/|.| ; (+1)/2*256 clipped to [0, 255.9] ; truncate   (:34-39, :51-54)
+// The kernels are bound by float64 VALU issue, not by memory (round 3: ~160 vector instructions per pixel), so the arithmetic is
+// kept to what the result needs:
+//   * ONE division, y = 1 / n: it is the z component, and the correctly rounded reciprocal turns the other two quotients into
+//     q0 = a y;  r = fma(-q0, n, a);  q = fma(r, y, q0)  -- Markstein's sequence, equal to the correctly rounded a / n for every
+//     operand of this kernel (oracle/check_normal_division.c: the significand of n is never all ones; enumerated);
+//   * (v + 1) / 2 * 256 = (v + 1) * 128 bit for bit (scaling by a power of two never rounds);
+//   * after the clip the value lies in [0, 255.9]: the float64 -> uint8 cast is one v_cvt_i32_f64, not the general numpy
+//     emulation (ds_f64_to_u8: int64 conversion + wrap) the unclipped paths of the stereo kernels need.
+// (n >= 1: no NaN, no zero divisor.  a = -0.0 gives +0.0 where the division gives -0.0: v + 1 is 1.0 either way.)
 __device__ __forceinline__ void nm_store(double zx, double zy, uint8_t *o)
 {
-    const double nx = zx, ny = -zy, nz = 1.0;
-    const double n = sqrt(nx * nx + ny * ny + nz * nz);
-    const double v[3] = { nx / n, ny / n, nz / n };
+    const double nx = zx, ny = -zy;
+    const double n = sqrt(nx * nx + ny * ny + 1.0);
+    const double y = 1.0 / n;
+    const double qx0 = nx * y, qy0 = ny * y;
+    const double v[3] = { __builtin_fma(__builtin_fma(-qx0, n, nx), y, qx0), __builtin_fma(__builtin_fma(-qy0, n, ny), y, qy0), y };
 #pragma unroll
     for (int k = 0; k < 3; k++) {
-        double t = v[k] + 1.0;
-        t = t / 2.0;
-        t = t * 256.0;
+        double t = (v[k] + 1.0) * 128.0;
         t = t < 0.0 ? 0.0 : t;
         t = t > 256.0 - 0.1 ? 256.0 - 0.1 : t;
-        o[k] = ds_f64_to_u8(t);
+        o[k] = (uint8_t)(int)t;
     }
 }
 

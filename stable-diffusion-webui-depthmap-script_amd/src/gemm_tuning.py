@@ -1,8 +1,11 @@
-"""Library-GEMM selection for the network path.
+"""Library-GEMM selection for what is left of the library path.
 
-The transformer linears run in hipBLASLt / rocBLAS through torch (plain library GEMMs: not worth a hand-written kernel).
-Their default heuristic picks a 256x256 macro tile for the N=1024 GEMMs of a ViT-L block (fc2, proj, V^T), which covers
-the 256 CUs 2.1 times -> a third round that is 12 % full.  torch's TunableOp measures every solution of both libraries
+Since round 3 every Linear of the encoder blocks runs in the in-tree MFMA kernel (csrc/ds_linear.hip) whenever a launch
+fills the chip (vit_mi355x.LINEAR_HIP_MIN_TILES); hipBLASLt / rocBLAS through torch still serve the read-out GEMMs of the
+reassemble stage, small batches (a batch-1 ViT-B forward is nine 256 x 256 tiles: the library's small tiles are the better
+tool), float32, and DS_LINEAR=0 (the reference point of the route checks).  For those calls the libraries' default
+heuristic picks a 256x256 macro tile for the N=1024 GEMMs of a ViT-L block (fc2, proj, V^T), which covers the 256 CUs
+2.1 times -> a third round that is 12 % full.  torch's TunableOp measures every solution of both libraries
 once per GEMM shape and remembers the winner; `tunableop_gfx950.csv` (next to this file) holds the winners for the
 shapes of the shipped networks at the benchmark batch, found on an MI355X (tools/block_profile.py tune, bench.py
 --tune-gemms).  Shapes that are not in the file fall back to the library default unless tuning is switched on

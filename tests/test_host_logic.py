@@ -158,6 +158,17 @@ def test_u16_normalisation_identity_exhaustive(oracle):
     assert out.returncode == 0 and out.stdout.startswith("bad=0 of 4294901760"), out.stdout
 
 
+def test_normal_map_quotient_identity(oracle):
+    """The fused normal-map kernels divide ONCE (1 / n, the z component) and get x / n and y / n from that reciprocal with a
+    multiplication and two FMAs (Markstein's sequence); the C program compares with true float64 division on the operand set of
+    the 3 x 3 Sobel path: exhaustively on a 6001 x 6001 block, and on 2 * 10^9 random pairs of the full range."""
+    import subprocess
+    here = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle")
+    subprocess.check_call(["make", "-C", here, "-s", "check_normal_division"])
+    out = subprocess.run([os.path.join(here, "check_normal_division")], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0 and out.stdout.startswith("bad=0 of "), out.stdout
+
+
 def test_heatmap_table_and_gemm_tuning_host_side():
     """The colour table the heat map uploads is the one the golden run saw (same matplotlib in the image), and the GEMM
     tuning switch is a no-op without a GPU; its results file carries the validator header torch checks."""
