@@ -667,7 +667,20 @@ def run_c4(args):
         nm = nmg.create_normalmap_batch(d16) if not args.no_normalmap else None
         return sbs, nm
 
+    # algorithmic flops of one image: every convolution of the two networks, counted by hooks during the (untimed) priming step
+    flops = [0.0]
+
+    def count(mod, inp, outp):
+        w = mod.weight
+        if isinstance(mod, torch.nn.ConvTranspose2d):
+            flops[0] += 2.0 * inp[0].numel() * w.shape[1] * w.shape[2] * w.shape[3]
+        else:
+            flops[0] += 2.0 * outp.numel() * w.shape[1] * w.shape[2] * w.shape[3]
+    hooks = [m.register_forward_hook(count) for net_ in (net, p2p) for m in net_.modules()
+             if isinstance(m, (torch.nn.Conv2d, torch.nn.ConvTranspose2d))]
     step()
+    for hk in hooks:
+        hk.remove()
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
@@ -683,11 +696,19 @@ def run_c4(args):
         torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    fl = torch.tensor([flops[0]], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(fl, op=dist.ReduceOp.SUM)
     elapsed = float(t.item())
     if rank == 0:
+        ach = float(fl.item()) / (elapsed / args.steps) / 1e12
         print(json.dumps({
+            # the step is float32 convolutions of two library-backed networks (Boost never runs them in half: reference :271): the
+            # roofline is the float32 MFMA peak (157.3 TF/s per GPU, MI355X_MICROARCH.md) against the convolutions' algorithmic flops
+            "roofline": {"bound": "mfma", "kernel": "MIOpen float32 convolutions of LeReS res101 + the pix2pix U-Net (library), whole step",
+                         "achieved": ach, "peak": 157.3 * world, "unit": "TFLOP/s", "frac": ach / (157.3 * world), "traffic": None,
+                         "algorithmic_flops_per_image": float(fl.item()), "source": "forward hooks on every convolution (priming step) / wall time of the timed steps"},
             "metric": f"Boost depth+stereo images/sec @{W}x{H}", "value": args.steps / elapsed, "unit": "images/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32 (networks) / f64 (stereo, normal map)",

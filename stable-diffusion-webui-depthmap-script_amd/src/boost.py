@@ -309,7 +309,7 @@ def _gather_ragged(local, counts, group, dst):
 
 @torch.no_grad()
 def estimateboost(image_u8, net, model_type, pix2pix, whole_size_threshold=1600, chunk=8, stats=None, group=None, dst=0,
-                  blend=None):
+                  blend=None, trace=None):
     """:774-941.  image_u8: uint8 [H, W, 3] on the device, channel order as the funnel hands it over (RGB).
     Returns the boosted float32 [H, W] prediction (device).
 
@@ -320,7 +320,10 @@ def estimateboost(image_u8, net, model_type, pix2pix, whole_size_threshold=1600,
     1024^2 patches and their coefficients to `dst`, and `dst` blends them in the original order (:1098, :936) with one
     launch.  Chunk-aligned shards keep every network batch identical to the single-rank run, so the result does not
     depend on the number of ranks.  Ranks other than `dst` return None.
-    blend: test hook replacing ds_boost_blend (CPU runs of the sharding logic); the product always uses the HIP kernel."""
+    blend: test hook replacing ds_boost_blend (CPU runs of the sharding logic); the product always uses the HIP kernel.
+    trace: optional dict that receives the stage outputs (float32 / float64 CPU copies): the whole-image double estimate, the
+    base at merge size, the merged patches and their polyfit coefficients, the blended estimate -- what the per-stage error
+    budget of the GPU test compares between the device run and its CPU twin."""
     import torch.distributed as dist
     multi = group is not None and dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
     rank = dist.get_rank(group) if multi else 0
@@ -366,6 +369,8 @@ def estimateboost(image_u8, net, model_type, pix2pix, whole_size_threshold=1600,
     rgb_image = _resize_hwc(img_r, size_m, 'bicubic')
     if rank == dst:
         base = _resize(whole_estimate, size_m, 'bicubic').float().contiguous()
+        if trace is not None:
+            trace["whole_estimate"], trace["base"] = whole_estimate.float().cpu(), base.cpu()
     else:
         base = torch.empty(size_m, dtype=torch.float32, device=dev)
     if multi:
@@ -408,7 +413,11 @@ def estimateboost(image_u8, net, model_type, pix2pix, whole_size_threshold=1600,
                 mapped = payload[:, :n_px].reshape(-1, PIX2PIX_SIZE, PIX2PIX_SIZE)
                 coef = payload[:, n_px:].contiguous().view(torch.float64).reshape(-1, 2)
         if rank == dst:
+            if trace is not None:
+                trace["mapped"], trace["coef"] = mapped[:, ::4, ::4].float().cpu(), coef.double().cpu()
             blend(dst_img, rects, [tuple(c) for c in coef.tolist()], mapped, generatemask(MASK_SIZE, dev))     # :916-937
+            if trace is not None:
+                trace["blended"] = dst_img.float().cpu()
     if rank != dst:
         return None
     return _resize(dst_img, (H, W), 'bicubic')                                                                # :940
