@@ -568,6 +568,7 @@ def main():
                        "network_precision_vs_reference": "fp16 = the reference's GPU default; held to 2e-2 of its float32 output "
                                                          "(float32 path: 1e-4), tests/test_gpu_models.py",
                        "forward_launch": ("hipGraph replay" if (fwd is not None and fwd.graphs) else "eager"),
+                       "graph_capture_failures": (len(fwd.failed) if fwd is not None else None),
                        "library_convolutions": "MIOpen, solver search on (torch.backends.cudnn.benchmark)" if miopen_find else "MIOpen, heuristic solver choice",
                        "overlap": "per-pixel kernels of step k on a second stream beside the forward of step k+1" if post is not None else "single stream",
                        "parallelism": f"units sharded over {world} GPU(s), no data-path collective"

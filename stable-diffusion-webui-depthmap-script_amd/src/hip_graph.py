@@ -46,14 +46,17 @@ class GraphedForward:
             self.epoch = vm.CACHE_EPOCH[0]
         hit = self.graphs.get(key)
         if hit is None:
-            try:
-                hit = self._capture(x, key)
-            except Exception:            # anything uncapturable on this shape: stay eager, loudly once
-                import traceback
-                traceback.print_exc()
-                self.failed.add(key)
-                torch.cuda.synchronize()
-                return self.fn(x)
+            for attempt in (0, 1):       # a capture whose validation fails is retried ONCE (library kernels picked inside a capture
+                try:                     # can differ from the eager ones at a single pixel); then the shape stays eager, loudly
+                    hit = self._capture(x, key)
+                    break
+                except Exception:
+                    import traceback
+                    traceback.print_exc()
+                    torch.cuda.synchronize()
+                    if attempt == 1:
+                        self.failed.add(key)
+                        return self.fn(x)
         g, static_in, static_out = hit
         static_in.copy_(x)
         g.replay()

@@ -316,6 +316,12 @@ def test_boost_gpu_error_budget_per_stage(gpu, oracle):
         assert a.shape == b.shape, k
         budget[k] = ((a - b).abs().max() / a.abs().max()).item()
     print("boost GPU-vs-CPU error budget (max |difference| / max |value| per stage):", {k: f"{v:.2e}" for k, v in budget.items()})
+    scratch = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    if os.path.isdir(scratch):                                   # kept with the GPU call's outputs (copied to profiles/ by hand)
+        import json
+        with open(os.path.join(scratch, "boost_error_budget.json"), "w") as f:
+            json.dump({"what": "estimateboost on the GPU vs the same code on the CPU (float32), max |difference| / max |value| per stage",
+                       "image": "tests/golden/boost_cases.npz (480 x 640, 18 patches)", "budget": budget}, f, indent=1)
     # the networks' outputs on the two devices agree to float32 convolution noise; nothing downstream amplifies it by more than
     # an order of magnitude, and the final depth stays inside the 5e-4 the end-to-end test holds against the reference
     assert budget["whole_estimate"] < 3e-4 and budget["base"] < 3e-4, budget
