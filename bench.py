@@ -251,6 +251,8 @@ def main():
     ap.add_argument("--depth", default="steps", choices=["steps", "smooth"],
                     help="--model none only: synthetic prediction with steps + occluders (default), or smooth only")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-route-check", action="store_true", help="leave out the untimed route check (profile runs: its library-routed "
+                                                                  "forward would show up in the kernel statistics of the step)")
     ap.add_argument("--tune-gemms", default=None, metavar="CSV",
                     help="run with TunableOp tuning ON and accumulate the winners in CSV (maintenance: regenerates "
                          "src/tunableop_gfx950.csv); the default run only READS the shipped file")
@@ -502,7 +504,7 @@ def main():
     # needs the batch -- against the SAME network on the same images with every GEMM / 3x3 convolution sent to the ROCm
     # libraries (vm.library_routing), plus how often the fused entry points were reached in one forward of the step
     route = None
-    if model is not None:
+    if model is not None and not args.no_route_check:
         names = ("ds_linear", "ds_linear_residual", "ds_linear_vt", "ds_conv3x3_nhwc", "ds_attention_fwd", "ds_residual_layernorm",
                  "ds_dpt_head_tail", "ds_preprocess_bicubic")
         before = dict(nat.CALLS)

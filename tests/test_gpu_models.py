@@ -262,8 +262,8 @@ def test_boost_end_to_end_vs_reference_estimateboost(gpu):
     """Boost end to end ON THE DEVICE (float32 networks, device-side Sobel / resizes / selection, batched patch estimation,
     the one-launch HIP blend) against the reference's OWN estimateboost run on the CPU (tests/golden/make_golden_boost.py;
     src/depthmap_generation.py:774-941, LeReS + pix2pix with name-seeded weights, 480 x 640 image): the same 18 patches, final
-    depth within 5e-4 of full scale and 5e-5 on average (CPU twin of this test: 9.5e-5 / 5e-6; the GPU's float32 convolutions
-    sum in another order).  What stays unpinned: OpenCV's own resize / blur arithmetic (numpy restatements in the golden)."""
+    depth within 1.5e-4 of full scale and 2e-5 on average (CPU twin of this test: 9.5e-5 / 5e-6; the device adds 1.6e-5 to it,
+    per-stage budget in the next test).  What stays unpinned: OpenCV's own resize / blur arithmetic (numpy restatements in the golden)."""
     from lib.multi_depth_model_woauxi import RelDepthModel
     from pix2pix.models.pix2pix4depth_model import Pix2Pix4DepthModel
     from src import boost
@@ -279,7 +279,10 @@ def test_boost_end_to_end_vs_reference_estimateboost(gpu):
     got = out[::2, ::2]
     assert stats["patches"] == 18 and stats["whole_image_optimal_size"] == 896, stats
     rel = np.abs(got - want).max() / np.abs(want).max()
-    assert rel < 5e-4 and np.abs(got - want).mean() < 5e-5, (rel, float(np.abs(got - want).mean()))
+    # the bar: the CPU twin's 9.5e-5 against the reference (float32 torch resizes against the golden's float64 stand-ins) plus what
+    # the device adds to the CPU twin, 1.6e-5 at the output (test_boost_gpu_error_budget_per_stage, profiles/round4_boost_error_
+    # budget.json) -- 1.1e-4 by the triangle inequality, held with a margin
+    assert rel < 1.5e-4 and np.abs(got - want).mean() < 2e-5, (rel, float(np.abs(got - want).mean()))
 
 
 def test_boost_gpu_error_budget_per_stage(gpu, oracle):
@@ -324,9 +327,11 @@ def test_boost_gpu_error_budget_per_stage(gpu, oracle):
                        "image": "tests/golden/boost_cases.npz (480 x 640, 18 patches)", "budget": budget}, f, indent=1)
     # the networks' outputs on the two devices agree to float32 convolution noise; nothing downstream amplifies it by more than
     # an order of magnitude, and the final depth stays inside the 5e-4 the end-to-end test holds against the reference
-    assert budget["whole_estimate"] < 3e-4 and budget["base"] < 3e-4, budget
-    assert budget["mapped"] < 5e-4 and budget["coef"] < 5e-4, budget
-    assert budget["blended"] < 5e-4 and budget["out"] < 5e-4, budget
+    # measured (profiles/round4_boost_error_budget.json): whole estimate 2.5e-5, base 1.8e-5, merged patches 7.6e-5, polyfit
+    # coefficients 2e-6, blended and final depth 1.6e-5
+    assert budget["whole_estimate"] < 1e-4 and budget["base"] < 1e-4, budget
+    assert budget["mapped"] < 3e-4 and budget["coef"] < 1e-4, budget
+    assert budget["blended"] < 1e-4 and budget["out"] < 1e-4, budget
 
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
