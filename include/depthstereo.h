@@ -304,7 +304,8 @@ int ds_linear_reload_env(void);
  * x [batch, height, width, in_channels] (channels_last), W [out_channels, 3, 3, in_channels] (the channels_last memory of
  * torch's [out, in, 3, 3] weight), bias [out_channels] or NULL, res1 / res2 / y [batch, height, width, out_channels].
  * act: 0 none, 2 ReLU (applied after the adds).  f16/bf16, fp32 accumulation.  in_channels % 128 == 0,
- * out_channels % 256 == 0, batch * height * width >= 256.  y must not alias x, res1 or res2.
+ * out_channels % 128 == 0 (a multiple of 256 runs 256 x 256 tiles; otherwise 256 x 128 tiles, without residual operands:
+ * the head's 256 -> 128 convolution, dmidas/dpt_depth.py:150), batch * height * width >= 256.  y must not alias x, res1 or res2.
  */
 int ds_conv3x3_nhwc(ds_ctx *ctx, const void *x, const void *w, const void *bias, const void *res1, const void *res2, void *y,
                     int batch, int height, int width, int in_channels, int out_channels, int act, int dtype, void *stream);

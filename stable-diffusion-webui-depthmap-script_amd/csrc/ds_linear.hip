@@ -69,6 +69,7 @@ struct LinParams {
     void *y;
     int M, N, K;                // K = reduction length (CONV: 9 * C)
     int nbm, nbn;
+    int bnw;                    // columns per tile: 256, or 128 for the NH = 1 instantiations (out_features % 256 == 128)
     int ablate;                 // -DDS_EXPERIMENTS builds only (DS_LIN_ABLATE, results are WRONG): 1 = no epilogue stores, 2 = no K loop
     int stagger;                // -DDS_EXPERIMENTS builds only (DS_LIN_STAGGER_US): every other workgroup of an XCD starts this many 10 ns ticks late
     int H, W, C, cpt, magic;    // CONV: image height / width, input channels, K-tiles per tap (C / 64), 65536 / cpt + 1
@@ -88,7 +89,7 @@ __device__ __forceinline__ void ln_tile_origin(const LinParams &P, const int til
     const int rows8 = min(8, P.nbm - 8 * grp8);
     const int bn = rem8 / rows8, bm = 8 * grp8 + (rem8 - bn * rows8);
     bm0 = min(bm * 256, P.M - 256);
-    bn0 = bn * 256;
+    bn0 = bn * P.bnw;
 }
 
 // element offset of output (row, col .. col + 7), col a multiple of 8.  VT: the GEMM computes W_v . h^T with the TOKENS as its
@@ -174,7 +175,12 @@ __device__ __forceinline__ void ln_dma_v(const void *ptr, unsigned lds_uniform)
 // GEMM is the implicit one of a 3 x 3, stride 1, zero-padded convolution: row m = output pixel, K-tile kt = 64 channels
 // kt / 9 of tap kt % 9 (tap-fastest: the pixels of a chunk are fetched once and hit in L2 for the other eight taps), whose
 // source is the same 128 bytes of the pixel shifted by (dy, dx) -- or the zero line.
-template <int BF16, int EPI, int CONV, int RES, int VT = 0>
+// NH = 1: a tile is 256 rows x 128 columns (the head's 256 -> 128 convolution of the DPT decoders, dmidas/dpt_depth.py:150): the
+// wave grid stays 2 x 4, every wave column owns 32 columns = the B0 half alone.  The phase schedule, the LDS map and every
+// counted wait stay exactly as they are -- the B1 half-tile is still staged (with B0's source: a dummy that keeps the DMA
+// count per phase), only its fragment reads and the MFMAs of the two (.., B1) quadrants are gone, and the epilogue stores 8
+// pieces per tile instead of 16 (the early mode's store count follows).  Half the MFMAs for ~2/3 of the phase time.
+template <int BF16, int EPI, int CONV, int RES, int VT = 0, int NH = 0>
 __global__ __launch_bounds__(LN_THREADS) void k_linear256(LinParams P)
 {
     typedef ln_traits<BF16> TR;
@@ -202,11 +208,11 @@ __global__ __launch_bounds__(LN_THREADS) void k_linear256(LinParams P)
         const int slot = (lane & 7) ^ ((j >> 1) & 7);
         rowA[i] = (j >> 6) * 128 + (j & 63);                                // A half h (+ 64 h rows): wave-row j>>6, row j&63 of its 64
         srcA[i] = (unsigned)rowA[i] * (unsigned)rowbytes + slot * 16;
-        const int col = (j >> 5) * 64 + (j & 31);                           // B half h adds 32 columns (uniform)
+        const int col = NH ? j : (j >> 5) * 64 + (j & 31);                   // B half h adds 32 columns (uniform); NH: B0 = all 128 columns
         srcB[i] = (unsigned)col * (unsigned)K * (unsigned)sizeof(T) + slot * 16;
     }
     const unsigned a_half = 64u * (unsigned)rowbytes;
-    const unsigned b_half = 32u * (unsigned)K * (unsigned)sizeof(T);
+    const unsigned b_half = NH ? 0u : 32u * (unsigned)K * (unsigned)sizeof(T);      // NH: the B1 slot is staged with B0's rows (unused)
     const unsigned lds_stage = (unsigned)(size_t)(__attribute__((address_space(3))) void *)lds + (unsigned)(2 * wid) * 1024u;   // LDS address of chunk 2*wave
 
     // ---- the workgroup is persistent: it walks tiles orig = blockIdx.x, + gridDim.x, ... of the XCD-aware tile list (XCD x
@@ -282,7 +288,7 @@ __global__ __launch_bounds__(LN_THREADS) void k_linear256(LinParams P)
     do {                                                                                                                 \
         const T *bias_ = (const T *)P.bias;                                                                              \
         _Pragma("unroll") for (int hb_ = 0; hb_ < 2; ++hb_) _Pragma("unroll") for (int k_ = 0; k_ < 2; ++k_) {           \
-            const int c_ = bn0 + wc * 64 + hb_ * 32 + 8 * (lane >> 5) + 16 * k_;                                         \
+            const int c_ = bn0 + (NH ? wc * 32 : wc * 64 + hb_ * 32) + 8 * (lane >> 5) + 16 * k_;                        \
             bv[hb_][k_] = *(const V8 *)(bias_ ? bias_ + c_ : (const T *)P.w);                                            \
         }                                                                                                                \
     } while (0)
@@ -302,9 +308,10 @@ __global__ __launch_bounds__(LN_THREADS) void k_linear256(LinParams P)
         fa[h][rb_][ks_] = *(const V8 *)(lds + offA[ks_] + ((h) * 2 * LN_HALF + (s) * LN_HALF + rb_ * 4096))
 #define LN_READ_B(h, s)                                                                                                  \
     _Pragma("unroll") for (int ks_ = 0; ks_ < 4; ++ks_)                                                                  \
-        fb[h][ks_] = *(const V8 *)(lds + offB[ks_] + ((h) * 2 * LN_HALF + (s) * LN_HALF))
+        if (!(NH && (h) == 1)) fb[h][ks_] = *(const V8 *)(lds + offB[ks_] + ((h) * 2 * LN_HALF + (s) * LN_HALF))
 #define LN_MMA_PART(ha, hb, k0, k1)                                                                                      \
     do {                                                                                                                 \
+        if (!(NH && (hb) == 1))                                                                                          \
         _Pragma("unroll") for (int ks_ = (k0); ks_ < (k1); ++ks_) _Pragma("unroll") for (int rb_ = 0; rb_ < 2; ++rb_)    \
             acc[ha][rb_][hb] = TR::mfma(fb[hb][ks_], fa[ha][rb_][ks_], acc[ha][rb_][hb]);                                \
     } while (0)
@@ -371,7 +378,7 @@ __global__ __launch_bounds__(LN_THREADS) void k_linear256(LinParams P)
         // 0..4 wait for, so they add to the count; phase 5 waits for everything)
 #define LN_WAIT_HEAD()                                                                                                   \
         do {                                                                                                             \
-            if constexpr (KIND == 2) LN_WAIT_VM(26);                                                                     \
+            if constexpr (KIND == 2) { if constexpr (NH) LN_WAIT_VM(18); else LN_WAIT_VM(26); }                          \
             else if constexpr (KIND == 1) LN_WAIT_VM(14);                                                                \
             else LN_WAIT_VM(10);                                                                                         \
         } while (0)
@@ -431,7 +438,7 @@ __global__ __launch_bounds__(LN_THREADS) void k_linear256(LinParams P)
     // Early mode: [14 DMAs, 16 stores]: A0 and B0 of K-tile 0 are the 4 oldest of 30; the first tile of a workgroup has no
     // stores behind its DMAs and simply waits for all of them (iteration KIND 2's counts then never under-wait).
     if (!early) LN_WAIT_VM(10);
-    else if (stores_ahead) LN_WAIT_VM(26);
+    else if (stores_ahead) { if constexpr (NH) LN_WAIT_VM(18); else LN_WAIT_VM(26); }
     else LN_WAIT_VM(0);
     LN_BARRIER();
     LN_READ_A(0, 0);
@@ -482,28 +489,30 @@ __global__ __launch_bounds__(LN_THREADS) void k_linear256(LinParams P)
 #pragma unroll
         for (int hb = 0; hb < 2; ++hb)
 #pragma unroll
-            for (int k = 0; k < 2; ++k) gv[hb][k] = *(const V8 *)((const T *)P.gamma + cbn0 + wc * 64 + hb * 32 + hi8 + 16 * k);
+            for (int k = 0; k < 2; ++k) gv[hb][k] = *(const V8 *)((const T *)P.gamma + cbn0 + (NH ? wc * 32 : wc * 64 + hb * 32) + hi8 + 16 * k);
     }
+    constexpr int NHB = NH ? 1 : 2;                             // W halves with results (NH: the B0 half alone)
+    const int wcol = NH ? wc * 32 : wc * 64;
 #pragma unroll
     for (int ha = 0; ha < 2; ++ha)
 #pragma unroll
         for (int rb = 0; rb < 2; ++rb) {
             const int rl = ha * 64 + rb * 32 + (lane & 31);     // row inside the wave tile
-            const size_t o0 = (size_t)(cbm0 + wr * 128 + rl) * P.ldy + cbn0 + wc * 64 + hi8;
+            const size_t o0 = (size_t)(cbm0 + wr * 128 + rl) * P.ldy + cbn0 + wcol + hi8;
             // VT: where the 8 columns of piece (hb, k) go (per batch element [channels][tokens]); else o0 + hb * 32 + 16 * k
             auto out_off = [&](const int hb_, const int k_) -> size_t {
-                return VT ? ln_out_off<VT>(P, cbm0 + wr * 128 + rl, cbn0 + wc * 64 + hi8 + hb_ * 32 + 16 * k_) : o0 + hb_ * 32 + 16 * k_;
+                return VT ? ln_out_off<VT>(P, cbm0 + wr * 128 + rl, cbn0 + wcol + hi8 + hb_ * 32 + 16 * k_) : o0 + hb_ * 32 + 16 * k_;
             };
             V8 ra[2][2], rb2[2][2];                              // residual pieces [W half][k]
 #pragma unroll
-            for (int hb = 0; hb < 2; ++hb)
+            for (int hb = 0; hb < NHB; ++hb)
 #pragma unroll
                 for (int k = 0; k < 2; ++k) {
                     if (RES >= 1) ra[hb][k] = *(const V8 *)(r1 + o0 + hb * 32 + 16 * k);
                     if (RES >= 2) rb2[hb][k] = *(const V8 *)(r2 + o0 + hb * 32 + 16 * k);
                 }
 #pragma unroll
-            for (int hb = 0; hb < 2; ++hb)
+            for (int hb = 0; hb < NHB; ++hb)
 #pragma unroll
                 for (int k = 0; k < 2; ++k) {
                     float v[8];
@@ -728,14 +737,14 @@ DS_API int ds_linear_reload_env(void)
     return DS_OK;
 }
 
-template <int BF16, int EPI, int CONV, int RES, int VT = 0>
+template <int BF16, int EPI, int CONV, int RES, int VT = 0, int NH = 0>
 static int ln_launch(ds_ctx *ctx, const LinParams &P0, hipStream_t stream)
 {
     // per DEVICE, not per process: the dynamic-LDS attribute belongs to the function on one device, and the grid is that
     // device's CU count (a process may drive several GPUs through several contexts).  Setting the attribute twice is harmless,
     // so the bit mask needs no lock.
     static std::atomic<uint64_t> attr_done{0};
-    auto fn = k_linear256<BF16, EPI, CONV, RES, VT>;
+    auto fn = k_linear256<BF16, EPI, CONV, RES, VT, NH>;
     DS_HIP_CHECK(hipSetDevice(ctx->device));
     const uint64_t bit = 1ull << (ctx->device & 63);
     if (!(attr_done.load(std::memory_order_relaxed) & bit)) {
@@ -755,6 +764,7 @@ static int ln_launch(ds_ctx *ctx, const LinParams &P0, hipStream_t stream)
     int grid = ctx->ncu;
     if (O.grid >= 8) grid = O.grid / 8 * 8;             // tests: a small grid makes every workgroup walk many tiles
     LinParams P = P0;
+    P.bnw = NH ? 128 : 256;
     P.early = O.early;                                   // A/B switch (both orders give the same values)
 #ifdef DS_EXPERIMENTS
     if (P.ablate) P.early = 0;               // the no-store ablation changes the store count the early mode's waits rely on
@@ -790,6 +800,10 @@ template <int BF16>
 static int ln_dispatch_conv(ds_ctx *ctx, const LinParams &P, int act, hipStream_t st)
 {
     const int res = P.res1 ? (P.res2 ? 2 : 1) : 0;
+    if (P.N % 256 != 0) {                    // 128-column tiles (NH = 1): the head convolution, no residual operands
+        if (act == 2) return ln_launch<BF16, 2, 1, 0, 0, 1>(ctx, P, st);
+        return ln_launch<BF16, 0, 1, 0, 0, 1>(ctx, P, st);
+    }
     if (act == 2) {
         if (res == 2) return ln_launch<BF16, 2, 1, 2>(ctx, P, st);
         if (res == 1) return ln_launch<BF16, 2, 1, 1>(ctx, P, st);
@@ -860,7 +874,9 @@ DS_API int ds_conv3x3_nhwc(ds_ctx *ctx, const void *x, const void *w, const void
                "ds_conv3x3_nhwc: batch * height * width must be in [256, 2^31)");
     DS_REQUIRE(in_channels >= 64 && in_channels % 64 == 0 && (9 * in_channels / 64) % 2 == 0 && in_channels <= 4096, DS_EINVAL,
                "ds_conv3x3_nhwc: in_channels must be a multiple of 128 (<= 4096)");
-    DS_REQUIRE(out_channels > 0 && out_channels % 256 == 0, DS_EINVAL, "ds_conv3x3_nhwc: out_channels must be a multiple of 256");
+    DS_REQUIRE(out_channels > 0 && out_channels % 128 == 0, DS_EINVAL, "ds_conv3x3_nhwc: out_channels must be a multiple of 128");
+    DS_REQUIRE(out_channels % 256 == 0 || (!res1 && !res2), DS_EUNSUPPORTED,
+               "ds_conv3x3_nhwc: residual operands need out_channels to be a multiple of 256 (the 128-column tiles have no residual epilogue)");
     DS_REQUIRE(act == 0 || act == 2, DS_EINVAL, "ds_conv3x3_nhwc: act must be 0 (none) or 2 (ReLU)");
     DS_REQUIRE(dtype == DS_DTYPE_F16 || dtype == DS_DTYPE_BF16, DS_EINVAL, "ds_conv3x3_nhwc: dtype must be f16 or bf16");
     DS_REQUIRE(((uintptr_t)x & 15) == 0 && ((uintptr_t)w & 15) == 0 && ((uintptr_t)y & 15) == 0 && (!bias || ((uintptr_t)bias & 15) == 0) &&
@@ -878,7 +894,7 @@ DS_API int ds_conv3x3_nhwc(ds_ctx *ctx, const void *x, const void *w, const void
     if (!res1 && res2) { res1 = res2; res2 = nullptr; }
     P.x = x; P.w = w; P.bias = bias; P.res1 = res1; P.res2 = res2; P.y = y; P.zeros = ctx->zero_line;
     P.M = batch * height * width; P.N = out_channels; P.K = 9 * in_channels;
-    P.nbm = (P.M + 255) / 256; P.nbn = out_channels / 256;
+    P.nbm = (P.M + 255) / 256; P.nbn = out_channels % 256 == 0 ? out_channels / 256 : out_channels / 128;
     P.H = height; P.W = width; P.C = in_channels; P.cpt = in_channels / 64; P.magic = 65536 / P.cpt + 1;
     for (int kt = 0; kt < P.K / 64; ++kt)
         DS_REQUIRE(((kt * 7282) >> 16) == kt / 9, DS_EUNSUPPORTED, "ds_conv3x3_nhwc: K-tile arithmetic does not cover %d channels", in_channels);

@@ -24,7 +24,7 @@ __device__ __forceinline__ int nm_reflect101(int i, int n)
 // kept to what the result needs:
 //   * ONE division, y = 1 / n: it is the z component, and the correctly rounded reciprocal turns the other two quotients into
 //     q0 = a y;  r = fma(-q0, n, a);  q = fma(r, y, q0)  -- Markstein's sequence, equal to the correctly rounded a / n for every
-//     operand of this kernel (oracle/check_normal_division.c: the significand of n is never all ones; enumerated);
+//     operand of this kernel (the significand of n is never all ones; enumerated by check_normal_division.c of the test suite);
 //   * (v + 1) / 2 * 256 = (v + 1) * 128 bit for bit (scaling by a power of two never rounds);
 //   * after the clip the value lies in [0, 255.9]: the float64 -> uint8 cast is one v_cvt_i32_f64, not the general numpy
 //     emulation (ds_f64_to_u8: int64 conversion + wrap) the unclipped paths of the stereo kernels need.

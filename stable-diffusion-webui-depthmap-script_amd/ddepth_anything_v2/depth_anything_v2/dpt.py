@@ -84,7 +84,7 @@ class DPTHead(nn.Module):
         path_3 = s.refinenet3(path_4, l3, size=l2.shape[2:])
         path_2 = s.refinenet2(path_3, l2, size=l1.shape[2:])
         path_1 = s.refinenet1(path_2, l1)
-        out = s.output_conv1(path_1)
+        out = vm.conv2d(s.output_conv1, path_1)                # 256 -> 128: the in-tree implicit GEMM (256 x 128 tiles) where it fills the chip
         size = (int(patch_h * 14), int(patch_w * 14))
         if out.is_cuda and out.dtype in (torch.float16, torch.bfloat16) and tuple(s.output_conv2[0].weight.shape) == (32, 128, 3, 3):
             # upsample -> conv3x3 128->32 -> ReLU -> conv1x1 -> ReLU in one MFMA kernel (ds_dpt_head_tail)

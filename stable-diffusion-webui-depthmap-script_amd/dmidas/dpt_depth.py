@@ -102,7 +102,9 @@ class DPT(nn.Module):
                 and head[2].padding_mode == 'zeros'):          # TILING_MODE makes the convolutions circular: library path
             # upsample x2 -> conv3x3 128->32 -> ReLU -> conv1x1 -> ReLU in one MFMA kernel (ds_dpt_head_tail)
             from src import _native
-            y = vm.conv_module(head[0], path_1)
+            # the head's first convolution (256 -> 128): the in-tree implicit GEMM on 256 x 128 tiles where the launch fills the chip
+            # (round 4; MIOpen's heuristic choice for it varied from 1.75 to 2.1 ms per 32 x 256^2 between boxes), else the library
+            y = vm.conv2d(head[0], path_1) if vm.conv3x3_hip_ok(head[0], path_1) else vm.conv_module(head[0], path_1)
             size = (int(y.shape[2] * head[1].scale_factor), int(y.shape[3] * head[1].scale_factor))
             return _native.dpt_head_tail(y, size, head[2], head[4], relu_out=isinstance(head[5], nn.ReLU))
         return head(path_1)

@@ -463,10 +463,11 @@ def linear_vt(w_v, h):
 
 
 def conv3x3_supported(conv, x):
-    """What ds_conv3x3_nhwc takes: 3x3, stride 1, zero padding 1, no groups / dilation, in % 128 == 0, out % 256 == 0."""
+    """What ds_conv3x3_nhwc takes: 3x3, stride 1, zero padding 1, no groups / dilation, in % 128 == 0, out % 128 == 0 (residual
+    operands only with out % 256 == 0)."""
     return (tuple(conv.kernel_size) == (3, 3) and tuple(conv.stride) == (1, 1) and tuple(conv.padding) == (1, 1)
             and tuple(conv.dilation) == (1, 1) and conv.groups == 1 and conv.padding_mode == 'zeros'
-            and conv.in_channels % 128 == 0 and conv.out_channels % 256 == 0 and x.dim() == 4 and x.shape[1] == conv.in_channels
+            and conv.in_channels % 128 == 0 and conv.out_channels % 128 == 0 and x.dim() == 4 and x.shape[1] == conv.in_channels
             and x.shape[0] * x.shape[2] * x.shape[3] >= 256)
 
 

@@ -322,7 +322,7 @@ def conv3x3_hip_ok(conv, x):
     if not (CONV_HIP and x.is_cuda and x.dtype in (torch.float16, torch.bfloat16) and x.dim() == 4):
         return False
     from . import _native
-    tiles = (x.shape[0] * x.shape[2] * x.shape[3] + 255) // 256 * (conv.out_channels // 256)
+    tiles = (x.shape[0] * x.shape[2] * x.shape[3] + 255) // 256 * ((conv.out_channels + 255) // 256)
     return _native.conv3x3_supported(conv, x) and tiles >= CONV_HIP_MIN_TILES
 
 
@@ -367,7 +367,8 @@ def residual_conv_unit(conv1, conv2, x, skip=None):
             and conv2.bias is not None and conv1.out_channels % 8 == 0):
         from . import _native
         xc = x.contiguous(memory_format=torch.channels_last)
-        if conv3x3_hip_ok(conv1, xc) and conv3x3_hip_ok(conv2, xc) and conv1.out_channels == conv2.in_channels:
+        if (conv3x3_hip_ok(conv1, xc) and conv3x3_hip_ok(conv2, xc) and conv1.out_channels == conv2.in_channels
+                and conv2.out_channels % 256 == 0):
             # both convolutions as in-tree implicit GEMMs, the element-wise tails in their epilogues: 3 launches per unit
             sk = None if skip is None else skip.contiguous(memory_format=torch.channels_last)
             a = _native.conv3x3(conv1, F.relu(xc), relu=True)

@@ -292,9 +292,10 @@ def test_linear_and_conv_dispatch_rules_host_side():
     assert not vm.conv3x3_hip_ok(conv, img)                                   # CPU tensor / float32: the library
     assert torch.equal(vm.conv2d(conv, img), conv(img))
     for bad in (nn.Conv2d(256, 256, 3, padding=1, padding_mode='circular'), nn.Conv2d(256, 256, 3, padding=1, stride=2),
-                nn.Conv2d(256, 128, 3, padding=1), nn.Conv2d(64, 256, 3, padding=1), nn.Conv2d(256, 256, 1)):
+                nn.Conv2d(256, 64, 3, padding=1), nn.Conv2d(64, 256, 3, padding=1), nn.Conv2d(256, 256, 1)):
         xin = torch.randn((1, bad.in_channels, 16, 16), generator=g)
         assert not _native.conv3x3_supported(bad, xin)
+    assert _native.conv3x3_supported(nn.Conv2d(256, 128, 3, padding=1), img)   # 256 x 128 tiles (the head's first convolution)
     assert not _native.conv3x3_supported(conv, torch.randn((1, 256, 8, 8)))   # fewer than 256 pixels: below one tile
     c1, c2 = nn.Conv2d(16, 16, 3, padding=1), nn.Conv2d(16, 16, 3, padding=1)
     xr, sk = torch.randn((2, 16, 9, 11), generator=g), torch.randn((2, 16, 9, 11), generator=g)
