@@ -316,12 +316,15 @@ def interpolate_bilinear(x, size=None, scale_factor=None, align_corners=True):
 # chip (>= CONV_HIP_MIN_TILES tiles of 256 x 256); "0" keeps every convolution in the library.
 CONV_HIP = os.environ.get("DS_CONV", "1") != "0"
 CONV_HIP_MIN_TILES = 128
+CONV_HEAD_HIP = os.environ.get("DS_CONV_HEAD", "1") != "0"      # A/B switch: the 256 x 128 tiles (out_channels % 256 == 128)
 
 
 def conv3x3_hip_ok(conv, x):
     if not (CONV_HIP and x.is_cuda and x.dtype in (torch.float16, torch.bfloat16) and x.dim() == 4):
         return False
     from . import _native
+    if conv.out_channels % 256 != 0 and not CONV_HEAD_HIP:
+        return False
     tiles = (x.shape[0] * x.shape[2] * x.shape[3] + 255) // 256 * ((conv.out_channels + 255) // 256)
     return _native.conv3x3_supported(conv, x) and tiles >= CONV_HIP_MIN_TILES
 
