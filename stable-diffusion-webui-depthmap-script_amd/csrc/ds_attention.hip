@@ -355,6 +355,11 @@ __device__ __forceinline__ float at_max3(float a, float b, float c)
 //   half a tile late (two waves of one SIMD otherwise run the same phase at the same time)   4096 (NQB = 1) late fetches --
 //   the bias of a tile is requested at the top of that tile, K / V^T of the next one after S -- to fit 128 VGPRs: 4 waves/SIMD
 // NQB = 32-row query blocks per wave: 2 (64 rows, <= 256 VGPRs, two waves per SIMD) or 1 (32 rows, four waves per SIMD).
+// (Round 4 measured software-pipelined fragment reads -- the K / V^T fragments of slice s + 2 requested while slice s is multiplied,
+// the first four ahead of the bias MFMAs, the two key blocks' accumulators alternating -- against this loop, whose S and P.V
+// phases compile to "two reads, wait, two dependent MFMAs" four times each: 0.289 vs 0.285 ms at N = 1025 + bias, 0.375 vs 0.386 at
+// N = 1370, 0.250 vs 0.250 at N = 2443, 0.848 vs 0.819 at N = 4097 + bias.  Three waves per SIMD already cover those round trips;
+// the variant was removed.)
 template <int BF16, int HAS_BIAS, int NQB, int ABL>
 __global__ __launch_bounds__(AT_THREADS, NQB == 2 ? 2 : ((ABL & 4096) ? 4 : 3)) void k_attention_fwd2(AttnParams P)
 {
