@@ -285,39 +285,33 @@ def test_boost_end_to_end_vs_reference_estimateboost(gpu):
     assert rel < 1.5e-4 and np.abs(got - want).mean() < 2e-5, (rel, float(np.abs(got - want).mean()))
 
 
-def test_boost_gpu_error_budget_per_stage(gpu, oracle):
+def test_boost_gpu_error_budget_per_stage(gpu):
     """Where the GPU twin of Boost leaves its CPU twin (which holds 9.5e-5 against the reference's own estimateboost,
-    tests/test_models_cpu.py): the same estimateboost on the device (MIOpen float32 convolutions, HIP blend) and on the CPU
-    (torch float32, the blend through the oracle), stage by stage -- whole-image double estimate (2 LeReS forwards + the
-    merge network), base at merge size, the 18 merged patches (2 x 18 LeReS forwards + 2 x 18 merge-network forwards), their
-    polyfit coefficients, the blend, the final resize.  Every stage is a float32 network output renormalised to [0, 1]
-    (pix2pix4depth_model.py:100-104 min-max normalises its inputs; doubleestimate :1046-1048 its output): a stage's error is
-    the convolutions' summation-order noise of a ~100-layer float32 ResNeXt times the gain of that renormalisation, and the
-    stages do not compound beyond the merge network's own sensitivity.  The printed budget is what DESIGN.md quotes."""
+    tests/test_models_cpu.py): estimateboost on the device (MIOpen float32 convolutions, HIP blend) against the stage outputs
+    of the SAME code on the CPU (torch float32, the blend through the oracle; tests/golden/make_golden_boost_stages.py) --
+    whole-image double estimate (2 LeReS forwards + the merge network), base at merge size, the 18 merged patches (2 x 18 LeReS
+    forwards + 2 x 18 merge-network forwards), their polyfit coefficients, the blend, the final resize.  Every stage is a float32
+    network output renormalised to [0, 1] (pix2pix4depth_model.py:100-104 min-max normalises its inputs; doubleestimate
+    :1046-1048 its output): a stage's error is the convolutions' summation-order noise of a ~100-layer float32 ResNeXt times the
+    gain of that renormalisation, and the stages do not compound beyond the merge network's own sensitivity."""
     from lib.multi_depth_model_woauxi import RelDepthModel
     from pix2pix.models.pix2pix4depth_model import Pix2Pix4DepthModel
     from src import boost
+    import make_golden_boost_stages as mk
     z = np.load(os.path.join(os.path.dirname(GOLD), "boost_cases.npz"))
+    want = np.load(os.path.join(os.path.dirname(GOLD), "boost_stage_cases.npz"))
     net = RelDepthModel('resnext101').eval()
     net.load_state_dict(mw.fill_state_dict(net.state_dict()), strict=True)
     p2p = Pix2Pix4DepthModel().eval()
     p2p.netG.load_state_dict(mw.fill_state_dict(p2p.netG.state_dict()), strict=True)
-
-    def oracle_blend(dst, rects, coefs, preds, mask):
-        out = oracle.boost_blend(dst.numpy(), rects, coefs, preds.numpy(), mask.numpy())
-        dst.copy_(torch.from_numpy(out))
-        return dst
-    t_cpu, t_gpu = {}, {}
-    img = torch.from_numpy(z["image"])
-    rmax = int(z["rmax"][0])
-    out_cpu = boost.estimateboost(img, net, 0, p2p, whole_size_threshold=rmax, blend=oracle_blend, trace=t_cpu)
-    out_gpu = boost.estimateboost(img.cuda(), net.cuda(), 0, p2p.cuda(), whole_size_threshold=rmax, trace=t_gpu).cpu()
-    t_cpu["out"], t_gpu["out"] = out_cpu, out_gpu
+    trace = {}
+    out = boost.estimateboost(torch.from_numpy(z["image"]).cuda(), net.cuda(), 0, p2p.cuda(), whole_size_threshold=int(z["rmax"][0]), trace=trace)
+    trace["out"] = out.cpu()
     budget = {}
-    for k in ("whole_estimate", "base", "mapped", "coef", "blended", "out"):
-        a, b = t_cpu[k].double(), t_gpu[k].double()
-        assert a.shape == b.shape, k
-        budget[k] = ((a - b).abs().max() / a.abs().max()).item()
+    for k in mk.STRIDES:
+        a, b = want[k].astype(np.float64), mk.subsample(k, trace[k]).astype(np.float64)
+        assert a.shape == b.shape, (k, a.shape, b.shape)
+        budget[k] = float(np.abs(a - b).max() / np.abs(a).max())
     print("boost GPU-vs-CPU error budget (max |difference| / max |value| per stage):", {k: f"{v:.2e}" for k, v in budget.items()})
     scratch = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
     if os.path.isdir(scratch):                                   # kept with the GPU call's outputs (copied to profiles/ by hand)
@@ -325,10 +319,8 @@ def test_boost_gpu_error_budget_per_stage(gpu, oracle):
         with open(os.path.join(scratch, "boost_error_budget.json"), "w") as f:
             json.dump({"what": "estimateboost on the GPU vs the same code on the CPU (float32), max |difference| / max |value| per stage",
                        "image": "tests/golden/boost_cases.npz (480 x 640, 18 patches)", "budget": budget}, f, indent=1)
-    # the networks' outputs on the two devices agree to float32 convolution noise; nothing downstream amplifies it by more than
-    # an order of magnitude, and the final depth stays inside the 5e-4 the end-to-end test holds against the reference
-    # measured (profiles/round4_boost_error_budget.json): whole estimate 2.5e-5, base 1.8e-5, merged patches 7.6e-5, polyfit
-    # coefficients 2e-6, blended and final depth 1.6e-5
+    # measured (profiles/round4_boost_error_budget.json, both twins run on one box): whole estimate 2.5e-5, base 1.8e-5, merged
+    # patches 7.6e-5, polyfit coefficients 2e-6, blended and final depth 1.6e-5
     assert budget["whole_estimate"] < 1e-4 and budget["base"] < 1e-4, budget
     assert budget["mapped"] < 3e-4 and budget["coef"] < 1e-4, budget
     assert budget["blended"] < 1e-4 and budget["out"] < 1e-4, budget
