@@ -469,8 +469,8 @@ def main():
             lin_flops = 2.0 * m_rows * 4 * dim * dim
             lin = {"bound": "mfma", "kernel": "k_linear256 (fc1 + erf-GELU)", "achieved": lin_flops / (lin_ms * 1e-3) / 1e12,
                    "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": lin_flops / (lin_ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS,
-                   "traffic": None, "traffic_from_profile": traffic_from_profile("k_linear256<0, 1, 0, 0, 0>", batch) if args.config == "c3" else None,
-                   "in_step_from_profile": in_step_from_profile("k_linear256<0, 1, 0, 0, 0>", lin_flops, MFMA_PEAK_TFLOPS, 1e12) if args.config == "c3" else None,
+                   "traffic": None, "traffic_from_profile": traffic_from_profile("k_linear256<0, 1, 0, 0, 0", batch) if args.config == "c3" else None,
+                   "in_step_from_profile": in_step_from_profile("k_linear256<0, 1, 0, 0, 0", lin_flops, MFMA_PEAK_TFLOPS, 1e12) if args.config == "c3" else None,
                    "algorithmic_flops_per_launch": lin_flops, "avg_kernel_ms": lin_ms, "operands": "random (randn)",
                    "source": "microbenchmark: separate launches at the in-step shape on randn operands, HIP events on the launch stream",
                    "launches_per_step": minfo["depth"], "shape": {"rows": m_rows, "out_features": 4 * dim, "in_features": dim}}

@@ -1034,9 +1034,16 @@ def test_linear_ragged_round_vt_and_fused_residual(gpu, dtype, tol):
         x, w, b = mk(4352, 384).to(dtype).cuda(), (mk(256, 384) * 384 ** -0.5).to(dtype).cuda(), mk(256).to(dtype).cuda()
         gam, res = mk(256).to(dtype).cuda(), mk(4352, 256).to(dtype).cuda()
         outs = []
+        import torch.nn as nn
+        hv, wv = mk(4, 320, 256).to(dtype).cuda(), (mk(512, 256) * 256 ** -0.5).to(dtype).cuda()
+        cv = nn.Conv2d(128, 256, 3, padding=1).to(dtype).cuda()
+        xc, rc = (mk(2, c, 37, 41).to(dtype).cuda().contiguous(memory_format=torch.channels_last) for c in (128, 256))
         for early, ring in (("1", "3"), ("0", "3"), ("1", "6"), ("0", "6")):
             _native.linear_env(DS_LIN_EARLY=early, DS_LIN_RAGGED_RING=ring)
-            outs.append((_native.linear(x, w, b, True), _native.linear(x, w, None, False), _native.linear_residual(x, w, b, gam, res)))
+            # every epilogue variant whose store count the early prologue's waits rely on: GELU, plain without a bias, LayerScale +
+            # residual, V^T, convolution with ReLU and with two residual operands
+            outs.append((_native.linear(x, w, b, True), _native.linear(x, w, None, False), _native.linear_residual(x, w, b, gam, res),
+                         _native.linear_vt(wv, hv), _native.conv3x3(cv, xc, relu=True), _native.conv3x3(cv, xc, res1=rc, res2=rc)))
         _native.linear_env(DS_LIN_EARLY=None, DS_LIN_RAGGED_RING=None)
         for o in outs[1:]:
             assert all(torch.equal(a, c) for a, c in zip(o, outs[0])), "DS_LIN_EARLY / ring depth changed the values"
