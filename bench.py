@@ -208,6 +208,28 @@ def traffic_from_profile(kernel, batch):
     return None
 
 
+def clock_from_profile(kernel, flops, batch):
+    """Effective shader clock and MFMA cycle fraction of the kernel whose name contains `kernel` inside the step, from the committed
+    profiles: GRBM_GUI_ACTIVE (busy cycles, summed over the 8 XCDs by rocprofv3) of the PMC summary / 8 = cycles of one launch;
+    / the average duration of the kernel-trace summary = the clock the power management granted (MI355X_MICROARCH.md, "DVFS
+    give-back"); the MFMA work of `flops` is flops / (1024 SIMDs x 1024 flop per cycle) cycles.  None when a profile lacks it."""
+    try:
+        import csv
+        with open(os.path.join(ROOT, PMC_SUMMARY)) as f:
+            j = json.load(f)
+        if int(j.get("batch", -1)) != int(batch):
+            return None
+        cyc = next(float(r["GRBM_GUI_ACTIVE"]) / 8.0 for n, r in j.items() if isinstance(r, dict) and kernel in n and "GRBM_GUI_ACTIVE" in r)
+        with open(os.path.join(ROOT, KERNEL_STATS)) as f:
+            ns = next(float(r["AverageNs"]) for r in csv.DictReader(f) if kernel in r["Name"])
+        mfma = flops / (1024.0 * 1024.0)
+        return {"busy_cycles_per_launch": cyc, "effective_clock_ghz": cyc / ns, "mfma_cycles": mfma, "mfma_cycle_frac": mfma / cyc,
+                "note": "the chip clocks down under dense MFMA work on random operands (DESIGN.md 3.10): `frac` is against the 2.4 GHz peak, "
+                        "`mfma_cycle_frac` is the share of the launch's cycles that are MFMA issue cycles", "source": PMC_SUMMARY + " + " + KERNEL_STATS}
+    except Exception:
+        return None
+
+
 def in_step_from_profile(kernel, work, peak, unit_scale):
     """Average duration of the kernel whose name contains `kernel` INSIDE the timed step, from the committed rocprofv3
     --kernel-trace --stats summary of the default bench command, and what that duration means for `work` (flops or bytes per
@@ -445,6 +467,7 @@ def main():
                 "traffic": None,                          # PMC counters cannot be read from inside the run ...
                 "traffic_from_profile": traffic_from_profile("k_attention_fwd2", batch) if args.config == "c3" else None,
                 "in_step_from_profile": in_step_from_profile("k_attention_fwd2", attn_flops, MFMA_PEAK_TFLOPS, 1e12) if args.config == "c3" else None,
+                "clock_from_profile": clock_from_profile("k_attention_fwd2", attn_flops * 20.0 / 16.0, batch) if (args.config == "c3" and minfo["bias"]) else None,
                 "algorithmic_flops_per_launch": attn_flops, "avg_kernel_ms": attn_ms, "operands": "random (randn)",
                 "source": "microbenchmark: separate launches at the in-step shape on randn operands, HIP events on the launch stream",
                 "launches_per_step": minfo["depth"], "shape": {"batch": batch, "tokens": n_tok, "heads": minfo["heads"], "bias": minfo["bias"]}}
@@ -471,6 +494,7 @@ def main():
                    "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": lin_flops / (lin_ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS,
                    "traffic": None, "traffic_from_profile": traffic_from_profile("k_linear256<0, 1, 0, 0, 0", batch) if args.config == "c3" else None,
                    "in_step_from_profile": in_step_from_profile("k_linear256<0, 1, 0, 0, 0", lin_flops, MFMA_PEAK_TFLOPS, 1e12) if args.config == "c3" else None,
+                   "clock_from_profile": clock_from_profile("k_linear256<0, 1, 0, 0, 0", lin_flops, batch) if args.config == "c3" else None,
                    "algorithmic_flops_per_launch": lin_flops, "avg_kernel_ms": lin_ms, "operands": "random (randn)",
                    "source": "microbenchmark: separate launches at the in-step shape on randn operands, HIP events on the launch stream",
                    "launches_per_step": minfo["depth"], "shape": {"rows": m_rows, "out_features": 4 * dim, "in_features": dim}}
