@@ -467,7 +467,7 @@ def main():
                 "traffic": None,                          # PMC counters cannot be read from inside the run ...
                 "traffic_from_profile": traffic_from_profile("k_attention_fwd2", batch) if args.config == "c3" else None,
                 "in_step_from_profile": in_step_from_profile("k_attention_fwd2", attn_flops, MFMA_PEAK_TFLOPS, 1e12) if args.config == "c3" else None,
-                "clock_from_profile": clock_from_profile("k_attention_fwd2", attn_flops * 20.0 / 16.0, batch) if (args.config == "c3" and minfo["bias"]) else None,
+                "clock_from_profile": clock_from_profile("k_attention_fwd2", attn_flops, batch) if (args.config == "c3" and minfo["bias"]) else None,
                 "algorithmic_flops_per_launch": attn_flops, "avg_kernel_ms": attn_ms, "operands": "random (randn)",
                 "source": "microbenchmark: separate launches at the in-step shape on randn operands, HIP events on the launch stream",
                 "launches_per_step": minfo["depth"], "shape": {"batch": batch, "tokens": n_tok, "heads": minfo["heads"], "bias": minfo["bias"]}}
