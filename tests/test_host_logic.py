@@ -364,3 +364,20 @@ def test_funnel_rgbx_pixel_export_is_only_taken_where_it_is_safe():
                Image.new("RGB", (3000, 2000))]                             # 24 MB of pixels: more than one 16 MB block
     for im in refused:
         assert core._rgbx_pixels(im) is None, (im.mode, im.size)
+
+
+def test_tight_token_pad_rules():
+    """vm.pad_len: without a batch the pad is a multiple of 64 (one key tile); with one it is the tightest multiple of 8 / 16 / 32
+    whose batch x stride rows are whole 256-row panels (what ds_linear_vt needs for its columns), else 64."""
+    from src import vit_mi355x as vm
+    assert vm.pad_len(1025) == 1088 and vm.pad_len(64) == 64 and vm.pad_len(1) == 64
+    assert vm.pad_len(1025, 32) == 1032 and (32 * 1032) % 256 == 0          # dpt_beit_large_512 at the benchmark's batch: 129 panels
+    assert vm.pad_len(2443, 8) == 2464 and (8 * 2464) % 256 == 0            # Depth-Anything-V2 ViT-L, 1080p, batch 8
+    assert vm.pad_len(1025, 16) == 1040 and vm.pad_len(577, 32) == 584
+    for b, n in ((1, 1025), (2, 1025), (3, 577), (4, 2443), (8, 4097)):     # no tight pad keeps whole panels: 64 as before
+        assert vm.pad_len(n, b) == vm.pad_len(n)
+    for b in range(1, 70):
+        for n in (1, 63, 64, 65, 577, 1025, 1370, 2443, 4097):
+            s = vm.pad_len(n, b)
+            assert s >= n and s % 8 == 0 and s <= vm.pad_len(n)
+            assert s == vm.pad_len(n) or (b * s) % 256 == 0
