@@ -374,7 +374,8 @@ def test_tight_token_pad_rules():
     assert vm.pad_len(1025, 32) == 1032 and (32 * 1032) % 256 == 0          # dpt_beit_large_512 at the benchmark's batch: 129 panels
     assert vm.pad_len(2443, 8) == 2464 and (8 * 2464) % 256 == 0            # Depth-Anything-V2 ViT-L, 1080p, batch 8
     assert vm.pad_len(1025, 16) == 1040 and vm.pad_len(577, 32) == 584
-    for b, n in ((1, 1025), (2, 1025), (3, 577), (4, 2443), (8, 4097)):     # no tight pad keeps whole panels: 64 as before
+    assert vm.pad_len(4097, 8) == 4128                                       # net 1024 (NET_SIZE_MATCH), batch 8: 129 panels again
+    for b, n in ((1, 1025), (2, 1025), (3, 577), (4, 2443)):                # no tight pad keeps whole panels: 64 as before
         assert vm.pad_len(n, b) == vm.pad_len(n)
     for b in range(1, 70):
         for n in (1, 63, 64, 65, 577, 1025, 1370, 2443, 4097):
