@@ -312,10 +312,15 @@ def interpolate_bilinear(x, size=None, scale_factor=None, align_corners=True):
     return F.interpolate(x, scale_factor=scale_factor, mode="bilinear", align_corners=align_corners)
 
 
-# 3x3 decoder convolutions through the in-tree implicit GEMM (csrc/ds_linear.hip) when the launch fills at least half the
-# chip (>= CONV_HIP_MIN_TILES tiles of 256 x 256); "0" keeps every convolution in the library.
+# 3x3 decoder convolutions through the in-tree implicit GEMM (csrc/ds_linear.hip) when the launch has at least
+# CONV_HIP_MIN_TILES tiles of 256 x 256 (DS_CONV_MIN_TILES); "0" keeps every convolution in the library.  A launch below 256
+# tiles is ONE round of the persistent kernel whatever its size (~60 us at K = 2304), so small maps only pay where the library
+# is worse than that: at 128 tiles (32 x 32^2 maps of the batch-32 benchmark) the two are level (61 vs 70 us), at 32 tiles
+# (16^2 maps) the library is ahead -- but for Depth-Anything-V2's 37 x 66 maps at batch 8 (76 tiles) MIOpen's heuristic picks a
+# 327 us kernel.  Round 4: 128 -> 48 (c5 213.9 -> 216.5 pairs/s on one box; 16 would give 219.2 there and cost the batch-32
+# benchmark 0.6 %).
 CONV_HIP = os.environ.get("DS_CONV", "1") != "0"
-CONV_HIP_MIN_TILES = 128
+CONV_HIP_MIN_TILES = int(os.environ.get("DS_CONV_MIN_TILES", 48))
 CONV_HEAD_HIP = os.environ.get("DS_CONV_HEAD", "1") != "0"      # A/B switch: the 256 x 128 tiles (out_channels % 256 == 128)
 
 
