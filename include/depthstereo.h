@@ -260,7 +260,9 @@ int ds_bias_act_nhwc(ds_ctx *ctx, const void *x, const void *bias, const void *r
  * in_features % 128 == 0, rows >= 256 (the last 256-row panel is shifted up to end at the last row).  y must not alias x.
  * 256 x 256 tiles on the MFMA units, walked by one persistent workgroup per CU; when the last round of that walk would be
  * at most a quarter full, its tiles are rendered as 128 x 64 pieces by a second kernel on the same stream (the "ragged
- * round": 544 tiles on 256 CUs cost 2 rounds + the pieces instead of 3 rounds).
+ * round": 544 tiles on 256 CUs cost 2 rounds + the pieces instead of 3 rounds).  Long contractions (>= 2048) of a small ragged
+ * round are shared by up to 8 workgroups per piece through a per-context workspace (8 MB, allocated at the first such launch:
+ * one more reason why calls on one ctx go to one stream at a time); results stay bit-reproducible run to run.
  */
 int ds_linear(ds_ctx *ctx, const void *x, const void *w, const void *bias, void *y, int64_t rows, int64_t out_features,
               int64_t in_features, int64_t ldy, int act, int dtype, void *stream);

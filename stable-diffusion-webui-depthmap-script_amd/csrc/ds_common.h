@@ -42,6 +42,8 @@ struct ds_ctx {
     void *tmp_b;       size_t tmp_b_bytes;
     void *zero_line;   size_t zero_line_bytes;   // 256 zero bytes: the padding ring of ds_conv3x3_nhwc
     int zero_line_cleared;
+    void *lin_ws;      size_t lin_ws_bytes;      // ds_linear's ragged round with a K split: arrival counters + fp32 partials
+    void *lin_ws_cleared;                        // the block whose counters have been zeroed
     int ncu;                                     // CU count of `device` rounded down to a multiple of 8 (0 = not read yet)
     int64_t last_exact_rows_valid;
     // optional kernel timing (ds_profile_enable)

@@ -79,6 +79,9 @@ struct LinParams {
     int n_main;                 // the persistent kernel walks positions [0, n_main) of the tile list; k_linear_ragged takes the rest
     int vt_np, vt_c;            // VT: column j of the GEMM is token j % vt_np of batch element j / vt_np, the output is [batch][vt_c rows][vt_np]
     unsigned vt_magic;          // VT: floor(2^32 / vt_np) + 1  (j / vt_np == umulhi(j, vt_magic) for j * vt_np < 2^32)
+    float *rg_ws;               // ragged round with K split over 2^rg_ksl workgroups per piece: one 32 KB fp32 partial per workgroup ...
+    int *rg_cnt;                // ... and one arrival counter per piece (zero between launches)
+    int rg_ksl;
 };
 
 // position in the tile list -> origin of the tile.  The list is ordered in groups of 8 row panels, rows fastest inside a group
@@ -590,12 +593,15 @@ __global__ __launch_bounds__(LN_THREADS, S == 3 ? 4 : 2) void k_linear_ragged(Li
     const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     // the 8 pieces of a tile run on ONE XCD (workgroup b lands on XCD b & 7): its L2 serves the shared x rows / W rows
-    const int p = (int)(blockIdx.x & 7) * (int)(gridDim.x >> 3) + (int)(blockIdx.x >> 3);
+    // (K split, P.rg_ksl > 0: the 2^rg_ksl workgroups of a piece are neighbours in this order, hence on one XCD as well)
+    const int q = (int)(blockIdx.x & 7) * (int)(gridDim.x >> 3) + (int)(blockIdx.x >> 3);
+    const int ksl = P.rg_ksl;
+    const int p = q >> ksl, kpart = q & ((1 << ksl) - 1);
     const int tile = P.n_main + (p >> 3), piece = p & 7;
     int bm0, bn0;
     ln_tile_origin(P, tile, bm0, bn0);
     const int row0 = bm0 + (piece >> 2) * 128, col0 = bn0 + (piece & 3) * 64;
-    const int K = P.K, nt = K >> 6;
+    const int K = P.K, nt = (K >> 6) >> ksl;           // K-tiles of THIS workgroup: [kpart * nt, (kpart + 1) * nt)
     const unsigned rowbytes = (unsigned)K * (unsigned)sizeof(T);
     // staging: a 1 KB chunk = 8 rows x 128 bytes, LDS row j = 8 c + (lane >> 3), LDS slot lane & 7 holds SOURCE slot
     // (lane & 7) ^ ((j >> 1) & 7).  Wave w stages x chunks 2 w, 2 w + 1 (rows 16 w .. 16 w + 15) and W chunk w (rows 8 w .. + 7)
@@ -609,8 +615,8 @@ __global__ __launch_bounds__(LN_THREADS, S == 3 ? 4 : 2) void k_linear_ragged(Li
         const int j = 8 * wid + (lane >> 3);
         srcB = (unsigned)j * rowbytes + (unsigned)(((lane & 7) ^ ((j >> 1) & 7)) << 4);
     }
-    const unsigned char *xb = (const unsigned char *)P.x + (size_t)row0 * rowbytes;
-    const unsigned char *wb = (const unsigned char *)P.w + (size_t)col0 * rowbytes;
+    const unsigned char *xb = (const unsigned char *)P.x + (size_t)row0 * rowbytes + (size_t)(kpart * nt) * 128;
+    const unsigned char *wb = (const unsigned char *)P.w + (size_t)col0 * rowbytes + (size_t)(kpart * nt) * 128;
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) void *)lds;
 #define RG_STAGE(kt_)                                                                                                    \
     do {                                                                                                                 \
@@ -663,6 +669,61 @@ __global__ __launch_bounds__(LN_THREADS, S == 3 ? 4 : 2) void k_linear_ragged(Li
     for (int r = 0; r < 16; ++r) mine[r] += mine2[r];
 #undef RG_STAGE
 
+    // ---- K split: every workgroup of a piece leaves its fp32 partial in its own slot of the workspace ([wave][16][64 lanes]),
+    // the LAST one to arrive (a counter per piece) adds the slots in the order of the K ranges -- the result does not depend on
+    // which workgroup that is: bit-reproducible -- and runs the epilogue.  Nobody waits for anybody; the counter is back at zero
+    // when the launch ends.  Visibility: the partials are written and read with agent-scope accesses (the sc1 bit: coherent
+    // across the L2s of the XCDs, whichever XCD a workgroup runs on) and are complete (vmcnt(0)) before the arrival is counted.
+    // NOT __threadfence(): its agent-scope release / acquire is a write-back + invalidate of the whole L2 (buffer_wbl2 sc1 /
+    // buffer_inv sc1) issued by every wave -- measured: +55 us per launch, behind a main kernel that leaves the L2s dirty.
+    if (ksl > 0) {
+        __shared__ int s_last;
+        float *slot = P.rg_ws + ((size_t)q * 8 + wid) * 1024 + lane;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) __hip_atomic_store(slot + r * 64, mine[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        LN_WAIT_VM(0);
+        __syncthreads();
+        if (tid == 0) {
+            const int arrived = atomicAdd(P.rg_cnt + p, 1);
+            const int last = arrived == (1 << ksl) - 1;
+            if (last) atomicExch(P.rg_cnt + p, 0);
+            s_last = last;
+        }
+        __syncthreads();
+        if (!s_last) return;
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mine[r] = 0.f;
+        const float *first = P.rg_ws + ((size_t)(q - kpart) * 8 + wid) * 1024 + lane;
+        // four (two) slots in flight per round trip, added in the order of the K ranges
+        if (ksl >= 2) {
+            for (int kp = 0; kp < (1 << ksl); kp += 4) {
+                float part[4][16];
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        part[u][r] = __hip_atomic_load(first + (size_t)(kp + u) * 8192 + r * 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) mine[r] += part[u][r];
+            }
+        } else {
+            float part[2][16];
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    part[u][r] = __hip_atomic_load(first + (size_t)u * 8192 + r * 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) mine[r] += part[u][r];
+        }
+    }
+
     // ---- epilogue of block wid = (32-row block wid >> 1, 32-column block wid & 1), as in k_linear256: register r = column
     // (r & 3) + 8 (r >> 2) + 4 hi of row l31; one permlane32 swap per register pair gives each lane 8 consecutive columns
     const int row = row0 + (wid >> 1) * 32 + l31;
@@ -711,7 +772,10 @@ __global__ __launch_bounds__(LN_THREADS, S == 3 ? 4 : 2) void k_linear_ragged(Li
 //   DS_LIN_EARLY    1 (default) the next tile's prologue DMAs are issued before the epilogue, 0 after it
 //   DS_LIN_GRID     number of persistent workgroups (default: one per CU)
 //   DS_LIN_RAGGED / DS_LIN_RAGGED_DEN / DS_LIN_RAGGED_RING   the ragged round: on / "at most 1/DEN full" / ring depth 3 or 6
-struct LinOptions { int early, grid, ragged, ragged_den, ragged_ring; };
+//   DS_LIN_RAGGED_KSPLIT   the ragged round: at most this many workgroups share the K range of a piece (default 8, 1 = no split;
+//                          the values differ by the fp32 summation order, like every other split of a contraction), for
+//   DS_LIN_RAGGED_KSPLIT_MIN / _KEEP   contractions of at least MIN K-tiles (default 32), every workgroup keeping >= KEEP (default 8)
+struct LinOptions { int early, grid, ragged, ragged_den, ragged_ring, ragged_ksplit, ragged_ksplit_min, ragged_ksplit_keep; };
 static LinOptions g_lin_options;
 static std::atomic<int> g_lin_options_state{0};
 static void ln_read_options()
@@ -723,6 +787,10 @@ static void ln_read_options()
     o.ragged = geti("DS_LIN_RAGGED", 1);
     o.ragged_den = geti("DS_LIN_RAGGED_DEN", 4);
     o.ragged_ring = geti("DS_LIN_RAGGED_RING", 0);
+    o.ragged_ksplit = geti("DS_LIN_RAGGED_KSPLIT", 8);
+    o.ragged_ksplit_min = geti("DS_LIN_RAGGED_KSPLIT_MIN", 32);
+    o.ragged_ksplit_keep = geti("DS_LIN_RAGGED_KSPLIT_KEEP", 8);
+    if (o.ragged_ksplit_keep < 1) o.ragged_ksplit_keep = 1;
     g_lin_options = o;
     g_lin_options_state.store(1, std::memory_order_release);
 }
@@ -734,6 +802,25 @@ static const LinOptions &ln_options()
 DS_API int ds_linear_reload_env(void)
 {
     ln_read_options();
+    return DS_OK;
+}
+
+// Workspace of the ragged round's K split: arrival counters (zeroed once; every launch leaves them at zero) + one 32 KB
+// partial per workgroup of the largest launch (grid workgroups).  Returns 1 when the block would have to be allocated or
+// cleared while the stream is being captured into a graph (the caller then launches without the split: the eager warm-up
+// calls that precede a capture normally have it in place).
+#define LN_RG_COUNTER_BYTES 4096
+static int ln_ragged_workspace(ds_ctx *ctx, int grid, hipStream_t stream)
+{
+    const size_t need = LN_RG_COUNTER_BYTES + (size_t)(grid > 256 ? grid : 256) * 32768;
+    if (ctx->lin_ws && ctx->lin_ws_bytes >= need && ctx->lin_ws_cleared == ctx->lin_ws) return DS_OK;
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(stream, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) { (void)hipGetLastError(); return 1; }
+    const int rc = ds_ctx_reserve(ctx, &ctx->lin_ws, &ctx->lin_ws_bytes, need);
+    if (rc != DS_OK) return rc;
+    DS_HIP_CHECK(hipMemsetAsync(ctx->lin_ws, 0, LN_RG_COUNTER_BYTES, stream));
+    DS_HIP_CHECK(hipStreamSynchronize(stream));
+    ctx->lin_ws_cleared = ctx->lin_ws;
     return DS_OK;
 }
 
@@ -778,10 +865,28 @@ static int ln_launch(ds_ctx *ctx, const LinParams &P0, hipStream_t stream)
         if (O.ragged && r > 0 && O.ragged_den > 0 && O.ragged_den * r <= grid) ragged = r;
     }
     P.n_main = ntiles - ragged;
+    // the ragged round's K split: a launch of few pieces (4 tiles = 32 pieces on 256 CUs) is bound by the latency of one
+    // piece's K loop (0.35 us per K-tile), so up to 8 workgroups share a long one, as long as all of them run at once (one per
+    // CU: the deep ring) and each keeps at least 8 K-tiles.  Measured at batch 32 (profiles/round4_microbench_gemms_ksplit.txt):
+    // fc2 (K = 4096, 4 tiles) 270.1 -> 253.9 us; at K = 1024 the loop is 6 of the launch's 12 us and the split buys nothing
+    // (fc1 274.4 / 275.0, qk 148.2 / 148.1, proj 85.9 / 87.6 with 2 K-tiles each), hence the lower bound of 32 K-tiles.
+    const int deep = O.ragged_ring ? O.ragged_ring == 6 : 8 * ragged <= grid;
+    int ksl = 0;
+    if (CONV == 0 && ragged && deep && 8 * ragged * (int)sizeof(int) <= LN_RG_COUNTER_BYTES) {
+        const int nt = P.K / 64;
+        while (nt >= O.ragged_ksplit_min && (2 << ksl) <= O.ragged_ksplit && 8 * ragged * (2 << ksl) <= grid && nt % (2 << ksl) == 0 &&
+               nt / (2 << ksl) >= O.ragged_ksplit_keep) ++ksl;
+    }
+    if (ksl > 0) {
+        const int rc = ln_ragged_workspace(ctx, grid, stream);
+        if (rc == DS_OK) { P.rg_cnt = (int *)ctx->lin_ws; P.rg_ws = (float *)((char *)ctx->lin_ws + LN_RG_COUNTER_BYTES); }
+        else if (rc == 1) ksl = 0;                       // not available inside a stream capture before its first eager use
+        else return rc;
+    }
+    P.rg_ksl = ksl;
     hipLaunchKernelGGL(fn, dim3(P.n_main < grid ? P.n_main : grid), dim3(LN_THREADS), LN_LDS_BYTES, stream, P);
     if constexpr (CONV == 0) {
-        const int deep = O.ragged_ring ? O.ragged_ring == 6 : 8 * ragged <= grid;
-        if (ragged && deep) hipLaunchKernelGGL((k_linear_ragged<BF16, EPI, RES, VT, 6>), dim3(8 * ragged), dim3(LN_THREADS), 6 * RG_SLOT, stream, P);
+        if (ragged && deep) hipLaunchKernelGGL((k_linear_ragged<BF16, EPI, RES, VT, 6>), dim3((8 * ragged) << ksl), dim3(LN_THREADS), 6 * RG_SLOT, stream, P);
         else if (ragged) hipLaunchKernelGGL((k_linear_ragged<BF16, EPI, RES, VT, 3>), dim3(8 * ragged), dim3(LN_THREADS), 3 * RG_SLOT, stream, P);
     }
     DS_HIP_CHECK(hipGetLastError());

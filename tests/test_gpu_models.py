@@ -1091,6 +1091,31 @@ def test_linear_vt_and_fused_fc2_at_benchmark_shapes(gpu, npad):
         worst = max(worst, (got[r0:r0 + 4352].float() - want).abs().max().item() / (1 + want.abs().max().item()))
     assert worst < 1.5e-3, worst
     assert torch.equal(_native.linear_residual(a, w2, b2, gam, res), got)
+    # the ragged round's K split (up to 8 workgroups share the K range of a 128 x 64 piece and the last one to arrive adds
+    # their fp32 partials in K order): launches of different split factors alternate on the same arrival counters and stay
+    # bit-reproducible; against the unsplit kernel only the fp32 summation order of the ragged tiles differs
+    x1 = a[:, :1024].contiguous()
+    w1, b1 = (torch.randn((4096, 1024), generator=g) / 32).half().cuda(), torch.randn(4096, generator=g).half().cuda()
+    first = None
+    try:
+        _native.linear_env(DS_LIN_RAGGED_KSPLIT_MIN="1", DS_LIN_RAGGED_KSPLIT_KEEP="2")  # split the K = 1024 launches too (8 / 8 / 4 / 2 ways)
+        for _ in range(3):
+            outs = (_native.linear_residual(a, w2, b2, gam, res), _native.linear(x1, w1, b1, True), _native.linear_vt(wv, h),
+                    _native.linear(x1, w1[:2048].contiguous(), b1[:2048].contiguous(), False))
+            if first is None:
+                first = outs
+            assert all(torch.equal(o, f) for o, f in zip(outs, first)), "K-split ragged round: run-to-run difference"
+        _native.linear_env(DS_LIN_RAGGED_KSPLIT="1")
+        plain = (_native.linear_residual(a, w2, b2, gam, res), _native.linear(x1, w1, b1, True), _native.linear_vt(wv, h),
+                 _native.linear(x1, w1[:2048].contiguous(), b1[:2048].contiguous(), False))
+    finally:
+        _native.linear_env(DS_LIN_RAGGED_KSPLIT=None, DS_LIN_RAGGED_KSPLIT_MIN=None, DS_LIN_RAGGED_KSPLIT_KEEP=None)
+    assert torch.equal(_native.linear_residual(a, w2, b2, gam, res), first[0])             # the default splits K = 4096 the same way
+    if npad == 1032:                                         # 516 / 1032 / 2064 tiles: ragged rounds of 4 / 8 / 16 tiles
+        assert not all(torch.equal(o, f) for o, f in zip(plain, first)), "the K split was not taken at the benchmark shapes"
+    for o, f in zip(plain, first):
+        assert (o.float() - f.float()).abs().max().item() < 1.5e-3 * (1 + f.float().abs().max().item())
+        assert (o != f).float().mean().item() < 0.02         # only ragged tiles (< 1 % of the outputs) may differ at all
 
 
 def test_preprocess_bicubic_kernel_vs_torch_chain(gpu):

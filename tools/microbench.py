@@ -157,7 +157,7 @@ def linear_ab():
     dev = torch.device("cuda")
     dt = torch.float16
     g = torch.Generator(device="cpu").manual_seed(5)
-    m = 34816
+    m = 32 * int(os.environ.get("DS_MB_NPAD", "1032"))        # token stride of dpt_beit_large_512 at batch 32 (1088 until round 4)
     x = torch.randn(m, 1024, generator=g).to(dev, dt)
     x4 = torch.randn(m, 4096, generator=g).to(dev, dt)
     res = torch.randn(m, 1024, generator=g).to(dev, dt)
@@ -167,19 +167,22 @@ def linear_ab():
         return (torch.randn(n, k, generator=g) * k ** -0.5).to(dev, dt)
     w_qk, w_v, w_p, w_1, w_2 = w_(2048, 1024), w_(1024, 1024), w_(1024, 1024), w_(4096, 1024), w_(1024, 4096)
     b_qk, b_p, b_1, b_2 = (torch.randn(n, generator=g).to(dev, dt) for n in (2048, 1024, 4096, 1024))
-    h3 = x.view(32, 1088, 1024)
+    h3 = x.view(32, m // 32, 1024)
     cases = [
-        ("qk       34816x2048x1024", 2.0 * m * 2048 * 1024, lambda: nat.linear(x, w_qk, b_qk, False), lambda: F.linear(x, w_qk, b_qk)),
-        ("v^T      1024x34816x1024", 2.0 * m * 1024 * 1024, lambda: nat.linear_vt(w_v, h3), lambda: torch.bmm(w_v.unsqueeze(0).expand(32, -1, -1), h3.transpose(1, 2))),
-        ("proj+res 34816x1024x1024", 2.0 * m * 1024 * 1024, lambda: nat.linear_residual(x, w_p, b_p, gam, res), lambda: F.linear(x, w_p, b_p)),
-        ("fc1+gelu 34816x4096x1024", 2.0 * m * 4096 * 1024, lambda: nat.linear(x, w_1, b_1, True), lambda: F.gelu(F.linear(x, w_1, b_1))),
-        ("fc2+res  34816x1024x4096", 2.0 * m * 1024 * 4096, lambda: nat.linear_residual(x4, w_2, b_2, gam, res), lambda: F.linear(x4, w_2, b_2)),
+        (f"qk       {m}x2048x1024", 2.0 * m * 2048 * 1024, lambda: nat.linear(x, w_qk, b_qk, False), lambda: F.linear(x, w_qk, b_qk)),
+        (f"v^T      1024x{m}x1024", 2.0 * m * 1024 * 1024, lambda: nat.linear_vt(w_v, h3), lambda: torch.bmm(w_v.unsqueeze(0).expand(32, -1, -1), h3.transpose(1, 2))),
+        (f"proj+res {m}x1024x1024", 2.0 * m * 1024 * 1024, lambda: nat.linear_residual(x, w_p, b_p, gam, res), lambda: F.linear(x, w_p, b_p)),
+        (f"fc1+gelu {m}x4096x1024", 2.0 * m * 4096 * 1024, lambda: nat.linear(x, w_1, b_1, True), lambda: F.gelu(F.linear(x, w_1, b_1))),
+        (f"fc2+res  {m}x1024x4096", 2.0 * m * 1024 * 4096, lambda: nat.linear_residual(x4, w_2, b_2, gam, res), lambda: F.linear(x4, w_2, b_2)),
     ]
     for name, fl, hip, libf in cases:
-        t = {"ragged": [], "walk": [], "lib": [], "late": []}
+        t = {"ragged": [], "walk": [], "lib": [], "late": [], "nosplit": []}
         for _ in range(3):
             nat.linear_env(DS_LIN_RAGGED="1", DS_LIN_EARLY="1")
             t["ragged"].append(timeit(hip, reps=10, warm=2))
+            nat.linear_env(DS_LIN_RAGGED_KSPLIT="1")
+            t["nosplit"].append(timeit(hip, reps=10, warm=2))
+            nat.linear_env(DS_LIN_RAGGED_KSPLIT=None)
             nat.linear_env(DS_LIN_EARLY="0")
             t["late"].append(timeit(hip, reps=10, warm=2))
             nat.linear_env(DS_LIN_RAGGED="0", DS_LIN_EARLY="1")
@@ -187,13 +190,14 @@ def linear_ab():
             t["lib"].append(timeit(libf, reps=10, warm=2))
         nat.linear_env(DS_LIN_RAGGED="1")
         r, wk, lb, lt = min(t["ragged"]), min(t["walk"]), min(t["lib"]), min(t["late"])
-        print(f"gemm {name}: in-tree {r * 1e3:7.1f} us {fl / r / 1e9:6.0f} TF | prologue after the epilogue (round 2 order) {lt * 1e3:7.1f} us | "
+        print(f"gemm {name}: in-tree {r * 1e3:7.1f} us {fl / r / 1e9:6.0f} TF | ragged round without its K split {min(t['nosplit']) * 1e3:7.1f} us | "
+              f"prologue after the epilogue (round 2 order) {lt * 1e3:7.1f} us | "
               f"without ragged round {wk * 1e3:7.1f} us | library (GEMM only) {lb * 1e3:7.1f} us {fl / lb / 1e9:6.0f} TF", flush=True)
     # the LayerNorm pass behind the fused epilogues reads one operand instead of two
     xs, br = torch.randn(m, 1024, device=dev, dtype=dt), torch.randn(m, 1024, device=dev, dtype=dt)
     t2 = timeit(lambda: nat.residual_layernorm(xs, br, gam, gam, gam, 1e-6))
     t1 = timeit(lambda: nat.residual_layernorm(xs, None, None, gam, gam, 1e-6))
-    print(f"residual_layernorm 34816x1024: with branch {t2 * 1e3:.1f} us, LayerNorm only {t1 * 1e3:.1f} us")
+    print(f"residual_layernorm {m}x1024: with branch {t2 * 1e3:.1f} us, LayerNorm only {t1 * 1e3:.1f} us")
 
 
 def single_shapes(which):
