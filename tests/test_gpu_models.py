@@ -995,9 +995,9 @@ def _lin_ref(x, w, b=None, gamma=None, res=None, gelu=False):
 @pytest.mark.parametrize("dtype,tol", [(torch.float16, 1.5e-3), (torch.bfloat16, 1.2e-2)])
 def test_linear_ragged_round_vt_and_fused_residual(gpu, dtype, tol):
     """The pieces of csrc/ds_linear.hip added in round 3, at small sizes with a small persistent grid (DS_LIN_GRID) so that
-    every path is taken: k_linear_ragged (the last, nearly empty round of tiles rendered as 128 x 64 pieces with K split over
-    the 8 waves and summed through LDS) behind plain / GELU / LayerScale + residual epilogues, a shifted last row panel,
-    K = 128 (some waves get an empty K range); ds_linear_vt (V^T written per batch element by the epilogue) with and without
+    every path is taken: k_linear_ragged (the last, nearly empty round of tiles rendered as 128 x 64 pieces, one LDS-staged
+    GEMM per workgroup; some shapes here also take its two-way K split) behind plain / GELU / LayerScale + residual epilogues, a
+    shifted last row panel, K = 128 (two K-tiles); ds_linear_vt (V^T written per batch element by the epilogue) with and without
     a ragged round.  Against float64 on the same rounded operands; repeated launches bit-identical; ragged on == ragged off
     to rounding."""
     import os
