@@ -583,7 +583,10 @@ __global__ __launch_bounds__(LN_THREADS) void k_linear256(LinParams P)
 // S = slots of the ring: 3 (72 KB: two workgroups per CU, for launches with more pieces than CUs) or 6 (144 KB, one
 // workgroup per CU with five K-tiles in flight: a piece is bound by the latency of its DMA chain, not by its 4 MFMAs per K-tile)
 #define RG_SLOT 24576            // one K-tile in LDS: x rows 0..127 (16 KB) | W rows 0..63 (8 KB)
-template <int BF16, int EPI, int RES, int VT, int S>
+// PIPE = 1 (deep ring only): the fragments of K-tile kt + 1 are requested BEFORE the MFMAs of K-tile kt (two register sets,
+// the loop unrolled by two), and the epilogue's operands (bias, LayerScale factor, residual rows) are requested before the
+// first DMA -- the chain "barrier -> fragment reads -> dependent MFMAs" of a K-tile loses its middle link.
+template <int BF16, int EPI, int RES, int VT, int S, int PIPE = 0>
 __global__ __launch_bounds__(LN_THREADS, S == 3 ? 4 : 2) void k_linear_ragged(LinParams P)
 {
     typedef ln_traits<BF16> TR;
@@ -640,8 +643,67 @@ __global__ __launch_bounds__(LN_THREADS, S == 3 ? 4 : 2) void k_linear_ragged(Li
 #pragma unroll
     for (int r = 0; r < 16; ++r) mine[r] = mine2[r] = 0.f;
 
+    // epilogue operands of this wave's 32 x 32 block (see the epilogue below): with PIPE they are requested here, ahead of every
+    // DMA (vmcnt retires in order: they are the oldest entries, the counted waits of the loop are unaffected)
+    const int e_row = row0 + (wid >> 1) * 32 + l31;
+    const int e_cb = col0 + (wid & 1) * 32 + 8 * hi;
+    V8 e_bv[2], e_gv[2], e_rv[2];
+    if constexpr (PIPE) {
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int col = e_cb + 16 * k;
+            if (P.bias) e_bv[k] = *(const V8 *)((const T *)P.bias + col);
+            if (EPI == 3) e_gv[k] = *(const V8 *)((const T *)P.gamma + col);
+            if (RES >= 1) e_rv[k] = *(const V8 *)((const T *)P.res1 + ln_out_off<VT>(P, e_row, col));
+        }
+    }
 #pragma unroll
     for (int t = 0; t < S - 1; ++t) RG_STAGE(t);
+    if constexpr (PIPE) {
+        static_assert(!PIPE || S == 6, "the pipelined loop is written for the 6-slot ring");
+        V8 fa0[4], fb0[4], fa1[4], fb1[4];
+#define RG_READ(fa_, fb_, kt_)                                                                                           \
+        do {                                                                                                             \
+            const unsigned char *sb_ = lds + ((kt_) % S) * RG_SLOT;                                                      \
+            _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) {                                                           \
+                fa_[ks] = *(const V8 *)(sb_ + offA[ks]);                                                                 \
+                fb_[ks] = *(const V8 *)(sb_ + offB[ks]);                                                                 \
+            }                                                                                                            \
+        } while (0)
+        // K-tile kt: [its fragments were requested one step earlier] wait for this wave's pieces of K-tile kt + 1 (the three
+        // younger K-tiles stay in flight) | barrier: everybody's have landed, and everybody has consumed K-tile kt - 1 (read
+        // in step kt - 2, waited for at the end of it) | stage K-tile kt + 5 into that slot | request the fragments of K-tile
+        // kt + 1 (past the end: a slot holding a clamped re-load, never multiplied) | 4 MFMAs on K-tile kt | wait for them
+#define RG_STEP(ca_, cb_, na_, nb_, kt_)                                                                                 \
+        do {                                                                                                             \
+            LN_WAIT_VM(9);                                                                                               \
+            LN_BARRIER();                                                                                                \
+            RG_STAGE((kt_) + S - 1);                                                                                     \
+            RG_READ(na_, nb_, (kt_) + 1);                                                                                \
+            __builtin_amdgcn_sched_barrier(0);                                                                           \
+            mine = TR::mfma(cb_[0], ca_[0], mine);                                                                       \
+            mine2 = TR::mfma(cb_[1], ca_[1], mine2);                                                                     \
+            mine = TR::mfma(cb_[2], ca_[2], mine);                                                                       \
+            mine2 = TR::mfma(cb_[3], ca_[3], mine2);                                                                     \
+            __builtin_amdgcn_sched_barrier(0);                                                                           \
+            LN_WAIT_LGKM0();                                                                                             \
+            __builtin_amdgcn_sched_barrier(0);                                                                           \
+        } while (0)
+        LN_WAIT_VM(12);                                  // K-tile 0 has landed (1 .. 4 in flight)
+        LN_BARRIER();
+        RG_READ(fa0, fb0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        LN_WAIT_LGKM0();
+        __builtin_amdgcn_sched_barrier(0);
+        int kt = 0;
+        for (; kt + 1 < nt; kt += 2) {
+            RG_STEP(fa0, fb0, fa1, fb1, kt);
+            RG_STEP(fa1, fb1, fa0, fb0, kt + 1);
+        }
+        if (kt < nt) RG_STEP(fa0, fb0, fa1, fb1, kt);
+#undef RG_STEP
+#undef RG_READ
+    } else
     for (int kt = 0; kt < nt; ++kt) {
         // this wave's pieces of K-tile kt have landed (the S - 2 younger K-tiles, 3 DMAs each, stay in flight)
         if constexpr (S == 3) LN_WAIT_VM(3); else LN_WAIT_VM(12);
@@ -736,13 +798,13 @@ __global__ __launch_bounds__(LN_THREADS, S == 3 ? 4 : 2) void k_linear_ragged(Li
         const int col = cb + 16 * k;
         const size_t off = ln_out_off<VT>(P, row, col);
         V8 bv, gv, rv;
-        if (bias) bv = *(const V8 *)(bias + col);
+        if (bias) bv = PIPE ? e_bv[k] : *(const V8 *)(bias + col);
         else {
 #pragma unroll
             for (int t = 0; t < 8; ++t) bv[t] = (T)0.f;
         }
-        if (EPI == 3) gv = *(const V8 *)((const T *)P.gamma + col);
-        if (RES >= 1) rv = *(const V8 *)(r1 + off);
+        if (EPI == 3) gv = PIPE ? e_gv[k] : *(const V8 *)((const T *)P.gamma + col);
+        if (RES >= 1) rv = PIPE ? e_rv[k] : *(const V8 *)(r1 + off);
         float v[8];
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
@@ -774,8 +836,9 @@ __global__ __launch_bounds__(LN_THREADS, S == 3 ? 4 : 2) void k_linear_ragged(Li
 //   DS_LIN_RAGGED / DS_LIN_RAGGED_DEN / DS_LIN_RAGGED_RING   the ragged round: on / "at most 1/DEN full" / ring depth 3 or 6
 //   DS_LIN_RAGGED_KSPLIT   the ragged round: at most this many workgroups share the K range of a piece (default 8, 1 = no split;
 //                          the values differ by the fp32 summation order, like every other split of a contraction), for
+//   DS_LIN_RAGGED_PIPE     the ragged round (deep ring): 1 (default) software-pipelined fragment reads + early epilogue operands
 //   DS_LIN_RAGGED_KSPLIT_MIN / _KEEP   contractions of at least MIN K-tiles (default 32), every workgroup keeping >= KEEP (default 8)
-struct LinOptions { int early, grid, ragged, ragged_den, ragged_ring, ragged_ksplit, ragged_ksplit_min, ragged_ksplit_keep; };
+struct LinOptions { int early, grid, ragged, ragged_den, ragged_ring, ragged_ksplit, ragged_ksplit_min, ragged_ksplit_keep, ragged_pipe; };
 static LinOptions g_lin_options;
 static std::atomic<int> g_lin_options_state{0};
 static void ln_read_options()
@@ -791,6 +854,7 @@ static void ln_read_options()
     o.ragged_ksplit_min = geti("DS_LIN_RAGGED_KSPLIT_MIN", 32);
     o.ragged_ksplit_keep = geti("DS_LIN_RAGGED_KSPLIT_KEEP", 8);
     if (o.ragged_ksplit_keep < 1) o.ragged_ksplit_keep = 1;
+    o.ragged_pipe = geti("DS_LIN_RAGGED_PIPE", 1);
     g_lin_options = o;
     g_lin_options_state.store(1, std::memory_order_release);
 }
@@ -839,6 +903,7 @@ static int ln_launch(ds_ctx *ctx, const LinParams &P0, hipStream_t stream)
         if constexpr (CONV == 0) {
             DS_HIP_CHECK(hipFuncSetAttribute((const void *)k_linear_ragged<BF16, EPI, RES, VT, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * RG_SLOT));
             DS_HIP_CHECK(hipFuncSetAttribute((const void *)k_linear_ragged<BF16, EPI, RES, VT, 6>, hipFuncAttributeMaxDynamicSharedMemorySize, 6 * RG_SLOT));
+            DS_HIP_CHECK(hipFuncSetAttribute((const void *)k_linear_ragged<BF16, EPI, RES, VT, 6, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 6 * RG_SLOT));
         }
         attr_done.fetch_or(bit, std::memory_order_relaxed);
     }
@@ -886,7 +951,8 @@ static int ln_launch(ds_ctx *ctx, const LinParams &P0, hipStream_t stream)
     P.rg_ksl = ksl;
     hipLaunchKernelGGL(fn, dim3(P.n_main < grid ? P.n_main : grid), dim3(LN_THREADS), LN_LDS_BYTES, stream, P);
     if constexpr (CONV == 0) {
-        if (ragged && deep) hipLaunchKernelGGL((k_linear_ragged<BF16, EPI, RES, VT, 6>), dim3((8 * ragged) << ksl), dim3(LN_THREADS), 6 * RG_SLOT, stream, P);
+        if (ragged && deep && O.ragged_pipe) hipLaunchKernelGGL((k_linear_ragged<BF16, EPI, RES, VT, 6, 1>), dim3((8 * ragged) << ksl), dim3(LN_THREADS), 6 * RG_SLOT, stream, P);
+        else if (ragged && deep) hipLaunchKernelGGL((k_linear_ragged<BF16, EPI, RES, VT, 6>), dim3((8 * ragged) << ksl), dim3(LN_THREADS), 6 * RG_SLOT, stream, P);
         else if (ragged) hipLaunchKernelGGL((k_linear_ragged<BF16, EPI, RES, VT, 3>), dim3(8 * ragged), dim3(LN_THREADS), 3 * RG_SLOT, stream, P);
     }
     DS_HIP_CHECK(hipGetLastError());

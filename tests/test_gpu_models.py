@@ -1004,7 +1004,7 @@ def test_linear_ragged_round_vt_and_fused_residual(gpu, dtype, tol):
     from src import _native
     g = torch.Generator().manual_seed(77)
     mk = lambda *s: torch.randn(s, generator=g)  # noqa: E731
-    old = {k: os.environ.get(k) for k in ("DS_LIN_GRID", "DS_LIN_RAGGED", "DS_LIN_EARLY", "DS_LIN_RAGGED_RING")}
+    old = {k: os.environ.get(k) for k in ("DS_LIN_GRID", "DS_LIN_RAGGED", "DS_LIN_EARLY", "DS_LIN_RAGGED_RING", "DS_LIN_RAGGED_PIPE")}
     try:
         # (rows, out, in, grid): tiles % grid <= grid / 4 -> a ragged round of 1 .. 4 tiles
         for (m, n, k, grid) in [(4352, 256, 384, 8), (2304, 512, 1024, 8), (2637, 768, 640, 16), (4352, 256, 128, 8), (8448, 256, 256, 32)]:
@@ -1038,13 +1038,13 @@ def test_linear_ragged_round_vt_and_fused_residual(gpu, dtype, tol):
         hv, wv = mk(4, 320, 256).to(dtype).cuda(), (mk(512, 256) * 256 ** -0.5).to(dtype).cuda()
         cv = nn.Conv2d(128, 256, 3, padding=1).to(dtype).cuda()
         xc, rc = (mk(2, c, 37, 41).to(dtype).cuda().contiguous(memory_format=torch.channels_last) for c in (128, 256))
-        for early, ring in (("1", "3"), ("0", "3"), ("1", "6"), ("0", "6")):
-            _native.linear_env(DS_LIN_EARLY=early, DS_LIN_RAGGED_RING=ring)
+        for early, ring, pipe in (("1", "3", "1"), ("0", "3", "1"), ("1", "6", "1"), ("0", "6", "1"), ("1", "6", "0")):
+            _native.linear_env(DS_LIN_EARLY=early, DS_LIN_RAGGED_RING=ring, DS_LIN_RAGGED_PIPE=pipe)
             # every epilogue variant whose store count the early prologue's waits rely on: GELU, plain without a bias, LayerScale +
             # residual, V^T, convolution with ReLU and with two residual operands
             outs.append((_native.linear(x, w, b, True), _native.linear(x, w, None, False), _native.linear_residual(x, w, b, gam, res),
                          _native.linear_vt(wv, hv), _native.conv3x3(cv, xc, relu=True), _native.conv3x3(cv, xc, res1=rc, res2=rc)))
-        _native.linear_env(DS_LIN_EARLY=None, DS_LIN_RAGGED_RING=None)
+        _native.linear_env(DS_LIN_EARLY=None, DS_LIN_RAGGED_RING=None, DS_LIN_RAGGED_PIPE=None)
         for o in outs[1:]:
             assert all(torch.equal(a, c) for a, c in zip(o, outs[0])), "DS_LIN_EARLY / ring depth changed the values"
         assert (outs[0][1].double() - _lin_ref(x, w)).abs().max().item() < tol * 10

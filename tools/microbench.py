@@ -176,13 +176,15 @@ def linear_ab():
         (f"fc2+res  {m}x1024x4096", 2.0 * m * 1024 * 4096, lambda: nat.linear_residual(x4, w_2, b_2, gam, res), lambda: F.linear(x4, w_2, b_2)),
     ]
     for name, fl, hip, libf in cases:
-        t = {"ragged": [], "walk": [], "lib": [], "late": [], "nosplit": []}
+        t = {"ragged": [], "walk": [], "lib": [], "late": [], "nosplit": [], "nopipe": []}
         for _ in range(3):
             nat.linear_env(DS_LIN_RAGGED="1", DS_LIN_EARLY="1")
             t["ragged"].append(timeit(hip, reps=10, warm=2))
             nat.linear_env(DS_LIN_RAGGED_KSPLIT="1")
             t["nosplit"].append(timeit(hip, reps=10, warm=2))
-            nat.linear_env(DS_LIN_RAGGED_KSPLIT=None)
+            nat.linear_env(DS_LIN_RAGGED_KSPLIT=None, DS_LIN_RAGGED_PIPE="0")
+            t["nopipe"].append(timeit(hip, reps=10, warm=2))
+            nat.linear_env(DS_LIN_RAGGED_PIPE=None)
             nat.linear_env(DS_LIN_EARLY="0")
             t["late"].append(timeit(hip, reps=10, warm=2))
             nat.linear_env(DS_LIN_RAGGED="0", DS_LIN_EARLY="1")
@@ -190,7 +192,7 @@ def linear_ab():
             t["lib"].append(timeit(libf, reps=10, warm=2))
         nat.linear_env(DS_LIN_RAGGED="1")
         r, wk, lb, lt = min(t["ragged"]), min(t["walk"]), min(t["lib"]), min(t["late"])
-        print(f"gemm {name}: in-tree {r * 1e3:7.1f} us {fl / r / 1e9:6.0f} TF | ragged round without its K split {min(t['nosplit']) * 1e3:7.1f} us | "
+        print(f"gemm {name}: in-tree {r * 1e3:7.1f} us {fl / r / 1e9:6.0f} TF | ragged round without its K split {min(t['nosplit']) * 1e3:7.1f} us, without pipelined reads {min(t['nopipe']) * 1e3:7.1f} us | "
               f"prologue after the epilogue (round 2 order) {lt * 1e3:7.1f} us | "
               f"without ragged round {wk * 1e3:7.1f} us | library (GEMM only) {lb * 1e3:7.1f} us {fl / lb / 1e9:6.0f} TF", flush=True)
     # the LayerNorm pass behind the fused epilogues reads one operand instead of two
