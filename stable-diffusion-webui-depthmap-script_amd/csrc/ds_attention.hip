@@ -673,6 +673,300 @@ __global__ __launch_bounds__(AT_THREADS, NQB == 2 ? 2 : ((ABL & 4096) ? 4 : 3)) 
     }
 }
 
+#ifdef DS_EXPERIMENTS
+// ---- generation 3: PREPARED at the end of round 4 (no GPU time was left to run it), compiled only in -DDS_EXPERIMENTS builds
+// and selected there by DS_ATT_GEN=3 for the shapes generation 2 serves with 32-row waves.  Motivation: in
+// generation 2 a wave's tile is one serial chain -- S MFMAs -> softmax -> P.V MFMAs -- and the counters show the vector pipe
+// (53 % of the cycles) and the matrix pipe (38 %) taking turns.  Here the chain is skewed by one tile INSIDE the wave:
+//     iteration t:  S(t + 1) MFMAs   beside   row maxima + first half of the exponentials of tile t      (phase A)
+//                   P.V(t) MFMAs of key block 0   beside   the second half of the exponentials             (phase B)
+//                   P.V(t) MFMAs of key block 1                                                             (phase C)
+// so that the vector work of a tile runs in the shadow of MFMAs that do not depend on it.  Cost: a second set of S accumulators
+// (two waves per SIMD instead of three) and K staged one tile ahead of V^T.  Operands, work order, LDS image, bias operand,
+// deferred maximum and every arithmetic operation are those of generation 2 with NQB = 1: the results must be bit-identical.
+// LDS: K[2] | V^T[2] as before.  At the top of iteration t the buffers hold K(t + 1) in K[(t + 1) & 1] and V^T(t) in V[t & 1];
+// K(t + 2) and V^T(t + 1) are fetched into registers during the iteration and stashed at its end into K[t & 1] (last read for
+// S(t), one iteration ago) and V[(t + 1) & 1] (last read for P.V(t - 1)): one barrier per tile, no hazard inside an iteration.
+template <int BF16, int HAS_BIAS>
+__global__ __launch_bounds__(AT_THREADS, 2) void k_attention_fwd3(AttnParams P)
+{
+    typedef at_traits<BF16> TR;
+    typedef typename TR::T T;
+    typedef typename TR::V8 V8;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[4 * AT2_TILE];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, hi = lane >> 5, l31 = lane & 31;
+    int L = blockIdx.x;
+    if (P.chunk > 0) {
+        L = (int)(blockIdx.x & 7) * P.chunk + (int)(blockIdx.x >> 3);
+        if (L >= P.total) return;
+    }
+    int qblk, b, h;
+    if (P.flags & 2) { b = L % P.B; qblk = (L / P.B) % P.nq; h = L / (P.B * P.nq); }
+    else { qblk = L % P.nq; b = (L / P.nq) % P.B; h = L / (P.nq * P.B); }
+    const int q0 = qblk * 128 + wave * 32;
+    const int Np = P.Np, H = P.H;
+    const int Np64 = (Np + 63) & ~63;
+    const size_t tok_stride = (size_t)2 * H * AT_D;
+    const T *qk = (const T *)P.qk + (size_t)b * Np * tok_stride;
+    const T *q_base = qk + (size_t)h * AT_D;
+    const T *k_base = qk + (size_t)(H + h) * AT_D;
+    const T *vt = (const T *)P.vt + ((size_t)b * H + h) * AT_D * (size_t)Np;
+    T *out_base = (T *)P.out + (size_t)b * Np * (size_t)(H * AT_D) + (size_t)h * AT_D;
+    const bool wave_live = q0 < P.n_valid;
+    if (!wave_live && q0 < Np) {
+        const int row = q0 + lane;
+        if (row < Np && lane < 32) {
+            uint4 z = make_uint4(0, 0, 0, 0);
+#pragma unroll
+            for (int c = 0; c < 8; c++) *reinterpret_cast<uint4 *>(out_base + (size_t)row * (H * AT_D) + 8 * c) = z;
+        }
+    }
+    V8 qf[4];
+    {
+        const int qrow = min(q0 + l31, Np - 1);
+        const T *qp = q_base + (size_t)qrow * tok_stride + 8 * hi;
+#pragma unroll
+        for (int s = 0; s < 4; s++) qf[s] = *reinterpret_cast<const V8 *>(qp + 16 * s);
+    }
+    V8 ident[2];
+#pragma unroll
+    for (int s = 0; s < 2; s++)
+#pragma unroll
+        for (int t = 0; t < 8; t++) ident[s][t] = TR::from_f32((16 * s + 8 * hi + t) == l31 ? 1.0f : 0.0f);
+    f32x16 o_acc[2];
+#pragma unroll
+    for (int d = 0; d < 2; d++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) o_acc[d][r] = 0.f;
+    float m_run = -__builtin_inff(), l_run = 0.f;
+
+    const int st_row = tid >> 3, st_chunk = tid & 7;
+    u32x4 kreg0, kreg1, vreg0, vreg1;
+    const __amdgpu_buffer_rsrc_t rs_k = __builtin_amdgcn_make_buffer_rsrc(
+        (void *)k_base, 0, (int)(((size_t)Np * tok_stride - (size_t)(H + h) * AT_D) * sizeof(T)), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_v = __builtin_amdgcn_make_buffer_rsrc((void *)vt, 0, (int)((size_t)AT_D * Np * sizeof(T)), 0x00020000);
+    const int vo_k = (int)((st_row * tok_stride + 8 * st_chunk) * sizeof(T));
+    const int vo_v = (int)((st_row * Np + 8 * st_chunk) * sizeof(T));
+    const int so_k32 = (int)(32 * tok_stride * sizeof(T)), so_r32 = (int)(32 * Np * sizeof(T));
+#define A3_FETCH_K(kt_) do {                                                                                           \
+        const int sk_ = __builtin_amdgcn_readfirstlane((kt_) * AT_KB * (int)(tok_stride * sizeof(T)));                  \
+        kreg0 = __builtin_amdgcn_raw_buffer_load_b128(rs_k, vo_k, sk_, 0);                                              \
+        kreg1 = __builtin_amdgcn_raw_buffer_load_b128(rs_k, vo_k, sk_ + so_k32, 0);                                     \
+    } while (0)
+#define A3_FETCH_V(kt_) do {                                                                                           \
+        const int sv_ = __builtin_amdgcn_readfirstlane((kt_) * AT_KB * (int)sizeof(T));                                 \
+        vreg0 = __builtin_amdgcn_raw_buffer_load_b128(rs_v, vo_v, sv_, 0);                                              \
+        vreg1 = __builtin_amdgcn_raw_buffer_load_b128(rs_v, vo_v, sv_ + so_r32, 0);                                     \
+    } while (0)
+    const int vst_lo = ((st_chunk & ~1) << 4) + ((st_chunk & 1) << 3), vst_hi = vst_lo + 16;
+#define A3_STASH_K(buf_) do {                                                                                          \
+        *reinterpret_cast<u32x4 *>(smem + (buf_) * AT2_TILE + st_row * AT2_ROW + (st_chunk << 4)) = kreg0;              \
+        *reinterpret_cast<u32x4 *>(smem + (buf_) * AT2_TILE + (st_row + 32) * AT2_ROW + (st_chunk << 4)) = kreg1;       \
+    } while (0)
+#define A3_STASH_V(buf_) do {                                                                                          \
+        unsigned char *vd0_ = smem + (2 + (buf_)) * AT2_TILE + st_row * AT2_ROW;                                        \
+        unsigned char *vd1_ = vd0_ + 32 * AT2_ROW;                                                                      \
+        *reinterpret_cast<uint2 *>(vd0_ + vst_lo) = make_uint2(vreg0.x, vreg0.y);                                       \
+        *reinterpret_cast<uint2 *>(vd0_ + vst_hi) = make_uint2(vreg0.z, vreg0.w);                                       \
+        *reinterpret_cast<uint2 *>(vd1_ + vst_lo) = make_uint2(vreg1.x, vreg1.y);                                       \
+        *reinterpret_cast<uint2 *>(vd1_ + vst_hi) = make_uint2(vreg1.z, vreg1.w);                                       \
+    } while (0)
+    u32x4 breg[4];
+    const int n_kt = Np64 / AT_KB;
+    const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc(
+        (void *)(HAS_BIAS ? (const T *)P.bias + (size_t)h * Np64 * (size_t)Np64 : (const T *)P.qk), 0,
+        (int)((size_t)Np64 * Np64 * sizeof(T)), 0x00020000);
+    const int vo_b = (int)((((size_t)(q0 / 32) * n_kt) * 2048 + (size_t)lane * 8) * sizeof(T));
+#define A3_FETCH_BIAS(kt_) do {                                                                                        \
+        const int sb_ = __builtin_amdgcn_readfirstlane((kt_) * (int)(2048 * sizeof(T)));                                \
+        _Pragma("unroll") for (int c_i = 0; c_i < 4; c_i++)                                                             \
+            breg[c_i] = __builtin_amdgcn_raw_buffer_load_b128(rs_b, vo_b + c_i * 1024, sb_, 0);                         \
+    } while (0)
+    // S^T of one tile into sacc_[2]: the two key blocks' accumulation chains alternate (a dependent MFMA waits for its
+    // predecessor: two chains keep the pipe fed); the bias of THAT tile is in breg
+#define A3_S(sacc_, kbuf_) do {                                                                                        \
+        const unsigned char *s_k_ = smem + (kbuf_) * AT2_TILE;                                                          \
+        if (HAS_BIAS) {                                                                                                 \
+            f32x16 z_;                                                                                                  \
+            _Pragma("unroll") for (int r_ = 0; r_ < 16; r_++) z_[r_] = 0.f;                                             \
+            union { u32x4 u; V8 v; } b00_, b01_, b10_, b11_;                                                            \
+            b00_.u = breg[0]; b01_.u = breg[1]; b10_.u = breg[2]; b11_.u = breg[3];                                     \
+            sacc_[0] = TR::mfma(b00_.v, ident[0], z_);                                                                  \
+            sacc_[1] = TR::mfma(b10_.v, ident[0], z_);                                                                  \
+            sacc_[0] = TR::mfma(b01_.v, ident[1], sacc_[0]);                                                            \
+            sacc_[1] = TR::mfma(b11_.v, ident[1], sacc_[1]);                                                            \
+        } else {                                                                                                        \
+            _Pragma("unroll") for (int r_ = 0; r_ < 16; r_++) sacc_[0][r_] = sacc_[1][r_] = 0.f;                        \
+        }                                                                                                               \
+        _Pragma("unroll") for (int s_ = 0; s_ < 4; s_++)                                                                \
+        _Pragma("unroll") for (int kb_ = 0; kb_ < 2; kb_++) {                                                           \
+            const V8 kf_ = *reinterpret_cast<const V8 *>(s_k_ + (kb_ * 32 + l31) * AT2_ROW + (hi << 4) + (s_ << 5));    \
+            sacc_[kb_] = TR::mfma(kf_, qf[s_], sacc_[kb_]);                                                             \
+        }                                                                                                               \
+    } while (0)
+
+    const int ntiles = (P.n_valid + AT_KB - 1) / AT_KB;
+    const float c_ = P.c_exp;
+    const float thr_x = AT2_THR / c_;
+    f32x16 sA[2], sB[2];
+    // prologue: K(0), V^T(0) [, K(1)] into LDS, S(0) into sA, the bias of tile 1 requested
+    A3_FETCH_K(0);
+    A3_FETCH_V(0);
+    if (HAS_BIAS && wave_live) A3_FETCH_BIAS(0);
+    A3_STASH_K(0);
+    A3_STASH_V(0);
+    if (ntiles > 1) {
+        A3_FETCH_K(1);
+        A3_STASH_K(1);
+    }
+    __syncthreads();
+    if (wave_live) {
+        A3_S(sA, 0);
+        if (HAS_BIAS && ntiles > 1) A3_FETCH_BIAS(1);
+    }
+    // iteration 0 ends by stashing K(2) over K(0): every wave must be done with S(0) first (found by the tile-level model,
+    // tools/emulate_attention_skew.py, which flags a buffer written in the barrier interval in which it is read)
+    __syncthreads();
+    // one iteration: tile t from scur_ (S(t), complete), S(t + 1) into snxt_ when NEXT
+    auto iter = [&](f32x16 (&scur)[2], f32x16 (&snxt)[2], const int t, auto next_tag, auto masked_tag) __attribute__((always_inline)) {
+        constexpr bool NEXT = decltype(next_tag)::value, MASKED = decltype(masked_tag)::value;
+        const bool more2 = t + 2 < ntiles;
+        if (more2) A3_FETCH_K(t + 2);
+        if (NEXT) A3_FETCH_V(t + 1);
+        if (wave_live) {
+            const int key0 = t * AT_KB;
+            const unsigned char *s_v = smem + (2 + (t & 1)) * AT2_TILE;
+            V8 pf[2][2];
+            if (MASKED) {
+#pragma unroll
+                for (int kb = 0; kb < 2; kb++)
+#pragma unroll
+                    for (int r = 0; r < 16; r++)
+                        if (key0 + kb * 32 + at_crow(r, hi) >= P.n_valid) scur[kb][r] = -__builtin_inff();
+            }
+            // ---- phase A: S(t + 1) MFMAs beside the row maximum and the exponentials of key block 0 ----
+            if (NEXT) A3_S(snxt, (t + 1) & 1);
+            float mx = at_max3(scur[0][0], scur[1][0], scur[0][1]);
+            mx = at_max3(mx, scur[1][1], scur[0][2]);
+            mx = at_max3(mx, scur[1][2], scur[0][3]);
+#pragma unroll
+            for (int r = 3; r < 15; r += 2) {
+                mx = at_max3(mx, scur[1][r], scur[0][r + 1]);
+                mx = at_max3(mx, scur[1][r + 1], scur[0][r + 2]);
+            }
+            mx = at_max3(mx, scur[1][15], mx);
+            {   // the other 32 keys of the row sit in lane ^ 32: one v_permlane32_swap (no LDS round trip in the chain)
+                const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
+                mx = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+            }
+            const bool grow = mx > m_run + thr_x;
+            const float mn = grow ? mx : m_run;
+            const float alpha = __builtin_amdgcn_exp2f((m_run - mn) * c_);
+            m_run = mn;
+            const float mc = -mn * c_;
+            float l0 = 0.f, l1 = 0.f;
+#define A3_EXP(kb_) do {                                                                                               \
+                _Pragma("unroll") for (int j_ = 0; j_ < 2; j_++)                                                        \
+                _Pragma("unroll") for (int t_ = 0; t_ < 8; t_ += 2) {                                                   \
+                    const float p0_ = __builtin_amdgcn_exp2f(__builtin_fmaf(scur[kb_][8 * j_ + t_], c_, mc));           \
+                    const float p1_ = __builtin_amdgcn_exp2f(__builtin_fmaf(scur[kb_][8 * j_ + t_ + 1], c_, mc));       \
+                    pf[kb_][j_][t_] = TR::from_f32(p0_);                                                                \
+                    pf[kb_][j_][t_ + 1] = TR::from_f32(p1_);                                                            \
+                    l0 += p0_; l1 += p1_;                                                                               \
+                }                                                                                                       \
+            } while (0)
+            A3_EXP(0);
+            // (the probabilities of key block 0 are only consumed behind the branches below: without this use the compiler
+            // sinks their whole computation past them, out of the MFMAs' shadow)
+            asm volatile("" :: "v"(pf[0][0]), "v"(pf[0][1]), "v"(l0), "v"(l1), "v"(alpha));
+            if (NEXT) {
+                // 12 (8 without a bias) MFMAs, each followed by its share of the ~80 vector instructions above
+#pragma unroll
+                for (int g = 0; g < (HAS_BIAS ? 12 : 8); g++) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);       // one MFMA
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);       // the K fragment of the next one
+                    __builtin_amdgcn_sched_group_barrier(0x002, HAS_BIAS ? 7 : 10, 0);   // vector work
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            // breg is free: the bias of tile t + 2 (past the last tile the descriptor returns zeros or the next query block's
+            // first tile: never used -- no branch here, the phases stay in straight-line code)
+            if (HAS_BIAS && NEXT) A3_FETCH_BIAS(t + 2);
+            // the running maximum moved for some query of the wave: rescale (rare after the first tiles)
+            if (__any(grow)) {
+#pragma unroll
+                for (int d = 0; d < 2; d++)
+#pragma unroll
+                    for (int r = 0; r < 16; r++) o_acc[d][r] *= alpha;
+            }
+            // ---- phase B: P.V of key block 0 beside the exponentials of key block 1; phase C: P.V of key block 1 ----
+#define A3_PV(kb_) do {                                                                                                \
+                _Pragma("unroll") for (int j_ = 0; j_ < 2; j_++)                                                        \
+                _Pragma("unroll") for (int d_ = 0; d_ < 2; d_++) {                                                      \
+                    const V8 vf_ = *reinterpret_cast<const V8 *>(s_v + (d_ * 32 + l31) * AT2_ROW + (hi << 4) + (((kb_) * 4 + j_ * 2) << 4)); \
+                    o_acc[d_] = TR::mfma(vf_, pf[kb_][j_], o_acc[d_]);                                                  \
+                }                                                                                                       \
+            } while (0)
+            A3_PV(0);
+            A3_EXP(1);
+            __builtin_amdgcn_sched_group_barrier(0x100, 4, 1);           // the four V^T fragments of key block 0
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+                __builtin_amdgcn_sched_group_barrier(0x002, 14, 1);      // a quarter of the exponentials of key block 1
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 1);       // one P.V MFMA of key block 0
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            A3_PV(1);
+            l_run = l_run * alpha + (l0 + l1);
+#undef A3_EXP
+#undef A3_PV
+        }
+        if (more2) A3_STASH_K(t & 1);
+        if (NEXT) A3_STASH_V((t + 1) & 1);
+        __syncthreads();
+    };
+    const bool pad_keys = (P.n_valid & (AT_KB - 1)) != 0;
+    const int ntl = ntiles - 1;
+    int t = 0;
+    for (; t + 1 < ntl; t += 2) {
+        iter(sA, sB, t, std::true_type(), std::false_type());
+        iter(sB, sA, t + 1, std::true_type(), std::false_type());
+    }
+    if (t < ntl) {
+        iter(sA, sB, t, std::true_type(), std::false_type());
+        if (pad_keys) iter(sB, sA, ntl, std::false_type(), std::true_type());
+        else iter(sB, sA, ntl, std::false_type(), std::false_type());
+    } else {
+        if (pad_keys) iter(sA, sB, ntl, std::false_type(), std::true_type());
+        else iter(sA, sB, ntl, std::false_type(), std::false_type());
+    }
+#undef A3_S
+#undef A3_FETCH_BIAS
+#undef A3_STASH_V
+#undef A3_STASH_K
+#undef A3_FETCH_V
+#undef A3_FETCH_K
+    if (!wave_live) return;
+    {
+        const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+        const float inv = 1.0f / l_tot;
+        const int qrow = q0 + l31;
+        if (qrow < Np) {
+            T *op = out_base + (size_t)qrow * (size_t)(H * AT_D);
+#pragma unroll
+            for (int d = 0; d < 2; d++)
+#pragma unroll
+                for (int g = 0; g < 4; g++) {
+                    T v4[4];
+#pragma unroll
+                    for (int tt = 0; tt < 4; tt++) v4[tt] = TR::from_f32(o_acc[d][4 * g + tt] * inv);
+                    *reinterpret_cast<uint2 *>(op + d * 32 + 8 * g + 4 * hi) = *reinterpret_cast<const uint2 *>(v4);
+                }
+        }
+    }
+}
+#endif
+
 // bias operand of version 2: [H][Np/32][Np/64][4 chunks][64 lanes][8], values bias / scale (scale = 1/8: exact)
 template <int BF16>
 __global__ void k_attention_bias_pack2(const float *__restrict__ bias, typename at_traits<BF16>::T *__restrict__ out,
@@ -799,7 +1093,14 @@ DS_API int ds_attention_fwd(ds_ctx *ctx, const void *qk, const void *vt, const v
 #else
 #define A2_EXPERIMENT(BF_, BI_)
 #endif
+#ifdef DS_EXPERIMENTS
+        static const int gen_env = getenv("DS_ATT_GEN") ? atoi(getenv("DS_ATT_GEN")) : 2;
+#define A3_TRY(BF_, BI_) if (gen_env == 3 && nqb == 1) hipLaunchKernelGGL((k_attention_fwd3<BF_, BI_>), grid2, dim3(AT_THREADS), 0, st2, P); else
+#else
+#define A3_TRY(BF_, BI_)
+#endif
 #define A2_LAUNCH(BF_, BI_) do {                                                                                       \
+            A3_TRY(BF_, BI_)                                                                                            \
             A2_EXPERIMENT(BF_, BI_)                                                                                     \
             if (nqb == 1 && late) hipLaunchKernelGGL((k_attention_fwd2<BF_, BI_, 1, 256 + 4096>), grid2, dim3(AT_THREADS), 0, st2, P); \
             else if (nqb == 1) hipLaunchKernelGGL((k_attention_fwd2<BF_, BI_, 1, 256>), grid2, dim3(AT_THREADS), 0, st2, P); \
