@@ -1,6 +1,7 @@
 """Build libdepthstereo_hip.so (gfx950) in-tree with hipcc.
 
     python build_native.py [--force]
+    DS_EXPERIMENTS=1 python build_native.py [--force]      -> libdepthstereo_hip_experiments.so (load it with DS_NATIVE_LIB=<path>)
 
 Flags that matter for bit-exactness: -ffp-contract=off (no FMA contraction: every float64 operation
 rounds like numpy/numba), no -ffast-math.  f32/f64 division and sqrt are the correctly rounded
@@ -13,7 +14,10 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-OUT = os.path.join(HERE, "libdepthstereo_hip.so")
+EXPERIMENTS = bool(os.environ.get("DS_EXPERIMENTS"))
+# the experiments build is a SECOND library beside the product one (src/_native.py loads it only when DS_NATIVE_LIB names it)
+OUT = os.path.join(HERE, "libdepthstereo_hip_experiments.so" if EXPERIMENTS else "libdepthstereo_hip.so")
+OBJ_DIR = os.path.join(HERE, "build", "experiments") if EXPERIMENTS else os.path.join(HERE, "build")
 SOURCES = ["ds_api.hip", "ds_stereo.hip", "ds_stereo_polylines.hip", "ds_normalmap.hip", "ds_attention.hip", "ds_encoder_ops.hip", "ds_boost.hip", "ds_heatmap.hip", "ds_linear.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-fPIC",
          "-fvisibility=hidden", "-Wall", "-Wno-unused-function",
@@ -21,9 +25,10 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fn
          "-mllvm", "-amdgpu-mfma-vgpr-form=1"]
 
 
-if os.environ.get("DS_EXPERIMENTS"):
-    # timing ablations / superseded kernel generations (DS_ATT_ABLATE, DS_ATT_V1, DS_LIN_ABLATE, DS_PL_DEBUG ...): some of them
-    # produce WRONG results by design, so they are compiled only on request and never into the default library
+if EXPERIMENTS:
+    # timing ablations, superseded kernel generations and kernels that have not run on hardware yet (DS_ATT_ABLATE, DS_ATT_V1,
+    # DS_ATT_GEN=3, DS_LIN_ABLATE, DS_PL_DEBUG ...): some of them produce WRONG results by design, so they are compiled only on
+    # request, into a library of their own, never into the default one
     FLAGS.append("-DDS_EXPERIMENTS")
 
 
@@ -47,9 +52,9 @@ def build(force=False, verbose=True):
         return OUT
     objs = []
     procs = []
-    os.makedirs(os.path.join(HERE, "build"), exist_ok=True)
+    os.makedirs(OBJ_DIR, exist_ok=True)
     for s in SOURCES:
-        o = os.path.join(HERE, "build", s.replace(".hip", ".o"))
+        o = os.path.join(OBJ_DIR, s.replace(".hip", ".o"))
         cmd = [hipcc()] + FLAGS + ["-c", os.path.join(CSRC, s), "-o", o]
         if verbose:
             print(" ".join(cmd), flush=True)

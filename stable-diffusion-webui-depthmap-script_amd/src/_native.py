@@ -13,7 +13,8 @@ import threading
 import numpy as np
 
 _PKG_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-LIB_PATH = os.path.join(_PKG_ROOT, "libdepthstereo_hip.so")
+# DS_NATIVE_LIB: another build of the same library (the -DDS_EXPERIMENTS one of build_native.py, for A/B runs on hardware)
+LIB_PATH = os.environ.get("DS_NATIVE_LIB") or os.path.join(_PKG_ROOT, "libdepthstereo_hip.so")
 
 DS_DEPTH_U16, DS_DEPTH_F32, DS_DEPTH_F64 = 0, 1, 2
 FILL_IDS = {"none": 0, "naive": 1, "naive_interpolating": 2, "polylines_soft": 3, "polylines_sharp": 4}
