@@ -674,8 +674,11 @@ __global__ __launch_bounds__(AT_THREADS, NQB == 2 ? 2 : ((ABL & 4096) ? 4 : 3)) 
 }
 
 #ifdef DS_EXPERIMENTS
-// ---- generation 3: PREPARED at the end of round 4 (no GPU time was left to run it), compiled only in -DDS_EXPERIMENTS builds
-// and selected there by DS_ATT_GEN=3 for the shapes generation 2 serves with 32-row waves.  Motivation: in
+// ---- generation 3: built at the end of round 4, compiled only in -DDS_EXPERIMENTS builds and selected there by DS_ATT_GEN=3
+// for the shapes generation 2 serves with 32-row waves.  MEASURED (profiles/round4_attention_gen3_ab.txt, tools/att_ab.sh):
+// bit-identical to generation 2 at (32, 1025, 16 heads, bias) and NOT faster -- 0.3135 against 0.3120 ms: the overlap gained
+// inside a wave is paid for with the third wave per SIMD, and what binds both generations is the chain through the memory path
+// (DESIGN.md 7.1).  Kept as the correct starting point of the hand-scheduled kernel, not as a candidate.  Motivation: in
 // generation 2 a wave's tile is one serial chain -- S MFMAs -> softmax -> P.V MFMAs -- and the counters show the vector pipe
 // (53 % of the cycles) and the matrix pipe (38 %) taking turns.  Here the chain is skewed by one tile INSIDE the wave:
 //     iteration t:  S(t + 1) MFMAs   beside   row maxima + first half of the exponentials of tile t      (phase A)
