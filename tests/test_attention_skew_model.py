@@ -1,7 +1,8 @@
 """The tile-level numpy model of k_attention_fwd3's control flow (tools/emulate_attention_skew.py) against softmax attention.
 
 Not a test of a kernel: generation 3 of the attention kernel (S of tile t + 1 beside the softmax of tile t, K staged one tile
-ahead of V^T) exists only in -DDS_EXPERIMENTS builds and has not run on hardware yet.  The model keeps its bookkeeping honest
+ahead of V^T) exists only in -DDS_EXPERIMENTS builds (on hardware it reproduced generation 2 bit for bit at the benchmark shape
+and was not faster: profiles/round4_attention_gen3_ab.txt).  The model keeps its bookkeeping honest
 -- which tile sits in which LDS buffer when, the two alternating accumulator sets, the peeled masked iteration -- and flags a
 buffer that is written in the barrier interval in which it is read (that check found the missing barrier behind the prologue)."""
 import os

@@ -6,7 +6,7 @@ accumulator sets, the peeled last iteration with its key mask, the deferred runn
 checks: every LDS read sees the tile the algorithm means (buffers start as NaN and carry a tag), no buffer is written in the
 barrier interval in which it is read (the cross-wave hazard the one-barrier-per-tile schedule must not have), and the output
 equals softmax attention.  The build container has no GPU: the kernel's bookkeeping is debugged here, its transcription to HIP
-on hardware (the generation-2 tests of tests/test_gpu_models.py with DS_ATT_GEN=3).
+on hardware (tools/att_ab.sh: bit-identical to generation 2 at the benchmark shape, profiles/round4_attention_gen3_ab.txt).
 
     python tools/emulate_attention_skew.py
 """
