@@ -360,9 +360,25 @@ __device__ __forceinline__ float at_max3(float a, float b, float c)
 // phases compile to "two reads, wait, two dependent MFMAs" four times each: 0.289 vs 0.285 ms at N = 1025 + bias, 0.375 vs 0.386 at
 // N = 1370, 0.250 vs 0.250 at N = 2443, 0.848 vs 0.819 at N = 4097 + bias.  Three waves per SIMD already cover those round trips;
 // the variant was removed.)
+// Phase clock of generation 2 (-DDS_EXPERIMENTS builds, DS_ATT_PROF=1; ABL bit 8192): every wave accumulates the cycles between
+// seven points of a tile -- [0] loop top, [1] K / V^T fetch issued, [2] S complete (LDS fragment reads + MFMAs, drained by a read of
+// the last accumulator), [3] mask + softmax + rescale, [4] P.V complete, [5] K / V^T landed and stashed (vmcnt(0) + lgkmcnt(0)),
+// [6] barrier passed -- and adds them to g_att_prof at the end ([7] = live waves, [8] = all waves).  The ticks serialise the
+// phases (each one waits for what the phase started): the numbers say where a wave's time goes, not how fast the kernel is.
+#ifdef DS_EXPERIMENTS
+__device__ unsigned long long g_att_prof[16];
+#define A2_TICK(i_, wait_) do { if (PROF) { asm volatile(wait_ ::: "memory"); const unsigned long long t_ = __builtin_readcyclecounter(); \
+                                            tacc[i_] += t_ - tl; tl = t_; } } while (0)
+#define A2_DRAIN(v_) do { if (PROF) { float d_; asm volatile("v_mov_b32 %0, %1" : "=v"(d_) : "v"(v_)); asm volatile("" :: "v"(d_)); } } while (0)
+#else
+#define A2_TICK(i_, wait_) do { } while (0)
+#define A2_DRAIN(v_) do { } while (0)
+#endif
 template <int BF16, int HAS_BIAS, int NQB, int ABL>
 __global__ __launch_bounds__(AT_THREADS, NQB == 2 ? 2 : ((ABL & 4096) ? 4 : 3)) void k_attention_fwd2(AttnParams P)
 {
+    [[maybe_unused]] constexpr bool PROF = (ABL & 8192) != 0;
+    [[maybe_unused]] unsigned long long tacc[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }, tl = 0;
     typedef at_traits<BF16> TR;
     typedef typename TR::T T;
     typedef typename TR::V8 V8;
@@ -490,8 +506,10 @@ __global__ __launch_bounds__(AT_THREADS, NQB == 2 ? 2 : ((ABL & 4096) ? 4 : 3)) 
         // next tile's K / V^T: in flight while this tile is computed.  The staggered variant requests them after its first
         // mixed region, where the register pressure peaks (the remaining three regions still cover an L2 round trip)
         constexpr int abl = ABL;
+        A2_TICK(0, "");
         if (more && !(abl & 2) && (!(abl & 4096) || !wave_live)) A2_FETCH(kt + 1);
         if (HAS_BIAS && (abl & 4096) && wave_live) A2_FETCH_BIAS(kt);
+        A2_TICK(1, "");
         if (wave_live) {
             const int key0 = kt * AT_KB;
             f32x16 s_acc[2][2];
@@ -596,6 +614,8 @@ __global__ __launch_bounds__(AT_THREADS, NQB == 2 ? 2 : ((ABL & 4096) ? 4 : 3)) 
                     }
                 }
                 if (abl & 256) __builtin_amdgcn_s_setprio(0);
+                A2_DRAIN(s_acc[NQB - 1][1][15]);
+                A2_TICK(2, "s_waitcnt lgkmcnt(0)");
                 // the bias registers are free: next tile's fragments land under the softmax / P.V of this one
                 if (HAS_BIAS && more && !(abl & 2) && !(abl & 4096)) A2_FETCH_BIAS(kt + 1);
                 if ((abl & 4096) && more) A2_FETCH(kt + 1);
@@ -616,6 +636,7 @@ __global__ __launch_bounds__(AT_THREADS, NQB == 2 ? 2 : ((ABL & 4096) ? 4 : 3)) 
                     A2_SOFTMAX(0); A2_RESCALE(0);
                     if (NQB == 2) { A2_SOFTMAX(1); A2_RESCALE(1); }
                 }
+                A2_TICK(3, "");
                 if (!(abl & 8)) {
                     if (abl & 256) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -641,17 +662,31 @@ __global__ __launch_bounds__(AT_THREADS, NQB == 2 ? 2 : ((ABL & 4096) ? 4 : 3)) 
                 }
             }
         }
+        if (wave_live) A2_DRAIN(o_acc[NQB - 1][1][15]);
+        A2_TICK(4, "s_waitcnt lgkmcnt(0)");
         if (more && !(abl & 2)) {
             A2_STASH1(cur ^ 1, st_row, kreg0, vreg0);
             A2_STASH1(cur ^ 1, st_row + 32, kreg1, vreg1);
         }
+        A2_TICK(5, "s_waitcnt vmcnt(0) lgkmcnt(0)");
         if (!(abl & 4)) __syncthreads();
+        A2_TICK(6, "");
     };
     const bool pad_keys = (P.n_valid & (AT_KB - 1)) != 0;
     if ((ABL & 2048) && ((blockIdx.x >> 3) & 1)) __builtin_amdgcn_s_sleep(48);
+#ifdef DS_EXPERIMENTS
+    if (PROF) tl = __builtin_readcyclecounter();
+#endif
     for (int kt = 0; kt + 1 < ntiles; kt++) tile(kt, std::false_type());
     if (pad_keys) tile(ntiles - 1, std::true_type());
     else tile(ntiles - 1, std::false_type());
+#ifdef DS_EXPERIMENTS
+    if (PROF && lane == 0) {
+#pragma unroll
+        for (int i = 0; i < 7; i++) atomicAdd(&g_att_prof[i], tacc[i]);
+        atomicAdd(&g_att_prof[wave_live ? 7 : 8], 1ull);
+    }
+#endif
     if (!wave_live) return;
 #pragma unroll
     for (int qb = 0; qb < NQB; qb++) {
@@ -1041,6 +1076,21 @@ DS_API int ds_attention_bias_pack(ds_ctx *ctx, const float *bias, int H, int n, 
     return DS_OK;
 }
 
+#ifdef DS_EXPERIMENTS
+// experiments library only (not declared in include/depthstereo.h): the phase clock of generation 2, see g_att_prof
+DS_API int ds_experiments_attention_profile(unsigned long long *out16, int reset)
+{
+    DS_REQUIRE(out16 != nullptr, DS_EINVAL, "ds_experiments_attention_profile: null argument");
+    DS_HIP_CHECK(hipDeviceSynchronize());
+    DS_HIP_CHECK(hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_att_prof), 16 * sizeof(unsigned long long)));
+    if (reset) {
+        unsigned long long z[16] = { 0 };
+        DS_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_att_prof), z, sizeof(z)));
+    }
+    return DS_OK;
+}
+#endif
+
 DS_API int ds_attention_fwd(ds_ctx *ctx, const void *qk, const void *vt, const void *bias_packed, void *out,
                             int B, int Np, int H, int n_valid, float scale, int dtype, void *stream)
 {
@@ -1098,7 +1148,9 @@ DS_API int ds_attention_fwd(ds_ctx *ctx, const void *qk, const void *vt, const v
 #endif
 #ifdef DS_EXPERIMENTS
         static const int gen_env = getenv("DS_ATT_GEN") ? atoi(getenv("DS_ATT_GEN")) : 2;
-#define A3_TRY(BF_, BI_) if (gen_env == 3 && nqb == 1) hipLaunchKernelGGL((k_attention_fwd3<BF_, BI_>), grid2, dim3(AT_THREADS), 0, st2, P); else
+        static const int prof_env = getenv("DS_ATT_PROF") ? atoi(getenv("DS_ATT_PROF")) : 0;
+#define A3_TRY(BF_, BI_) if (gen_env == 3 && nqb == 1) hipLaunchKernelGGL((k_attention_fwd3<BF_, BI_>), grid2, dim3(AT_THREADS), 0, st2, P); \
+            else if (prof_env && nqb == 1 && !late && BF_ == 0) hipLaunchKernelGGL((k_attention_fwd2<0, BI_, 1, 256 + 8192>), grid2, dim3(AT_THREADS), 0, st2, P); else
 #else
 #define A3_TRY(BF_, BI_)
 #endif

@@ -24,6 +24,7 @@ typedef int (*ctx_destroy_t)(ds_ctx *);
 typedef const char *(*last_error_t)(void);
 typedef int (*bias_pack_t)(ds_ctx *, const float *, int, int, int, int, void *, void *);
 typedef int (*attn_t)(ds_ctx *, const void *, const void *, const void *, void *, int, int, int, int, float, int, void *);
+typedef int (*prof_t)(unsigned long long *, int);      // experiments library only: the phase clock of generation 2 (DS_ATT_PROF=1)
 
 static uint32_t lcg(uint32_t &s) { s = s * 1664525u + 1013904223u; return s; }
 static float unif(uint32_t &s) { return (float)(lcg(s) >> 8) * (1.0f / 16777216.0f) * 2.0f - 1.0f; }      // [-1, 1)
@@ -94,6 +95,19 @@ int main(int argc, char **argv)
     const double flops = 4.0 * n * (double)n * H * 64 * B;
     printf("attention B %d H %d n %d Np %d bias %d: %.4f ms  %.1f TF/s  checksum %.6f  non-finite or huge %zu\n", B, H, n, Np, with_bias, ms,
            flops / (ms * 1e-3) / 1e12, sum, bad);
+    if (auto prof = (prof_t)dlsym(lib, "ds_experiments_attention_profile")) {
+        unsigned long long acc[16];
+        prof(acc, 1);                                     // drop what the timed launches accumulated ...
+        attn(ctx, d_qk, d_vt, d_bias, d_out, B, Np, H, n, 0.125f, 1, nullptr);      // ... and clock ONE launch
+        if (prof(acc, 1) == 0 && acc[7] + acc[8] > 0) {
+            static const char *names[7] = { "loop top", "fetch issue", "S (fragment reads + MFMAs)", "mask + softmax + rescale", "P.V (reads + MFMAs)",
+                                            "K / V^T landed + stash", "barrier" };
+            unsigned long long tot = 0;
+            for (int i = 0; i < 7; i++) tot += acc[i];
+            printf("phase clock of one launch: %llu live + %llu idle waves, %.0f cycles per wave\n", acc[7], acc[8], (double)tot / (double)(acc[7] + acc[8]));
+            for (int i = 0; i < 7; i++) printf("  %5.1f %%  %s\n", 100.0 * (double)acc[i] / (double)tot, names[i]);
+        }
+    }
     ctx_destroy(ctx);
     return bad ? 3 : 0;
 }
