@@ -382,3 +382,25 @@ def test_tight_token_pad_rules():
             s = vm.pad_len(n, b)
             assert s >= n and s % 8 == 0 and s <= vm.pad_len(n)
             assert s == vm.pad_len(n) or (b * s) % 256 == 0
+
+
+def test_committed_profiles_parse_and_tell_the_same_story_as_the_docs():
+    """tools/step_anatomy.py on the committed rocprofv3 summaries: the families add up to the whole, the in-tree share the
+    documents quote (> 90 % of the step's kernel time) is what the file says, and the stalled LayerNorm launch of the final
+    verification box is reported instead of silently inflating an average."""
+    import contextlib
+    import io
+    import sys
+    ROOT = conftest.ROOT
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import step_anatomy
+    for name, expect_outlier in (("round4_kernel_stats.csv", True), ("round4_kernel_stats_before_pipelined_ragged.csv", False)):
+        buf = io.StringIO()
+        with contextlib.redirect_stdout(buf):
+            step_anatomy.main([os.path.join(ROOT, "profiles", name)])
+        text = buf.getvalue()
+        shares = [float(line.split("%")[0]) for line in text.splitlines()[1:] if "%" in line and "in-tree kernels" not in line and "outlier" not in line]
+        assert abs(sum(shares) - 100.0) < 0.2, text
+        in_tree = float([line for line in text.splitlines() if "in-tree kernels (hand-written HIP) in all" in line][0].split("%")[0])
+        assert in_tree > 90.0, text
+        assert ("outlier:" in text) == expect_outlier, text
