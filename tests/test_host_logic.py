@@ -404,3 +404,21 @@ def test_committed_profiles_parse_and_tell_the_same_story_as_the_docs():
         in_tree = float([line for line in text.splitlines() if "in-tree kernels (hand-written HIP) in all" in line][0].split("%")[0])
         assert in_tree > 90.0, text
         assert ("outlier:" in text) == expect_outlier, text
+
+
+def test_standalone_harnesses_compile(tmp_path):
+    """tools/att_harness.cpp and tools/stereo_harness.cpp (the Python-free A/B harnesses of the GPU rounds) keep compiling
+    against the HIP runtime and use the C ABI's current signatures by name (dlsym): every symbol they ask for is declared in
+    include/depthstereo.h, except the experiments-only profile reader."""
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    hdr = open(os.path.join(conftest.ROOT, "include", "depthstereo.h")).read()
+    for name in ("att_harness", "stereo_harness"):
+        src = os.path.join(conftest.ROOT, "tools", name + ".cpp")
+        text = open(src).read()
+        for sym in re.findall(r'dlsym\(lib, "(\w+)"\)', text):
+            assert sym == "ds_experiments_attention_profile" or re.search(r"\b%s\(" % sym, hdr), f"{name}: {sym} is not in the header"
+        subprocess.check_call([hipcc, "-O1", "-std=c++17", src, "-o", str(tmp_path / name), "-ldl"])
