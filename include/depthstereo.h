@@ -96,6 +96,25 @@ int ds_depth_minmax(ds_ctx *ctx, const void *depth, int depth_dtype, int n, int 
 int ds_profile_enable(ds_ctx *ctx, int enable);
 int ds_profile_last_ms(ds_ctx *ctx, float *render_ms, float *exact_ms);
 
+/* In-step kernel timers (no counterpart in the reference; bench.py's `roofline` is the average duration of a kernel INSIDE the
+ * timed step, measured on the stream it is launched on).  While enabled, the entry points below bracket their kernel launch with
+ * a pair of HIP events out of a ring of 1024 pairs per kind (launches beyond the ring, and launches made while the stream is
+ * being captured into a graph, are not timed); nothing synchronises until ds_kernel_timer_read, which waits for the last pair of
+ * the kind and returns how many launches were timed and the sum of their durations.  Enabling (or disabling) resets every ring.
+ * A GEMM kind that hands its last tiles to the ragged round has a second timer, kind + DS_KT_RAGGED, around that launch. */
+#define DS_KT_LINEAR_GELU      0   /* ds_linear, act = 1 (fc1 + GELU of an encoder block) */
+#define DS_KT_ATTENTION        1   /* ds_attention_fwd */
+#define DS_KT_LINEAR_RESIDUAL  2   /* ds_linear_residual (projection / fc2 + LayerScale + residual) */
+#define DS_KT_LINEAR           3   /* ds_linear, act = 0 or 2 */
+#define DS_KT_LINEAR_VT        4   /* ds_linear_vt */
+#define DS_KT_CONV3X3          5   /* ds_conv3x3_nhwc */
+#define DS_KT_LINEAR_READOUT   6   /* ds_linear_readout */
+#define DS_KT_LINEAR_SHUFFLE   7   /* ds_linear_shuffle */
+#define DS_KT_NORMALMAP        8   /* ds_normalmap (uint16, the fused kernel) */
+#define DS_KT_RAGGED          12   /* + kind: the ragged round (k_linear_ragged) of that GEMM kind */
+int ds_kernel_timer_enable(ds_ctx *ctx, int enable);
+int ds_kernel_timer_read(ds_ctx *ctx, int kind, int64_t *launches, double *total_ms);
+
 /* Number of image rows the last ds_stereo_warp on this ctx re-rendered with the exact sequential
  * sweep (polylines only; see DESIGN.md "exact fallback").  Synchronises the stream. */
 int ds_stereo_last_exact_rows(ds_ctx *ctx, int64_t *rows_out, void *stream);
@@ -137,6 +156,15 @@ int ds_normalmap(ds_ctx *ctx, const uint16_t *depth, int n, int h, int w, int pr
  */
 int ds_normalmap_f64(ds_ctx *ctx, const double *depth, int n, int h, int w, int pre_blur,
                      int sobel_ksize, int post_blur, int invert, uint8_t *out, void *stream);
+
+/*
+ * ds_normalmap_gradient_f32 -- create_normalmap(float32 depth, sobel_gradient=None) without blurs: the one combination the
+ * reference evaluates in FLOAT32 from end to end (src/normalmap_generation.py:20-21 keep float32, :31 np.gradient, :34-39
+ * np.linalg.norm + three divisions, :51-54 quantisation; cv2.Sobel would be fed np.float64(...) at :28-29, np.gradient is
+ * not).  One fused pass, every operation the correctly rounded binary32 one in numpy's order: bit-identical.
+ * depth n*h*w float32, h, w >= 2; out n*h*w*3 uint8.
+ */
+int ds_normalmap_gradient_f32(ds_ctx *ctx, const float *depth, int n, int h, int w, int invert, uint8_t *out, void *stream);
 
 /*
  * ds_depth_to_u16 -- replaces the depth post-processing of core_generation_funnel
@@ -290,8 +318,42 @@ int ds_linear_vt(ds_ctx *ctx, const void *w_v, const void *h, void *vt, int64_t 
                  int64_t in_features, int dtype, void *stream);
 
 /*
+ * ds_linear_shuffle -- ConvTranspose2d with kernel_size == stride as ONE GEMM with the pixel shuffle in the store address: the
+ * 4x4-stride-4 and 2x2-stride-2 transposed convolutions of the reassemble stage (dmidas/backbones/utils.py:196-205 and :215-224,
+ * `nn.ConvTranspose2d(features[i], features[i], kernel_size=4 / 2, stride=4 / 2, padding=0)`; ddepth_anything_v2/
+ * depth_anything_v2/dpt.py:57-71).  With kernel == stride no two input pixels write the same output pixel:
+ *     y[b, yy*s + ky, xx*s + kx, co] = bias[(ky*s + kx)*C + co] + sum_ci x[b, yy, xx, ci] * w[(ky*s + kx)*C + co, ci]
+ *   x     [pixels, in_features]   the NHWC input, pixels = batch * h * width (image-major rows)
+ *   w     [stride*stride*out_channels, in_features]: torch's [in, out, kH, kW] weight permuted to (kH, kW, out, in) by the host
+ *   bias  [stride*stride*out_channels] (the module's bias repeated per tap) or NULL
+ *   y     [batch, h*stride, width*stride, out_channels] NHWC
+ * stride*stride*out_channels % 256 == 0, out_channels % 8 == 0, in_features % 128 == 0, pixels >= 256.  f16 / bf16, fp32 accumulation.
+ */
+int ds_linear_shuffle(ds_ctx *ctx, const void *x, const void *w, const void *bias, void *y, int64_t pixels, int64_t in_features,
+                      int width, int stride, int out_channels, int dtype, void *stream);
+
+/*
+ * ds_linear_readout -- the read-out of the reassemble stage as one GEMM on the padded token sequence: ProjectReadout
+ * (dmidas/backbones/utils.py:28-39: `features = cat(x[:, start_index:], readout.expand_as(...)); project(features)` with project =
+ * Linear(2C -> C) + GELU) followed by the Transpose(1, 2) / Unflatten of :165-169.  The linear map of a concatenation splits,
+ * W.[tok ; cls] + b = W_tok.tok + (W_cls.cls + b), and the second term is one vector per image:
+ *     y[b*(tokens-1) + t - 1, :] = GELU( x[b*tokens_padded + t, :] . w_tok^T + cls_vec[b, :] ),   t = 1 .. tokens - 1
+ *   x        [images * tokens_padded, in_features]   block output as the encoder leaves it (row 0 of an image = cls token, rows >=
+ *            tokens = padding)
+ *   w_tok    [out_features, in_features]   the token half of the projection weight;  cls_vec [images, out_features]
+ *   y        [images * (tokens - 1) + 1, out_features]: token-major = NHWC of the [h, w] patch grid; the LAST row is a dummy that
+ *            receives the cls / pad rows of every image (a constant store count per tile)
+ * out_features % 256 == 0, in_features % 128 == 0, images * tokens_padded >= 256.  erf-GELU on the fp32 accumulator as ds_linear.
+ */
+int ds_linear_readout(ds_ctx *ctx, const void *x, const void *w_tok, const void *cls_vec, void *y, int64_t images,
+                      int64_t tokens_padded, int64_t tokens, int64_t out_features, int64_t in_features, int dtype, void *stream);
+
+/*
  * ds_linear_reload_env -- the GEMM path (ds_linear, ds_linear_residual, ds_linear_vt, ds_conv3x3_nhwc) reads its A/B switches
- * (DS_LIN_EARLY, DS_LIN_GRID, DS_LIN_RAGGED, DS_LIN_RAGGED_DEN, DS_LIN_RAGGED_RING; none changes a result) from
+ * (DS_LIN_EARLY, DS_LIN_GRID, DS_LIN_RAGGED, DS_LIN_RAGGED_DEN, DS_LIN_RAGGED_RING, DS_LIN_RAGGED_PIPE: none of these changes a
+ * result; DS_LIN_RAGGED_KSPLIT, DS_LIN_RAGGED_KSPLIT_MIN, DS_LIN_RAGGED_KSPLIT_KEEP: the K split of the ragged round changes the
+ * fp32 SUMMATION ORDER of the rows it touches -- results are equal within fp32 rounding, and bit-reproducible for a fixed
+ * setting, but NOT bitwise equal between two settings) from
  * the environment ONCE per process, not per launch; this re-reads them (tests and A/B runs that flip a switch in-process).
  * No counterpart in the reference.
  */

@@ -42,6 +42,11 @@ DS_API int ds_ctx_destroy(ds_ctx *ctx)
     void *blocks[] = { ctx->minmax, ctx->partials, ctx->row_flags, ctx->row_list, ctx->exact_ws, ctx->tmp_a, ctx->tmp_b, ctx->zero_line, ctx->lin_ws };
     for (void *b : blocks) if (b) (void)hipFree(b);
     if (ctx->ev_created) for (int i = 0; i < 4; i++) (void)hipEventDestroy(ctx->ev[i]);
+    for (int k = 0; k < DS_KT_KINDS; k++)
+        if (ctx->kt_ev[k]) {
+            for (int i = 0; i < DS_KT_RING; i++) { (void)hipEventDestroy(ctx->kt_ev[k][i][0]); (void)hipEventDestroy(ctx->kt_ev[k][i][1]); }
+            delete[] ctx->kt_ev[k];
+        }
     (void)hipSetDevice(prev);
     delete ctx;
     return DS_OK;
@@ -67,6 +72,61 @@ DS_API int ds_profile_last_ms(ds_ctx *ctx, float *render_ms, float *exact_ms)
     DS_HIP_CHECK(hipEventSynchronize(ctx->ev[3]));
     DS_HIP_CHECK(hipEventElapsedTime(render_ms, ctx->ev[0], ctx->ev[1]));
     DS_HIP_CHECK(hipEventElapsedTime(exact_ms, ctx->ev[2], ctx->ev[3]));
+    return DS_OK;
+}
+
+// ---- in-step kernel timers ---------------------------------------------------------------------------------------------------
+// bench.py's `roofline` wants the average duration of a kernel INSIDE the timed step, on the stream it is launched on: the entry
+// points bracket their launch with an event pair out of a per-kind ring (no synchronisation; an event record is a marker packet
+// on the stream), ds_kernel_timer_read synchronises once and adds the pairs up.
+int ds_kt_begin(ds_ctx *ctx, int kind, hipStream_t st)
+{
+    if (!ctx->ktimer || kind < 0 || kind >= DS_KT_KINDS || ctx->kt_n[kind] >= DS_KT_RING) return -1;
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) { (void)hipGetLastError(); return -1; }
+    if (!ctx->kt_ev[kind]) {
+        hipEvent_t (*ring)[2] = new (std::nothrow) hipEvent_t[DS_KT_RING][2];
+        if (!ring) return -1;
+        for (int i = 0; i < DS_KT_RING; i++)
+            if (hipEventCreate(&ring[i][0]) != hipSuccess || hipEventCreate(&ring[i][1]) != hipSuccess) { (void)hipGetLastError(); return -1; }
+        ctx->kt_ev[kind] = ring;
+    }
+    const int slot = ctx->kt_n[kind];
+    if (hipEventRecord(ctx->kt_ev[kind][slot][0], st) != hipSuccess) { (void)hipGetLastError(); return -1; }
+    return slot;
+}
+
+void ds_kt_end(ds_ctx *ctx, int kind, int slot, hipStream_t st)
+{
+    if (slot < 0) return;
+    if (hipEventRecord(ctx->kt_ev[kind][slot][1], st) == hipSuccess) ctx->kt_n[kind] = slot + 1;
+    else (void)hipGetLastError();
+}
+
+DS_API int ds_kernel_timer_enable(ds_ctx *ctx, int enable)
+{
+    DS_REQUIRE(ctx != nullptr, DS_EINVAL, "ds_kernel_timer_enable: ctx is NULL");
+    DS_HIP_CHECK(hipSetDevice(ctx->device));
+    ctx->ktimer = enable ? 1 : 0;
+    for (int k = 0; k < DS_KT_KINDS; k++) ctx->kt_n[k] = 0;
+    return DS_OK;
+}
+
+DS_API int ds_kernel_timer_read(ds_ctx *ctx, int kind, int64_t *launches, double *total_ms)
+{
+    DS_REQUIRE(ctx && launches && total_ms, DS_EINVAL, "ds_kernel_timer_read: null argument");
+    DS_REQUIRE(kind >= 0 && kind < DS_KT_KINDS, DS_EINVAL, "ds_kernel_timer_read: kind %d outside 0..%d", kind, DS_KT_KINDS - 1);
+    DS_HIP_CHECK(hipSetDevice(ctx->device));
+    const int n = ctx->kt_n[kind];
+    double sum = 0.0;
+    if (n > 0) DS_HIP_CHECK(hipEventSynchronize(ctx->kt_ev[kind][n - 1][1]));
+    for (int i = 0; i < n; i++) {
+        float ms = 0.f;
+        DS_HIP_CHECK(hipEventElapsedTime(&ms, ctx->kt_ev[kind][i][0], ctx->kt_ev[kind][i][1]));
+        sum += (double)ms;
+    }
+    *launches = n;
+    *total_ms = sum;
     return DS_OK;
 }
 

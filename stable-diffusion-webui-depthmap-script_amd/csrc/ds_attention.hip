@@ -1162,8 +1162,10 @@ DS_API int ds_attention_fwd(ds_ctx *ctx, const void *qk, const void *vt, const v
             else hipLaunchKernelGGL((k_attention_fwd2<BF_, BI_, 2, 256>), grid2, dim3(AT_THREADS), 0, st2, P);          \
         } while (0)
         if (batch_fastest) P.flags |= 2;
+        const int kt = ds_kt_begin(ctx, DS_KT_ATTENTION, st2);
         if (dtype == DS_DTYPE_F16) { if (bias) A2_LAUNCH(0, 1); else A2_LAUNCH(0, 0); }
         else { if (bias) A2_LAUNCH(1, 1); else A2_LAUNCH(1, 0); }
+        ds_kt_end(ctx, DS_KT_ATTENTION, kt, st2);
         DS_HIP_CHECK(hipGetLastError());
         return DS_OK;
     }

@@ -30,6 +30,8 @@ void ds_set_error(const char *fmt, ...);
     } while (0)
 
 // ---- context ----------------------------------------------------------------------------------
+#define DS_KT_KINDS 24          // DS_KT_* of include/depthstereo.h (0..11) and + 12 for the ragged round of a GEMM kind
+#define DS_KT_RING 1024
 struct ds_ctx {
     int device;
     // growable scratch blocks (device memory)
@@ -50,7 +52,16 @@ struct ds_ctx {
     int profile;
     hipEvent_t ev[4];          // render start/stop, exact start/stop
     int ev_created, ev_recorded;
+    // in-step kernel timers (ds_kernel_timer_enable): per kind a ring of event pairs recorded around the launches on the caller's stream
+    int ktimer;
+    hipEvent_t (*kt_ev[DS_KT_KINDS])[2];
+    int kt_n[DS_KT_KINDS];
 };
+
+// ds_kt_begin: -1 when the timer is off, the ring of this kind is full, or the stream is being captured; else the slot whose start
+// event was recorded.  ds_kt_end records the slot's stop event.  Two calls around ONE kernel launch on the same stream.
+int ds_kt_begin(ds_ctx *ctx, int kind, hipStream_t st);
+void ds_kt_end(ds_ctx *ctx, int kind, int slot, hipStream_t st);
 
 int ds_ctx_reserve(ds_ctx *ctx, void **slot, size_t *cur, size_t need);
 

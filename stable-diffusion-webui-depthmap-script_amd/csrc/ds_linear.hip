@@ -79,9 +79,18 @@ struct LinParams {
     int n_main;                 // the persistent kernel walks positions [0, n_main) of the tile list; k_linear_ragged takes the rest
     int vt_np, vt_c;            // VT: column j of the GEMM is token j % vt_np of batch element j / vt_np, the output is [batch][vt_c rows][vt_np]
     unsigned vt_magic;          // VT: floor(2^32 / vt_np) + 1  (j / vt_np == umulhi(j, vt_magic) for j * vt_np < 2^32)
+    // VT 2 (pixel shuffle: ConvTranspose2d with kernel == stride as a GEMM): row m = input pixel (image-major, ps_w pixels per image
+    // row), column j = (ky * ps_s + kx) * ps_c + co; the output is NHWC [batch, h * ps_s, ps_w * ps_s, ps_c]
+    int ps_w, ps_s, ps_c;
+    unsigned ps_w_magic, ps_c_magic;      // floor(2^32 / ps_w) + 1, floor(2^32 / ps_c) + 1
+    // VT 3 (read-out): row m = token m % rd_np of image m / rd_np; tokens 1 .. rd_n - 1 go to output row image * (rd_n - 1) + token - 1,
+    // the cls token and the pad rows to the DUMMY row rd_dummy behind the output; res1 is one vector per IMAGE ([images, N])
+    int rd_np, rd_n, rd_dummy;
+    unsigned rd_magic;                   // floor(2^32 / rd_np) + 1
     float *rg_ws;               // ragged round with K split over 2^rg_ksl workgroups per piece: one 32 KB fp32 partial per workgroup ...
     int *rg_cnt;                // ... and one arrival counter per piece (zero between launches)
     int rg_ksl;
+    int kt_kind;                // host side only: the in-step timer kind of this launch (DS_KT_*)
 };
 
 // position in the tile list -> origin of the tile.  The list is ordered in groups of 8 row panels, rows fastest inside a group
@@ -101,10 +110,34 @@ __device__ __forceinline__ void ln_tile_origin(const LinParams &P, const int til
 template <int VT>
 __device__ __forceinline__ size_t ln_out_off(const LinParams &P, const int row, const int col)
 {
-    if (!VT) return (size_t)row * P.ldy + col;
-    const unsigned b = __umulhi((unsigned)col, P.vt_magic);
-    const unsigned n = (unsigned)col - b * (unsigned)P.vt_np;
-    return ((size_t)b * P.vt_c + row) * (size_t)P.vt_np + n;
+    if (VT == 0) return (size_t)row * P.ldy + col;
+    if (VT == 1) {
+        const unsigned b = __umulhi((unsigned)col, P.vt_magic);
+        const unsigned n = (unsigned)col - b * (unsigned)P.vt_np;
+        return ((size_t)b * P.vt_c + row) * (size_t)P.vt_np + n;
+    }
+    if (VT == 2) {
+        // input pixel (q = image * h + y, x) and output tap (ky, kx) of the 8 columns' channel group (ps_c % 8 == 0: a group of 8
+        // columns never straddles two taps): output pixel (q * s + ky, x * s + kx) of an image row of ps_w * s pixels
+        const unsigned q = __umulhi((unsigned)row, P.ps_w_magic), x = (unsigned)row - q * (unsigned)P.ps_w;
+        const unsigned t = __umulhi((unsigned)col, P.ps_c_magic), co = (unsigned)col - t * (unsigned)P.ps_c;
+        const unsigned ky = t / (unsigned)P.ps_s, kx = t - ky * (unsigned)P.ps_s;
+        const size_t opix = ((size_t)q * P.ps_s + ky) * ((size_t)P.ps_w * P.ps_s) + (size_t)x * P.ps_s + kx;
+        return opix * (size_t)P.ps_c + co;
+    }
+    const unsigned b = __umulhi((unsigned)row, P.rd_magic), t = (unsigned)row - b * (unsigned)P.rd_np;
+    const bool live = t >= 1u && t < (unsigned)P.rd_n;
+    const size_t orow = live ? (size_t)b * (size_t)(P.rd_n - 1) + (t - 1u) : (size_t)P.rd_dummy;
+    return orow * (size_t)P.ldy + col;
+}
+// element offset of the residual operand's 8 values for output (row, col .. col + 7): laid out like y, except for the read-out
+// (VT 3), whose "residual" is one vector per image
+template <int VT>
+__device__ __forceinline__ size_t ln_res_off(const LinParams &P, const int row, const int col)
+{
+    if (VT != 3) return ln_out_off<VT>(P, row, col);
+    const unsigned b = __umulhi((unsigned)row, P.rd_magic);
+    return (size_t)b * (size_t)P.ldy + col;
 }
 
 // erf-GELU on the fp32 accumulator.  GELU(v) = v Phi(v) = max(v, 0) - |v| Phi(-|v|), and Phi(-u) = 2^-Q(u) with
@@ -511,7 +544,7 @@ __global__ __launch_bounds__(LN_THREADS) void k_linear256(LinParams P)
             for (int hb = 0; hb < NHB; ++hb)
 #pragma unroll
                 for (int k = 0; k < 2; ++k) {
-                    if (RES >= 1) ra[hb][k] = *(const V8 *)(r1 + o0 + hb * 32 + 16 * k);
+                    if (RES >= 1) ra[hb][k] = *(const V8 *)(r1 + (VT == 3 ? ln_res_off<VT>(P, cbm0 + wr * 128 + rl, cbn0 + wcol + hi8 + hb * 32 + 16 * k) : o0 + hb * 32 + 16 * k));
                     if (RES >= 2) rb2[hb][k] = *(const V8 *)(r2 + o0 + hb * 32 + 16 * k);
                 }
 #pragma unroll
@@ -657,7 +690,7 @@ __global__ __launch_bounds__(LN_THREADS, S == 3 ? 4 : 2) void k_linear_ragged(Li
             const int col = e_cb + 16 * k;
             if (P.bias) e_bv[k] = *(const V8 *)((const T *)P.bias + col);
             if (EPI == 3) e_gv[k] = *(const V8 *)((const T *)P.gamma + col);
-            if (RES >= 1) e_rv[k] = *(const V8 *)((const T *)P.res1 + ln_out_off<VT>(P, e_row, col));
+            if (RES >= 1) e_rv[k] = *(const V8 *)((const T *)P.res1 + ln_res_off<VT>(P, e_row, col));
         }
     }
 #pragma unroll
@@ -807,7 +840,7 @@ __global__ __launch_bounds__(LN_THREADS, S == 3 ? 4 : 2) void k_linear_ragged(Li
             for (int t = 0; t < 8; ++t) bv[t] = (T)0.f;
         }
         if (EPI == 3) gv = PIPE ? e_gv[k] : *(const V8 *)((const T *)P.gamma + col);
-        if (RES >= 1) rv = PIPE ? e_rv[k] : *(const V8 *)(r1 + off);
+        if (RES >= 1) rv = PIPE ? e_rv[k] : *(const V8 *)(r1 + ln_res_off<VT>(P, row, col));
         float v[8];
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
@@ -952,11 +985,15 @@ static int ln_launch(ds_ctx *ctx, const LinParams &P0, hipStream_t stream)
         else return rc;
     }
     P.rg_ksl = ksl;
+    const int kt0 = ds_kt_begin(ctx, P.kt_kind, stream);
     hipLaunchKernelGGL(fn, dim3(P.n_main < grid ? P.n_main : grid), dim3(LN_THREADS), LN_LDS_BYTES, stream, P);
+    ds_kt_end(ctx, P.kt_kind, kt0, stream);
     if constexpr (CONV == 0) {
+        const int kt1 = ragged ? ds_kt_begin(ctx, P.kt_kind + DS_KT_RAGGED, stream) : -1;
         if (ragged && deep && O.ragged_pipe) hipLaunchKernelGGL((k_linear_ragged<BF16, EPI, RES, VT, 6, 1>), dim3((8 * ragged) << ksl), dim3(LN_THREADS), 6 * RG_SLOT, stream, P);
         else if (ragged && deep) hipLaunchKernelGGL((k_linear_ragged<BF16, EPI, RES, VT, 6>), dim3((8 * ragged) << ksl), dim3(LN_THREADS), 6 * RG_SLOT, stream, P);
         else if (ragged) hipLaunchKernelGGL((k_linear_ragged<BF16, EPI, RES, VT, 3>), dim3(8 * ragged), dim3(LN_THREADS), 3 * RG_SLOT, stream, P);
+        ds_kt_end(ctx, P.kt_kind + DS_KT_RAGGED, kt1, stream);
     }
     DS_HIP_CHECK(hipGetLastError());
     return DS_OK;
@@ -1007,6 +1044,7 @@ DS_API int ds_linear(ds_ctx *ctx, const void *x, const void *w, const void *bias
     P.M = (int)rows; P.N = (int)out_features; P.K = (int)in_features;
     P.nbm = (int)((rows + 255) / 256); P.nbn = (int)(out_features / 256);
     P.ldy = ldy;
+    P.kt_kind = act == 1 ? DS_KT_LINEAR_GELU : DS_KT_LINEAR;
 #ifdef DS_EXPERIMENTS
     P.ablate = getenv("DS_LIN_ABLATE") ? atoi(getenv("DS_LIN_ABLATE")) : 0;
     P.stagger = getenv("DS_LIN_STAGGER_US") ? (int)(atof(getenv("DS_LIN_STAGGER_US")) * 100.0) : 0;
@@ -1034,6 +1072,7 @@ DS_API int ds_linear_residual(ds_ctx *ctx, const void *x, const void *w, const v
     P.M = (int)rows; P.N = (int)out_features; P.K = (int)in_features;
     P.nbm = (int)((rows + 255) / 256); P.nbn = (int)(out_features / 256);
     P.ldy = out_features;
+    P.kt_kind = DS_KT_LINEAR_RESIDUAL;
     hipStream_t st = (hipStream_t)stream;
     if (dtype == DS_DTYPE_F16) return gamma ? ln_launch<0, 3, 0, 1>(ctx, P, st) : ln_launch<0, 0, 0, 1>(ctx, P, st);
     return gamma ? ln_launch<1, 3, 0, 1>(ctx, P, st) : ln_launch<1, 0, 0, 1>(ctx, P, st);
@@ -1073,6 +1112,7 @@ DS_API int ds_conv3x3_nhwc(ds_ctx *ctx, const void *x, const void *w, const void
     for (int kt = 0; kt < P.K / 64; ++kt)
         DS_REQUIRE(((kt * 7282) >> 16) == kt / 9, DS_EUNSUPPORTED, "ds_conv3x3_nhwc: K-tile arithmetic does not cover %d channels", in_channels);
     P.ldy = out_channels;
+    P.kt_kind = DS_KT_CONV3X3;
 #ifdef DS_EXPERIMENTS
     P.ablate = getenv("DS_LIN_ABLATE") ? atoi(getenv("DS_LIN_ABLATE")) : 0;
     P.stagger = getenv("DS_LIN_STAGGER_US") ? (int)(atof(getenv("DS_LIN_STAGGER_US")) * 100.0) : 0;
@@ -1105,6 +1145,76 @@ DS_API int ds_linear_vt(ds_ctx *ctx, const void *w_v, const void *h, void *vt, i
     P.nbm = (int)((channels + 255) / 256); P.nbn = (int)(batch * tokens / 256);
     P.ldy = batch * tokens;
     P.vt_np = (int)tokens; P.vt_c = (int)channels; P.vt_magic = (unsigned)((1ull << 32) / (unsigned long long)tokens + 1ull);
+    P.kt_kind = DS_KT_LINEAR_VT;
     hipStream_t st = (hipStream_t)stream;
     return dtype == DS_DTYPE_F16 ? ln_launch<0, 0, 0, 0, 1>(ctx, P, st) : ln_launch<1, 0, 0, 0, 1>(ctx, P, st);
+}
+
+// ConvTranspose2d with kernel_size == stride (no overlap between the taps of neighbouring pixels) is a plain GEMM whose output
+// columns are (ky, kx, co): y[b, y*s + ky, x*s + kx, co] = bias[co] + sum_ci x[b, y, x, ci] * w[ci, co, ky, kx] -- the 4x4-s4 and
+// 2x2-s2 transposed convolutions of the reassemble stage (dmidas/backbones/utils.py:196-205,215-224; ddepth_anything_v2/
+// depth_anything_v2/dpt.py:57-71).  The epilogue stores every 8-channel group straight to its output pixel (pixel shuffle in the
+// store address): no [pixels, s*s*C] intermediate, no shuffle pass.
+DS_API int ds_linear_shuffle(ds_ctx *ctx, const void *x, const void *w, const void *bias, void *y, int64_t pixels, int64_t in_features,
+                             int width, int stride, int out_channels, int dtype, void *stream)
+{
+    DS_REQUIRE(ctx && x && w && y, DS_EINVAL, "ds_linear_shuffle: null argument");
+    DS_REQUIRE(stride >= 1 && stride <= 8 && width >= 1 && out_channels >= 8 && out_channels % 8 == 0, DS_EINVAL,
+               "ds_linear_shuffle: stride must be 1..8, out_channels a multiple of 8");
+    const int64_t n = (int64_t)stride * stride * out_channels;
+    DS_REQUIRE(pixels >= 256 && pixels % width == 0 && pixels < (1ll << 31) - 256, DS_EINVAL,
+               "ds_linear_shuffle: pixels must be >= 256 (one tile) and a whole number of image rows");
+    DS_REQUIRE(n % 256 == 0, DS_EUNSUPPORTED, "ds_linear_shuffle: stride^2 * out_channels must be a multiple of 256 (got %lld)", (long long)n);
+    DS_REQUIRE(in_features >= 128 && in_features % 128 == 0 && in_features <= 16384, DS_EINVAL,
+               "ds_linear_shuffle: in_features must be a multiple of 128 (<= 16384)");
+    DS_REQUIRE(pixels * width < (1ll << 32) && n * out_channels < (1ll << 32) && pixels * n < (1ll << 40), DS_EUNSUPPORTED,
+               "ds_linear_shuffle: shape too large for the index arithmetic");
+    DS_REQUIRE(dtype == DS_DTYPE_F16 || dtype == DS_DTYPE_BF16, DS_EINVAL, "ds_linear_shuffle: dtype must be f16 or bf16");
+    DS_REQUIRE(((uintptr_t)x & 15) == 0 && ((uintptr_t)w & 15) == 0 && ((uintptr_t)y & 15) == 0 && (!bias || ((uintptr_t)bias & 15) == 0), DS_EINVAL,
+               "ds_linear_shuffle: x, w, y and bias must be 16-byte aligned");
+    LinParams P;
+    memset(&P, 0, sizeof(P));
+    P.x = x; P.w = w; P.bias = bias; P.y = y;
+    P.M = (int)pixels; P.N = (int)n; P.K = (int)in_features;
+    P.nbm = (int)((pixels + 255) / 256); P.nbn = (int)(n / 256);
+    P.ldy = n;
+    P.ps_w = width; P.ps_s = stride; P.ps_c = out_channels;
+    P.ps_w_magic = (unsigned)((1ull << 32) / (unsigned long long)width + 1ull);
+    P.ps_c_magic = (unsigned)((1ull << 32) / (unsigned long long)out_channels + 1ull);
+    P.kt_kind = DS_KT_LINEAR_SHUFFLE;
+    hipStream_t st = (hipStream_t)stream;
+    return dtype == DS_DTYPE_F16 ? ln_launch<0, 0, 0, 0, 2>(ctx, P, st) : ln_launch<1, 0, 0, 0, 2>(ctx, P, st);
+}
+
+// The read-out of the reassemble stage (ProjectReadout, dmidas/backbones/utils.py:28-39: cat(token, cls) -> Linear(2C -> C) -> GELU,
+// then the Transpose / Unflatten of :165-169) as ONE GEMM on the padded token sequence the encoder leaves behind:
+//     y[b, t - 1, :] = GELU( x[b, t, :] . w_tok^T + cls_vec[b, :] )      for the tokens t = 1 .. tokens - 1 of image b
+// with cls_vec[b] = w_cls . x[b, 0] + bias (one small GEMM on the host side of the C ABI).  The cls row and the pad rows of every
+// image are computed like any other row and stored to the dummy row behind the output, so the store count of a tile is constant
+// (the early mode's counted waits rely on it): y must hold images * (tokens - 1) + 1 rows.
+DS_API int ds_linear_readout(ds_ctx *ctx, const void *x, const void *w_tok, const void *cls_vec, void *y, int64_t images,
+                             int64_t tokens_padded, int64_t tokens, int64_t out_features, int64_t in_features, int dtype, void *stream)
+{
+    DS_REQUIRE(ctx && x && w_tok && cls_vec && y, DS_EINVAL, "ds_linear_readout: null argument");
+    DS_REQUIRE(images > 0 && tokens >= 2 && tokens <= tokens_padded, DS_EINVAL, "ds_linear_readout: need 2 <= tokens <= tokens_padded");
+    const int64_t rows = images * tokens_padded;
+    DS_REQUIRE(rows >= 256 && rows < (1ll << 31) - 256 && rows * tokens_padded < (1ll << 32), DS_EINVAL,
+               "ds_linear_readout: images * tokens_padded must be in [256, 2^31) and images * tokens_padded^2 below 2^32");
+    DS_REQUIRE(out_features > 0 && out_features % 256 == 0, DS_EINVAL, "ds_linear_readout: out_features must be a multiple of 256");
+    DS_REQUIRE(in_features >= 128 && in_features % 128 == 0 && in_features <= 16384, DS_EINVAL,
+               "ds_linear_readout: in_features must be a multiple of 128 (<= 16384)");
+    DS_REQUIRE(dtype == DS_DTYPE_F16 || dtype == DS_DTYPE_BF16, DS_EINVAL, "ds_linear_readout: dtype must be f16 or bf16");
+    DS_REQUIRE(((uintptr_t)x & 15) == 0 && ((uintptr_t)w_tok & 15) == 0 && ((uintptr_t)y & 15) == 0 && ((uintptr_t)cls_vec & 15) == 0, DS_EINVAL,
+               "ds_linear_readout: x, w_tok, cls_vec and y must be 16-byte aligned");
+    LinParams P;
+    memset(&P, 0, sizeof(P));
+    P.x = x; P.w = w_tok; P.res1 = cls_vec; P.y = y;
+    P.M = (int)rows; P.N = (int)out_features; P.K = (int)in_features;
+    P.nbm = (int)((rows + 255) / 256); P.nbn = (int)(out_features / 256);
+    P.ldy = out_features;
+    P.rd_np = (int)tokens_padded; P.rd_n = (int)tokens; P.rd_dummy = (int)(images * (tokens - 1));
+    P.rd_magic = (unsigned)((1ull << 32) / (unsigned long long)tokens_padded + 1ull);
+    P.kt_kind = DS_KT_LINEAR_READOUT;
+    hipStream_t st = (hipStream_t)stream;
+    return dtype == DS_DTYPE_F16 ? ln_launch<0, 1, 0, 1, 3>(ctx, P, st) : ln_launch<1, 1, 0, 1, 3>(ctx, P, st);
 }

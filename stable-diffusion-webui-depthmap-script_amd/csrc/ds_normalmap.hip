@@ -293,8 +293,10 @@ static int nm_run(ds_ctx *ctx, const void *depth_any, int is_f64, int n, int h, 
         DS_REQUIRE(grid.y <= 65535, DS_EUNSUPPORTED, "ds_normalmap: image too tall");
         if ((w & 3) == 0 && w >= 4 && h >= 2 && (((uintptr_t)depth) & 7) == 0 && (((uintptr_t)out) & 3) == 0 && !getenv("DS_NM_SCALAR")) {
             dim3 grid4((w / 4 + NM_BX - 1) / NM_BX, grid.y, n);
+            const int kt = ds_kt_begin(ctx, DS_KT_NORMALMAP, st);
             if (sobel_ksize == 3) hipLaunchKernelGGL(k_normalmap_fused4<1>, grid4, block, 0, st, depth, h, w, invert ? 1 : 0, out);
             else hipLaunchKernelGGL(k_normalmap_fused4<0>, grid4, block, 0, st, depth, h, w, invert ? 1 : 0, out);
+            ds_kt_end(ctx, DS_KT_NORMALMAP, kt, st);
             DS_HIP_CHECK(hipGetLastError());
             return DS_OK;
         }
@@ -348,6 +350,57 @@ DS_API int ds_normalmap(ds_ctx *ctx, const uint16_t *depth, int n, int h, int w,
                         int sobel_ksize, int post_blur, int invert, uint8_t *out, void *stream)
 {
     return nm_run(ctx, depth, 0, n, h, w, pre_blur, sobel_ksize, post_blur, invert, out, stream);
+}
+
+// float32 depth with sobel_gradient None / <= 0 (src/normalmap_generation.py:31): the one combination the reference runs in
+// FLOAT32 from end to end -- `depthmap * (-1.0) / 256.0` keeps float32 (:20-21), np.gradient, np.dstack, np.linalg.norm
+// (x * x element-wise, the three squares added left to right, sqrt), the three divisions and `+= 1; /= 2; * 256; clip` are all
+// float32 operations, each correctly rounded (IEEE binary32; hipcc's default float32 division and sqrt are the correctly
+// rounded ones, and the library is built with -ffp-contract=off): one fused pass, bit-identical to numpy.
+__global__ __launch_bounds__(256) void k_nm_gradient_f32(const float *__restrict__ depth, int h, int w, int invert, uint8_t *__restrict__ out)
+{
+    const int img = blockIdx.z;
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= w || y >= h) return;
+    const float *p = depth + (size_t)img * h * w;
+    const float sgn = invert ? 1.0f : -1.0f;
+#define PV(yy, xx) ((p[(size_t)(yy) * w + (xx)] * sgn) / 256.0f)
+    float gx, gy;
+    if (x == 0) gx = (PV(y, 1) - PV(y, 0)) / 1.0f;
+    else if (x == w - 1) gx = (PV(y, w - 1) - PV(y, w - 2)) / 1.0f;
+    else gx = (PV(y, x + 1) - PV(y, x - 1)) / 2.0f;
+    if (y == 0) gy = (PV(1, x) - PV(0, x)) / 1.0f;
+    else if (y == h - 1) gy = (PV(h - 1, x) - PV(h - 2, x)) / 1.0f;
+    else gy = (PV(y + 1, x) - PV(y - 1, x)) / 2.0f;
+#undef PV
+    const float a = gx, b = -gy, c = 1.0f;
+    float s = a * a;
+    s = s + b * b;
+    s = s + c * c;
+    const float n = __fsqrt_rn(s);
+    const float v[3] = { __fdiv_rn(a, n), __fdiv_rn(b, n), __fdiv_rn(c, n) };
+    uint8_t *o = out + ((size_t)img * h * w + (size_t)y * w + x) * 3;
+    for (int k = 0; k < 3; k++) {
+        float t = v[k] + 1.0f;
+        t = t / 2.0f;
+        t = t * 256.0f;
+        t = t < 0.0f ? 0.0f : t;                             // np.clip(., 0, 256 - 0.1): the bounds become float32 (NEP 50)
+        t = t > (float)(256 - 0.1) ? (float)(256 - 0.1) : t;
+        o[k] = (t == t) ? (uint8_t)(int)t : (uint8_t)0;
+    }
+}
+
+DS_API int ds_normalmap_gradient_f32(ds_ctx *ctx, const float *depth, int n, int h, int w, int invert, uint8_t *out, void *stream)
+{
+    DS_REQUIRE(ctx && depth && out, DS_EINVAL, "ds_normalmap_gradient_f32: null argument");
+    DS_REQUIRE(n > 0 && n <= 65535 && h >= 2 && w >= 2, DS_EINVAL, "ds_normalmap_gradient_f32: np.gradient needs at least 2 samples per axis (n=%d h=%d w=%d)", n, h, w);
+    DS_HIP_CHECK(hipSetDevice(ctx->device));
+    dim3 g2((w + 63) / 64, (h + 3) / 4, n);
+    DS_REQUIRE(g2.y <= 65535, DS_EUNSUPPORTED, "ds_normalmap_gradient_f32: image too tall");
+    hipLaunchKernelGGL(k_nm_gradient_f32, g2, dim3(256), 0, (hipStream_t)stream, depth, h, w, invert ? 1 : 0, out);
+    DS_HIP_CHECK(hipGetLastError());
+    return DS_OK;
 }
 
 // Any other real dtype of the reference's `depthmap` argument (:20-21 promote it to float64; the host casts): the separable

@@ -119,14 +119,15 @@ class Block(vm.EncoderBlock):
         per block, 155 GB for the 24 blocks): the block then hands out a _LazyBias that gathers per query tile from the
         resized table, like the reference, which builds the bias transiently in every block (beit.py:29-62)."""
         a = self.attn
-        if not (dtype == torch.float32 or device.type != 'cuda'):
+        plain = dtype in (torch.float32, torch.float64) or device.type != 'cuda'     # attention_reference's dense [H, Np, Np] operand
+        if not plain:
             n_pad = (n_pad + 63) // 64 * 64            # the packed operand of the HIP kernel lives on whole 64-key tiles
         key = (tuple(grid_hw), n_pad, dtype, device, a.relative_position_bias_table._version)
         hit = self._bias_cache.get(key)
         if hit is not None:
             return hit
         with torch.no_grad():
-            if dtype == torch.float32 or device.type != 'cuda':
+            if plain:
                 heads = a.relative_position_bias_table.shape[1]
                 if heads * n_pad * n_pad * 4 > DENSE_BIAS_BYTES_MAX:
                     if self._bias_cache:

@@ -20,9 +20,10 @@ DS_DEPTH_U16, DS_DEPTH_F32, DS_DEPTH_F64 = 0, 1, 2
 FILL_IDS = {"none": 0, "naive": 1, "naive_interpolating": 2, "polylines_soft": 3, "polylines_sharp": 4}
 
 EXPORTS = [
-    "ds_version", "ds_last_error", "ds_normalmap_f64", "ds_reassemble_readout", "ds_bias_act_nhwc", "ds_linear", "ds_linear_residual", "ds_linear_vt", "ds_conv3x3_nhwc", "ds_ctx_create", "ds_ctx_destroy", "ds_stereo_warp", "ds_depth_minmax",
+    "ds_version", "ds_last_error", "ds_normalmap_f64", "ds_normalmap_gradient_f32", "ds_reassemble_readout", "ds_bias_act_nhwc", "ds_linear", "ds_linear_residual", "ds_linear_vt", "ds_conv3x3_nhwc", "ds_ctx_create", "ds_ctx_destroy", "ds_stereo_warp", "ds_depth_minmax",
     "ds_stereo_last_exact_rows", "ds_copy_view", "ds_overlap_red_cyan", "ds_normalmap", "ds_depth_to_u16",
     "ds_convert_to_i16", "ds_profile_enable", "ds_profile_last_ms", "ds_stereo_last_stats", "ds_attention_fwd", "ds_attention_bias_pack", "ds_colorize_u16", "ds_residual_layernorm", "ds_boost_blend", "ds_upsample_bilinear_nhwc", "ds_dpt_head_tail", "ds_preprocess_bicubic", "ds_linear_reload_env",
+    "ds_linear_shuffle", "ds_linear_readout", "ds_kernel_timer_enable", "ds_kernel_timer_read",
 ]
 
 
@@ -65,6 +66,7 @@ def lib():
             L.ds_overlap_red_cyan.argtypes = [vp, vp, i64, i64, vp, i64, i64, ci, ci, ci, ci, vp, vp]
             L.ds_normalmap.argtypes = [vp, vp, ci, ci, ci, ci, ci, ci, ci, vp, vp]
             L.ds_normalmap_f64.argtypes = [vp, vp, ci, ci, ci, ci, ci, ci, ci, vp, vp]
+            L.ds_normalmap_gradient_f32.argtypes = [vp, vp, ci, ci, ci, ci, vp, vp]
             L.ds_depth_to_u16.argtypes = [vp, vp, ci, ci, ci, ci, vp, vp, vp]
             L.ds_convert_to_i16.argtypes = [vp, vp, ci, i64, vp, vp]
             L.ds_stereo_last_stats.argtypes = [vp, ctypes.POINTER(i64), vp]
@@ -83,6 +85,10 @@ def lib():
             L.ds_linear_residual.argtypes = [vp, vp, vp, vp, vp, vp, vp, i64, i64, i64, ci, vp]
             L.ds_linear_vt.argtypes = [vp, vp, vp, vp, i64, i64, i64, i64, ci, vp]
             L.ds_conv3x3_nhwc.argtypes = [vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, vp]
+            L.ds_linear_shuffle.argtypes = [vp, vp, vp, vp, vp, i64, i64, ci, ci, ci, ci, vp]
+            L.ds_linear_readout.argtypes = [vp, vp, vp, vp, vp, i64, i64, i64, i64, i64, ci, vp]
+            L.ds_kernel_timer_enable.argtypes = [vp, ci]
+            L.ds_kernel_timer_read.argtypes = [vp, ci, ctypes.POINTER(i64), ctypes.POINTER(cd)]
             L.ds_profile_enable.argtypes = [vp, ci]
             L.ds_profile_last_ms.argtypes = [vp, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float)]
             for name in EXPORTS:          # fail at load time, not at first use, if a symbol is missing
@@ -232,11 +238,18 @@ def overlap_red_cyan(im1_ptr, r1, i1, im2_ptr, r2, i2, n, h, w, c, out):
 
 
 def normalmap(depth, pre_blur, sobel_ksize, post_blur, invert):
-    """depth [n,h,w]: uint16 (the funnel's depth maps; the fused kernel) or float64 (any other dtype, cast by the caller)."""
+    """depth [n,h,w]: uint16 (the funnel's depth maps; the fused kernel), float64 (any other dtype, cast by the caller), or
+    float32 with np.gradient and no blur (the reference's float32 evaluation: ds_normalmap_gradient_f32)."""
     torch = require_gpu()
     n, h, w = depth.shape
-    assert depth.dtype in (torch.uint16, torch.float64) and depth.is_contiguous()
+    assert depth.dtype in (torch.uint16, torch.float64, torch.float32) and depth.is_contiguous()
     out = torch.empty((n, h, w, 3), dtype=torch.uint8, device=depth.device)
+    if depth.dtype == torch.float32:
+        assert int(pre_blur) == 0 and int(post_blur) == 0 and int(sobel_ksize) == 0, "float32 depth: np.gradient without blurs only"
+        CALLS["ds_normalmap_gradient_f32"] += 1
+        _check(lib().ds_normalmap_gradient_f32(ctx_for(_dev_index(depth)), depth.data_ptr(), n, h, w, 1 if invert else 0,
+                                               out.data_ptr(), _stream(depth)))
+        return out
     fn = lib().ds_normalmap if depth.dtype == torch.uint16 else lib().ds_normalmap_f64
     CALLS["ds_normalmap" if depth.dtype == torch.uint16 else "ds_normalmap_f64"] += 1
     _check(fn(ctx_for(_dev_index(depth)), depth.data_ptr(), n, h, w, int(pre_blur), int(sobel_ksize),
@@ -437,6 +450,89 @@ def linear_residual(x, weight, bias, gamma, residual):
                                     None if g is None else g.data_ptr(), r2.data_ptr(), out.data_ptr(), x2.shape[0], n, k,
                                     1 if x.dtype == torch.float16 else 2, _stream(x)))
     return out.view(residual.shape)
+
+
+def linear_readout_supported(x_padded, w_tok):
+    """Shapes ds_linear_readout takes: x [B, Np, K] contiguous with B * Np >= 256, w_tok [N % 256 == 0, K % 128 == 0]."""
+    return (x_padded.dim() == 3 and x_padded.is_contiguous() and x_padded.shape[0] * x_padded.shape[1] >= 256
+            and w_tok.shape[0] % 256 == 0 and w_tok.shape[1] == x_padded.shape[2] and x_padded.shape[2] % 128 == 0
+            and 128 <= x_padded.shape[2] <= 16384 and x_padded.shape[0] * x_padded.shape[1] * x_padded.shape[1] < (1 << 32))
+
+
+def linear_readout(x_padded, n_tokens, w_tok, cls_vec):
+    """GELU(x[b, t] @ w_tok.T + cls_vec[b]) for the tokens t = 1 .. n_tokens - 1 of every image, token-major = the NHWC patch grid
+    (include/depthstereo.h: ds_linear_readout).  x_padded [B, Np, K] float16 / bfloat16 CUDA (the encoder's padded block output),
+    w_tok [N, K], cls_vec [B, N] -> [B, n_tokens - 1, N] (a view of a buffer with one dummy row behind it)."""
+    torch = require_gpu()
+    assert x_padded.is_cuda and x_padded.dtype in (torch.float16, torch.bfloat16) and linear_readout_supported(x_padded, w_tok)
+    b, npad, k = x_padded.shape
+    n = w_tok.shape[0]
+    assert 2 <= n_tokens <= npad and tuple(cls_vec.shape) == (b, n)
+    w = w_tok.detach()
+    w = w if (w.dtype == x_padded.dtype and w.is_contiguous()) else w.to(x_padded.dtype).contiguous()
+    cv = cls_vec if (cls_vec.dtype == x_padded.dtype and cls_vec.is_contiguous()) else cls_vec.to(x_padded.dtype).contiguous()
+    out = torch.empty((b * (n_tokens - 1) + 1, n), dtype=x_padded.dtype, device=x_padded.device)
+    CALLS["ds_linear_readout"] += 1
+    _check(lib().ds_linear_readout(ctx_for(_dev_index(x_padded)), x_padded.data_ptr(), w.data_ptr(), cv.data_ptr(), out.data_ptr(),
+                                   b, npad, n_tokens, n, k, 1 if x_padded.dtype == torch.float16 else 2, _stream(x_padded)))
+    return out[:b * (n_tokens - 1)].view(b, n_tokens - 1, n)
+
+
+def conv_transpose_shuffle_supported(layer, x):
+    """ConvTranspose2d layers ds_linear_shuffle takes: kernel == stride (square), no padding / output padding / groups / dilation,
+    in_channels % 128 == 0, out_channels % 8 == 0, stride^2 * out_channels % 256 == 0, at least 256 input pixels."""
+    ks, st = tuple(layer.kernel_size), tuple(layer.stride)
+    return (ks == st and ks[0] == ks[1] and 1 <= ks[0] <= 8 and tuple(layer.padding) == (0, 0) and tuple(layer.output_padding) == (0, 0)
+            and tuple(layer.dilation) == (1, 1) and layer.groups == 1 and layer.in_channels % 128 == 0 and 128 <= layer.in_channels <= 16384
+            and layer.out_channels % 8 == 0 and (ks[0] * ks[0] * layer.out_channels) % 256 == 0 and x.dim() == 4
+            and x.shape[1] == layer.in_channels and x.shape[0] * x.shape[2] * x.shape[3] >= 256)
+
+
+def conv_transpose_shuffle(layer, x):
+    """layer(x) for an nn.ConvTranspose2d with kernel == stride on a float16 / bfloat16 CUDA activation, channels_last in and out
+    (include/depthstereo.h: ds_linear_shuffle).  The [(kH, kW, out), in] weight image and the per-tap bias are cached on the module."""
+    torch = require_gpu()
+    assert x.is_cuda and x.dtype in (torch.float16, torch.bfloat16) and conv_transpose_shuffle_supported(layer, x)
+    x = x.contiguous(memory_format=torch.channels_last)
+    b, c, h, w = x.shape
+    s, co = layer.stride[0], layer.out_channels
+    key = (layer.weight.data_ptr(), layer.weight._version, x.dtype, None if layer.bias is None else layer.bias._version)
+    hit = getattr(layer, "_ds_shuffle", None)
+    if hit is None or hit[0] != key:
+        if hit is not None:
+            from . import vit_mi355x as _vm
+            _vm.cache_evicted()                 # a live hipGraph may still read the old weight image
+        wg = layer.weight.detach().permute(2, 3, 1, 0).reshape(s * s * co, c).to(x.dtype).contiguous()      # [in, out, kH, kW] -> [(kH, kW, out), in]
+        bg = None if layer.bias is None else layer.bias.detach().to(x.dtype).repeat(s * s).contiguous()
+        hit = (key, wg, bg)
+        if not torch.is_grad_enabled():
+            layer._ds_shuffle = hit
+    _, wg, bg = hit
+    out = torch.empty((b, h * s, w * s, co), dtype=x.dtype, device=x.device)
+    xr = x.permute(0, 2, 3, 1)                   # the NHWC memory as [b, h, w, c]: contiguous
+    CALLS["ds_linear_shuffle"] += 1
+    _check(lib().ds_linear_shuffle(ctx_for(_dev_index(x)), xr.data_ptr(), wg.data_ptr(), None if bg is None else bg.data_ptr(), out.data_ptr(),
+                                   b * h * w, c, w, s, co, 1 if x.dtype == torch.float16 else 2, _stream(x)))
+    return out.permute(0, 3, 1, 2)               # logical NCHW, channels_last memory
+
+
+KT_KINDS = {"linear_gelu": 0, "attention": 1, "linear_residual": 2, "linear": 3, "linear_vt": 4, "conv3x3": 5, "linear_readout": 6,
+            "linear_shuffle": 7, "normalmap": 8}
+KT_RAGGED = 12
+
+
+def kernel_timer_enable(device_index, enable=True):
+    """In-step kernel timers of the C ABI (include/depthstereo.h: ds_kernel_timer_enable): event pairs around the launches."""
+    _check(lib().ds_kernel_timer_enable(ctx_for(device_index), 1 if enable else 0))
+
+
+def kernel_timer_read(device_index, kind):
+    """(launches timed, sum of their durations in ms) of one kind: a name of KT_KINDS, or "<name>+ragged" for its ragged round."""
+    base, _, rag = kind.partition("+")
+    k = KT_KINDS[base] + (KT_RAGGED if rag == "ragged" else 0)
+    n, ms = ctypes.c_int64(), ctypes.c_double()
+    _check(lib().ds_kernel_timer_read(ctx_for(device_index), k, ctypes.byref(n), ctypes.byref(ms)))
+    return int(n.value), float(ms.value)
 
 
 def linear_vt_supported(w_v, h):

@@ -24,11 +24,18 @@ def create_normalmap(depthmap, pre_blur=None, sobel_gradient=3, post_blur=None, 
     if depth.dtype != np.uint16:
         # :20-21: `depthmap * (-1.0) / 256.0` promotes integers to float64 and keeps float32 as float32; cv2.Sobel is fed
         # np.float64(normalmap) (:28-29), which equals the float64 evaluation (negation and /256 are exact), but np.gradient
-        # (:31) and everything after it would run in float32 -- that one combination is not built.
-        if depth.dtype.kind == 'f' and depth.dtype.itemsize < 8 and _ksize(sobel_gradient) == 0:
-            raise _native.DepthStereoError('create_normalmap: float16/float32 depth with np.gradient (sobel_gradient None) runs '
-                                           'in float32 in the reference and is not built; pass float64 or use a Sobel size')
-        depth = depth.astype(np.float64)
+        # (:31) and everything after it run in the array's own precision: float32 has a kernel of its own (every operation
+        # in binary32, numpy's order); a blur in front of / behind it would be cv2's float32 GaussianBlur (unpinned: not built),
+        # and float16 arithmetic (numpy rounds every operation to half) is not built either.
+        f32_gradient = depth.dtype == np.float32 and _ksize(sobel_gradient) == 0
+        if f32_gradient and (_ksize(pre_blur) or _ksize(post_blur)):
+            raise _native.DepthStereoError('create_normalmap: float32 depth with np.gradient AND a Gaussian blur runs through cv2\'s '
+                                           'float32 GaussianBlur in the reference and is not built; pass float64 or use a Sobel size')
+        if depth.dtype == np.float16 and _ksize(sobel_gradient) == 0:
+            raise _native.DepthStereoError('create_normalmap: float16 depth with np.gradient (sobel_gradient None) runs in float16 '
+                                           'in the reference and is not built; pass float32 / float64 or use a Sobel size')
+        if not f32_gradient:
+            depth = depth.astype(np.float64)
     dev = torch.device('cuda', torch.cuda.current_device())
     d = torch.from_numpy(np.array(depth, order='C')).to(dev).unsqueeze(0)
     out = create_normalmap_batch(d, pre_blur, sobel_gradient, post_blur, invert)

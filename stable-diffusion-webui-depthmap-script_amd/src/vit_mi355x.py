@@ -108,9 +108,10 @@ def attention_reference(qk, vt, n_valid, scale, bias=None):
     Long sequences (Boost's whole-image pass reaches 10^4 tokens: B*H*Np^2 floats = 6.4 GB per block) are processed in
     query tiles of at most SCORE_BYTES_MAX bytes of logits; softmax rows are independent, so the result is the same."""
     b, npad, _, h, d = qk.shape
-    q = qk[:, :, 0].permute(0, 2, 1, 3).float()                # B H Np D
-    k = qk[:, :, 1].permute(0, 2, 1, 3).float()
-    v = vt.reshape(b, h, d, npad).permute(0, 1, 3, 2).float()   # B H Np D
+    ct = torch.float64 if qk.dtype == torch.float64 else torch.float32      # float64 in, float64 math: the "truth" evaluation
+    q = qk[:, :, 0].permute(0, 2, 1, 3).to(ct)                 # B H Np D     of the parity budgets (tests/test_gpu_models.py)
+    k = qk[:, :, 1].permute(0, 2, 1, 3).to(ct)
+    v = vt.reshape(b, h, d, npad).permute(0, 1, 3, 2).to(ct)    # B H Np D
     kt = k.transpose(-2, -1)
     rows = max(1, min(npad, SCORE_BYTES_MAX // max(1, b * h * npad * 4)))
     outs = []
@@ -119,7 +120,7 @@ def attention_reference(qk, vt, n_valid, scale, bias=None):
         att = (q[:, :, q0:q1] * scale) @ kt
         if bias is not None:
             bt = bias.rows(q0, q1) if hasattr(bias, "rows") else bias[:, q0:q1]
-            att = att + bt.float().unsqueeze(0)
+            att = att + bt.to(ct).unsqueeze(0)
         if n_valid < npad:
             att[..., n_valid:] = float('-inf')
         outs.append(att.softmax(dim=-1) @ v)
@@ -208,7 +209,7 @@ def linear(x, weight, bias=None, gelu=False):
 def fused_attention(qk, vt, n_valid, scale, bias=None):
     """bias: None, or what the block's attention_bias() cached for this dtype: the packed operand of the HIP kernel
     (_native.attention_bias_pack) for float16 / bfloat16, a padded [H, Np(query), Np(key)] tensor for float32."""
-    if qk.dtype == torch.float32:
+    if qk.dtype in (torch.float32, torch.float64):
         return attention_reference(qk, vt, n_valid, scale, bias)
     from . import _native
     return _native.attention_fwd(qk, vt, n_valid, scale, bias)

@@ -144,6 +144,21 @@ def main():
     u8 = rng.integers(0, 256, (16, 18), dtype=np.uint8)
     out['u8_16x18__depth'] = u8
     add('u8_16x18', u8, None, 3, None, False)
+    # float32 depth with np.gradient: the one combination the reference evaluates in FLOAT32 end to end (:20-21 keep float32,
+    # :31 np.gradient, :34-39 np.linalg.norm and the divisions, :51-54 the quantisation) -- arbitrary values, no cv2 call
+    f32r = rng.normal(0.0, 3000.0, (27, 33)).astype(np.float32)
+    out['f32normal27x33__depth'] = f32r
+    f32m = (rng.random((22, 45)) * 37.0 + 5.0).astype(np.float32)                       # a MiDaS-like raw prediction: small gradients
+    f32m[5:11, 10:30] += 11.5
+    out['f32midas22x45__depth'] = f32m
+    f32s = np.zeros((8, 9), np.float32)                                                # flat areas (n == 1 exactly) and huge steps
+    f32s[2:5, 3:7] = 6.0e4
+    f32s[6, :] = -3.0e38 / 1.0e33
+    out['f32steps8x9__depth'] = f32s
+    for nm_, arr in (('f32normal27x33', f32r), ('f32midas22x45', f32m), ('f32steps8x9', f32s)):
+        for inv in (False, True):
+            for sob in (None, 0):
+                add(nm_, arr, None, sob, None, inv)
     # blur structure (stand-in arithmetic, see the module docstring)
     for args in ((3, 3, None), (None, 3, 3), (5, None, 3), (3, 5, 5)):
         add('survey48x64', deps['survey48x64'], args[0], args[1], args[2], False, standin=1)

@@ -1,0 +1,170 @@
+#!/usr/bin/env python3
+"""Measured values behind the GPU parity bars that are looser than north_star's 1e-4 (float32) / the repo's own 2e-2 (float16),
+with a per-stage localisation of where the device leaves the CPU twin (round-4 verdict, "What's weak" 1):
+
+    ZoeDepth N / K / NK   float32 and float16 on the device against the reference-made golden (tests/golden/zoedepth_cases.npz),
+                          against the SAME network evaluated in float64 on the device ("truth"), and stage by stage against the
+                          float32 CPU twin (which holds 1e-4 against the reference: tests/test_models_cpu.py)
+    dpt_hybrid_384        float16 against the golden and stage by stage against the float32 forward on the device
+    Boost                 the device against the reference's own estimateboost (golden), float32
+
+    gpurun -- 'python tools/parity_probe.py > gpurun_out/parity_probe.json'
+
+Prints one JSON object; the numbers quoted in DESIGN.md section 4 and in the tests' comments come from profiles/round5_parity_probe.json.
+"""
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "stable-diffusion-webui-depthmap-script_amd"), os.path.join(ROOT, "tests"), os.path.join(ROOT, "tests", "golden")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+import model_weights as mw  # noqa: E402
+
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+def rel(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
+
+
+def first_tensor(o):
+    if torch.is_tensor(o):
+        return o
+    if isinstance(o, (tuple, list)):
+        for v in o:
+            t = first_tensor(v)
+            if t is not None:
+                return t
+    if isinstance(o, dict):
+        for v in o.values():
+            t = first_tensor(v)
+            if t is not None:
+                return t
+    return None
+
+
+def trace(model, names, run):
+    """{module name: first output tensor (float64 numpy) of its LAST call} while run() executes."""
+    got, hooks = {}, []
+    mods = dict(model.named_modules())
+    for n in names:
+        if n in mods:
+            hooks.append(mods[n].register_forward_hook(lambda m, i, o, n=n: got.__setitem__(n, first_tensor(o).detach().double().cpu().numpy())))
+    out = run()
+    for h in hooks:
+        h.remove()
+    return out, got
+
+
+def zoedepth(out):
+    from dzoedepth import build_zoedepth
+    z = np.load(os.path.join(GOLD, "zoedepth_cases.npz"))
+    stages = ["core.core.pretrained", "core.core.scratch.refinenet4", "core.core.scratch.refinenet1", "core.core", "conv2", "seed_bin_regressor",
+              "seed_bin_regressors.nyu", "seed_bin_regressors.kitti", "seed_projector", "projectors.0", "projectors.3", "attractors.0", "attractors.3",
+              "attractors.nyu.0", "attractors.nyu.3", "attractors.kitti.0", "attractors.kitti.3", "conditional_log_binomial",
+              "conditional_log_binomial.nyu", "conditional_log_binomial.kitti", "conditional_log_binomial.mlp"]
+    for tag, kind in (("n", "zoedepth_n"), ("k", "zoedepth_k"), ("nk", "zoedepth_nk")):
+        m, _ = build_zoedepth(kind, midas_model_type="DPT_BEiT_B_384")
+        m = m.eval()
+        m.load_state_dict(mw.fill_state_dict_zoe(m.state_dict()), strict=True)
+        x = torch.rand((1, 3, 88, 120), generator=torch.Generator().manual_seed(21))
+        m.core.set_net_size(160, 128)
+        ref = z[f"{tag}_88x120_infer"]
+        r = {"golden_range": [float(ref.min()), float(ref.max())]}
+        with torch.no_grad():
+            y_cpu, st_cpu = trace(m, stages, lambda: m.infer(x).numpy())
+            r["cpu32_vs_golden"] = rel(y_cpu, ref)
+            mg = m.cuda()
+            y32, st_gpu = trace(mg, stages, lambda: mg.infer(x.cuda()).cpu().numpy())
+            r["gpu32_vs_golden"] = rel(y32, ref)
+            r["gpu32_vs_cpu32"] = rel(y32, y_cpu)
+            r["stages_gpu32_vs_cpu32"] = {k: rel(st_gpu[k], st_cpu[k]) for k in stages if k in st_gpu and k in st_cpu}
+            # float32 matmul / convolution precision knobs of the libraries behind torch (nothing reduced is on by default)
+            r["allow_tf32"] = [bool(torch.backends.cuda.matmul.allow_tf32), bool(torch.backends.cudnn.allow_tf32)]
+            md = mg.double()
+            y64 = md.infer(x.double().cuda()).cpu().numpy()
+            r["gpu64_vs_golden"] = rel(y64, ref)
+            r["gpu32_vs_gpu64"] = rel(y32, y64)
+            r["cpu32_vs_gpu64"] = rel(y_cpu, y64)
+            mh = md.float().half()
+            y16, st16 = trace(mh, stages, lambda: mh.infer(x.half().cuda()).float().cpu().numpy())
+            r["gpu16_vs_golden"] = rel(y16, ref)
+            r["gpu16_finite"] = bool(np.isfinite(y16).all())
+            r["stages_gpu16_vs_cpu32"] = {k: rel(st16[k], st_cpu[k]) for k in stages if k in st16 and k in st_cpu}
+            # the same half network with every token GEMM / 3x3 convolution through the ROCm libraries
+            from src import vit_mi355x as vm
+            with vm.library_routing():
+                r["gpu16_library_routing_vs_golden"] = rel(mh.infer(x.half().cuda()).float().cpu().numpy(), ref)
+        out[f"zoedepth_{tag}"] = r
+        del m, mg, md, mh
+        torch.cuda.empty_cache()
+
+
+def hybrid(out):
+    from dmidas.dpt_depth import DPTDepthModel
+    z = np.load(os.path.join(GOLD, "model_cases.npz"))
+    m = DPTDepthModel(path=None, backbone="vitb_rn50_384", non_negative=True).eval()
+    m.load_state_dict(mw.fill_state_dict(m.state_dict()), strict=True)
+    x = mw.synthetic_image((2, 3, 160, 224), seed=14)
+    ref = z["dpt_hybrid_160x224_out"]
+    stages = ["pretrained.model.patch_embed.backbone.stem", "pretrained.model.patch_embed.backbone", "pretrained.model.patch_embed", "pretrained.model.blocks.0", "pretrained.model.blocks.5",
+              "pretrained.model.blocks.11", "pretrained", "scratch.layer1_rn", "scratch.layer4_rn", "scratch.refinenet4", "scratch.refinenet3",
+              "scratch.refinenet2", "scratch.refinenet1", "scratch.output_conv.0", "scratch.output_conv"]
+    r = {}
+    with torch.no_grad():
+        mg = m.cuda()
+        y32, s32 = trace(mg, stages, lambda: mg(x.cuda()).cpu().numpy())
+        r["gpu32_vs_golden"] = rel(y32, ref)
+        mh = mg.half()
+        y16, s16 = trace(mh, stages, lambda: mh(x.half().cuda().contiguous(memory_format=torch.channels_last)).float().cpu().numpy())
+        r["gpu16_vs_golden"] = rel(y16, ref)
+        r["gpu16_vs_gpu32"] = rel(y16, y32)
+        r["stages_gpu16_vs_gpu32"] = {k: rel(s16[k], s32[k]) for k in stages if k in s16 and k in s32}
+        r["golden_stats"] = {"max": float(np.abs(ref).max()), "std": float(ref.std()), "mean": float(ref.mean())}
+        from src import vit_mi355x as vm
+        with vm.library_routing():
+            r["gpu16_library_routing_vs_golden"] = rel(mh(x.half().cuda().contiguous(memory_format=torch.channels_last)).float().cpu().numpy(), ref)
+    out["dpt_hybrid"] = r
+
+
+def boost_case(out):
+    from lib.multi_depth_model_woauxi import RelDepthModel
+    from pix2pix.models.pix2pix4depth_model import Pix2Pix4DepthModel
+    from src import boost
+    z = np.load(os.path.join(GOLD, "boost_cases.npz"))
+    net = RelDepthModel('resnext101').eval()
+    net.load_state_dict(mw.fill_state_dict(net.state_dict()), strict=True)
+    p2p = Pix2Pix4DepthModel().eval()
+    p2p.netG.load_state_dict(mw.fill_state_dict(p2p.netG.state_dict()), strict=True)
+    stats = {}
+    o = boost.estimateboost(torch.from_numpy(z["image"]).cuda(), net.cuda(), 0, p2p.cuda(), whole_size_threshold=int(z["rmax"][0]), stats=stats).cpu().numpy()
+    want, got = z["depth_s2"], o[::2, ::2]
+    out["boost"] = {"gpu_vs_golden_max": rel(got, want), "gpu_vs_golden_mean": float(np.abs(got - want).mean() / np.abs(want).max()),
+                    "patches": stats.get("patches")}
+
+
+def main():
+    out = {"device": torch.cuda.get_device_name(0), "torch": torch.__version__}
+    which = sys.argv[1:] or ["hybrid", "zoedepth", "boost"]
+    for name in which:
+        try:
+            {"zoedepth": zoedepth, "hybrid": hybrid, "boost": boost_case}[name](out)
+        except Exception as e:                      # a probe: report and go on
+            import traceback
+            out[name + "_error"] = traceback.format_exc()[-1500:]
+    text = json.dumps(out, indent=1)
+    scratch = os.path.join(ROOT, "gpurun_out")
+    if os.path.isdir(scratch):
+        with open(os.path.join(scratch, "parity_probe.json"), "w") as f:
+            f.write(text)
+    print(text)
+
+
+if __name__ == "__main__":
+    main()
