@@ -39,7 +39,7 @@ class FeatureFusionBlock(nn.Module):
         output = self.resConfUnit2(output)
         # the reference interpolates, then applies the 1x1 out_conv; both are linear and the bilinear weights sum to one,
         # so they commute (bias included): the conv runs on 4x fewer pixels and the upsample writes the final tensor
-        output = self.out_conv(output)
+        output = vm.conv_module(self.out_conv, output)
         if size is None:
             return vm.interpolate_bilinear(output, scale_factor=2, align_corners=True)
         return vm.interpolate_bilinear(output, size=tuple(size), align_corners=True)
@@ -75,7 +75,9 @@ class DPTHead(nn.Module):
             x = x[0]
             # [B, ph*pw, C] IS the NHWC image: a channels_last view, not a permuted copy (reference: permute + reshape)
             x = x.reshape(x.shape[0], patch_h, patch_w, x.shape[-1]).permute(0, 3, 1, 2)
-            x = self.resize_layers[i](self.projects[i](x))
+            if vm.half_on_gpu(x) and not x.is_contiguous(memory_format=torch.channels_last):
+                x = x.contiguous(memory_format=torch.channels_last)     # (the tokens without their cls row: one copy, which a library convolution makes too)
+            x = vm.conv_module(self.resize_layers[i], vm.conv_module(self.projects[i], x))
             out.append(x)
         l1, l2, l3, l4 = out
         s = self.scratch
@@ -86,7 +88,7 @@ class DPTHead(nn.Module):
         path_1 = s.refinenet1(path_2, l1)
         out = vm.conv2d(s.output_conv1, path_1)                # 256 -> 128: the in-tree implicit GEMM (256 x 128 tiles) where it fills the chip
         size = (int(patch_h * 14), int(patch_w * 14))
-        if out.is_cuda and out.dtype in (torch.float16, torch.bfloat16) and tuple(s.output_conv2[0].weight.shape) == (32, 128, 3, 3):
+        if vm.half_on_gpu(out) and tuple(s.output_conv2[0].weight.shape) == (32, 128, 3, 3):
             # upsample -> conv3x3 128->32 -> ReLU -> conv1x1 -> ReLU in one MFMA kernel (ds_dpt_head_tail)
             from src import _native
             return _native.dpt_head_tail(out, size, s.output_conv2[0], s.output_conv2[2], relu_out=True)
@@ -139,7 +141,7 @@ class DepthAnythingV2(nn.Module):
         cv2 itself is not available in this environment: parity of the resize is unpinned."""
         b, h, w, _ = images_u8.shape
         nw, nh = lower_bound_size(w, h, input_size)
-        if images_u8.is_cuda and vm.PREPROCESS_HIP:
+        if images_u8.is_cuda and vm.PREPROCESS_HIP and not vm.STOCK[0]:
             # one pass over the image bytes (ds_preprocess_bicubic), already in the network's dtype
             from src import _native
             dtype = self.pretrained.blocks[0].norm1.weight.dtype

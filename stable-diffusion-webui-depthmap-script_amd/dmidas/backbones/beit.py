@@ -119,10 +119,10 @@ class Block(vm.EncoderBlock):
         per block, 155 GB for the 24 blocks): the block then hands out a _LazyBias that gathers per query tile from the
         resized table, like the reference, which builds the bias transiently in every block (beit.py:29-62)."""
         a = self.attn
-        plain = dtype in (torch.float32, torch.float64) or device.type != 'cuda'     # attention_reference's dense [H, Np, Np] operand
+        plain = dtype in (torch.float32, torch.float64) or device.type != 'cuda' or vm.STOCK[0]     # attention_reference's dense [H, Np, Np] operand
         if not plain:
             n_pad = (n_pad + 63) // 64 * 64            # the packed operand of the HIP kernel lives on whole 64-key tiles
-        key = (tuple(grid_hw), n_pad, dtype, device, a.relative_position_bias_table._version)
+        key = (tuple(grid_hw), n_pad, dtype, device, a.relative_position_bias_table._version, plain)
         hit = self._bias_cache.get(key)
         if hit is not None:
             return hit
@@ -204,15 +204,16 @@ class Beit(nn.Module):
                 if m.bias is not None:
                     nn.init.zeros_(m.bias)
 
-    def forward_taps(self, x, hooks):
-        """beit.py:110-129 + the forward hooks of utils.py:155-158: outputs of blocks `hooks`, unpadded [B, N, C]."""
+    def forward_taps(self, x, hooks, padded=False):
+        """beit.py:110-129 + the forward hooks of utils.py:155-158: outputs of blocks `hooks`, unpadded [B, N, C] (padded: the
+        padded [B, Np, C] block outputs, for ProjectReadout.forward_padded).  Returns (taps, grid, n_valid)."""
         grid = (x.shape[2] // 16, x.shape[3] // 16)
         t = self.patch_embed(x)
         t = torch.cat((self.cls_token.expand(t.shape[0], -1, -1).to(t.dtype), t), dim=1)
         n_valid = t.shape[1]
         t = vm.pad_tokens(t, vm.pad_len(n_valid, t.shape[0]))
-        _, taps = vm.run_blocks(self.blocks, t, n_valid, grid, set(hooks))
-        return [taps[i] for i in hooks], grid
+        _, taps = vm.run_blocks(self.blocks, t, n_valid, grid, set(hooks), padded_taps=padded)
+        return [taps[i] for i in hooks], grid, n_valid
 
 
 class ProjectReadout(nn.Module):       # utils.py:28-39
@@ -247,10 +248,22 @@ class ProjectReadout(nn.Module):       # utils.py:28-39
         w_tok, w_cls = self._split()
         clsvec = F.linear(x[:, 0], w_cls, self.project[0].bias)               # [B, C]
         proj = F.linear(x, w_tok)                                             # [B, N, C] (row 0 is not used)
-        if x.is_cuda and x.dtype in (torch.float16, torch.bfloat16) and x.shape[-1] % 8 == 0:
+        if vm.half_on_gpu(x) and x.shape[-1] % 8 == 0:
             from src import _native
             return _native.reassemble_readout(proj, clsvec)
         return F.gelu(proj[:, 1:] + clsvec[:, None])
+
+    def forward_padded(self, xp, n_valid):
+        """The same on the PADDED block output [B, Np, C] the encoder leaves behind (contiguous: no copy of the tap, which a
+        library GEMM on the sliced view x[:, :n_valid] makes): ONE in-tree GEMM whose epilogue adds the per-image cls vector,
+        applies the exact GELU, drops the cls / pad rows and leaves the tokens NHWC (ds_linear_readout).  -> [B, N-1, C]."""
+        from src import _native
+        w_tok, w_cls = self._split()
+        if (self.start_index == 1 and vm.READOUT_HIP and vm.LINEAR_HIP == "all" and vm.half_on_gpu(xp) and xp.is_contiguous()
+                and _native.linear_readout_supported(xp, w_tok) and vm.hip_gemm_ok(xp.shape[0] * xp.shape[1], w_tok.shape[0])):
+            clsvec = F.linear(xp[:, 0], w_cls, self.project[0].bias)         # [B, C]: one small library GEMM
+            return _native.linear_readout(xp, n_valid, w_tok, clsvec)
+        return self.forward(xp[:, :n_valid])
 
 
 class _Skip(nn.Module):                 # placeholder for Transpose / Unflatten slots (no parameters) so indices match
@@ -279,10 +292,10 @@ class BeitBackbone(nn.Module):
     def forward(self, x):
         """forward_beit = forward_adapted_unflatten (utils.py:83-124): readout-project, tokens -> [B, C, h/16, w/16]
         (run-time grid, not the constructor's), then the per-tap convolutions."""
-        taps, grid = self.model.forward_taps(x, self.hooks)
+        taps, grid, n_valid = self.model.forward_taps(x, self.hooks, padded=True)
         outs = []
         for tap, post in zip(taps, (self.act_postprocess1, self.act_postprocess2, self.act_postprocess3, self.act_postprocess4)):
-            y = post[0](tap)                                   # ProjectReadout: [B, N-1, C]
+            y = post[0].forward_padded(tap, n_valid)           # ProjectReadout: [B, N-1, C]
             y = y.reshape(y.shape[0], grid[0], grid[1], y.shape[2]).permute(0, 3, 1, 2)     # NHWC view, no copy
             for layer in list(post)[3:]:
                 y = vm.conv_module(layer, y)                    # library convolution + in-tree bias pass

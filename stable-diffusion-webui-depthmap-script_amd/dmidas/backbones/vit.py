@@ -234,8 +234,8 @@ class VisionTransformer(nn.Module):
         n_valid = t.shape[1]
         t = vm.pad_tokens(t, vm.pad_len(n_valid, t.shape[0]))
         block_hooks = list(hooks[n_stage_taps:])
-        _, taps = vm.run_blocks(self.blocks, t, n_valid, grid, set(block_hooks))
-        return stage_outs, [taps[i] for i in block_hooks], grid
+        _, taps = vm.run_blocks(self.blocks, t, n_valid, grid, set(block_hooks), padded_taps=True)
+        return stage_outs, [taps[i] for i in block_hooks], grid, n_valid
 
 
 def _token_postprocess(vit_features, out_features, tail):
@@ -265,14 +265,14 @@ class VitBackbone(nn.Module):
         self.act_postprocess1, self.act_postprocess2, self.act_postprocess3, self.act_postprocess4 = posts
 
     def forward(self, x):
-        stage_outs, taps, grid = self.model.forward_taps(x, self.hooks, self.number_stages)
+        stage_outs, taps, grid, n_valid = self.model.forward_taps(x, self.hooks, self.number_stages)
         posts = (self.act_postprocess1, self.act_postprocess2, self.act_postprocess3, self.act_postprocess4)
         outs = list(stage_outs)
         for tap, post in zip(taps, posts[self.number_stages:]):
-            y = post[0](tap)
+            y = post[0].forward_padded(tap, n_valid)           # ProjectReadout on the padded block output
             y = y.reshape(y.shape[0], grid[0], grid[1], y.shape[2]).permute(0, 3, 1, 2)      # NHWC view, no copy
             for layer in list(post)[3:]:
-                y = layer(y)
+                y = vm.conv_module(layer, y)
             outs.append(y)
         return outs
 

@@ -97,7 +97,7 @@ class DPT(nn.Module):
                 if i == 3:
                     features['out_conv'] = y
             return y
-        if (path_1.is_cuda and path_1.dtype in (torch.float16, torch.bfloat16) and isinstance(head[1], Interpolate)
+        if (vm.half_on_gpu(path_1) and isinstance(head[1], Interpolate)
                 and head[1].mode == "bilinear" and head[1].align_corners and tuple(head[2].weight.shape) == (32, 128, 3, 3)
                 and head[2].padding_mode == 'zeros'):          # TILING_MODE makes the convolutions circular: library path
             # upsample x2 -> conv3x3 128->32 -> ReLU -> conv1x1 -> ReLU in one MFMA kernel (ds_dpt_head_tail)
@@ -174,7 +174,7 @@ class DPTDepthModel(DPT):
         stand-in for cv2.resize (tests/golden/make_golden_transforms.py); cv2's arithmetic itself stays unpinned."""
         b, h, w, _ = images_u8.shape
         nw, nh = midas_net_size(w, h, int(net_size), int(net_size if net_h is None else net_h), resize_mode)
-        if images_u8.is_cuda and vm.PREPROCESS_HIP:
+        if images_u8.is_cuda and vm.PREPROCESS_HIP and not vm.STOCK[0]:
             # one pass over the image bytes (ds_preprocess_bicubic): flip, / 255, bicubic, normalise, cast, channels_last
             from src import _native
             return _native.preprocess_bicubic(images_u8, (nh, nw), mean, std, flip=True, dtype=dtype)

@@ -108,8 +108,10 @@ def attention_reference(qk, vt, n_valid, scale, bias=None):
     Long sequences (Boost's whole-image pass reaches 10^4 tokens: B*H*Np^2 floats = 6.4 GB per block) are processed in
     query tiles of at most SCORE_BYTES_MAX bytes of logits; softmax rows are independent, so the result is the same."""
     b, npad, _, h, d = qk.shape
-    ct = torch.float64 if qk.dtype == torch.float64 else torch.float32      # float64 in, float64 math: the "truth" evaluation
-    q = qk[:, :, 0].permute(0, 2, 1, 3).to(ct)                 # B H Np D     of the parity budgets (tests/test_gpu_models.py)
+    # float64 in, float64 math (the "truth" evaluation of the parity budgets); the stock twin (stock_routing) computes in the
+    # tensors' own dtype like the reference's modules do; float32 otherwise
+    ct = qk.dtype if (qk.dtype == torch.float64 or STOCK[0]) else torch.float32
+    q = qk[:, :, 0].permute(0, 2, 1, 3).to(ct)                 # B H Np D
     k = qk[:, :, 1].permute(0, 2, 1, 3).to(ct)
     v = vt.reshape(b, h, d, npad).permute(0, 1, 3, 2).to(ct)    # B H Np D
     kt = k.transpose(-2, -1)
@@ -134,7 +136,7 @@ def v_transposed(w_v, h):
     [C, Np] block.  Otherwise ONE batched library GEMM whose second operand is read transposed in place
     (torch.matmul(w_v, h.transpose(1, 2)) would first materialise h^T)."""
     b = h.shape[0]
-    if h.is_cuda and h.dtype in (torch.float16, torch.bfloat16) and LINEAR_HIP == "all":
+    if half_on_gpu(h) and LINEAR_HIP == "all":
         from . import _native
         if _native.linear_vt_supported(w_v, h) and hip_gemm_ok(w_v.shape[0], h.shape[0] * h.shape[1]):
             return _native.linear_vt(w_v, h)
@@ -180,6 +182,30 @@ def hip_gemm_ok(rows, out_features):
     return rows >= 256 and ((rows + 255) // 256) * (out_features // 256) >= LINEAR_HIP_MIN_TILES
 
 
+# Every "half precision on the GPU -> in-tree kernel" decision of the networks goes through this predicate, so that ONE switch
+# (stock_routing below) turns the same network into its stock-torch twin: aten LayerNorm / softmax / GELU / interpolate and library
+# GEMMs / convolutions in half, i.e. the arithmetic the reference itself runs on a GPU in half precision.
+STOCK = [False]
+
+
+def half_on_gpu(x):
+    return x.is_cuda and x.dtype in (torch.float16, torch.bfloat16) and not STOCK[0]
+
+
+@contextlib.contextmanager
+def stock_routing():
+    """Inside the block NO in-tree kernel runs: the networks take the plain torch operation sequence in whatever dtype they are in
+    (the float32 parity path's code, in half: attention as softmax(q.k^T * scale + bias) @ v with aten ops).  The yardstick of the
+    float16 parity tests -- how far the reference's OWN half-precision arithmetic is from float32 on a given network -- never a
+    product path."""
+    saved = STOCK[0]
+    STOCK[0] = True
+    try:
+        yield
+    finally:
+        STOCK[0] = saved
+
+
 @contextlib.contextmanager
 def library_routing():
     """Inside the block every token GEMM and every 3x3 convolution of the networks goes through the ROCm libraries behind
@@ -198,7 +224,7 @@ def library_routing():
 def linear(x, weight, bias=None, gelu=False):
     """[gelu](x @ weight.T + bias).  float16 / bfloat16 on a GPU: ds_linear when the switch above selects it (erf-GELU
     on the fp32 accumulator); everything else: the library GEMM and aten's exact GELU."""
-    if x.is_cuda and x.dtype in (torch.float16, torch.bfloat16) and (LINEAR_HIP == "all" or (gelu and LINEAR_HIP in ("gelu", "proj"))):
+    if half_on_gpu(x) and (LINEAR_HIP == "all" or (gelu and LINEAR_HIP in ("gelu", "proj"))):
         from . import _native
         if _native.linear_supported(x, weight) and (gelu or hip_gemm_ok(x.numel() // x.shape[-1], weight.shape[0])):
             return _native.linear(x, weight, bias, gelu)
@@ -209,7 +235,7 @@ def linear(x, weight, bias=None, gelu=False):
 def fused_attention(qk, vt, n_valid, scale, bias=None):
     """bias: None, or what the block's attention_bias() cached for this dtype: the packed operand of the HIP kernel
     (_native.attention_bias_pack) for float16 / bfloat16, a padded [H, Np(query), Np(key)] tensor for float32."""
-    if qk.dtype in (torch.float32, torch.float64):
+    if qk.dtype in (torch.float32, torch.float64) or STOCK[0]:
         return attention_reference(qk, vt, n_valid, scale, bias)
     from . import _native
     return _native.attention_fwd(qk, vt, n_valid, scale, bias)
@@ -253,17 +279,18 @@ class EncoderBlock(nn.Module):
         return x + (m if g2 is None else g2 * m)
 
 
-def run_blocks(blocks, x, n_valid, grid_hw, take):
-    """Run the encoder on the padded sequence x [B, Np, C]; returns (x, {index: tap}) with taps = unpadded block outputs.
+def run_blocks(blocks, x, n_valid, grid_hw, take, padded_taps=False):
+    """Run the encoder on the padded sequence x [B, Np, C]; returns (x, {index: tap}) with taps = unpadded block outputs
+    (padded_taps: the padded [B, Np, C] block outputs themselves -- contiguous, what ds_linear_readout reads).
     float16/bfloat16 on a GPU: LayerScale + residual + the NEXT LayerNorm are one fused pass (ds_residual_layernorm), so a
     block is 5 GEMMs + 1 attention + 1 GELU + 2 fused element-wise kernels.  Otherwise: the plain torch sequence."""
     taps = {}
-    fast = x.is_cuda and x.dtype in (torch.float16, torch.bfloat16)
+    fast = half_on_gpu(x)
     if not fast:
         for i, blk in enumerate(blocks):
             x = blk.forward_padded(x, n_valid, grid_hw)
             if i in take:
-                taps[i] = x[:, :n_valid]
+                taps[i] = x if padded_taps else x[:, :n_valid]
         return x, taps
     from . import _native
     n = len(blocks)
@@ -298,14 +325,14 @@ def run_blocks(blocks, x, n_valid, grid_hw, take):
             else:
                 x = x + (m if g2 is None else g2 * m)
         if i in take:
-            taps[i] = x[:, :n_valid]
+            taps[i] = x if padded_taps else x[:, :n_valid]
     return x, taps
 
 
 def interpolate_bilinear(x, size=None, scale_factor=None, align_corners=True):
     """F.interpolate(mode="bilinear") of the DPT decoders: the HIP kernel for half-precision channels_last activations on
     the GPU (one pass at HBM speed), torch everywhere else (float32 parity path, CPU)."""
-    if x.is_cuda and x.dtype in (torch.float16, torch.bfloat16) and x.shape[1] % 8 == 0:
+    if half_on_gpu(x) and x.shape[1] % 8 == 0:
         from . import _native
         return _native.upsample_bilinear(x, size=size, scale_factor=scale_factor, align_corners=align_corners)
     if size is not None:
@@ -326,7 +353,7 @@ CONV_HEAD_HIP = os.environ.get("DS_CONV_HEAD", "1") != "0"      # A/B switch: th
 
 
 def conv3x3_hip_ok(conv, x):
-    if not (CONV_HIP and x.is_cuda and x.dtype in (torch.float16, torch.bfloat16) and x.dim() == 4):
+    if not (CONV_HIP and half_on_gpu(x) and x.dim() == 4):
         return False
     from . import _native
     if conv.out_channels % 256 != 0 and not CONV_HEAD_HIP:
@@ -344,6 +371,43 @@ def conv2d(conv, x):
 
 
 CONV_BIAS_HIP = os.environ.get("DS_CONV_BIAS", "1") != "0"          # A/B switch
+# Round 5: the last library GEMM-shaped work of a forward goes through the in-tree GEMM (csrc/ds_linear.hip) -- A/B switches:
+CONV1X1_HIP = os.environ.get("DS_CONV1X1", "1") != "0"            # 1x1 convolutions (reassemble, fusion blocks' out_conv) = ds_linear on NHWC rows
+CONVT_HIP = os.environ.get("DS_CONVT", "1") != "0"                # ConvTranspose2d with kernel == stride = ds_linear_shuffle
+READOUT_HIP = os.environ.get("DS_READOUT", "1") != "0"            # the read-out projection on the padded taps = ds_linear_readout
+CONV1X1_MIN_TILES = int(os.environ.get("DS_CONV1X1_MIN_TILES", 96))
+
+
+def conv1x1_hip_ok(layer, x):
+    """A 1x1, stride-1 nn.Conv2d on a half-precision channels_last activation whose GEMM -- [pixels, in] x [out, in]^T -- fills the
+    chip: the NHWC memory IS the row-major [pixels, in] operand, no copy on either side."""
+    if not (CONV1X1_HIP and LINEAR_HIP == "all" and half_on_gpu(x) and x.dim() == 4 and type(layer) is nn.Conv2d):
+        return False
+    if not (tuple(layer.kernel_size) == (1, 1) and tuple(layer.stride) == (1, 1) and tuple(layer.padding) == (0, 0) and layer.groups == 1
+            and tuple(layer.dilation) == (1, 1)):
+        return False
+    pixels = x.shape[0] * x.shape[2] * x.shape[3]
+    return (layer.out_channels % 256 == 0 and layer.in_channels % 128 == 0 and 128 <= layer.in_channels <= 16384 and pixels >= 256
+            and ((pixels + 255) // 256) * (layer.out_channels // 256) >= CONV1X1_MIN_TILES and x.is_contiguous(memory_format=torch.channels_last))
+
+
+def conv1x1(layer, x):
+    from . import _native
+    b, c, h, w = x.shape
+    rows = x.permute(0, 2, 3, 1).reshape(b * h * w, c)                   # a view of the channels_last memory
+    y = _native.linear(rows, layer.weight.reshape(layer.out_channels, c), layer.bias)
+    return y.view(b, h, w, layer.out_channels).permute(0, 3, 1, 2)
+
+
+def conv_transpose_hip_ok(layer, x):
+    if not (CONVT_HIP and LINEAR_HIP == "all" and half_on_gpu(x) and x.dim() == 4 and type(layer) is nn.ConvTranspose2d):
+        return False
+    from . import _native
+    if not (_native.conv_transpose_shuffle_supported(layer, x) and x.is_contiguous(memory_format=torch.channels_last)):
+        return False
+    pixels = x.shape[0] * x.shape[2] * x.shape[3]
+    n = layer.stride[0] * layer.stride[0] * layer.out_channels
+    return ((pixels + 255) // 256) * (n // 256) >= CONV1X1_MIN_TILES
 PREPROCESS_HIP = os.environ.get("DS_PREPROCESS", "1") != "0"      # A/B switch: ds_preprocess_bicubic vs the torch chain
 
 
@@ -351,8 +415,16 @@ def conv_module(layer, x):
     """layer(x) for the library convolutions of the decoders (1x1, strided 3x3, ConvTranspose2d with a bias).  torch adds a
     convolution's bias with a separate strided broadcast kernel on ROCm; for half-precision channels_last activations the
     convolution runs WITHOUT its bias and ds_bias_act_nhwc adds it in place (a vectorised pass at HBM rate).  Everything else
-    -- float32, CPU, no bias, circular padding, other modules -- is the plain call."""
-    if (CONV_BIAS_HIP and x.is_cuda and x.dtype in (torch.float16, torch.bfloat16) and x.dim() == 4 and getattr(layer, "bias", None) is not None
+    -- float32, CPU, no bias, circular padding, other modules -- is the plain call.
+    Round 5: 1x1 convolutions and kernel == stride transposed convolutions that fill the chip are in-tree GEMMs with the bias in
+    the epilogue (conv1x1, _native.conv_transpose_shuffle); what is left for the libraries is the strided 3x3 of act_postprocess4
+    and maps too small for 256 x 256 tiles."""
+    if conv1x1_hip_ok(layer, x):
+        return conv1x1(layer, x)
+    if conv_transpose_hip_ok(layer, x):
+        from . import _native
+        return _native.conv_transpose_shuffle(layer, x)
+    if (CONV_BIAS_HIP and half_on_gpu(x) and x.dim() == 4 and getattr(layer, "bias", None) is not None
             and layer.out_channels % 8 == 0 and getattr(layer, "padding_mode", "zeros") == "zeros"):
         if type(layer) is nn.Conv2d:
             y = layer._conv_forward(x, layer.weight, None)
@@ -372,7 +444,7 @@ def residual_conv_unit(conv1, conv2, x, skip=None):
     (ddepth_anything_v2/.../util/blocks.py:56-85) and, with `skip`, the add of the fusion block around it (:427 / :135).
     Half precision on the GPU: the library convolutions run WITHOUT their bias and ds_bias_act_nhwc does bias + ReLU and
     bias + residual (+ skip) in one pass each.  Everything else: the plain torch sequence."""
-    if (x.is_cuda and x.dtype in (torch.float16, torch.bfloat16) and x.shape[1] % 8 == 0 and conv1.bias is not None
+    if (half_on_gpu(x) and x.shape[1] % 8 == 0 and conv1.bias is not None
             and conv2.bias is not None and conv1.out_channels % 8 == 0):
         from . import _native
         xc = x.contiguous(memory_format=torch.channels_last)

@@ -1186,7 +1186,7 @@ def test_dpt_beit_large_512_batch8_takes_the_benchmarked_route(gpu):
     m.load_state_dict(mw.fill_state_dict_beit(m.state_dict()), strict=True)
     m = m.cuda().half()
     x = _variants(mw.synthetic_image((1, 3, 512, 512), seed=31), 8).cuda().half().contiguous(memory_format=torch.channels_last)
-    names = ("ds_linear", "ds_linear_residual", "ds_linear_vt", "ds_conv3x3_nhwc", "ds_attention_fwd")
+    names = ("ds_linear", "ds_linear_residual", "ds_linear_vt", "ds_conv3x3_nhwc", "ds_attention_fwd", "ds_linear_readout", "ds_linear_shuffle")
     before = dict(_native.CALLS)
     with torch.no_grad():
         y = m(x).float()
@@ -1194,11 +1194,15 @@ def test_dpt_beit_large_512_batch8_takes_the_benchmarked_route(gpu):
     # 24 blocks: qk + fc1 through ds_linear, proj + fc2 through ds_linear_residual, V^T through ds_linear_vt
     assert calls["ds_linear"] >= 48 and calls["ds_linear_residual"] == 48 and calls["ds_linear_vt"] == 24, calls
     assert calls["ds_conv3x3_nhwc"] >= 4 and calls["ds_attention_fwd"] == 24, calls
+    # round 5, the reassemble stage (dmidas/backbones/utils.py:28-39,167-249): four read-out GEMMs on the padded taps, the two
+    # transposed convolutions as GEMMs with a pixel-shuffle store, the 1x1 convolutions that fill the chip through ds_linear
+    assert calls["ds_linear_readout"] == 4 and calls["ds_linear_shuffle"] == 2 and calls["ds_linear"] >= 50, calls
     before = dict(_native.CALLS)
     with torch.no_grad(), vm.library_routing():
         y_lib = m(x).float()
     calls_lib = _route_calls(before, names)
     assert calls_lib["ds_linear"] == calls_lib["ds_linear_residual"] == calls_lib["ds_linear_vt"] == calls_lib["ds_conv3x3_nhwc"] == 0, calls_lib
+    assert calls_lib["ds_linear_readout"] == calls_lib["ds_linear_shuffle"] == 0, calls_lib
     ref = gold["dpt_beitl512_512x512_out_s2"]
     scale = float(np.abs(ref).max())
     e0 = np.abs(y[0:1, ::2, ::2].cpu().numpy() - ref).max() / scale
@@ -1243,3 +1247,135 @@ def test_dav2_vitl_1080p_batch4_takes_the_benchmarked_route(gpu):
     e_mean = ((y - y_lib).abs().flatten(1).mean(1) / y_lib.abs().flatten(1).max(1).values).max().item()
     assert e_lib < 2e-2 and e_mean < 2e-3, (e_lib, e_mean)
     assert (y[1] - y[0]).abs().max().item() > 1e-3 * scale
+
+
+# ---- round 5: the reassemble stage in-tree ----------------------------------------------------------------------------------
+@pytest.mark.parametrize("b,cin,cout,h,w,s,grid", [
+    (32, 256, 256, 32, 32, 4, None),       # act_postprocess1 of dpt_beit_large_512 at batch 32 (dmidas/backbones/utils.py:196-205)
+    (32, 512, 512, 32, 32, 2, None),       # act_postprocess2 (:215-224)
+    (8, 256, 256, 37, 66, 4, None),        # Depth-Anything-V2 ViT-L on a 1080p frame (dpt.py:57-64): a non-square grid, 19 536 pixels
+    (2, 128, 96, 9, 15, 4, 8),             # out_channels not a power of two (16 * 96 = 1536 columns), 270 pixels, every workgroup walks tiles
+    (3, 256, 64, 11, 10, 2, 16),           # 4 * 64 = 256 columns: one column tile
+])
+def test_linear_shuffle_matches_conv_transpose(gpu, b, cin, cout, h, w, s, grid):
+    """ds_linear_shuffle (ConvTranspose2d with kernel == stride as a GEMM with the pixel shuffle in the store address) against
+    torch's conv_transpose2d in float32 on the same rounded operands, every output element; the module path
+    (vm.conv_module -> _native.conv_transpose_shuffle) with its cached weight image and per-tap bias."""
+    import torch.nn as nn
+    from src import _native
+    from src import vit_mi355x as vm
+    g = torch.Generator().manual_seed(50 + cin + s)
+    layer = nn.ConvTranspose2d(cin, cout, s, s, 0).cuda().half()
+    with torch.no_grad():
+        layer.weight.copy_((torch.randn(layer.weight.shape, generator=g) * cin ** -0.5).half())
+        layer.bias.copy_(torch.randn((cout,), generator=g).half())
+    x = torch.randn((b, cin, h, w), generator=g).half().cuda().contiguous(memory_format=torch.channels_last)
+    assert _native.conv_transpose_shuffle_supported(layer, x)
+    if grid:
+        _native.linear_env(DS_LIN_GRID=grid)
+    try:
+        before = _native.CALLS["ds_linear_shuffle"]
+        y = _native.conv_transpose_shuffle(layer, x)
+        y2 = _native.conv_transpose_shuffle(layer, x)
+        assert _native.CALLS["ds_linear_shuffle"] == before + 2
+    finally:
+        if grid:
+            _native.linear_env(DS_LIN_GRID=None)
+    assert tuple(y.shape) == (b, cout, h * s, w * s) and y.is_contiguous(memory_format=torch.channels_last)
+    assert torch.equal(y, y2)
+    with torch.no_grad():
+        ref = torch.nn.functional.conv_transpose2d(x.float(), layer.weight.float(), layer.bias.float(), stride=s)
+    err = (y.float() - ref).abs().max().item()
+    assert err < 2e-3 * (1 + ref.abs().max().item()), (err, ref.abs().max().item())
+    if not grid and vm.conv_transpose_hip_ok(layer, x):          # what the networks call
+        with torch.no_grad():
+            y3 = vm.conv_module(layer, x)
+        assert torch.equal(y3, y)
+
+
+@pytest.mark.parametrize("b,npad,n,c,grid", [
+    (32, 1032, 1025, 1024, None),          # dpt_beit_large_512 at batch 32: the bench's shape (129 row panels x 4 column tiles)
+    (8, 2464, 2443, 1024, None),           # a padded sequence whose pad is longer than one row group
+    (3, 136, 130, 256, 8),                 # small: 408 rows, one column tile, every workgroup walks several tiles
+    (2, 584, 577, 768, 16),                # ViT-B / hybrid at 384^2 (768 features = 3 column tiles)
+])
+def test_linear_readout_matches_definition(gpu, b, npad, n, c, grid):
+    """ds_linear_readout against the definition of ProjectReadout (dmidas/backbones/utils.py:28-39) + Transpose / Unflatten
+    (:165-169) in float32 on the same rounded operands: GELU(tokens @ w_tok^T + (w_cls @ cls + bias)), the cls row and the pad
+    rows dropped, token-major output; junk (NaN) in the pad rows must not reach any output row; ProjectReadout.forward_padded
+    (the module path) equals ProjectReadout.forward on the unpadded tap within float16 rounding."""
+    from dmidas.backbones.beit import ProjectReadout
+    from src import _native
+    g = torch.Generator().manual_seed(60 + c)
+    ro = ProjectReadout(c).cuda().half()
+    with torch.no_grad():
+        ro.project[0].weight.copy_((torch.randn((c, 2 * c), generator=g) * (2 * c) ** -0.5).half())
+        ro.project[0].bias.copy_(torch.randn((c,), generator=g).half())
+    xp = torch.randn((b, npad, c), generator=g).half().cuda()
+    xp[:, n:] = float("nan")                                        # pad rows: never read as anything that matters
+    if grid:
+        _native.linear_env(DS_LIN_GRID=grid)
+    try:
+        before = _native.CALLS["ds_linear_readout"]
+        with torch.no_grad():
+            y = ro.forward_padded(xp, n)
+            y2 = ro.forward_padded(xp, n)
+        assert _native.CALLS["ds_linear_readout"] == before + 2
+    finally:
+        if grid:
+            _native.linear_env(DS_LIN_GRID=None)
+    assert tuple(y.shape) == (b, n - 1, c) and y.is_contiguous() and torch.equal(y, y2)
+    w = ro.project[0].weight.float()
+    x = xp[:, :n].float()
+    ref = torch.nn.functional.gelu(x[:, 1:] @ w[:, :c].t() + (x[:, 0] @ w[:, c:].t() + ro.project[0].bias.float())[:, None])
+    assert torch.isfinite(y).all()
+    err = (y.float() - ref).abs().max().item()
+    assert err < 2e-3 * (1 + ref.abs().max().item()), (err, ref.abs().max().item())
+    with torch.no_grad():
+        y_lib = ro(xp[:, :n])                                        # split library GEMM + ds_reassemble_readout
+    assert (y.float() - y_lib.float()).abs().max().item() < 4e-3 * (1 + ref.abs().max().item())
+
+
+def test_conv1x1_through_the_in_tree_gemm(gpu):
+    """1x1 convolutions of the reassemble stage / fusion blocks as ds_linear on the NHWC rows (vm.conv1x1) against the library
+    convolution: same values within float16 rounding, channels_last in and out, and the routing rule (chip-filling launches only)."""
+    import torch.nn as nn
+    from src import _native
+    from src import vit_mi355x as vm
+    g = torch.Generator().manual_seed(71)
+    for (b, cin, cout, h, w) in [(32, 1024, 256, 32, 32), (32, 256, 256, 64, 64), (8, 1024, 512, 37, 66)]:
+        layer = nn.Conv2d(cin, cout, 1).cuda().half()
+        x = torch.randn((b, cin, h, w), generator=g).half().cuda().contiguous(memory_format=torch.channels_last)
+        assert vm.conv1x1_hip_ok(layer, x)
+        before = _native.CALLS["ds_linear"]
+        with torch.no_grad():
+            y = vm.conv_module(layer, x)
+            ref = torch.nn.functional.conv2d(x.float(), layer.weight.float(), layer.bias.float())
+        assert _native.CALLS["ds_linear"] == before + 1
+        assert y.shape == ref.shape and y.is_contiguous(memory_format=torch.channels_last)
+        assert (y.float() - ref).abs().max().item() < 2e-3 * (1 + ref.abs().max().item())
+    small = torch.randn((1, 256, 16, 16), generator=g).half().cuda().contiguous(memory_format=torch.channels_last)
+    assert not vm.conv1x1_hip_ok(nn.Conv2d(256, 256, 1).cuda().half(), small)       # one tile: the library's small kernels
+
+
+def test_kernel_timers_bracket_the_launches(gpu):
+    """ds_kernel_timer_enable / ds_kernel_timer_read: every timed kind reports the launches made while the timer was on, with a
+    plausible duration, and nothing once it is off (bench.py's in-step roofline reads these)."""
+    from src import _native
+    dev = torch.cuda.current_device()
+    x = torch.randn((8192, 1024)).half().cuda()
+    w = (torch.randn((4096, 1024)) / 32).half().cuda()
+    _native.linear(x, w, None, True)
+    torch.cuda.synchronize()
+    _native.kernel_timer_enable(dev, True)
+    for _ in range(3):
+        _native.linear(x, w, None, True)
+    _native.linear(x, w, None, False)
+    n, ms = _native.kernel_timer_read(dev, "linear_gelu")
+    assert n == 3 and 0.01 < ms / n < 5.0, (n, ms)
+    n2, ms2 = _native.kernel_timer_read(dev, "linear")
+    assert n2 == 1 and ms2 > 0.0
+    assert _native.kernel_timer_read(dev, "attention") == (0, 0.0)
+    _native.kernel_timer_enable(dev, False)
+    _native.linear(x, w, None, True)
+    assert _native.kernel_timer_read(dev, "linear_gelu") == (0, 0.0)

@@ -377,7 +377,8 @@ def test_full_size_properties(sg, native, oracle, gpu):
 def test_normalmap_accepts_any_real_dtype(gpu, oracle):
     """create_normalmap takes any real array like the reference (src/normalmap_generation.py:20-21 promote to float64):
     integer / float64 / float32 depth through ds_normalmap_f64 against the oracle's float64 restatement, every gradient
-    mode; float32 + np.gradient (a float32 pipeline in the reference) is refused, as are non-real / non-2-D inputs."""
+    mode; float32 + np.gradient is a float32 pipeline in the reference and has a kernel of its own (round 5): against the oracle
+    run on the float32 array itself; float32 + np.gradient + a blur is refused, as are non-real / non-2-D inputs."""
     import src.normalmap_generation as nm
     import src._native as nat
     rng = np.random.default_rng(21)
@@ -388,8 +389,8 @@ def test_normalmap_accepts_any_real_dtype(gpu, oracle):
         for inv in (False, True):
             for args in ((None, 3, None), (None, 5, None), (3, 3, 3), (None, None, None)):
                 if dep.dtype == np.float32 and args[1] is None:
-                    with pytest.raises(nat.DepthStereoError):
-                        nm.create_normalmap(dep, *args, inv)
+                    want = oracle.create_normalmap_array(dep, args[0], args[1], args[2], inv)          # float32 throughout
+                    assert np.array_equal(want, np.asarray(nm.create_normalmap(dep, *args, inv))), (inv, args)
                     continue
                 want = oracle.create_normalmap_array(dep.astype(np.float64), args[0], args[1], args[2], inv)
                 got = np.asarray(nm.create_normalmap(dep, args[0], args[1], args[2], inv))
@@ -713,3 +714,26 @@ def test_funnel_reference_f16_postproc(gpu, oracle):
                                            if opts.get('clipdepth') else oracle.depth_normalize01(p32, inv))
             assert np.array_equal(d32, want32), (mt, opts)
     core.model_holder.update_settings(reference_f16_postproc=None)
+
+
+def test_normalmap_float32_gradient_is_the_reference_float32_evaluation(gpu, oracle):
+    """create_normalmap(float32 depth, sobel_gradient=None): the reference evaluates this combination in FLOAT32 end to end
+    (src/normalmap_generation.py:20-21,31,34-39,51-54); ds_normalmap_gradient_f32 must reproduce numpy's float32 arithmetic bit
+    for bit -- against the oracle's restatement (itself pinned by the reference-made goldens, tests/golden/normalmap_cases.npz:
+    the f32* cases) on larger frames than the goldens hold, both inversions, incl. flat areas and a 2 x 2 image."""
+    import src.normalmap_generation as nm
+    rng = np.random.default_rng(77)
+    cases = [rng.normal(0.0, 900.0, (257, 381)).astype(np.float32), (rng.random((64, 1030)) * 37 + 5).astype(np.float32),
+             np.zeros((5, 7), np.float32), rng.normal(0, 1e-3, (2, 2)).astype(np.float32),
+             (rng.integers(0, 65536, (130, 90)).astype(np.float32))]
+    cases[1][10:30, 100:600] += 11.5
+    for d in cases:
+        for inv in (False, True):
+            for sob in (None, 0, -1):
+                want = oracle.create_normalmap_array(d, None, sob, None, inv)
+                got = np.asarray(nm.create_normalmap(d, None, sob, None, inv))
+                assert got.dtype == np.uint8 and np.array_equal(got, want), (d.shape, inv, sob, int((got != want).sum()))
+    with pytest.raises(Exception):
+        nm.create_normalmap(cases[0], 3, None, None, False)          # float32 + np.gradient + blur: cv2's float32 GaussianBlur, not built
+    with pytest.raises(Exception):
+        nm.create_normalmap(cases[0].astype(np.float16), None, None, None, False)
