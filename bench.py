@@ -21,20 +21,31 @@ fp16 forward to 2e-2 of the reference's float32 output and the float32 forward t
     dpt_hybrid_384       MiDaS 3.0 ViT-B/16 + ResNetV2-50, net 384 (reference model id 4; BASELINE config 2)
     none                 no network: the float32 prediction is a synthetic INPUT, only the per-pixel path is timed
 `--config` presets: c2 (dpt_hybrid_384, batch 1, 512x512: latency), c3 (default), c3match (config 3 with NET_SIZE_MATCH:
-net 1024, 4097 tokens), c5 (dav2_vitl on 1920x1080 frames, 2443 tokens).  Only c3 is the metric's line; the others are
-kept profile lines (profiles/round2_*).
+net 1024, 4097 tokens), c4 (Boost on one 4K image), c5 (dav2_vitl on 1920x1080 frames, 2443 tokens).  c3 is the metric's line;
+the default invocation ALSO runs short legs of c5, c2 and c4 (sub-processes, after the timed region) and carries their digests
+under `other_configs`, so that the driver's one line holds four driver-timed configurations.
 
-Contract: `python bench.py --gpus N --steps K --warmup W`; for N > 1 the driver launches one rank per GPU with
-torch.distributed.run.  Units are sharded across ranks (weak scaling: every rank renders its own batch, no data-path
-collective) and the collated outputs (stereo pair + uint16 depth + normal map, packed into one byte buffer) are gathered
-to rank 0 with ONE RCCL gather per step, overlapped with the next step's kernels (--no-gather to leave it out).  Rank 0
-prints ONE JSON line; on one GPU the metric's config also carries `funnel`: the same batch through the drop-in boundary
-(core_generation_funnel, PIL in -> PIL out), reported beside `value`, never as it.
+Contract: `python bench.py --gpus N --steps K --warmup W`.  For N > 1 the driver launches one rank per GPU with
+torch.distributed.run; run WITHOUT a launcher (`python bench.py --gpus 8`), bench.py launches the N ranks itself (the same
+torch.distributed.run command, rendezvous on 127.0.0.1) and rank 0's line is the output.  Units are sharded across ranks (weak
+scaling: every rank renders its own batch, no data-path collective) and the collated outputs (stereo pair + uint16 depth + normal
+map, packed into one byte buffer) are gathered to rank 0 with ONE RCCL gather per step, overlapped with the next step's kernels
+(--no-gather to leave it out); after the timed region rank 0 re-renders the LAST rank's units itself and compares them with the
+gathered bytes (`gather_check`).  Rank 0 prints ONE JSON line; on one GPU the metric's config also carries
+`funnel`: the same batch through the drop-in boundary (core_generation_funnel, PIL in -> PIL out), reported beside `value`,
+never as it.
+
+`roofline` is the dominant in-tree kernel of the step by its time INSIDE the timed region: the C ABI brackets its launches with
+HIP events on the launch stream while the steps are timed (ds_kernel_timer_enable, include/depthstereo.h), `achieved` = algorithmic
+flops per launch / that average duration.  The microbenchmark of the same launch shape on randn operands is the side note
+(`microbenchmark`), not the figure.
 """
 import argparse
 import contextlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -50,8 +61,8 @@ H = W = 1024
 HBM_PEAK_GBPS = 8000.0            # MI355X HBM3E spec peak (guides/MI355X_MICROARCH.md)
 HBM_COPY_GBPS = 6290.0            # what a float4 copy kernel reaches on this chip (same guide: 79 % of the spec peak)
 MFMA_PEAK_TFLOPS = 2500.0         # dense f16/bf16 MFMA peak (same guide)
-PMC_SUMMARY = "profiles/round4_pmc_summary.json"      # tools/pmc_summary.py over rocprofv3 --pmc passes of THIS command
-KERNEL_STATS = "profiles/round4_kernel_stats.csv"     # rocprofv3 --kernel-trace --stats of THIS command
+PMC_SUMMARY = "profiles/round5_pmc_summary.json"      # tools/pmc_summary.py over rocprofv3 --pmc passes of THIS command
+KERNEL_STATS = "profiles/round5_kernel_stats.csv"     # rocprofv3 --kernel-trace --stats of THIS command
 
 DEPTH_KIND = "steps"
 
@@ -123,13 +134,113 @@ def run_forward(model, model_name, img, net_size, net_h=None):
     # (Round 4 tried the batch as 2 / 4 micro-batches on as many streams, GEMMs on half the CUs, so that one micro-batch's
     # attention / LayerNorm / decoder kernels run beside another's GEMMs: 792.6 / 778.5 / 688.2 pairs/s against 791.6 on the same
     # box -- the chip is power limited during the GEMMs, concurrency moves work around without adding any; removed.)
-    return _forward_one(model, model_name, img, net_size, net_h)
-
-
-def _forward_one(model, model_name, img, net_size, net_h=None):
     if model_name == "dav2_vitl":
         return model.infer_batch(img, net_size)
     return model.infer_batch(img, net_size=net_size, resize_mode="minimal", net_h=net_h)
+
+
+# ---- launching the ranks ------------------------------------------------------------------------------------------------
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launch_command(n, argv, port=None):
+    """The command the driver itself uses for N > 1 (one rank per GPU of ONE node, rendezvous on 127.0.0.1)."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+            "--master-port", str(port or _free_port()), os.path.abspath(__file__)] + list(argv)
+
+
+def self_launch(args, argv):
+    """`python bench.py --gpus N` WITHOUT a launcher (no WORLD_SIZE in the environment): start the N ranks here.  The ranks' output
+    passes through; rank 0 prints the one JSON line.  Returns the launcher's exit code."""
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")            # dmabuf IPC: what RCCL needs on this host driver
+    env.setdefault("MASTER_ADDR", "127.0.0.1")
+    return subprocess.call(launch_command(args.gpus, argv), env=env)
+
+
+def dist_setup(backend, device=None):
+    """(rank, world, local_rank) from the launcher's environment; the process group when world > 1."""
+    import torch.distributed as dist
+    rank, world, local_rank = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if device is not None:
+            dist.init_process_group(backend, device_id=device)
+        else:
+            dist.init_process_group(backend)
+    return rank, world, local_rank
+
+
+def max_over_ranks(elapsed, world, device="cpu"):
+    import torch
+    import torch.distributed as dist
+    t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def compare_gathered(got_u8, want_u8, layout, exact):
+    """gather_check: rank 0's own render of another rank's units against the bytes that rank sent through the gather.  `layout`
+    = multigpu.pack_collated's; per part the fraction of equal bytes and, for the uint16 depth, the largest code difference.
+    exact (the per-pixel path alone, --model none): everything is integer / IEEE float64 work, the bytes must be identical."""
+    import torch
+    from src import multigpu
+    a, b = multigpu.unpack_collated(got_u8, layout), multigpu.unpack_collated(want_u8, layout)
+    out = {"units": int(got_u8.shape[0]), "identical": bool(torch.equal(got_u8, want_u8)), "parts": []}
+    for x, y in zip(a, b):
+        part = {"dtype": str(x.dtype).replace("torch.", ""), "shape_per_unit": list(x.shape[1:]),
+                "equal_fraction": float((x == y).float().mean().item())}
+        if x.dtype == torch.uint16:
+            part["max_code_difference"] = int((x.to(torch.int32) - y.to(torch.int32)).abs().max().item())
+        out["parts"].append(part)
+    if exact:
+        assert out["identical"], f"gather_check: the gathered bytes differ from rank 0's own render of the same units: {out}"
+    return out
+
+
+def selftest_launch(args):
+    """--selftest-launch (CPU, gloo; tests/test_multigpu_gloo.py): the launcher path of `--gpus N` end to end WITHOUT a GPU -- rank
+    environment, process group, ONE gather of packed per-unit byte buffers to rank 0, gather_check against rank 0's own render of
+    the last rank's units, barrier + max-over-ranks timing, one JSON line from rank 0.  The "render" is a seeded byte pattern: what
+    is under test is the plumbing bench.py shares with the real path, not a kernel."""
+    import torch
+    import torch.distributed as dist
+    from src import multigpu
+    rank, world, _ = dist_setup("gloo")
+    batch = args.batch or 2
+
+    def render(r):
+        rng = np.random.default_rng(1000 + r)
+        sbs = torch.from_numpy(rng.integers(0, 256, (batch, 4, 16, 3), dtype=np.uint8))
+        d16 = torch.from_numpy(rng.integers(0, 65536, (batch, 4, 8), dtype=np.uint16))
+        return multigpu.pack_collated([sbs, d16])
+    packed, layout = render(rank)
+    gathered = [torch.empty_like(packed) for _ in range(world)] if rank == 0 else None
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        if world > 1:
+            dist.gather(packed, gathered, dst=0)
+    if world > 1:
+        dist.barrier()
+    elapsed = max_over_ranks(time.perf_counter() - t0, world)
+    if rank == 0:
+        check = None
+        if world > 1:
+            check = compare_gathered(gathered[world - 1], render(world - 1)[0], layout, exact=True)
+            check["rank"] = world - 1
+        print(json.dumps({"metric": "selftest: launcher + gather plumbing (no kernel)", "value": batch * world * args.steps / max(elapsed, 1e-9),
+                          "unit": "units/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "selftest": True,
+                          "gather_check": check}))
+    if world > 1:
+        dist.destroy_process_group()
 
 
 # ---- CPU baseline -------------------------------------------------------------------------------------------------------
@@ -181,13 +292,16 @@ def cpu_baseline(model_name, net_size, net_h, distinct_units, seed, min_seconds,
         got = oracle_py.create_stereoimages_arrays(sub, sd, 2.5, 0.0, ['left-right'], 0.0, 1.0, 'polylines_sharp')[0]
         dt1 = time.perf_counter() - t1
         same = bool(np.array_equal(got, orc.create_stereoimages_arrays(sub, sd, 2.5, 0.0, ['left-right'], 0.0, 1.0, 'polylines_sharp')[0]))
-        out["python_fallback"] = {"value": 1.0 / dt1, "unit": "pairs/s", "cores": 1, "kind": "port",
+        # kind "port-of-fallback": oracle/oracle_py.py restates the reference's numba-LESS fallback (pure-Python loops); the
+        # reference's own fallback file timed on the build box took 12.4 s for the same unit (profiles/round2_reference_fallback.json)
+        out["python_fallback"] = {"value": 1.0 / dt1, "unit": "pairs/s", "cores": 1, "kind": "port-of-fallback",
                                   "sample": f"1 unit of {s}x{s} (BASELINE config 1's size), polylines_sharp left-right, pure-Python "
                                             f"restatement of the reference's numba-less fallback, {dt1:.2f} s; stereo stage only",
                                   "identical_to_c_port": same}
     return out
 
 
+# ---- figures out of the committed profiles (labelled as such) --------------------------------------------------------------
 def traffic_from_profile(kernel, batch):
     """HBM bytes per launch of the kernel whose name contains `kernel`, from the committed rocprofv3 PMC summary of the default
     bench command (separate --pmc passes for FETCH_SIZE and WRITE_SIZE, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes
@@ -230,26 +344,199 @@ def clock_from_profile(kernel, flops, batch):
         return None
 
 
-def in_step_from_profile(kernel, work, peak, unit_scale):
-    """Average duration of the kernel whose name contains `kernel` INSIDE the timed step, from the committed rocprofv3
-    --kernel-trace --stats summary of the default bench command, and what that duration means for `work` (flops or bytes per
-    launch): the microbenchmark figures beside it run the same launch shape on randn operands."""
+def stats_from_profile(kernel):
+    """Average duration of the kernel whose name contains `kernel` in the committed rocprofv3 --kernel-trace --stats summary of the
+    default bench command: what the live in-step figure must agree with."""
     try:
         import csv
         with open(os.path.join(ROOT, KERNEL_STATS)) as f:
             for row in csv.DictReader(f):
                 if kernel in row["Name"]:
-                    ms = float(row["AverageNs"]) * 1e-6
-                    ach = work / (ms * 1e-3) / unit_scale
-                    return {"avg_kernel_ms": ms, "calls": int(row["Calls"]), "achieved": ach, "frac": ach / peak, "kernel": row["Name"],
-                            "source": KERNEL_STATS}
+                    return {"avg_kernel_ms": float(row["AverageNs"]) * 1e-6, "calls": int(row["Calls"]), "kernel": row["Name"], "source": KERNEL_STATS}
     except Exception:
         pass
     return None
 
 
-def main():
-    global H, W, DEPTH_KIND
+# ---- microbenchmarks: one launch shape on randn operands (the side note of every roofline object) ----------------------------
+def _event_ms(fn, reps, warm=3):
+    import torch
+    for _ in range(warm):
+        fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    e1.synchronize()
+    return e0.elapsed_time(e1) / reps
+
+
+def microbench_attention(nat, vm, dev, batch, minfo):
+    import torch
+    n_tok = minfo["tokens"]
+    npad = vm.pad_len(n_tok, batch)
+    qk = torch.randn(batch, npad, 2, minfo["heads"], 64, device=dev, dtype=torch.float16)
+    vt = torch.randn(batch, minfo["heads"] * 64, npad, device=dev, dtype=torch.float16)
+    bias = None
+    if minfo["bias"]:
+        bias = nat.attention_bias_pack(torch.randn(minfo["heads"], n_tok, n_tok, device=dev), npad, torch.float16)
+    return _event_ms(lambda: nat.attention_fwd(qk, vt, n_tok, 0.125, bias), 20)
+
+
+def microbench_linear(nat, vm, dev, batch, minfo, kind):
+    """fc1 + GELU ("linear_gelu") or the fc2 / projection pair with LayerScale + residual ("linear_residual": the average of the two
+    shapes one block launches) at the step's row count, randn operands."""
+    import torch
+    m_rows, dim = batch * vm.pad_len(minfo["tokens"], batch), minfo["dim"]
+    x1 = torch.randn(m_rows, dim, device=dev, dtype=torch.float16)
+    if kind == "linear_gelu":
+        w = torch.randn(4 * dim, dim, device=dev, dtype=torch.float16) * dim ** -0.5
+        b = torch.randn(4 * dim, device=dev, dtype=torch.float16)
+        if not nat.linear_supported(x1, w):
+            return None
+        return _event_ms(lambda: nat.linear(x1, w, b, True), 20)
+    x4 = torch.randn(m_rows, 4 * dim, device=dev, dtype=torch.float16)
+    wp = torch.randn(dim, dim, device=dev, dtype=torch.float16) * dim ** -0.5
+    w2 = torch.randn(dim, 4 * dim, device=dev, dtype=torch.float16) * (4 * dim) ** -0.5
+    b = torch.randn(dim, device=dev, dtype=torch.float16)
+    g = torch.randn(dim, device=dev, dtype=torch.float16)
+    if not (nat.linear_supported(x1, wp) and nat.linear_supported(x4, w2)):
+        return None
+
+    def both():
+        nat.linear_residual(x1, wp, b, g, x1)
+        nat.linear_residual(x4, w2, b, g, x1)
+    return _event_ms(both, 10) / 2.0
+
+
+def microbench_conv(nat, vm, dev, batch, net_size, net_h):
+    import torch
+    import torch.nn as nn
+    hw = (net_h or net_size) // 4, net_size // 4
+    cv = nn.Conv2d(256, 256, 3, padding=1).to(dev, torch.float16)
+    xc = torch.randn(batch, 256, hw[0], hw[1], device=dev, dtype=torch.float16).contiguous(memory_format=torch.channels_last)
+    if not vm.conv3x3_hip_ok(cv, xc):
+        return None, hw
+    return _event_ms(lambda: nat.conv3x3(cv, xc, relu=True), 10), hw
+
+
+def mfma_roofline(kernel, flops, ms, launches_per_step, source, shape, **extra):
+    ach = flops / (ms * 1e-3) / 1e12
+    out = {"bound": "mfma", "kernel": kernel, "achieved": ach, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / MFMA_PEAK_TFLOPS,
+           "traffic": None, "algorithmic_flops_per_launch": flops, "avg_kernel_ms": ms, "launches_per_step": launches_per_step,
+           "source": source, "shape": shape}
+    out.update(extra)
+    return out
+
+
+IN_STEP = ("in-step: HIP events recorded by the C ABI around every launch of this kernel on the launch stream, INSIDE the timed region "
+           "(ds_kernel_timer_enable, include/depthstereo.h); average over {n} launches")
+MICRO = "microbenchmark: separate launches at the in-step shape on randn operands, HIP events on the launch stream"
+
+
+def encoder_rooflines(nat, vm, dev, local_rank, batch, minfo, config, timed):
+    """Roofline objects of the encoder's three big kernels.  `timed`: {kind: (launches, total ms)} read from the C ABI's in-step
+    timers after the timed region -- the figure of each object when present; the microbenchmark of the same launch shape on randn
+    operands is the side note.  Algorithmic flops use the VALID tokens (batch x n), not the padded rows the kernels walk."""
+    n_tok, dim, heads, depth = minfo["tokens"], minfo["dim"], minfo["heads"], minfo["depth"]
+    rows = batch * n_tok
+    c3 = config == "c3"
+    specs = {
+        "linear_gelu": ("k_linear256<EPI 1> (fc1 + erf-GELU)", "k_linear256<0, 1, 0, 0, 0", 2.0 * rows * 4 * dim * dim, depth,
+                        {"rows_valid": rows, "rows_padded": batch * vm.pad_len(n_tok, batch), "out_features": 4 * dim, "in_features": dim}),
+        "linear_residual": ("k_linear256<EPI 3, RES 1> (projection and fc2 + LayerScale + residual: the average of the two launches of a block)",
+                            "k_linear256<0, 3, 0, 1", 2.0 * rows * dim * (dim + 4 * dim) / 2.0, 2 * depth,
+                            {"rows_valid": rows, "rows_padded": batch * vm.pad_len(n_tok, batch), "out_features": dim, "in_features": [dim, 4 * dim]}),
+        "attention": ("k_attention_fwd2 (fused attention" + (", relative-position bias through the MFMA pipe)" if minfo["bias"] else ")"),
+                      "k_attention_fwd2", 4.0 * n_tok * n_tok * dim * batch, depth,
+                      {"batch": batch, "tokens": n_tok, "heads": heads, "bias": minfo["bias"]}),
+    }
+    out = {}
+    for kind, (label, prof_name, flops, per_step, shape) in specs.items():
+        if kind == "attention":
+            micro_ms = microbench_attention(nat, vm, dev, batch, minfo)
+        else:
+            micro_ms = microbench_linear(nat, vm, dev, batch, minfo, kind) if vm.LINEAR_HIP == "all" else None
+        micro = None if micro_ms is None else {"avg_kernel_ms": micro_ms, "achieved": flops / (micro_ms * 1e-3) / 1e12,
+                                               "frac": flops / (micro_ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS, "operands": "random (randn)", "source": MICRO}
+        n, ms = timed.get(kind, (0, 0.0))
+        if n > 0:
+            r = mfma_roofline(label, flops, ms / n, per_step, IN_STEP.format(n=n), shape, microbenchmark=micro)
+            rag = timed.get(kind + "+ragged", (0, 0.0))
+            if rag[0] > 0:                                   # the ragged round of the same GEMMs (k_linear_ragged), launched behind them
+                r["ragged_round"] = {"launches": rag[0], "avg_kernel_ms": rag[1] / rag[0],
+                                     "note": "k_linear_ragged renders the last, nearly empty round of tiles; its time is NOT in avg_kernel_ms, "
+                                             "its flops are (the whole GEMM's algorithmic flops over the main kernel's time: an upper bound "
+                                             "of a few percent)"}
+                r["avg_gemm_ms_with_ragged_round"] = ms / n + rag[1] / n
+                r["achieved_with_ragged_round"] = flops / ((ms / n + rag[1] / n) * 1e-3) / 1e12
+        elif micro is not None:
+            r = mfma_roofline(label, flops, micro_ms, per_step, MICRO, shape, operands="random (randn)")
+        else:
+            continue
+        if c3:
+            r["traffic_from_profile"] = traffic_from_profile(prof_name, batch)
+            r["profile_avg"] = stats_from_profile(prof_name)
+            r["clock_from_profile"] = clock_from_profile(prof_name, flops, batch)
+        out[kind] = r
+    return out
+
+
+def route_check_leg(nat, vm, model, model_name, img, batch, net_size, net_h):
+    """route_check (untimed): the forward the step runs -- every block GEMM, the reassemble stage and the decoder's 3x3 convolutions
+    in-tree, which needs the batch -- against the SAME network on the same images with every GEMM / convolution sent to the ROCm
+    libraries (vm.library_routing), plus how often the fused entry points were reached in one forward of the step."""
+    import torch
+    names = ("ds_linear", "ds_linear_residual", "ds_linear_vt", "ds_linear_readout", "ds_linear_shuffle", "ds_conv3x3_nhwc", "ds_attention_fwd",
+             "ds_residual_layernorm", "ds_dpt_head_tail", "ds_preprocess_bicubic")
+    before = dict(nat.CALLS)
+    with torch.no_grad():
+        p_hip = run_forward(model, model_name, img, net_size, net_h).float()
+    calls = {n: nat.CALLS[n] - before.get(n, 0) for n in names}
+    nlib = min(batch, 4)
+    with torch.no_grad(), vm.library_routing():
+        p_lib = run_forward(model, model_name, img[:nlib], net_size, net_h).float()
+    span = (p_lib.flatten(1).max(1).values - p_lib.flatten(1).min(1).values).clamp_min(1e-12)
+    err = (p_hip[:nlib] - p_lib).abs().flatten(1).max(1).values / span
+    return {"max_abs_diff_over_prediction_range": float(err.max().item()), "units_compared": nlib,
+            "what": "prediction of the timed forward (in-tree GEMM / convolution routing at the step's batch) vs the same network on "
+                    "the same images with every token GEMM and convolution through hipBLASLt / MIOpen; fp16 both sides",
+            "c_abi_calls_per_forward": calls}
+
+
+def other_configs_leg(timeout_s):
+    """Short legs of the other BASELINE configurations, each in a sub-process of its own after the timed region (a leg that fails or
+    hangs costs its timeout, never the line): c5 (3 steps), c2 (20 hipGraph replays), c4 (1 image).  A digest of each leg's own JSON
+    line -- value, ms per step, workload, roofline -- goes under `other_configs`."""
+    legs = [("c5", ["--config", "c5", "--steps", "3", "--warmup", "1"], timeout_s),
+            ("c2", ["--config", "c2", "--steps", "20", "--warmup", "3"], timeout_s),
+            ("c4", ["--config", "c4", "--steps", "1", "--warmup", "0"], 2 * timeout_s)]
+    out = {}
+    for name, extra, limit in legs:
+        cmd = [sys.executable, os.path.abspath(__file__)] + extra + ["--no-cpu-baseline", "--no-route-check", "--no-funnel", "--no-other-configs"]
+        t0 = time.perf_counter()
+        try:
+            p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=limit, text=True)
+            line = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+            if p.returncode != 0 or not line:
+                out[name] = {"error": f"exit code {p.returncode}", "stderr_tail": p.stderr[-400:], "seconds": time.perf_counter() - t0}
+                continue
+            j = json.loads(line[-1])
+            roof = j.get("roofline") or {}
+            out[name] = {"metric": j.get("metric"), "value": j.get("value"), "unit": j.get("unit"), "ms_per_step": j.get("ms_per_step"),
+                         "steps": j.get("steps"), "warmup": j.get("warmup"), "n_gpus": j.get("n_gpus"), "dtype": j.get("dtype"),
+                         "workload": (j.get("config") or {}).get("workload"), "forward_launch": (j.get("config") or {}).get("forward_launch"),
+                         "roofline": {k: roof.get(k) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "avg_kernel_ms", "source")},
+                         "command": "python bench.py " + " ".join(extra), "seconds": time.perf_counter() - t0}
+        except subprocess.TimeoutExpired:
+            out[name] = {"error": f"timed out after {limit} s", "seconds": time.perf_counter() - t0}
+        except Exception as e:                                # a leg must never take the line down
+            out[name] = {"error": repr(e)[:300], "seconds": time.perf_counter() - t0}
+    return out
+
+
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
@@ -275,6 +562,12 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-route-check", action="store_true", help="leave out the untimed route check (profile runs: its library-routed "
                                                                   "forward would show up in the kernel statistics of the step)")
+    ap.add_argument("--no-kernel-timers", action="store_true", help="do not bracket the kernels with events inside the timed region (A/B of the "
+                                                                    "timers' own cost; the rooflines then fall back to the microbenchmarks)")
+    ap.add_argument("--no-other-configs", action="store_true", help="default invocation only: skip the short c5 / c2 / c4 legs behind the metric's line")
+    ap.add_argument("--other-configs-timeout", type=float, default=240.0, help="seconds per other-config leg (c4: twice that)")
+    ap.add_argument("--no-micro", action="store_true", help="skip the microbenchmarks beside the in-step rooflines (profile runs)")
+    ap.add_argument("--selftest-launch", action="store_true", help="CPU / gloo: exercise the launcher + gather plumbing without a GPU (tests)")
     ap.add_argument("--tune-gemms", default=None, metavar="CSV",
                     help="run with TunableOp tuning ON and accumulate the winners in CSV (maintenance: regenerates "
                          "src/tunableop_gfx950.csv); the default run only READS the shipped file")
@@ -282,9 +575,24 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="minimum wall time of the CPU baseline leg")
     ap.add_argument("--cpu-python-unit", type=int, default=512, help="side of the one unit timed through the pure-Python port (0 = skip)")
     ap.add_argument("--boost-rmax", type=int, default=1600, help="c4: Boost's whole-image size limit (standalone default 1600, paper 3000)")
-    args = ap.parse_args()
+    return ap.parse_args(argv)
+
+
+def main(argv=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
+    args = parse_args(argv)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # run as the driver runs N = 1 -- plain `python bench.py --gpus N` -- there is no launcher around us: be the launcher
+        sys.exit(self_launch(args, argv))
+    if args.selftest_launch:
+        return selftest_launch(args)
     if args.config == "c4":
         return run_c4(args)
+    return run_pipeline(args)
+
+
+def run_pipeline(args):
+    global H, W, DEPTH_KIND
     preset = {"c2": ("dpt_hybrid_384", 1, 512, 512, None), "c3": ("dpt_beit_large_512", 32, 1024, 1024, None),
               "c3match": ("dpt_beit_large_512", 8, 1024, 1024, 0), "c5": ("dav2_vitl", 8, 1080, 1920, None)}[args.config]
     model_name = args.model or preset[0]
@@ -299,14 +607,11 @@ def main():
         net_size, net_h = (W + 31) // 32 * 32, (H + 31) // 32 * 32
     DEPTH_KIND = args.depth
     normalmap = not args.no_normalmap
+    default_invocation = (args.config == "c3" and args.model is None and args.batch is None and args.height is None and args.width is None
+                          and args.net_size is None)
 
     import torch
     import torch.distributed as dist
-    # MIOpen's search over its solvers for the ~15 library convolution shapes of a forward (the 256 -> 128 head convolution gets a
-    # CK kernel at 880 us instead of the heuristic's 2.0 ms igemm): +2.4-3 % on the step, ~40 s of the untimed priming pass on a
-    # fresh box (measured: 9 s -> 49 s wall for the whole command).  DS_CUDNN_BENCHMARK=0 leaves the heuristic choice.
-    # (not for the batch-1 latency line c2: its forward is replayed from a hipGraph, where MIOpen cannot be given a workspace,
-    # and the searched choices measured slower there: 4.99 vs 4.58 ms)
     # MIOpen's solver search (torch.backends.cudnn.benchmark): off by default since the end of round 3.  It bought 1.3-3 % while the
     # library convolutions still carried their bias; since they run without it (vit_mi355x.conv_module) the heuristic choice is
     # the same CK kernels: 806.6 (search) vs 809.7 (heuristic) pairs/s on the same box, and the search costs ~40 s of the untimed
@@ -314,16 +619,12 @@ def main():
     miopen_find = os.environ.get("DS_CUDNN_BENCHMARK", "0") != "0"
     if miopen_find:
         torch.backends.cudnn.benchmark = True
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU path exists)")
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+    rank, world, _ = dist_setup("nccl", dev)
 
     import src._native as nat
     import src.normalmap_generation as nmg
@@ -380,11 +681,18 @@ def main():
         from src.hip_graph import GraphedForward
         fwd = GraphedForward(lambda x: run_forward(model, model_name, x, net_size, net_h))
 
-    def step(check=False):
+    layout_box = []
+
+    def render(images, pred_given=None, forward=None):
+        """One pass of the hot path over `images`: (stereo pairs, normal maps, uint16 depth)."""
         if model is not None:
-            pred = fwd(img) if fwd is not None else run_forward(model, model_name, img, net_size, net_h)
+            pred = forward(images) if forward is not None else run_forward(model, model_name, images, net_size, net_h)
         else:
-            pred = pred_in
+            pred = pred_given
+        return pred
+
+    def step(check=False):
+        pred = render(img, pred_in, fwd)
         if check:                                            # outside the timed region: every unit's prediction varies
             lo, hi = pred.flatten(1).min(1).values, pred.flatten(1).max(1).values
             assert bool((hi > lo).all()), "degenerate (constant) depth prediction: the stereo leg would be meaningless"
@@ -398,7 +706,9 @@ def main():
             sbs = sg.create_stereoimages_batch(img, d16, 2.5, 0.0, ['left-right'], 0.0, 1.0, args.fill)[0]
             nmap = nmg.create_normalmap_batch(d16) if normalmap else None
             if gather_ok:
-                packed, _ = multigpu.pack_collated([sbs, d16] + ([nmap] if normalmap else []))
+                packed, layout = multigpu.pack_collated([sbs, d16] + ([nmap] if normalmap else []))
+                if not layout_box:
+                    layout_box.append(layout)
                 ev = torch.cuda.Event()
                 ev.record()
                 with torch.cuda.stream(side):
@@ -411,6 +721,11 @@ def main():
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
+    # in-step kernel timers: event pairs around the launches of the big in-tree kernels, recorded INSIDE the timed region (an event
+    # record is a marker on the stream: ~100 per step; --no-kernel-timers measures what they cost: nothing outside the noise)
+    timers_on = model is not None and not args.no_kernel_timers
+    if timers_on:
+        nat.kernel_timer_enable(local_rank, True)
     if world > 1:
         dist.barrier()
         torch.cuda.synchronize()
@@ -422,10 +737,17 @@ def main():
         dist.barrier()
         torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    timed = {}
+    if timers_on:
+        for kind in ("linear_gelu", "linear_residual", "attention", "linear", "linear_vt", "conv3x3", "linear_readout", "linear_shuffle", "normalmap"):
+            timed[kind] = nat.kernel_timer_read(local_rank, kind)
+            if kind.startswith("linear"):
+                timed[kind + "+ragged"] = nat.kernel_timer_read(local_rank, kind + "+ragged")
+        nat.kernel_timer_enable(local_rank, False)
 
-    # per-kernel timing in separate untimed passes (event synchronisation must not perturb the throughput measurement):
-    # k_polylines via HIP events recorded inside the C ABI on the launch stream, ds_normalmap via events on torch's current
-    # stream (which IS the launch stream of the ctypes call) ...
+    # per-kernel timing of the per-pixel path in separate untimed passes (event synchronisation must not perturb the throughput
+    # measurement): k_polylines via HIP events recorded inside the C ABI on the launch stream, ds_normalmap via events on torch's
+    # current stream (which IS the launch stream of the ctypes call)
     render_ms, exact_ms, nm_ms = [], [], []
     for _ in range(min(args.steps, 5)):
         _, _, d16 = step()
@@ -441,120 +763,59 @@ def main():
             e1.synchronize()
             nm_ms.append(e0.elapsed_time(e1))
     exact_rows, general_px = nat.last_stats(img)
-    # ... and the fused attention kernel at exactly the shape one encoder block launches it with
-    attn = None
+
+    # gather_check (N > 1, untimed): rank 0 renders the LAST rank's units itself (its inputs are a function of the rank) and compares
+    # them with the bytes that rank sent through the gather in the last step
+    gather_check = None
+    if gather_ok and rank == 0:
+        torch.cuda.synchronize()
+        side.synchronize()
+        o_img_np, o_pred_np = synth_batch(batch, seed=1000 + world - 1)
+        o_img = torch.from_numpy(o_img_np).to(dev)
+        with torch.no_grad():
+            o_pred = render(o_img, torch.from_numpy(o_pred_np).to(dev), None)
+        o_d16 = nat.depth_to_u16(o_pred, False)
+        o_sbs = sg.create_stereoimages_batch(o_img, o_d16, 2.5, 0.0, ['left-right'], 0.0, 1.0, args.fill)[0]
+        o_parts = [o_sbs, o_d16] + ([nmg.create_normalmap_batch(o_d16)] if normalmap else [])
+        want, layout = multigpu.pack_collated(o_parts)
+        gather_check = compare_gathered(gathered[world - 1], want, layout, exact=(model is None))
+        gather_check["rank"] = world - 1
+        gather_check["what"] = ("rank 0's own render of the last rank's units vs the bytes gathered from that rank"
+                                + ("" if model is None else "; the network's library convolutions with split-K atomics are not bit-reproducible "
+                                   "between launches, so the network path reports fractions instead of asserting identity"))
+        del o_img, o_pred, o_d16, o_sbs, o_parts, want
+
+    roofs, conv_roof = {}, None
     if model is not None:
-        n_tok = minfo["tokens"]
-        npad = vm.pad_len(n_tok, batch)
-        qk = torch.randn(batch, npad, 2, minfo["heads"], 64, device=dev, dtype=torch.float16)
-        vt = torch.randn(batch, minfo["heads"] * 64, npad, device=dev, dtype=torch.float16)
-        bias = None
-        if minfo["bias"]:
-            bias = nat.attention_bias_pack(torch.randn(minfo["heads"], n_tok, n_tok, device=dev), npad, torch.float16)
-        for _ in range(3):
-            nat.attention_fwd(qk, vt, n_tok, 0.125, bias)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        reps = 20
-        e0.record()
-        for _ in range(reps):
-            nat.attention_fwd(qk, vt, n_tok, 0.125, bias)
-        e1.record()
-        e1.synchronize()
-        attn_ms = e0.elapsed_time(e1) / reps
-        attn_flops = 4.0 * n_tok * n_tok * minfo["dim"] * batch            # QK^T + PV, 2 flops per MAC
-        attn = {"bound": "mfma", "kernel": "k_attention_fwd", "achieved": attn_flops / (attn_ms * 1e-3) / 1e12,
-                "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": attn_flops / (attn_ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS,
-                "traffic": None,                          # PMC counters cannot be read from inside the run ...
-                "traffic_from_profile": traffic_from_profile("k_attention_fwd2", batch) if args.config == "c3" else None,
-                "in_step_from_profile": in_step_from_profile("k_attention_fwd2", attn_flops, MFMA_PEAK_TFLOPS, 1e12) if args.config == "c3" else None,
-                "clock_from_profile": clock_from_profile("k_attention_fwd2", attn_flops, batch) if (args.config == "c3" and minfo["bias"]) else None,
-                "algorithmic_flops_per_launch": attn_flops, "avg_kernel_ms": attn_ms, "operands": "random (randn)",
-                "source": "microbenchmark: separate launches at the in-step shape on randn operands, HIP events on the launch stream",
-                "launches_per_step": minfo["depth"], "shape": {"batch": batch, "tokens": n_tok, "heads": minfo["heads"], "bias": minfo["bias"]}}
-    # ... and the in-tree MFMA GEMM (csrc/ds_linear.hip) at the shapes it runs at: fc1 + GELU of one encoder block, and the
-    # 3x3 convolution of the decoder's last residual units (256 -> 256 at net/4 resolution), random operands
-    lin = conv_roof = None
-    if model is not None and vm.LINEAR_HIP != "0":
-        m_rows, dim = batch * vm.pad_len(minfo["tokens"], batch), minfo["dim"]
-        xw = torch.randn(m_rows, dim, device=dev, dtype=torch.float16)
-        ww = torch.randn(4 * dim, dim, device=dev, dtype=torch.float16) * dim ** -0.5
-        bw = torch.randn(4 * dim, device=dev, dtype=torch.float16)
-        if nat.linear_supported(xw, ww):
-            for _ in range(3):
-                nat.linear(xw, ww, bw, True)
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            for _ in range(20):
-                nat.linear(xw, ww, bw, True)
-            e1.record()
-            e1.synchronize()
-            lin_ms = e0.elapsed_time(e1) / 20
-            lin_flops = 2.0 * m_rows * 4 * dim * dim
-            lin = {"bound": "mfma", "kernel": "k_linear256 (fc1 + erf-GELU)", "achieved": lin_flops / (lin_ms * 1e-3) / 1e12,
-                   "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": lin_flops / (lin_ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS,
-                   "traffic": None, "traffic_from_profile": traffic_from_profile("k_linear256<0, 1, 0, 0, 0", batch) if args.config == "c3" else None,
-                   "in_step_from_profile": in_step_from_profile("k_linear256<0, 1, 0, 0, 0", lin_flops, MFMA_PEAK_TFLOPS, 1e12) if args.config == "c3" else None,
-                   "clock_from_profile": clock_from_profile("k_linear256<0, 1, 0, 0, 0", lin_flops, batch) if args.config == "c3" else None,
-                   "algorithmic_flops_per_launch": lin_flops, "avg_kernel_ms": lin_ms, "operands": "random (randn)",
-                   "source": "microbenchmark: separate launches at the in-step shape on randn operands, HIP events on the launch stream",
-                   "launches_per_step": minfo["depth"], "shape": {"rows": m_rows, "out_features": 4 * dim, "in_features": dim}}
-        del xw, ww, bw
-    if model is not None and vm.CONV_HIP and model_name.startswith("dpt_"):
-        import torch.nn as nn
-        hw = (net_h or net_size) // 4, net_size // 4
-        cv = nn.Conv2d(256, 256, 3, padding=1).to(dev, torch.float16)
-        xc = torch.randn(batch, 256, hw[0], hw[1], device=dev, dtype=torch.float16).contiguous(memory_format=torch.channels_last)
-        if vm.conv3x3_hip_ok(cv, xc):
-            for _ in range(3):
-                nat.conv3x3(cv, xc, relu=True)
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            for _ in range(10):
-                nat.conv3x3(cv, xc, relu=True)
-            e1.record()
-            e1.synchronize()
-            cv_ms = e0.elapsed_time(e1) / 10
-            cv_flops = 2.0 * batch * hw[0] * hw[1] * 256 * 9 * 256
-            conv_roof = {"bound": "mfma", "kernel": "k_linear256 (implicit 3x3 convolution + bias + ReLU)",
-                         "achieved": cv_flops / (cv_ms * 1e-3) / 1e12, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": cv_flops / (cv_ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS, "traffic": None,
-                         "algorithmic_flops_per_launch": cv_flops, "avg_kernel_ms": cv_ms, "operands": "random (randn)",
-                         "source": "microbenchmark: separate launches at the in-step shape on randn operands, HIP events on the launch stream",
-                         "shape": {"batch": batch, "height": hw[0], "width": hw[1], "in_channels": 256, "out_channels": 256}}
-        del cv, xc
+        if args.no_micro:
+            roofs = {}
+            for kind, (n, ms) in timed.items():
+                if n > 0 and "+" not in kind:
+                    roofs[kind] = {"kernel": kind, "avg_kernel_ms": ms / n, "launches": n, "source": IN_STEP.format(n=n)}
+        else:
+            roofs = encoder_rooflines(nat, vm, dev, local_rank, batch, minfo, args.config, timed)
+            if vm.CONV_HIP and model_name.startswith("dpt_"):
+                cv_ms, hw = microbench_conv(nat, vm, dev, batch, net_size, net_h)
+                if cv_ms is not None:
+                    conv_roof = mfma_roofline("k_linear256<CONV> (implicit 3x3 convolution + bias + ReLU)", 2.0 * batch * hw[0] * hw[1] * 256 * 9 * 256,
+                                              cv_ms, None, MICRO, {"batch": batch, "height": hw[0], "width": hw[1], "in_channels": 256, "out_channels": 256},
+                                              operands="random (randn)")
+                    n, ms = timed.get("conv3x3", (0, 0.0))
+                    if n > 0:
+                        conv_roof["in_step_all_shapes"] = {"launches": n, "avg_kernel_ms": ms / n, "source": IN_STEP.format(n=n),
+                                                           "note": "every ds_conv3x3_nhwc launch of the decoder (several shapes): a time share, not a rate"}
     torch.cuda.synchronize()
 
-    # ---- route_check (untimed): the forward the step runs -- every block GEMM and the decoder's 3x3 convolutions in-tree, which
-    # needs the batch -- against the SAME network on the same images with every GEMM / 3x3 convolution sent to the ROCm
-    # libraries (vm.library_routing), plus how often the fused entry points were reached in one forward of the step
     route = None
     if model is not None and not args.no_route_check:
-        names = ("ds_linear", "ds_linear_residual", "ds_linear_vt", "ds_conv3x3_nhwc", "ds_attention_fwd", "ds_residual_layernorm",
-                 "ds_dpt_head_tail", "ds_preprocess_bicubic")
-        before = dict(nat.CALLS)
-        with torch.no_grad():
-            p_hip = run_forward(model, model_name, img, net_size, net_h).float()
-        calls = {n: nat.CALLS[n] - before.get(n, 0) for n in names}
-        nlib = min(batch, 4)
-        with torch.no_grad(), vm.library_routing():
-            p_lib = run_forward(model, model_name, img[:nlib], net_size, net_h).float()
-        span = (p_lib.flatten(1).max(1).values - p_lib.flatten(1).min(1).values).clamp_min(1e-12)
-        err = (p_hip[:nlib] - p_lib).abs().flatten(1).max(1).values / span
-        route = {"max_abs_diff_over_prediction_range": float(err.max().item()), "units_compared": nlib,
-                 "what": "prediction of the timed forward (in-tree GEMM / convolution routing at the step's batch) vs the same network on "
-                         "the same images with every token GEMM and 3x3 convolution through hipBLASLt / MIOpen; fp16 both sides",
-                 "c_abi_calls_per_forward": calls}
-        del p_hip, p_lib
+        route = route_check_leg(nat, vm, model, model_name, img, batch, net_size, net_h)
 
     funnel = None
-    want_funnel = args.funnel or (args.config == "c3" and world == 1 and args.model is None and args.batch is None)
+    want_funnel = args.funnel or (default_invocation and world == 1)
     if want_funnel and not args.no_funnel and rank == 0 and model is not None:
         funnel = funnel_leg(model, model_name, img_np, net_size, net_h, normalmap)
 
-    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed = float(t.item())
+    elapsed = max_over_ranks(elapsed, world, dev)
 
     if rank == 0:
         units = batch * world * args.steps
@@ -601,21 +862,23 @@ def main():
                                       + (", ONE RCCL gather of the collated outputs (stereo pair + uint16 depth"
                                          + (" + normal map" if normalmap else "") + f", {unit_bytes} bytes per unit) to rank 0 per step, overlapped"
                                          if gather_ok else "")},
-            # the dominant hand-written kernel of the step (largest launches x average duration): the fc1 + GELU GEMM or the
-            # fused attention when a network runs, else the stereo kernel; the others follow under their own keys
+            # the dominant hand-written kernel of the step by its time INSIDE the timed region (in-step launches x average duration);
+            # the others follow under their own keys; with no network it is the stereo kernel
             "roofline": stereo_roof,
         }
-        if attn is not None:
-            cands = [r for r in (attn, lin) if r is not None]
-            out["roofline"] = max(cands, key=lambda r: r["avg_kernel_ms"] * r["launches_per_step"])
-            out["roofline_attention"] = attn
-            if lin is not None:
-                out["roofline_linear"] = lin
+        if roofs and not args.no_micro:
+            out["roofline"] = max(roofs.values(), key=lambda r: r["avg_kernel_ms"] * r["launches_per_step"])
+            for kind, key in (("attention", "roofline_attention"), ("linear_gelu", "roofline_linear"), ("linear_residual", "roofline_linear_residual")):
+                if kind in roofs:
+                    out[key] = roofs[kind]
             if conv_roof is not None:
                 out["roofline_conv3x3"] = conv_roof
             out["roofline_stereo"] = stereo_roof
-            enc = vm.count_encoder_flops(minfo["depth"], minfo["tokens"], minfo["dim"]) * batch
-            out["encoder_tflops_per_step"] = enc / 1e12
+            out["encoder_tflops_per_step"] = vm.count_encoder_flops(minfo["depth"], minfo["tokens"], minfo["dim"]) * batch / 1e12
+        elif roofs:
+            out["in_step_kernel_ms"] = roofs
+        if timed:
+            out["in_step_kernel_time_ms_per_step"] = {k: v[1] / args.steps for k, v in timed.items() if v[0] > 0}
         if normalmap and nm_ms:
             a = batch * algo_bytes_normalmap() / (float(np.mean(nm_ms)) * 1e-3) / 1e9
             out["roofline_normalmap"] = {"bound": "hbm", "kernel": "k_normalmap_fused", "achieved": a, "peak": HBM_PEAK_GBPS,
@@ -634,6 +897,8 @@ def main():
                     r["traffic"] = tp["hbm_bytes_per_launch"]
                 if r.get("bound") == "hbm":
                     r["frac_of_measured_copy_peak"] = r["achieved"] / HBM_COPY_GBPS
+        if gather_check is not None:
+            out["gather_check"] = gather_check
         if route is not None:
             out["route_check"] = route
         if funnel is not None:
@@ -642,6 +907,10 @@ def main():
             out["cpu_baseline"] = cpu_baseline(model_name, net_size, net_h, args.cpu_sample, seed=1000, min_seconds=args.cpu_seconds,
                                                normalmap=normalmap, python_unit=args.cpu_python_unit,
                                                init_seed=minfo["init_seed"] if minfo else 0)
+        if default_invocation and world == 1 and not args.no_other_configs:
+            # the other BASELINE configurations, driver-timed in the same command (sub-processes; the parent's GPU work is done)
+            torch.cuda.empty_cache()
+            out["other_configs"] = other_configs_leg(args.other_configs_timeout)
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
@@ -658,16 +927,12 @@ def run_c4(args):
     import torch
     import torch.distributed as dist
     H, W = args.height or 2160, args.width or 3840
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU path exists)")
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+    rank, world, _ = dist_setup("nccl", dev)
     import src._native as nat
     import src.normalmap_generation as nmg
     import src.stereoimage_generation as sg
@@ -721,13 +986,10 @@ def run_c4(args):
     if world > 1:
         dist.barrier()
         torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    elapsed = max_over_ranks(time.perf_counter() - t0, world, dev)
     fl = torch.tensor([flops[0]], dtype=torch.float64, device=dev)
     if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dist.all_reduce(fl, op=dist.ReduceOp.SUM)
-    elapsed = float(t.item())
     if rank == 0:
         ach = float(fl.item()) / (elapsed / args.steps) / 1e12
         print(json.dumps({
@@ -735,6 +997,7 @@ def run_c4(args):
             # roofline is the float32 MFMA peak (157.3 TF/s per GPU, MI355X_MICROARCH.md) against the convolutions' algorithmic flops
             "roofline": {"bound": "mfma", "kernel": "MIOpen float32 convolutions of LeReS res101 + the pix2pix U-Net (library), whole step",
                          "achieved": ach, "peak": 157.3 * world, "unit": "TFLOP/s", "frac": ach / (157.3 * world), "traffic": None,
+                         "avg_kernel_ms": elapsed / args.steps * 1e3,
                          "algorithmic_flops_per_image": float(fl.item()), "source": "forward hooks on every convolution (priming step) / wall time of the timed steps"},
             "metric": f"Boost depth+stereo images/sec @{W}x{H}", "value": args.steps / elapsed, "unit": "images/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,

@@ -76,9 +76,61 @@ def install_stubs():
     cv2 = types.ModuleType("cv2")
     cv2.INTER_NEAREST, cv2.INTER_LINEAR, cv2.INTER_CUBIC, cv2.INTER_AREA, cv2.COLOR_BGR2RGB, cv2.CV_64F = 0, 1, 2, 3, 4, 6
 
+    # float32 images are resized in FLOAT32, as OpenCV does for CV_32F (resize.cpp: float coefficients from interpolateCubic /
+    # the linear weights, float products and sums, the horizontal pass first, then the vertical one); float64 images and integer
+    # images (promoted) keep the float64 restatement of the oracle.  Round 5: the first golden used the float64 restatement for
+    # float32 images too (one rounding at the end) -- a summation order no float32 implementation has, and what put the product's
+    # float32 CPU twin at 9.5e-5 of this golden through the networks' conditioning.
+    def _taps_cubic32(n_out, n_in):
+        f = ((np.arange(n_out, dtype=np.float64) + 0.5) * (n_in / n_out) - 0.5).astype(np.float32)      # fx = (float)((dx + 0.5) * scale - 0.5)
+        i = np.floor(f).astype(np.int64)
+        t = (f - i.astype(np.float32)).astype(np.float32)
+        A, one = np.float32(-0.75), np.float32(1)
+        w = np.empty((n_out, 4), np.float32)
+        w[:, 0] = ((A * (t + one) - np.float32(5) * A) * (t + one) + np.float32(8) * A) * (t + one) - np.float32(4) * A
+        w[:, 1] = ((A + np.float32(2)) * t - (A + np.float32(3))) * t * t + one
+        w[:, 2] = ((A + np.float32(2)) * (one - t) - (A + np.float32(3))) * (one - t) * (one - t) + one
+        w[:, 3] = one - w[:, 0] - w[:, 1] - w[:, 2]
+        return np.clip(i[:, None] - 1 + np.arange(4)[None, :], 0, n_in - 1), w
+
+    def _cubic32(src, hw):
+        src = np.asarray(src, np.float32)
+        iy, wy = _taps_cubic32(hw[0], src.shape[0])
+        ix, wx = _taps_cubic32(hw[1], src.shape[1])
+        rows = src[:, ix[:, 0]] * wx[:, 0][None, :]
+        for k in range(1, 4):
+            rows = rows + src[:, ix[:, k]] * wx[:, k][None, :]
+        out = rows[iy[:, 0], :] * wy[:, 0][:, None]
+        for k in range(1, 4):
+            out = out + rows[iy[:, k], :] * wy[:, k][:, None]
+        assert out.dtype == np.float32
+        return out
+
+    def _taps_linear32(n_out, n_in):
+        f = ((np.arange(n_out, dtype=np.float64) + 0.5) * (n_in / n_out) - 0.5).astype(np.float32)
+        i = np.floor(f).astype(np.int64)
+        t = (f - i.astype(np.float32)).astype(np.float32)
+        t = np.where(i < 0, np.float32(0), t)
+        i = np.where(i < 0, 0, i)
+        t = np.where(i >= n_in - 1, np.float32(1), t).astype(np.float32)
+        i = np.where(i >= n_in - 1, n_in - 2, i)
+        return i, t
+
+    def _linear32(src, hw):
+        src = np.asarray(src, np.float32)
+        iy, ty = _taps_linear32(hw[0], src.shape[0])
+        ix, tx = _taps_linear32(hw[1], src.shape[1])
+        one = np.float32(1)
+        rows = src[:, ix] * (one - tx)[None, :] + src[:, ix + 1] * tx[None, :]
+        out = rows[iy, :] * (one - ty)[:, None] + rows[iy + 1, :] * ty[:, None]
+        assert out.dtype == np.float32
+        return out
+
     def resize(img, size, dst=None, fx=None, fy=None, interpolation=1):
         f = orc._cv_cubic_resize if interpolation == cv2.INTER_CUBIC else orc._cv_linear_resize
         img = np.asarray(img)
+        if img.dtype == np.float32 and os.environ.get("DS_GOLDEN_RESIZE", "f32") == "f32":
+            f = _cubic32 if interpolation == cv2.INTER_CUBIC else _linear32
         hw = (size[1], size[0])
         if img.shape[:2] == hw:
             return img.copy()

@@ -439,11 +439,14 @@ def test_video_two_pass_pipeline_single_rank(gpu, oracle):
         assert np.array_equal(res['left-right'][i].cpu().numpy(), want)
 
 
-@pytest.mark.parametrize("tag,kind", [("k", "zoedepth_k"), ("nk", "zoedepth_nk")])
+@pytest.mark.parametrize("tag,kind", [("n", "zoedepth_n"), ("k", "zoedepth_k"), ("nk", "zoedepth_nk")])
 def test_zoedepth_gpu_vs_reference_fp32(gpu, tag, kind):
-    """ZoeDepth (ids 8, 9 run in half on a GPU, src/depthmap_generation.py:266-272) on the device: float32 against the
-    outputs of the reference's own ZoeDepth code (tests/golden/zoedepth_cases.npz; 1e-4 is the CPU bar, the GPU's
-    float32 convolutions / GEMMs sum in another order), then float16 with the fused kernels inside the DPT core."""
+    """ZoeDepth (ids 7, 8, 9; 8 and 9 run in half on a GPU, src/depthmap_generation.py:266-272) on the device against the outputs of
+    the reference's own ZoeDepth code (tests/golden/zoedepth_cases.npz): float32 at north_star's 1e-4, float16 (fused kernels
+    inside the DPT core) at 2e-2.  MEASURED (profiles/round5_parity_probe.json, tools/parity_probe.py): float32 6.5e-7 (N), 8.3e-7
+    (K), 7.6e-7 (NK) -- the device is as close to the golden as the float64 evaluation of the same network is (8e-7 .. 1.1e-6), no
+    stage above 1.1e-5; float16 2.9e-4 / 2.2e-3 / 2.6e-4, the same as the network's stock-torch half twin (3.0e-4 / 2.3e-3 /
+    2.2e-4).  (Rounds 1-4 held 5e-4 / 5e-2 here without a measured value.)"""
     from dzoedepth import build_zoedepth
     z = np.load(os.path.join(os.path.dirname(GOLD), "zoedepth_cases.npz"))
     m, _ = build_zoedepth(kind, midas_model_type="DPT_BEiT_B_384")
@@ -455,11 +458,13 @@ def test_zoedepth_gpu_vs_reference_fp32(gpu, tag, kind):
     ref = z[f"{tag}_88x120_infer"]
     with torch.no_grad():
         y32 = m.infer(x).cpu().numpy()
-    assert np.abs(y32 - ref).max() / np.abs(ref).max() < 5e-4
+    e32 = np.abs(y32 - ref).max() / np.abs(ref).max()
+    assert e32 < 1e-4, e32
     with torch.no_grad():
         y16 = m.half().infer(x.half()).float().cpu().numpy()
     assert np.isfinite(y16).all()
-    assert np.abs(y16 - ref).max() / np.abs(ref).max() < 5e-2
+    e16 = np.abs(y16 - ref).max() / np.abs(ref).max()
+    assert e16 < 2e-2, e16
 
 
 def test_funnel_with_zoedepth(gpu):
@@ -607,10 +612,25 @@ def test_leres_and_hybrid_gpu_fp32_vs_reference(gpu):
     with torch.no_grad():
         y32 = m.cuda()(x4).cpu().numpy()
     assert np.abs(y32 - ref).max() / np.abs(ref).max() < 1e-4, np.abs(y32 - ref).max() / np.abs(ref).max()
+    # float16: this network with name-seeded weights loses 4-5e-2 in half precision WHATEVER runs it -- measured (profiles/
+    # round5_parity_probe.json): in-tree kernels 4.1e-2 / 4.8e-2 (two runs: the library's split-K convolutions are not
+    # bit-reproducible), every GEMM / convolution through the libraries 4.6e-2, the stock-torch twin (no in-tree kernel at all:
+    # the arithmetic the reference's own modules run in half) 4.8e-2; stage by stage the two agree (the four taps: 4e-3, 1.4e-2,
+    # 7.9e-2, 7.0e-2 against 5e-3, 1.7e-2, 7.5e-2, 6.9e-2: the loss is made inside the ViT-B blocks on the ResNetV2 stem's
+    # output, by half precision itself).  The 2e-2 rule therefore cannot hold for this network; the bar is the stock twin's own
+    # error with a margin for the run-to-run spread, and 2e-2 wherever the stock twin itself meets it.
+    from src import vit_mi355x as vm
+    mh = m.half()
+    xh = x4.half().contiguous(memory_format=torch.channels_last)
     with torch.no_grad():
-        y16 = m.half()(x4.half().contiguous(memory_format=torch.channels_last)).float().cpu().numpy()
-    # the ResNetV2 stem (weight-standardised convolutions, GroupNorm) in half precision with synthetic weights: 3.7e-2 measured
-    assert np.abs(y16 - ref).max() / np.abs(ref).max() < 6e-2
+        y16 = mh(xh).float().cpu().numpy()
+        with vm.stock_routing():
+            y16_stock = mh(xh).float().cpu().numpy()
+    e16 = np.abs(y16 - ref).max() / np.abs(ref).max()
+    e16_stock = np.abs(y16_stock - ref).max() / np.abs(ref).max()
+    print(f"dpt_hybrid float16 vs the reference's float32 output: in-tree {e16:.3e}, stock-torch half twin {e16_stock:.3e}")
+    assert e16 < max(2e-2, 1.3 * e16_stock), (e16, e16_stock)
+    assert e16_stock < 1e-1, e16_stock                      # the yardstick itself is a half-precision forward, not garbage
 
 
 @pytest.mark.parametrize("dtype,tol", [(torch.float16, 2e-3), (torch.bfloat16, 1.6e-2)])
@@ -1318,8 +1338,14 @@ def test_linear_readout_matches_definition(gpu, b, npad, n, c, grid):
     try:
         before = _native.CALLS["ds_linear_readout"]
         with torch.no_grad():
-            y = ro.forward_padded(xp, n)
-            y2 = ro.forward_padded(xp, n)
+            if grid:                     # below the routing threshold of the module path (a chip-filling launch): the kernel itself
+                w_tok, w_cls = ro._split()
+                clsvec = torch.nn.functional.linear(xp[:, 0], w_cls, ro.project[0].bias)
+                y = _native.linear_readout(xp, n, w_tok, clsvec)
+                y2 = _native.linear_readout(xp, n, w_tok, clsvec)
+            else:
+                y = ro.forward_padded(xp, n)
+                y2 = ro.forward_padded(xp, n)
         assert _native.CALLS["ds_linear_readout"] == before + 2
     finally:
         if grid:

@@ -50,12 +50,20 @@ def first_tensor(o):
 
 
 def trace(model, names, run):
-    """{module name: first output tensor (float64 numpy) of its LAST call} while run() executes."""
+    """{module name: first output tensor (float64 numpy) of its LAST call} while run() executes; a module that returns a list of
+    tensors (the backbone's four taps) is recorded as name[0], name[1], ..."""
     got, hooks = {}, []
     mods = dict(model.named_modules())
+
+    def keep(n, o):
+        if isinstance(o, (list, tuple)) and len(o) > 1 and all(torch.is_tensor(t) for t in o):
+            for i, t in enumerate(o):
+                got[f"{n}[{i}]"] = t.detach().double().cpu().numpy()
+        else:
+            got[n] = first_tensor(o).detach().double().cpu().numpy()
     for n in names:
         if n in mods:
-            hooks.append(mods[n].register_forward_hook(lambda m, i, o, n=n: got.__setitem__(n, first_tensor(o).detach().double().cpu().numpy())))
+            hooks.append(mods[n].register_forward_hook(lambda m, i, o, n=n: keep(n, o)))
     out = run()
     for h in hooks:
         h.remove()
@@ -84,7 +92,7 @@ def zoedepth(out):
             y32, st_gpu = trace(mg, stages, lambda: mg.infer(x.cuda()).cpu().numpy())
             r["gpu32_vs_golden"] = rel(y32, ref)
             r["gpu32_vs_cpu32"] = rel(y32, y_cpu)
-            r["stages_gpu32_vs_cpu32"] = {k: rel(st_gpu[k], st_cpu[k]) for k in stages if k in st_gpu and k in st_cpu}
+            r["stages_gpu32_vs_cpu32"] = {k: rel(st_gpu[k], st_cpu[k]) for k in st_gpu if k in st_cpu}
             # float32 matmul / convolution precision knobs of the libraries behind torch (nothing reduced is on by default)
             r["allow_tf32"] = [bool(torch.backends.cuda.matmul.allow_tf32), bool(torch.backends.cudnn.allow_tf32)]
             md = mg.double()
@@ -96,11 +104,16 @@ def zoedepth(out):
             y16, st16 = trace(mh, stages, lambda: mh.infer(x.half().cuda()).float().cpu().numpy())
             r["gpu16_vs_golden"] = rel(y16, ref)
             r["gpu16_finite"] = bool(np.isfinite(y16).all())
-            r["stages_gpu16_vs_cpu32"] = {k: rel(st16[k], st_cpu[k]) for k in stages if k in st16 and k in st_cpu}
-            # the same half network with every token GEMM / 3x3 convolution through the ROCm libraries
+            r["stages_gpu16_vs_cpu32"] = {k: rel(st16[k], st_cpu[k]) for k in st16 if k in st_cpu}
+            # the same half network with every token GEMM / 3x3 convolution through the ROCm libraries, and as its stock-torch
+            # twin (no in-tree kernel at all: the arithmetic the reference's own modules run in half precision)
             from src import vit_mi355x as vm
             with vm.library_routing():
                 r["gpu16_library_routing_vs_golden"] = rel(mh.infer(x.half().cuda()).float().cpu().numpy(), ref)
+            with vm.stock_routing():
+                ys, sts = trace(mh, stages, lambda: mh.infer(x.half().cuda()).float().cpu().numpy())
+            r["gpu16_stock_torch_vs_golden"] = rel(ys, ref)
+            r["stages_gpu16_stock_vs_cpu32"] = {k: rel(sts[k], st_cpu[k]) for k in sts if k in st_cpu}
         out[f"zoedepth_{tag}"] = r
         del m, mg, md, mh
         torch.cuda.empty_cache()
@@ -125,11 +138,15 @@ def hybrid(out):
         y16, s16 = trace(mh, stages, lambda: mh(x.half().cuda().contiguous(memory_format=torch.channels_last)).float().cpu().numpy())
         r["gpu16_vs_golden"] = rel(y16, ref)
         r["gpu16_vs_gpu32"] = rel(y16, y32)
-        r["stages_gpu16_vs_gpu32"] = {k: rel(s16[k], s32[k]) for k in stages if k in s16 and k in s32}
+        r["stages_gpu16_vs_gpu32"] = {k: rel(s16[k], s32[k]) for k in s16 if k in s32}
         r["golden_stats"] = {"max": float(np.abs(ref).max()), "std": float(ref.std()), "mean": float(ref.mean())}
         from src import vit_mi355x as vm
         with vm.library_routing():
             r["gpu16_library_routing_vs_golden"] = rel(mh(x.half().cuda().contiguous(memory_format=torch.channels_last)).float().cpu().numpy(), ref)
+        with vm.stock_routing():
+            ys, ss = trace(mh, stages, lambda: mh(x.half().cuda()).float().cpu().numpy())
+        r["gpu16_stock_torch_vs_golden"] = rel(ys, ref)
+        r["stages_gpu16_stock_vs_gpu32"] = {k: rel(ss[k], s32[k]) for k in ss if k in s32}
     out["dpt_hybrid"] = r
 
 
