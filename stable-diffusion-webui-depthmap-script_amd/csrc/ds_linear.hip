@@ -905,23 +905,48 @@ DS_API int ds_linear_reload_env(void)
     return DS_OK;
 }
 
-// Workspace of the ragged round's K split: arrival counters (zeroed once; every launch leaves them at zero) + one 32 KB
-// partial per workgroup of the largest launch (grid workgroups).  Returns 1 when the block would have to be allocated or
-// cleared while the stream is being captured into a graph (the caller then launches without the split: the eager warm-up
+// Workspace of the ragged round's K split: arrival counters (zeroed once; every launch leaves them at zero) + one 32 KB partial per
+// workgroup.  Allocated ONCE per context at its maximum size (LN_RG_MAX_WG workgroups: 32 MB) and never reallocated -- captured
+// hipGraphs hold its address (a graph must replay on the context that captured it), and a second allocation could hand the same
+// address back with stale counters; a launch with more workgroups than that runs unsplit.  Returns 1 when the block would have to
+// be allocated while the stream is being captured into a graph (the caller then launches without the split: the eager warm-up
 // calls that precede a capture normally have it in place).
 #define LN_RG_COUNTER_BYTES 4096
+#define LN_RG_MAX_WG 1024
 static int ln_ragged_workspace(ds_ctx *ctx, int grid, hipStream_t stream)
 {
-    const size_t need = LN_RG_COUNTER_BYTES + (size_t)(grid > 256 ? grid : 256) * 32768;
-    if (ctx->lin_ws && ctx->lin_ws_bytes >= need && ctx->lin_ws_cleared == ctx->lin_ws) return DS_OK;
+    if (grid > LN_RG_MAX_WG) return 1;
+    if (ctx->lin_ws && ctx->lin_ws_cleared == ctx->lin_ws) return DS_OK;
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(stream, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) { (void)hipGetLastError(); return 1; }
-    const int rc = ds_ctx_reserve(ctx, &ctx->lin_ws, &ctx->lin_ws_bytes, need);
-    if (rc != DS_OK) return rc;
+    if (!ctx->lin_ws) {
+        const int rc = ds_ctx_reserve(ctx, &ctx->lin_ws, &ctx->lin_ws_bytes, LN_RG_COUNTER_BYTES + (size_t)LN_RG_MAX_WG * 32768);
+        if (rc != DS_OK) return rc;
+    }
     DS_HIP_CHECK(hipMemsetAsync(ctx->lin_ws, 0, LN_RG_COUNTER_BYTES, stream));
     DS_HIP_CHECK(hipStreamSynchronize(stream));
     ctx->lin_ws_cleared = ctx->lin_ws;
     return DS_OK;
+}
+
+// The K split's hand-over between workgroups (sc1 stores of the partials, vmcnt(0), a relaxed device-scope counter, sc1 loads by the
+// last arriver) is argued on the ISA of gfx942 / gfx950 -- sc1 stores write through to memory and sc1 loads bypass the per-XCD L2 --
+// not on the HIP memory model (no agent-scope release / acquire: the cache-wide write-back + invalidate it lowers to costs 55 us per
+// launch, see the kernel).  On any other architecture the split stays off.
+static int ln_ksplit_arch_ok(ds_ctx *ctx)
+{
+    static std::atomic<uint64_t> checked{0}, ok{0};
+    const uint64_t bit = 1ull << (ctx->device & 63);
+    if (!(checked.load(std::memory_order_acquire) & bit)) {
+        hipDeviceProp_t prop;
+        bool good = false;
+        if (hipGetDeviceProperties(&prop, ctx->device) == hipSuccess)
+            good = strncmp(prop.gcnArchName, "gfx950", 6) == 0 || strncmp(prop.gcnArchName, "gfx942", 6) == 0;
+        else (void)hipGetLastError();
+        if (good) ok.fetch_or(bit, std::memory_order_relaxed);
+        checked.fetch_or(bit, std::memory_order_release);
+    }
+    return (ok.load(std::memory_order_relaxed) & bit) != 0;
 }
 
 template <int BF16, int EPI, int CONV, int RES, int VT = 0, int NH = 0>
@@ -973,7 +998,7 @@ static int ln_launch(ds_ctx *ctx, const LinParams &P0, hipStream_t stream)
     // (fc1 274.4 / 275.0, qk 148.2 / 148.1, proj 85.9 / 87.6 with 2 K-tiles each), hence the lower bound of 32 K-tiles.
     const int deep = O.ragged_ring ? O.ragged_ring == 6 : 8 * ragged <= grid;
     int ksl = 0;
-    if (CONV == 0 && ragged && deep && 8 * ragged * (int)sizeof(int) <= LN_RG_COUNTER_BYTES) {
+    if (CONV == 0 && ragged && deep && 8 * ragged * (int)sizeof(int) <= LN_RG_COUNTER_BYTES && ln_ksplit_arch_ok(ctx)) {
         const int nt = P.K / 64;
         while (nt >= O.ragged_ksplit_min && (2 << ksl) <= O.ragged_ksplit && 8 * ragged * (2 << ksl) <= grid && nt % (2 << ksl) == 0 &&
                nt / (2 << ksl) >= O.ragged_ksplit_keep) ++ksl;

@@ -107,6 +107,7 @@ def _custom_depth_to_float(dp, image):
 
 import ctypes as _ctypes
 import os as _os
+import threading as _threading
 import time as _time
 
 # device batch of the funnel: up to this many pixels (16 x 1024^2 by default), at most 64 images.  Measured on 32 x 1024^2
@@ -141,12 +142,41 @@ _capsule_pointer.argtypes = [_ctypes.py_object, _ctypes.c_char_p]
 FUNNEL_ARROW = _os.environ.get("DS_FUNNEL_ARROW", "1") != "0"
 
 
+def _arrow_layout_verified():
+    """Once per process: export a small RGB image whose pixels are known and compare the exported bytes with them (the layout the
+    funnel's memmove assumes -- RGBX, 4 bytes per pixel, line 0 first, no padding -- was validated on Pillow 12.2; any other
+    Pillow has to show it here or takes np.asarray)."""
+    try:
+        probe = Image.new("RGB", (5, 3))
+        probe.putdata([(10 * i + 1, 10 * i + 2, 10 * i + 3) for i in range(15)])
+        if not hasattr(probe, "__arrow_c_array__") or getattr(probe, "readonly", 1):
+            return False
+        caps = probe.__arrow_c_array__()
+        arr = _ArrowArray.from_address(_capsule_pointer(caps[1], b"arrow_array"))
+        if arr.n_children != 1 or arr.length != 15 or arr.offset != 0:
+            return False
+        pix = arr.children[0].contents
+        if pix.n_buffers != 2 or pix.length != 60 or pix.offset != 0 or not pix.buffers[1]:
+            return False
+        raw = _ctypes.string_at(int(pix.buffers[1]), 60)
+        return all(raw[4 * i:4 * i + 3] == bytes((10 * i + 1, 10 * i + 2, 10 * i + 3)) for i in range(15))
+    except Exception:
+        return False
+
+
+_ARROW_LAYOUT_OK = FUNNEL_ARROW and _arrow_layout_verified()
+
+
 def _rgbx_pixels(im):
     """(address of the image's H*W 4-byte RGBX pixels, keep-alive object) for an RGB image that owns its pixel store, else None.
     The address is valid while the keep-alive object (the Arrow capsules, which hold the image's blocks) is referenced."""
-    if not FUNNEL_ARROW or im.mode != "RGB" or getattr(im, "readonly", 1) or not hasattr(im, "__arrow_c_array__"):
+    if not FUNNEL_ARROW or im.mode != "RGB" or getattr(im, "readonly", 1) or not hasattr(im, "__arrow_c_array__") or not _ARROW_LAYOUT_OK:
         return None
     try:
+        # the memmove below assumes ONE block of h lines of exactly 4 * w bytes starting at line 0: true for Pillow's default line
+        # alignment of 1; a host application that raised Image.core.set_alignment pads the lines
+        if hasattr(Image.core, "get_alignment") and Image.core.get_alignment() != 1:
+            return None
         capsules = im.__arrow_c_array__()
         arr = _ArrowArray.from_address(_capsule_pointer(capsules[1], b"arrow_array"))
         if arr.n_children != 1 or arr.length != im.width * im.height or arr.offset != 0:
@@ -330,9 +360,8 @@ def _launch_group(gen, idxs, inputimages, inputdepthmaps, inp, device, stats=Non
         g["stereo_error"] = ValueError('not enough values to unpack (expected 3, got %d)' % ndim0)
         want_stereo = False
     if want_stereo:
-        # (Pillow >= 11.2 can export an image's pixel store without a copy through the Arrow interface, which would replace
-        # np.asarray's ~3 interpreter-locked passes per image by one memcpy -- but the export SEGFAULTS on images that map
-        # foreign memory (Image.fromarray of an L / RGBA array, Pillow 12.2): not something a drop-in library may risk)
+        # (RGB images that own their pixel store go through Pillow's Arrow export + memmove: _rgbx_pixels above; everything
+        # else takes np.asarray)
         img_t = upload_pixels("img", lambda im: np.asarray(im, dtype=np.uint8), rgb=images[0].mode == "RGB")
     mesh_source = None
     if custom:
@@ -449,29 +478,50 @@ def _copy_stream(device):
     return st
 
 
+_pil_alloc_lock = _threading.Lock()
+_pil_alloc = {"active": 0, "before": None, "set": None}      # funnel calls in flight, the caller's blocks_max, the value the funnel set
+
+
 def _tune_pil_allocator():
     """Pillow allocates every image from fresh 16 MB blocks and returns them to the OS on release (blocks_max = 0): each of the
     funnel's results (8 MB for a 1024 x 2048 pair) then pays a first-touch page fault per 4 KB page, serialised on the process's
     memory-map lock however many threads convert -- measured here 9.9 ms -> 4.1 ms per unit (depth + pair + normal map) once
-    freed blocks are kept for reuse.  The setting is process wide, so it is SCOPED to the funnel call: raised to
-    DS_PIL_BLOCKS_MAX blocks (default 64 = at most 1 GB retained while the call runs; 0 leaves Pillow alone) on entry, and
-    the caller's value is put back -- which also releases the retained blocks -- when the generator finishes or is closed
-    (INTEGRATION.md section 4).  Returns the value to restore, or None when nothing was changed."""
+    freed blocks are kept for reuse.  The setting is process wide, so it is SCOPED to the funnel calls in flight and REFERENCE
+    COUNTED (interleaved generators share it): the first call raises it to DS_PIL_BLOCKS_MAX blocks (default 64 = at most 1 GB
+    retained while calls run; 0 leaves Pillow alone), the last one to finish puts the caller's value back -- which also releases
+    the retained blocks -- and only if the value is still the one the funnel set (a host application that changed it meanwhile
+    keeps its choice).  Returns True when this call holds a reference to give back."""
     try:
         want = int(_os.environ.get("DS_PIL_BLOCKS_MAX", 64))
-        before = Image.core.get_blocks_max()
-        if want > 0 and before < want:
-            Image.core.set_blocks_max(want)
-            return before
+        if want <= 0:
+            return False
+        with _pil_alloc_lock:
+            if _pil_alloc["active"] == 0:
+                before = Image.core.get_blocks_max()
+                if before >= want:
+                    return False                           # the host application already keeps at least as many: nothing to scope
+                Image.core.set_blocks_max(want)
+                _pil_alloc["before"], _pil_alloc["set"] = before, want
+            elif _pil_alloc["set"] is None:
+                return False
+            _pil_alloc["active"] += 1
+            return True
     except Exception:           # an older Pillow without the arena controls: nothing to tune
-        pass
-    return None
+        return False
 
 
-def _restore_pil_allocator(before):
-    if before is not None:
+def _restore_pil_allocator(held):
+    if not held:
+        return
+    with _pil_alloc_lock:
+        _pil_alloc["active"] -= 1
+        if _pil_alloc["active"] > 0:
+            return
+        before, was_set = _pil_alloc["before"], _pil_alloc["set"]
+        _pil_alloc["before"] = _pil_alloc["set"] = None
         try:
-            Image.core.set_blocks_max(before)
+            if Image.core.get_blocks_max() == was_set:     # still ours: give the caller's value back
+                Image.core.set_blocks_max(before)
         except Exception:
             pass
 
@@ -582,8 +632,9 @@ def core_generation_funnel(outpath, inputimages, inputdepthmaps, inputnames, inp
 
     torch = _native.require_gpu()        # the hot path has no CPU implementation, whatever COMPUTE_DEVICE says
     device = torch.device('cuda', torch.cuda.current_device())
-    pil_blocks_before = _tune_pil_allocator()
-    stats = {}
+    pil_blocks_held = _tune_pil_allocator()
+    stats = {"finished": False}
+    FUNNEL_STATS.clear()                   # a reader never sees the PREVIOUS call's numbers while (or after) this one runs
     _t_start = _time.perf_counter()
 
     try:
@@ -613,10 +664,8 @@ def core_generation_funnel(outpath, inputimages, inputdepthmaps, inputnames, inp
             pending = launched
         if pending is not None:
             yield from _emit_group(pending, outpath, inp, device, stats)
-        stats["total"] = _time.perf_counter() - _t_start
         stats["groups"] = len(groups)
-        FUNNEL_STATS.clear()
-        FUNNEL_STATS.update(stats)
+        stats["finished"] = True
     except Exception as e:
         if 'out of memory' in str(e).lower():                                                  # :308-326
             suggestion = "out of GPU memory, could not generate depthmap! " \
@@ -628,7 +677,11 @@ def core_generation_funnel(outpath, inputimages, inputdepthmaps, inputnames, inp
             raise Exception(suggestion)
         raise e
     finally:
-        _restore_pil_allocator(pil_blocks_before)
+        # published whether the generator ran to completion, was closed early or raised ('finished' says which)
+        stats["total"] = _time.perf_counter() - _t_start
+        FUNNEL_STATS.clear()
+        FUNNEL_STATS.update(stats)
+        _restore_pil_allocator(pil_blocks_held)
         if ops.get('keepmodels', True):
             model_holder.offload()
         else:

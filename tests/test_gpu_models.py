@@ -262,8 +262,12 @@ def test_boost_end_to_end_vs_reference_estimateboost(gpu):
     """Boost end to end ON THE DEVICE (float32 networks, device-side Sobel / resizes / selection, batched patch estimation,
     the one-launch HIP blend) against the reference's OWN estimateboost run on the CPU (tests/golden/make_golden_boost.py;
     src/depthmap_generation.py:774-941, LeReS + pix2pix with name-seeded weights, 480 x 640 image): the same 18 patches, final
-    depth within 1.5e-4 of full scale and 2e-5 on average (CPU twin of this test: 9.5e-5 / 5e-6; the device adds 1.6e-5 to it,
-    per-stage budget in the next test).  What stays unpinned: OpenCV's own resize / blur arithmetic (numpy restatements in the golden)."""
+    depth within north_star's 1e-4 of full scale and 2e-5 on average.  MEASURED on the device: 9.5e-5 against the round-4 golden
+    (profiles/round5_parity_probe_boost.json), and the golden regenerated in round 5 with float32 stand-ins for cv2's float32
+    resizes sits 1.7e-5 closer to the product's arithmetic (CPU twin 9.5e-5 -> 7.8e-5, tests/test_models_cpu.py); the device adds
+    1.4-1.6e-5 to its CPU twin (per-stage budget in the next test).  Noise floor of the comparison: one ulp on every weight moves
+    the output by 3.3e-5 (profiles/round5_boost_conditioning.txt).  What stays unpinned: OpenCV's own resize / blur arithmetic
+    (numpy restatements in the golden)."""
     from lib.multi_depth_model_woauxi import RelDepthModel
     from pix2pix.models.pix2pix4depth_model import Pix2Pix4DepthModel
     from src import boost
@@ -279,10 +283,8 @@ def test_boost_end_to_end_vs_reference_estimateboost(gpu):
     got = out[::2, ::2]
     assert stats["patches"] == 18 and stats["whole_image_optimal_size"] == 896, stats
     rel = np.abs(got - want).max() / np.abs(want).max()
-    # the bar: the CPU twin's 9.5e-5 against the reference (float32 torch resizes against the golden's float64 stand-ins) plus what
-    # the device adds to the CPU twin, 1.6e-5 at the output (test_boost_gpu_error_budget_per_stage, profiles/round4_boost_error_
-    # budget.json) -- 1.1e-4 by the triangle inequality, held with a margin
-    assert rel < 1.5e-4 and np.abs(got - want).mean() < 2e-5, (rel, float(np.abs(got - want).mean()))
+    print(f"boost on the device vs the reference's estimateboost: max {rel:.3e}, mean {float(np.abs(got - want).mean()):.3e}")
+    assert rel < 1e-4 and np.abs(got - want).mean() < 2e-5, (rel, float(np.abs(got - want).mean()))
 
 
 def test_boost_gpu_error_budget_per_stage(gpu):
@@ -1405,3 +1407,80 @@ def test_kernel_timers_bracket_the_launches(gpu):
     _native.kernel_timer_enable(dev, False)
     _native.linear(x, w, None, True)
     assert _native.kernel_timer_read(dev, "linear_gelu") == (0, 0.0)
+
+
+def test_linear_ragged_ksplit_stress_small_grid(gpu):
+    """The advisor's stress test of the ragged round's K split (its cross-workgroup hand-over is argued on the gfx950 ISA, not on the
+    HIP memory model): 60 back-to-back launches on a SMALL grid (every workgroup walks many tiles and the ragged pieces' workgroups
+    arrive at their counters at very different times), two shapes alternating on the same counters and workspace -- every launch
+    bit-identical to the first of its shape (a stale partial or a torn counter would show as a run-to-run difference), and within
+    fp32-summation-order distance of the unsplit result."""
+    from src import _native
+    g = torch.Generator().manual_seed(97)
+    shapes = [(40 * 256 + 256, 1024, 4096), (72 * 256 + 512, 2048, 1024)]          # tiles mod grid leave small ragged rounds
+    ops = []
+    for rows, n, k in shapes:
+        x = torch.randn((rows, k), generator=g).half().cuda()
+        w = (torch.randn((n, k), generator=g) * k ** -0.5).half().cuda()
+        b = torch.randn((n,), generator=g).half().cuda()
+        ops.append((x, w, b))
+    try:
+        _native.linear_env(DS_LIN_GRID=64, DS_LIN_RAGGED_KSPLIT_MIN="1", DS_LIN_RAGGED_KSPLIT_KEEP="2", DS_LIN_RAGGED_DEN="2")
+        first = [None, None]
+        for it in range(60):
+            i = it & 1
+            y = _native.linear(*ops[i], False)
+            if first[i] is None:
+                first[i] = y
+            else:
+                assert torch.equal(y, first[i]), f"K-split ragged round: launch {it} differs from the first of its shape"
+        _native.linear_env(DS_LIN_RAGGED_KSPLIT="1")
+        plain = [_native.linear(*ops[i], False) for i in range(2)]
+    finally:
+        _native.linear_env(DS_LIN_GRID=None, DS_LIN_RAGGED_KSPLIT=None, DS_LIN_RAGGED_KSPLIT_MIN=None, DS_LIN_RAGGED_KSPLIT_KEEP=None,
+                           DS_LIN_RAGGED_DEN=None)
+    for (x, w, b), y, p in zip(ops, first, plain):
+        ref = x.float() @ w.float().T + b.float()
+        assert (y.float() - ref).abs().max().item() < 1.5e-3 * (1 + ref.abs().max().item())
+        assert (y.float() - p.float()).abs().max().item() < 1.5e-3 * (1 + ref.abs().max().item())
+
+
+def test_dpt_beit_large_512_at_the_metrics_batch_is_pinned_on_three_units(gpu):
+    """The metric's batch itself (round-4 verdict, weak 3: the reference-made golden was compared at batch 1 and at unit 0 of batch 8
+    only): dpt_beit_large_512 at 512^2, BATCH 32, float16 -- the launch shapes bench.py times (33 024 padded token rows: 129 row
+    panels, fc1 2064 tiles with its ragged round, 4096 / 2048-tile transposed convolutions, the read-out on 129 x 4 tiles).  The
+    golden image sits at units 0, 13 and 31 (first, middle, last: first / middle / last row panels and the shifted last panel),
+    the other units are flips / rolls of it: each of the three against the reference's own float32 output at 2e-2, bit-identical
+    to each other (the units of a batch are independent), every unit against library routing."""
+    from dmidas.dpt_depth import DPTDepthModel
+    from src import _native
+    from src import vit_mi355x as vm
+    gold = np.load(GOLD_LARGE)
+    m = DPTDepthModel(path=None, backbone="beitl16_512", non_negative=True).eval()
+    m.load_state_dict(mw.fill_state_dict_beit(m.state_dict()), strict=True)
+    m = m.cuda().half()
+    base = mw.synthetic_image((1, 3, 512, 512), seed=31)
+    x = _variants(base, 32)
+    x[13], x[31] = base[0], base[0]
+    x = x.cuda().half().contiguous(memory_format=torch.channels_last)
+    before = dict(_native.CALLS)
+    with torch.no_grad():
+        y = m(x).float()
+    calls = _route_calls(before, ("ds_linear", "ds_linear_residual", "ds_linear_vt", "ds_linear_readout", "ds_linear_shuffle", "ds_conv3x3_nhwc"))
+    assert calls["ds_linear_residual"] == 48 and calls["ds_linear_vt"] == 24 and calls["ds_linear_readout"] == 4 and calls["ds_linear_shuffle"] == 2, calls
+    assert calls["ds_linear"] >= 48 + 4 and calls["ds_conv3x3_nhwc"] >= 12, calls     # qk + fc1, the reassemble 1x1 convolutions; the decoder
+    ref = gold["dpt_beitl512_512x512_out_s2"]
+    scale = float(np.abs(ref).max())
+    for u in (0, 13, 31):
+        e = np.abs(y[u:u + 1, ::2, ::2].cpu().numpy() - ref).max() / scale
+        assert e < 2e-2, (u, e)
+    # the same image at three positions of the batch: the in-tree kernels give the same bits wherever a unit sits (row panels,
+    # ragged round and K split included); the library convolutions left on the path (split-K with atomics) need not, so compare at
+    # float16 noise level and report identity
+    d13, d31 = (y[13] - y[0]).abs().max().item(), (y[31] - y[0]).abs().max().item()
+    assert d13 < 2e-3 * scale and d31 < 2e-3 * scale, (d13, d31)
+    with torch.no_grad(), vm.library_routing():
+        y_lib = m(x[:8]).float()
+    e_lib = ((y[:8] - y_lib).abs().flatten(1).max(1).values / y_lib.abs().flatten(1).max(1).values).max().item()
+    assert e_lib < 2e-2, e_lib
+    assert (y[1] - y[0]).abs().max().item() > 1e-3 * scale

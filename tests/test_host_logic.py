@@ -366,6 +366,53 @@ def test_funnel_rgbx_pixel_export_is_only_taken_where_it_is_safe():
         assert core._rgbx_pixels(im) is None, (im.mode, im.size)
 
 
+def test_funnel_rgbx_export_refuses_padded_lines_and_unverified_layouts(monkeypatch):
+    """The advisor's scenario: a host application that raised Pillow's line alignment pads every image line, and the funnel's
+    memmove of h * w * 4 bytes would copy the padding as pixels -- the export must be refused; so it must when the once-per-process
+    layout probe (a known image exported and compared byte for byte) has not passed."""
+    from PIL import Image
+    import src.core as core
+    im = Image.new("RGB", (9, 5), (1, 2, 3))
+    if not hasattr(im, "__arrow_c_array__"):
+        return
+    assert core._ARROW_LAYOUT_OK and core._rgbx_pixels(im) is not None
+    if hasattr(Image.core, "get_alignment"):
+        monkeypatch.setattr(Image.core, "get_alignment", lambda: 4, raising=False)
+        assert core._rgbx_pixels(im) is None
+        monkeypatch.undo()
+    monkeypatch.setattr(core, "_ARROW_LAYOUT_OK", False)
+    assert core._rgbx_pixels(im) is None
+
+
+def test_funnel_pil_allocator_scope_is_reference_counted():
+    """Two interleaved funnel calls share ONE scoped change of Pillow's blocks_max: the first raises it, the LAST one to finish
+    restores the caller's value (round 4: the first to finish restored it under the second), and a value the host application set
+    in the meantime is left alone."""
+    from PIL import Image
+    import src.core as core
+    if not hasattr(Image.core, "get_blocks_max"):
+        return
+    start = Image.core.get_blocks_max()
+    try:
+        Image.core.set_blocks_max(0)
+        a = core._tune_pil_allocator()
+        assert a and Image.core.get_blocks_max() == int(os.environ.get("DS_PIL_BLOCKS_MAX", 64))
+        b = core._tune_pil_allocator()
+        assert b
+        core._restore_pil_allocator(a)                     # the first call finishes: the second is still running
+        assert Image.core.get_blocks_max() == int(os.environ.get("DS_PIL_BLOCKS_MAX", 64))
+        core._restore_pil_allocator(b)
+        assert Image.core.get_blocks_max() == 0            # the last one out restores the caller's value
+        c = core._tune_pil_allocator()
+        Image.core.set_blocks_max(7)                       # the host application changes it while a call runs
+        core._restore_pil_allocator(c)
+        assert Image.core.get_blocks_max() == 7            # ... and keeps its choice
+        Image.core.set_blocks_max(1000)                    # already larger than the funnel would ask for: nothing to scope
+        assert core._tune_pil_allocator() is False and Image.core.get_blocks_max() == 1000
+    finally:
+        Image.core.set_blocks_max(start)
+
+
 def test_tight_token_pad_rules():
     """vm.pad_len: without a batch the pad is a multiple of 64 (one key tile); with one it is the tightest multiple of 8 / 16 / 32
     whose batch x stride rows are whole 256-row panels (what ds_linear_vt needs for its columns), else 64."""

@@ -425,9 +425,13 @@ def test_boost_end_to_end_matches_reference_estimateboost():
     selection on the integral image, merge network, np.polyfit, Gaussian-mask blend in patch order) run unmodified on the
     same 480 x 640 image with the reference's own LeReS and pix2pix modules and name-seeded weights
     (tests/golden/make_golden_boost.py; cv2 / skimage calls replaced by numpy restatements of their documented behaviour --
-    OpenCV's own arithmetic is what stays unpinned).  Same number of patches, final depth within 2e-4 of full scale
-    (measured 9.5e-5, mean |difference| 5e-6: float32 torch resizes against the float64 stand-ins).  The blend here is the
-    oracle's through the test hook; the HIP blend is GPU-tested against the same oracle function and in the GPU twin of this test."""
+    OpenCV's own arithmetic is what stays unpinned).  Same number of patches, final depth within north_star's 1e-4 of full scale
+    (measured 7.8e-5, mean |difference| 5.6e-6).  Round 5 regenerated the golden with FLOAT32 stand-ins for cv2's resizes of float32
+    images (what OpenCV does for CV_32F; rounds 3-4 used a float64 restatement with one rounding at the end, which no float32
+    implementation reproduces: the golden itself moved by 3.5e-5, this twin went from 9.5e-5 to 7.8e-5).  How much of 1e-4 is
+    noise floor: a ONE-ulp perturbation of every weight moves this pipeline's output by 3.3e-5 of full scale (profiles/
+    round5_boost_conditioning.txt) -- the networks renormalise to [0, 1] stage after stage.  The blend here is the oracle's through
+    the test hook; the HIP blend is GPU-tested against the same oracle function and in the GPU twin of this test."""
     from lib.multi_depth_model_woauxi import RelDepthModel
     from pix2pix.models.pix2pix4depth_model import Pix2Pix4DepthModel
     from src import boost
@@ -442,6 +446,6 @@ def test_boost_end_to_end_matches_reference_estimateboost():
     want = z["depth_s2"]
     got = out[::2, ::2]
     assert stats["patches"] == 18 and stats["whole_image_optimal_size"] == 896, stats
-    assert np.abs(got - want).max() / np.abs(want).max() < 2e-4, np.abs(got - want).max() / np.abs(want).max()
+    assert np.abs(got - want).max() / np.abs(want).max() < 1e-4, np.abs(got - want).max() / np.abs(want).max()
     assert np.abs(got - want).mean() < 2e-5
     assert abs(float(out.mean()) - float(z["stats"][2])) < 1e-5

@@ -31,13 +31,13 @@ for step in "$@"; do
     bench) timeout 600 python bench.py $arg > "$O/${i}_bench.json" 2> "$log"; tail -2 "$log"; python tools/show_bench.py "$O/${i}_bench.json";;
     micro) timeout 600 python tools/microbench.py $arg > "$log" 2>&1; grep -v MIOpen "$log" | tail -40;;
     py) timeout 900 python $arg > "$log" 2>&1; grep -v MIOpen "$log" | tail -60;;
-    prof) (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/prof" -o k -- python "$R/bench.py" --steps 10 --warmup 2 --no-cpu-baseline --no-funnel --no-route-check $arg > "$log" 2>&1)
+    prof) (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/prof" -o k -- python "$R/bench.py" --steps 10 --warmup 2 --no-cpu-baseline --no-funnel --no-route-check --no-micro --no-other-configs $arg > "$log" 2>&1)
           find "$O/prof" -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} "$O/kernel_stats.csv"; rm -rf "$O/prof"; head -24 "$O/kernel_stats.csv" | cut -c1-150;;
     pmc) for c in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU" "SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_SALU SQ_INSTS_VMEM_RD TCC_HIT_sum TCC_MISS_sum" "GRBM_GUI_ACTIVE"; do
            n=$(echo $c | tr ' ' '_' | cut -c1-30)
-           (cd /tmp && timeout 400 rocprofv3 --pmc $c -d "$O/pmc_$n" -o a -- python "$R/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-funnel --no-route-check $arg > "$O/pmc_$n.log" 2>&1)
+           (cd /tmp && timeout 400 rocprofv3 --pmc $c -d "$O/pmc_$n" -o a -- python "$R/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-funnel --no-route-check --no-micro --no-other-configs --no-kernel-timers $arg > "$O/pmc_$n.log" 2>&1)
          done
-         python tools/pmc_summary.py "$O"/pmc_* --set=batch=32 "--set=command=rocprofv3 --pmc <one counter group per pass> -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-funnel --no-route-check $arg" > "$O/pmc_summary.json" 2>&1
+         python tools/pmc_summary.py "$O"/pmc_* --set=batch=32 "--set=command=rocprofv3 --pmc <one counter group per pass> -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-funnel --no-route-check --no-micro --no-other-configs --no-kernel-timers $arg" > "$O/pmc_summary.json" 2>&1
          rm -rf "$O"/pmc_*/; head -c 300 "$O/pmc_summary.json";;
     *) echo "unknown step $step";;
   esac
