@@ -488,8 +488,8 @@ def route_check_leg(nat, vm, model, model_name, img, batch, net_size, net_h):
     in-tree, which needs the batch -- against the SAME network on the same images with every GEMM / convolution sent to the ROCm
     libraries (vm.library_routing), plus how often the fused entry points were reached in one forward of the step."""
     import torch
-    names = ("ds_linear", "ds_linear_residual", "ds_linear_vt", "ds_linear_readout", "ds_linear_shuffle", "ds_conv3x3_nhwc", "ds_attention_fwd",
-             "ds_residual_layernorm", "ds_dpt_head_tail", "ds_preprocess_bicubic")
+    names = ("ds_linear", "ds_linear_ln", "ds_linear_residual", "ds_linear_vt", "ds_linear_vt_ln", "ds_row_stats", "ds_linear_readout",
+             "ds_linear_shuffle", "ds_conv3x3_nhwc", "ds_attention_fwd", "ds_residual_layernorm", "ds_dpt_head_tail", "ds_preprocess_bicubic")
     before = dict(nat.CALLS)
     with torch.no_grad():
         p_hip = run_forward(model, model_name, img, net_size, net_h).float()

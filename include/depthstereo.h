@@ -349,6 +349,26 @@ int ds_linear_readout(ds_ctx *ctx, const void *x, const void *w_tok, const void 
                       int64_t tokens_padded, int64_t tokens, int64_t out_features, int64_t in_features, int dtype, void *stream);
 
 /*
+ * LayerNorm folded into the Linear behind it -- the norm1 -> qkv and norm2 -> fc1 pairs of every encoder block (timm's Block as run
+ * by dmidas/backbones/beit.py:94-107: `x + gamma_1 * attn(norm1(x))`, `x + gamma_2 * mlp(norm2(x))`; ddepth_anything_v2/
+ * depth_anything_v2/dinov2_layers/block.py:82-107).  With W' = W . diag(ln_weight), colsum[n] = sum_k W'[n][k] (of the rounded
+ * weights) and b' = b + W . ln_bias, all prepared once per module by the host,
+ *     LN(x) . W^T + b  =  rstd[m] * (x . W'^T)[m][n]  -  mean[m] * rstd[m] * colsum[n]  +  b'[n],
+ * so the GEMM reads the residual stream itself and the LayerNorm pass (read x, write the normalised copy: 2 x 67 MB per call at
+ * the benchmark's shape) becomes a statistics pass (read x, write 8 bytes per token).
+ *   ds_row_stats     stats[m] = {rstd, -mean * rstd} (float32 pairs) of the rows of x [rows, channels]; channels in 384 / 768 /
+ *                    1024 / 1536; mean and the centred sum of squares in float32 like ds_residual_layernorm
+ *   ds_linear_ln     y = act(rstd (x . w_scaled^T) + (-mean rstd) colsum + bias); shapes and act (0 none, 1 erf-GELU) as ds_linear
+ *   ds_linear_vt_ln  ds_linear_vt on the un-normalised x: vt[b][c][n] = rstd[b,n] (w_v_scaled . x[b,n]) + (-mean rstd)[b,n] colsum[c]
+ *                    (the constant W_v . ln_bias commutes with the attention like the V bias: the host folds it into the projection bias)
+ */
+int ds_row_stats(ds_ctx *ctx, const void *x, void *stats, int64_t rows, int channels, float eps, int dtype, void *stream);
+int ds_linear_ln(ds_ctx *ctx, const void *x, const void *w_scaled, const float *colsum, const void *bias, const void *stats, void *y,
+                 int64_t rows, int64_t out_features, int64_t in_features, int64_t ldy, int act, int dtype, void *stream);
+int ds_linear_vt_ln(ds_ctx *ctx, const void *w_v_scaled, const float *colsum, const void *x, const void *stats, void *vt,
+                    int64_t channels, int64_t batch, int64_t tokens, int64_t in_features, int dtype, void *stream);
+
+/*
  * ds_linear_reload_env -- the GEMM path (ds_linear, ds_linear_residual, ds_linear_vt, ds_conv3x3_nhwc) reads its A/B switches
  * (DS_LIN_EARLY, DS_LIN_GRID, DS_LIN_RAGGED, DS_LIN_RAGGED_DEN, DS_LIN_RAGGED_RING, DS_LIN_RAGGED_PIPE: none of these changes a
  * result; DS_LIN_RAGGED_KSPLIT, DS_LIN_RAGGED_KSPLIT_MIN, DS_LIN_RAGGED_KSPLIT_KEEP: the K split of the ragged round changes the

@@ -106,6 +106,61 @@ DS_API int ds_residual_layernorm(ds_ctx *ctx, const void *x, const void *branch,
     return DS_OK;
 }
 
+// ds_row_stats: the statistics half of a LayerNorm -- per row {rstd, -mean * rstd} in float32 (mean, then the centred sum of
+// squares, exactly as k_residual_layernorm computes them) -- for the GEMMs that fold the LayerNorm into their epilogue
+// (ds_linear_ln, ds_linear_vt_ln in csrc/ds_linear.hip): reads x once, writes 8 bytes per row instead of a normalised copy.
+template <int BF16, int EPL, int W>
+__global__ __launch_bounds__(256) void k_row_stats(const void *x_, float2 *stats, int M, float eps)
+{
+    typedef typename eo_traits<BF16>::T T;
+    constexpr int C = EPL * 64;
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const T *x = (const T *)x_ + (size_t)row * C;
+    float v[EPL];
+    float sum = 0.f;
+#pragma unroll
+    for (int k = 0; k < EPL / W; k++) {
+        T xv[W];
+        __builtin_memcpy(xv, x + (k * 64 + lane) * W, sizeof(xv));
+#pragma unroll
+        for (int t = 0; t < W; t++) { v[k * W + t] = (float)xv[t]; sum += v[k * W + t]; }
+    }
+#pragma unroll
+    for (int s = 32; s > 0; s >>= 1) sum += __shfl_xor(sum, s, 64);
+    const float mean = sum * (1.0f / C);
+    float sq = 0.f;
+#pragma unroll
+    for (int i = 0; i < EPL; i++) { const float d = v[i] - mean; sq += d * d; }
+#pragma unroll
+    for (int s = 32; s > 0; s >>= 1) sq += __shfl_xor(sq, s, 64);
+    const float rstd = rsqrtf(sq * (1.0f / C) + eps);
+    if (lane == 0) stats[row] = make_float2(rstd, -mean * rstd);
+}
+
+DS_API int ds_row_stats(ds_ctx *ctx, const void *x, void *stats, int64_t rows, int channels, float eps, int dtype, void *stream)
+{
+    DS_REQUIRE(ctx && x && stats, DS_EINVAL, "ds_row_stats: null argument");
+    DS_REQUIRE(rows > 0 && rows < (1ll << 31), DS_EINVAL, "ds_row_stats: bad row count");
+    DS_REQUIRE(dtype == DS_DTYPE_F16 || dtype == DS_DTYPE_BF16, DS_EINVAL, "ds_row_stats: dtype must be f16 or bf16");
+    DS_REQUIRE(((uintptr_t)x & 15) == 0 && ((uintptr_t)stats & 15) == 0, DS_EINVAL, "ds_row_stats: operands must be 16-byte aligned");
+    DS_HIP_CHECK(hipSetDevice(ctx->device));
+    dim3 grid((unsigned)((rows + 3) / 4)), block(256);
+    hipStream_t st = (hipStream_t)stream;
+    float2 *out = (float2 *)stats;
+    const int M = (int)rows;
+#define RS_CASE(C_, EPL_, W_) case C_: if (dtype == DS_DTYPE_F16) hipLaunchKernelGGL((k_row_stats<0, EPL_, W_>), grid, block, 0, st, x, out, M, eps); \
+                                       else hipLaunchKernelGGL((k_row_stats<1, EPL_, W_>), grid, block, 0, st, x, out, M, eps); break;
+    switch (channels) {
+    RS_CASE(384, 6, 2) RS_CASE(768, 12, 4) RS_CASE(1024, 16, 8) RS_CASE(1536, 24, 8)
+    default: ds_set_error("ds_row_stats: channel count %d not built (384, 768, 1024, 1536)", channels); return DS_EUNSUPPORTED;
+    }
+#undef RS_CASE
+    DS_HIP_CHECK(hipGetLastError());
+    return DS_OK;
+}
+
 // ------------------------------------------------------------------------------------------------------------------------
 // ds_upsample_bilinear_nhwc: F.interpolate(x, size, mode="bilinear", align_corners=...) for channels_last activations of the
 // DPT decoders (dmidas/blocks.py:429-431, ddepth_anything_v2/.../util/blocks.py:141-145, the heads' Interpolate).  The

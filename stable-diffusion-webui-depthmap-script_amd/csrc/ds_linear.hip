@@ -91,6 +91,10 @@ struct LinParams {
     int *rg_cnt;                // ... and one arrival counter per piece (zero between launches)
     int rg_ksl;
     int kt_kind;                // host side only: the in-step timer kind of this launch (DS_KT_*)
+    // EPI 4 / 5 (LayerNorm folded into the GEMM): x is the UN-normalised residual stream, w holds W . diag(ln_weight); per token
+    // {rstd, -mean * rstd} and per output feature colsum = sum_k w[n][k] (of the rounded weights) complete the affine map in the epilogue
+    const float2 *ln_stats;     // one pair per token: rows of x (VT: columns of the GEMM)
+    const float *ln_colsum;     // one value per output feature: columns of y (VT: rows of the GEMM)
 };
 
 // position in the tile list -> origin of the tile.  The list is ordered in groups of 8 row panels, rows fastest inside a group
@@ -207,7 +211,10 @@ __device__ __forceinline__ void ln_dma_v(const void *ptr, unsigned lds_uniform)
         __builtin_amdgcn_sched_barrier(0);        \
     } while (0)
 
-// EPI: 0 none, 1 erf-GELU, 2 ReLU, 3 per-column scale (LayerScale: y = res1 + gamma * (x.W^T + b)).  RES: number of residual addends (res1, res2).  CONV: 0 = x is a dense [M, K] matrix; 1 = x is an NHWC image [batch, H, W, C] and the
+// EPI: 0 none, 1 erf-GELU, 2 ReLU, 3 per-column scale (LayerScale: y = res1 + gamma * (x.W^T + b)), 4 / 5 = 0 / 1 with the LayerNorm
+// in front of the Linear folded in: y = act(rstd[m] * acc + (-mean[m] rstd[m]) * colsum[n] + b[n]) -- LN(x) . W^T = rstd (x . W'^T - mean
+// colsum) with W' = W diag(ln_weight), b += W . ln_bias (host), so the GEMM reads the residual stream itself and the LayerNorm pass
+// (read x, write h) shrinks to a statistics pass (read x).  RES: number of residual addends (res1, res2).  CONV: 0 = x is a dense [M, K] matrix; 1 = x is an NHWC image [batch, H, W, C] and the
 // GEMM is the implicit one of a 3 x 3, stride 1, zero-padded convolution: row m = output pixel, K-tile kt = 64 channels
 // kt / 9 of tap kt % 9 (tap-fastest: the pixels of a chunk are fetched once and hit in L2 for the other eight taps), whose
 // source is the same 128 bytes of the pixel shifted by (dy, dx) -- or the zero line.
@@ -540,6 +547,12 @@ __global__ __launch_bounds__(LN_THREADS) void k_linear256(LinParams P)
                 return VT ? ln_out_off<VT>(P, cbm0 + wr * 128 + rl, cbn0 + wcol + hi8 + hb_ * 32 + 16 * k_) : o0 + hb_ * 32 + 16 * k_;
             };
             V8 ra[2][2], rb2[2][2];                              // residual pieces [W half][k]
+            constexpr bool LNF = EPI == 4 || EPI == 5;
+            float2 st_row = {1.f, 0.f};                          // LNF, row-major output: {rstd, -mean rstd} of this lane's token
+            float cs_row = 0.f;                                  // LNF, VT: colsum of this lane's output channel
+            static_assert(!LNF || VT == 0 || VT == 1, "the folded LayerNorm exists for the row-major and the V^T store only");
+            if (LNF && VT == 0) st_row = P.ln_stats[cbm0 + wr * 128 + rl];
+            if (LNF && VT == 1) cs_row = P.ln_colsum[cbm0 + wr * 128 + rl];
 #pragma unroll
             for (int hb = 0; hb < NHB; ++hb)
 #pragma unroll
@@ -561,13 +574,29 @@ __global__ __launch_bounds__(LN_THREADS) void k_linear256(LinParams P)
                         v[4 + t] = __uint_as_float(sw[1]);
                     }
                     V8 o;
+                    if (LNF) {                                   // fold the LayerNorm back in (fp32, before bias and activation)
+                        const int c0 = cbn0 + wcol + hi8 + hb * 32 + 16 * k;
+                        if (!VT) {
+                            const float4 s0 = *(const float4 *)(P.ln_colsum + c0), s1 = *(const float4 *)(P.ln_colsum + c0 + 4);
+                            const float sc[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
+#pragma unroll
+                            for (int t = 0; t < 8; ++t) v[t] = __builtin_fmaf(v[t], st_row.x, st_row.y * sc[t]);
+                        } else {                                 // VT: the 8 columns are 8 tokens, the row is one channel
+                            const float4 *sp = (const float4 *)(P.ln_stats + c0);
+                            const float4 q0 = sp[0], q1 = sp[1], q2 = sp[2], q3 = sp[3];
+                            const float rs[8] = {q0.x, q0.z, q1.x, q1.z, q2.x, q2.z, q3.x, q3.z};
+                            const float nm[8] = {q0.y, q0.w, q1.y, q1.w, q2.y, q2.w, q3.y, q3.w};
+#pragma unroll
+                            for (int t = 0; t < 8; ++t) v[t] = __builtin_fmaf(v[t], rs[t], nm[t] * cs_row);
+                        }
+                    }
 #pragma unroll
                     for (int t = 0; t < 8; t += 2) {
                         lf32x2 u = {v[t] + (float)bv[hb][k][t], v[t + 1] + (float)bv[hb][k][t + 1]};
                         if (EPI == 3) u *= (lf32x2){(float)gv[hb][k][t], (float)gv[hb][k][t + 1]};
                         if (RES >= 1) u += (lf32x2){(float)ra[hb][k][t], (float)ra[hb][k][t + 1]};
                         if (RES >= 2) u += (lf32x2){(float)rb2[hb][k][t], (float)rb2[hb][k][t + 1]};
-                        if (EPI == 1) u = ln_gelu2(u);
+                        if (EPI == 1 || EPI == 5) u = ln_gelu2(u);
                         if (EPI == 2) u = (lf32x2){fmaxf(u[0], 0.f), fmaxf(u[1], 0.f)};
                         o[t] = (T)u[0];
                         o[t + 1] = (T)u[1];
@@ -849,13 +878,30 @@ __global__ __launch_bounds__(LN_THREADS, S == 3 ? 4 : 2) void k_linear_ragged(Li
             v[t] = __uint_as_float(sw[0]);
             v[4 + t] = __uint_as_float(sw[1]);
         }
+        if (EPI == 4 || EPI == 5) {                          // the folded LayerNorm, as in k_linear256
+            if (!VT) {
+                const float2 st = P.ln_stats[row];
+                const float4 s0 = *(const float4 *)(P.ln_colsum + col), s1 = *(const float4 *)(P.ln_colsum + col + 4);
+                const float sc[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
+#pragma unroll
+                for (int t = 0; t < 8; ++t) v[t] = __builtin_fmaf(v[t], st.x, st.y * sc[t]);
+            } else {
+                const float cs = P.ln_colsum[row];
+                const float4 *sp = (const float4 *)(P.ln_stats + col);
+                const float4 q0 = sp[0], q1 = sp[1], q2 = sp[2], q3 = sp[3];
+                const float rs[8] = {q0.x, q0.z, q1.x, q1.z, q2.x, q2.z, q3.x, q3.z};
+                const float nm[8] = {q0.y, q0.w, q1.y, q1.w, q2.y, q2.w, q3.y, q3.w};
+#pragma unroll
+                for (int t = 0; t < 8; ++t) v[t] = __builtin_fmaf(v[t], rs[t], nm[t] * cs);
+            }
+        }
         V8 o;
 #pragma unroll
         for (int t = 0; t < 8; t += 2) {
             lf32x2 u = {v[t] + (float)bv[t], v[t + 1] + (float)bv[t + 1]};
             if (EPI == 3) u *= (lf32x2){(float)gv[t], (float)gv[t + 1]};
             if (RES >= 1) u += (lf32x2){(float)rv[t], (float)rv[t + 1]};
-            if (EPI == 1) u = ln_gelu2(u);
+            if (EPI == 1 || EPI == 5) u = ln_gelu2(u);
             if (EPI == 2) u = (lf32x2){fmaxf(u[0], 0.f), fmaxf(u[1], 0.f)};
             o[t] = (T)u[0];
             o[t + 1] = (T)u[1];
@@ -1242,4 +1288,60 @@ DS_API int ds_linear_readout(ds_ctx *ctx, const void *x, const void *w_tok, cons
     P.kt_kind = DS_KT_LINEAR_READOUT;
     hipStream_t st = (hipStream_t)stream;
     return dtype == DS_DTYPE_F16 ? ln_launch<0, 1, 0, 1, 3>(ctx, P, st) : ln_launch<1, 1, 0, 1, 3>(ctx, P, st);
+}
+
+// LayerNorm folded into the Linear that follows it (the norm1 -> qkv and norm2 -> fc1 pairs of every encoder block: timm's Block as
+// run by dmidas/backbones/beit.py:94-107, ddepth_anything_v2/depth_anything_v2/dinov2_layers/block.py:82-107): with
+// W' = W diag(ln_weight), colsum[n] = sum_k W'[n][k] and b' = b + W . ln_bias (all three prepared once per module by the host),
+//     LN(x) . W^T + b = rstd[m] (x . W'^T)[m][n] - mean[m] rstd[m] colsum[n] + b'[n],
+// so the GEMM reads the residual stream x itself and the LayerNorm pass (read x, write the normalised copy) is replaced by
+// ds_row_stats (read x, write 8 bytes per token).  act: 0 none, 1 erf-GELU.
+DS_API int ds_linear_ln(ds_ctx *ctx, const void *x, const void *w_scaled, const float *colsum, const void *bias, const void *stats, void *y,
+                        int64_t rows, int64_t out_features, int64_t in_features, int64_t ldy, int act, int dtype, void *stream)
+{
+    DS_REQUIRE(ctx && x && w_scaled && colsum && stats && y, DS_EINVAL, "ds_linear_ln: null argument");
+    DS_REQUIRE(rows >= 256 && rows < (1ll << 31) - 256, DS_EINVAL, "ds_linear_ln: rows must be >= 256 (one tile)");
+    DS_REQUIRE(out_features > 0 && out_features % 256 == 0, DS_EINVAL, "ds_linear_ln: out_features must be a multiple of 256");
+    DS_REQUIRE(in_features >= 128 && in_features % 128 == 0 && in_features <= 16384, DS_EINVAL, "ds_linear_ln: in_features must be a multiple of 128 (<= 16384)");
+    DS_REQUIRE(ldy >= out_features && ldy % 8 == 0, DS_EINVAL, "ds_linear_ln: ldy must be >= out_features and a multiple of 8");
+    DS_REQUIRE(((uintptr_t)x & 15) == 0 && ((uintptr_t)w_scaled & 15) == 0 && ((uintptr_t)y & 15) == 0 && (!bias || ((uintptr_t)bias & 15) == 0) &&
+               ((uintptr_t)colsum & 15) == 0 && ((uintptr_t)stats & 15) == 0, DS_EINVAL, "ds_linear_ln: operands must be 16-byte aligned");
+    DS_REQUIRE(act == 0 || act == 1, DS_EINVAL, "ds_linear_ln: act must be 0 (none) or 1 (erf-GELU)");
+    DS_REQUIRE(dtype == DS_DTYPE_F16 || dtype == DS_DTYPE_BF16, DS_EINVAL, "ds_linear_ln: dtype must be f16 or bf16");
+    LinParams P;
+    memset(&P, 0, sizeof(P));
+    P.x = x; P.w = w_scaled; P.bias = bias; P.y = y; P.ln_stats = (const float2 *)stats; P.ln_colsum = colsum;
+    P.M = (int)rows; P.N = (int)out_features; P.K = (int)in_features;
+    P.nbm = (int)((rows + 255) / 256); P.nbn = (int)(out_features / 256);
+    P.ldy = ldy;
+    P.kt_kind = act == 1 ? DS_KT_LINEAR_GELU : DS_KT_LINEAR;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == DS_DTYPE_F16) return act == 1 ? ln_launch<0, 5, 0, 0>(ctx, P, st) : ln_launch<0, 4, 0, 0>(ctx, P, st);
+    return act == 1 ? ln_launch<1, 5, 0, 0>(ctx, P, st) : ln_launch<1, 4, 0, 0>(ctx, P, st);
+}
+
+// ds_linear_vt with the LayerNorm folded in: vt[b][c][n] = rstd[b, n] (w_v' . x[b, n]) - mean[b, n] rstd[b, n] colsum[c]; the constant
+// W_v . ln_bias (like the V bias) commutes with the attention and is folded into the output projection's bias by the host.
+DS_API int ds_linear_vt_ln(ds_ctx *ctx, const void *w_v_scaled, const float *colsum, const void *x, const void *stats, void *vt,
+                           int64_t channels, int64_t batch, int64_t tokens, int64_t in_features, int dtype, void *stream)
+{
+    DS_REQUIRE(ctx && w_v_scaled && colsum && x && stats && vt, DS_EINVAL, "ds_linear_vt_ln: null argument");
+    DS_REQUIRE(channels >= 256, DS_EINVAL, "ds_linear_vt_ln: channels must be >= 256 (one tile)");
+    DS_REQUIRE(batch > 0 && tokens > 0 && tokens % 8 == 0 && (batch * tokens) % 256 == 0 && batch * tokens < (1ll << 31) - 256, DS_EINVAL,
+               "ds_linear_vt_ln: tokens must be a multiple of 8 and batch * tokens a multiple of 256");
+    DS_REQUIRE(batch * tokens * tokens < (1ll << 32), DS_EUNSUPPORTED, "ds_linear_vt_ln: batch * tokens^2 must stay below 2^32");
+    DS_REQUIRE(in_features >= 128 && in_features % 128 == 0 && in_features <= 16384, DS_EINVAL, "ds_linear_vt_ln: in_features must be a multiple of 128 (<= 16384)");
+    DS_REQUIRE(dtype == DS_DTYPE_F16 || dtype == DS_DTYPE_BF16, DS_EINVAL, "ds_linear_vt_ln: dtype must be f16 or bf16");
+    DS_REQUIRE(((uintptr_t)w_v_scaled & 15) == 0 && ((uintptr_t)x & 15) == 0 && ((uintptr_t)vt & 15) == 0 && ((uintptr_t)colsum & 15) == 0 &&
+               ((uintptr_t)stats & 15) == 0, DS_EINVAL, "ds_linear_vt_ln: operands must be 16-byte aligned");
+    LinParams P;
+    memset(&P, 0, sizeof(P));
+    P.x = w_v_scaled; P.w = x; P.y = vt; P.ln_stats = (const float2 *)stats; P.ln_colsum = colsum;
+    P.M = (int)channels; P.N = (int)(batch * tokens); P.K = (int)in_features;
+    P.nbm = (int)((channels + 255) / 256); P.nbn = (int)(batch * tokens / 256);
+    P.ldy = batch * tokens;
+    P.vt_np = (int)tokens; P.vt_c = (int)channels; P.vt_magic = (unsigned)((1ull << 32) / (unsigned long long)tokens + 1ull);
+    P.kt_kind = DS_KT_LINEAR_VT;
+    hipStream_t st = (hipStream_t)stream;
+    return dtype == DS_DTYPE_F16 ? ln_launch<0, 4, 0, 0, 1>(ctx, P, st) : ln_launch<1, 4, 0, 0, 1>(ctx, P, st);
 }

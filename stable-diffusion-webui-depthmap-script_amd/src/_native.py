@@ -24,6 +24,7 @@ EXPORTS = [
     "ds_stereo_last_exact_rows", "ds_copy_view", "ds_overlap_red_cyan", "ds_normalmap", "ds_depth_to_u16",
     "ds_convert_to_i16", "ds_profile_enable", "ds_profile_last_ms", "ds_stereo_last_stats", "ds_attention_fwd", "ds_attention_bias_pack", "ds_colorize_u16", "ds_residual_layernorm", "ds_boost_blend", "ds_upsample_bilinear_nhwc", "ds_dpt_head_tail", "ds_preprocess_bicubic", "ds_linear_reload_env",
     "ds_linear_shuffle", "ds_linear_readout", "ds_kernel_timer_enable", "ds_kernel_timer_read",
+    "ds_row_stats", "ds_linear_ln", "ds_linear_vt_ln",
 ]
 
 
@@ -87,6 +88,9 @@ def lib():
             L.ds_conv3x3_nhwc.argtypes = [vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, vp]
             L.ds_linear_shuffle.argtypes = [vp, vp, vp, vp, vp, i64, i64, ci, ci, ci, ci, vp]
             L.ds_linear_readout.argtypes = [vp, vp, vp, vp, vp, i64, i64, i64, i64, i64, ci, vp]
+            L.ds_row_stats.argtypes = [vp, vp, vp, i64, ci, ctypes.c_float, ci, vp]
+            L.ds_linear_ln.argtypes = [vp, vp, vp, vp, vp, vp, vp, i64, i64, i64, i64, ci, ci, vp]
+            L.ds_linear_vt_ln.argtypes = [vp, vp, vp, vp, vp, vp, i64, i64, i64, i64, ci, vp]
             L.ds_kernel_timer_enable.argtypes = [vp, ci]
             L.ds_kernel_timer_read.argtypes = [vp, ci, ctypes.POINTER(i64), ctypes.POINTER(cd)]
             L.ds_profile_enable.argtypes = [vp, ci]
@@ -533,6 +537,52 @@ def kernel_timer_read(device_index, kind):
     n, ms = ctypes.c_int64(), ctypes.c_double()
     _check(lib().ds_kernel_timer_read(ctx_for(device_index), k, ctypes.byref(n), ctypes.byref(ms)))
     return int(n.value), float(ms.value)
+
+
+def row_stats(x, eps):
+    """Per row {rstd, -mean * rstd} (float32 [rows, 2]) of x [..., C]: the statistics half of a LayerNorm, for the GEMMs that fold
+    the LayerNorm into their epilogue (include/depthstereo.h: ds_row_stats).  C in 384 / 768 / 1024 / 1536."""
+    torch = require_gpu()
+    assert x.is_cuda and x.dtype in (torch.float16, torch.bfloat16) and x.is_contiguous()
+    c = x.shape[-1]
+    rows = x.numel() // c
+    out = torch.empty((rows, 2), dtype=torch.float32, device=x.device)
+    CALLS["ds_row_stats"] += 1
+    _check(lib().ds_row_stats(ctx_for(_dev_index(x)), x.data_ptr(), out.data_ptr(), rows, c, float(eps),
+                              1 if x.dtype == torch.float16 else 2, _stream(x)))
+    return out
+
+
+def linear_ln(x, w_scaled, colsum, bias, stats, gelu=False):
+    """[gelu](LN(x) @ W.T + b) with the LayerNorm folded into the GEMM (include/depthstereo.h: ds_linear_ln): x [..., K] is the
+    UN-normalised input, w_scaled = W * ln_weight [N, K], colsum = w_scaled.sum(1) float32 [N], bias = b + W @ ln_bias [N] or None,
+    stats = row_stats(x)."""
+    torch = require_gpu()
+    assert x.is_cuda and x.dtype in (torch.float16, torch.bfloat16) and linear_supported(x, w_scaled) and x.is_contiguous()
+    k, n = x.shape[-1], w_scaled.shape[0]
+    rows = x.numel() // k
+    assert rows >= 256 and w_scaled.dtype == x.dtype and w_scaled.is_contiguous() and colsum.dtype == torch.float32 and colsum.numel() == n
+    assert stats.dtype == torch.float32 and stats.numel() == 2 * rows and (bias is None or (bias.dtype == x.dtype and bias.is_contiguous()))
+    out = torch.empty((rows, n), dtype=x.dtype, device=x.device)
+    CALLS["ds_linear_ln"] += 1
+    _check(lib().ds_linear_ln(ctx_for(_dev_index(x)), x.data_ptr(), w_scaled.data_ptr(), colsum.data_ptr(), None if bias is None else bias.data_ptr(),
+                              stats.data_ptr(), out.data_ptr(), rows, n, k, n, 1 if gelu else 0, 1 if x.dtype == torch.float16 else 2, _stream(x)))
+    return out.view(x.shape[:-1] + (n,))
+
+
+def linear_vt_ln(w_v_scaled, colsum, x, stats):
+    """V^T with the LayerNorm folded in (include/depthstereo.h: ds_linear_vt_ln): x [B, Np, K] un-normalised -> [B, C, Np]."""
+    torch = require_gpu()
+    assert x.is_cuda and x.dtype in (torch.float16, torch.bfloat16) and linear_vt_supported(w_v_scaled, x) and x.is_contiguous()
+    b, npad, k = x.shape
+    c = w_v_scaled.shape[0]
+    assert w_v_scaled.dtype == x.dtype and w_v_scaled.is_contiguous() and colsum.dtype == torch.float32 and colsum.numel() == c
+    assert stats.dtype == torch.float32 and stats.numel() == 2 * b * npad
+    out = torch.empty((b, c, npad), dtype=x.dtype, device=x.device)
+    CALLS["ds_linear_vt_ln"] += 1
+    _check(lib().ds_linear_vt_ln(ctx_for(_dev_index(x)), w_v_scaled.data_ptr(), colsum.data_ptr(), x.data_ptr(), stats.data_ptr(), out.data_ptr(),
+                                 c, b, npad, k, 1 if x.dtype == torch.float16 else 2, _stream(x)))
+    return out
 
 
 def linear_vt_supported(w_v, h):

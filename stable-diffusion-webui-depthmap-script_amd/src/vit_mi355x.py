@@ -279,6 +279,92 @@ class EncoderBlock(nn.Module):
         return x + (m if g2 is None else g2 * m)
 
 
+# Round 5 experiment, built, measured, NOT the default: the LayerNorm in front of qkv and of fc1 folded INTO those GEMMs (ds_linear_ln /
+# ds_linear_vt_ln: the GEMM reads the residual stream, its epilogue applies rstd and -mean * rstd * colsum), the LayerNorm pass -- read
+# x, write the normalised copy -- replaced by a statistics pass that only reads x (the round-4 verdict's "do less" item, estimated at
+# -0.6 ms per step).  Measured on one box, back to back (profiles/round5_ln_fold_ab.txt): 789.2 / 790.7 pairs/s folded against 798.7 /
+# 798.3 with ds_residual_layernorm -- per step the Q/K GEMMs take +0.54 ms and fc1 + GELU +0.40 ms (17-22 us per launch: the
+# epilogue is exposed time of a workgroup that owns its CU, and it now waits for two more operand fetches per tile and does three
+# more multiply-adds per output), the statistics passes save 0.53 ms against the LayerNorm passes (11 us of 23 each): a net loss of
+# 0.45 ms.  A bandwidth-bound streaming pass is the cheaper place for this arithmetic.  DS_LN_FOLD=1 takes the folded route.
+LN_FOLD = os.environ.get("DS_LN_FOLD", "0") != "0"
+LN_FOLD_CHANNELS = (384, 768, 1024, 1536)
+
+
+def _ln_fold_params(blk, dtype):
+    """Per block, once per parameter version: W' = W diag(ln_weight) (rounded to the network's dtype), colsum = W'.sum(1) in float32
+    (of the ROUNDED weights: the identity LN(x) W^T = rstd (x W'^T - mean colsum) then holds exactly for what the MFMA computes),
+    b' = b + W ln_bias, for the Q/K projection, V (whose constant goes into the projection bias like the V bias) and fc1."""
+    w_qk, b_qk, w_v, b_v = blk.qkv_weights()
+    n1, n2, fc1, pr = blk.norm1, blk.norm2, blk.mlp.fc1, blk.attn.proj
+    tensors = (w_qk, b_qk, w_v, b_v, n1.weight, n1.bias, n2.weight, n2.bias, fc1.weight, fc1.bias, pr.weight, pr.bias)
+    key = tuple((None if t is None else (t._version, t.data_ptr())) for t in tensors) + (dtype,)
+    hit = getattr(blk, "_ln_fold", None)
+    if hit is not None and hit[0] == key:
+        return hit[1]
+    if hit is not None:
+        cache_evicted()                     # a live hipGraph may still read the old tensors
+
+    def fold(w, b, ln):
+        wf = w.float()
+        ws = (wf * ln.weight.float()[None, :]).to(dtype).contiguous()
+        const = wf @ ln.bias.float() + (0.0 if b is None else b.float())
+        return ws, ws.float().sum(1).contiguous(), const
+    wqk, sqk, cqk = fold(w_qk, b_qk, n1)
+    wv, sv, cv = fold(w_v, b_v, n1)
+    w1, s1, c1 = fold(fc1.weight, fc1.bias, n2)
+    # attn @ (v + c_v) = attn @ v + c_v (softmax rows sum to one): V's constant -- its bias and W_v . ln_bias -- joins the projection bias
+    pb = ((0.0 if pr.bias is None else pr.bias.float()) + pr.weight.float() @ cv).to(dtype).contiguous()
+    out = {"wqk": wqk, "sqk": sqk, "bqk": cqk.to(dtype).contiguous(), "wv": wv, "sv": sv, "proj_bias": pb,
+           "w1": w1, "s1": s1, "b1": c1.to(dtype).contiguous()}
+    if not torch.is_grad_enabled():
+        blk._ln_fold = (key, out)
+    return out
+
+
+def _ln_fold_ok(blocks, x):
+    if not (LN_FOLD and LINEAR_HIP == "all" and half_on_gpu(x) and x.is_contiguous() and x.shape[2] in LN_FOLD_CHANNELS):
+        return False
+    from . import _native
+    rows = x.shape[0] * x.shape[1]
+    if not hip_gemm_ok(rows, x.shape[2]):
+        return False
+    for blk in blocks:
+        mlp, pr = getattr(blk, "mlp", None), getattr(getattr(blk, "attn", None), "proj", None)
+        if not (isinstance(mlp, Mlp) and pr is not None and mlp.fc2.bias is not None and hasattr(blk, "qkv_weights")
+                and isinstance(getattr(blk, "norm1", None), nn.LayerNorm) and isinstance(getattr(blk, "norm2", None), nn.LayerNorm)
+                and blk.norm1.elementwise_affine and blk.norm2.elementwise_affine and blk.norm1.bias is not None and blk.norm2.bias is not None):
+            return False
+        w_qk, _, w_v, _ = blk.qkv_weights()
+        if not (_native.linear_supported(x, w_qk) and _native.linear_supported(x, pr.weight) and _native.linear_supported(x, mlp.fc1.weight)
+                and mlp.fc2.weight.shape[0] % 256 == 0 and mlp.fc2.weight.shape[1] % 128 == 0 and _native.linear_vt_supported(w_v, x)):
+            return False
+    return True
+
+
+def _run_blocks_ln_fold(blocks, x, n_valid, grid_hw, take, padded_taps):
+    """The encoder with every LayerNorm folded into the GEMM behind it: per block 2 statistics passes, 5 GEMMs (Q/K, V^T, projection +
+    LayerScale + residual, fc1 + GELU, fc2 + LayerScale + residual) and the fused attention -- no normalised copy of the residual
+    stream is ever written."""
+    from . import _native
+    taps = {}
+    b, npad, c = x.shape
+    for i, blk in enumerate(blocks):
+        p = _ln_fold_params(blk, x.dtype)
+        g1, g2 = blk.gammas()
+        st = _native.row_stats(x, blk.norm1.eps)
+        qk = _native.linear_ln(x, p["wqk"], p["sqk"], p["bqk"], st).view(b, npad, 2, blk.num_heads, HEAD_DIM)
+        vt = _native.linear_vt_ln(p["wv"], p["sv"], x, st)
+        o = fused_attention(qk, vt, n_valid, blk.scale, blk.attention_bias(npad, grid_hw, x.dtype, x.device))
+        x = _native.linear_residual(o, blk.attn.proj.weight, p["proj_bias"], g1, x)
+        st = _native.row_stats(x, blk.norm2.eps)
+        a = _native.linear_ln(x, p["w1"], p["s1"], p["b1"], st, gelu=True)
+        x = _native.linear_residual(a, blk.mlp.fc2.weight, blk.mlp.fc2.bias, g2, x)
+        if i in take:
+            taps[i] = x if padded_taps else x[:, :n_valid]
+    return x, taps
+
+
 def run_blocks(blocks, x, n_valid, grid_hw, take, padded_taps=False):
     """Run the encoder on the padded sequence x [B, Np, C]; returns (x, {index: tap}) with taps = unpadded block outputs
     (padded_taps: the padded [B, Np, C] block outputs themselves -- contiguous, what ds_linear_readout reads).
@@ -292,6 +378,8 @@ def run_blocks(blocks, x, n_valid, grid_hw, take, padded_taps=False):
             if i in take:
                 taps[i] = x if padded_taps else x[:, :n_valid]
         return x, taps
+    if _ln_fold_ok(blocks, x):
+        return _run_blocks_ln_fold(blocks, x, n_valid, grid_hw, take, padded_taps)
     from . import _native
     n = len(blocks)
     _, h = _native.residual_layernorm(x, None, None, blocks[0].norm1.weight, blocks[0].norm1.bias, blocks[0].norm1.eps)
