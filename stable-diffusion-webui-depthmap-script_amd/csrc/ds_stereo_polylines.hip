@@ -1212,20 +1212,25 @@ __global__ __launch_bounds__(64) void k_polylines_exact(PolyParams P, ExactScrat
 // #{j : x_j < x_i} + #{j < i : x_j == x_i}; a point can only be overtaken by points of columns within |divergence_px| + 2 of
 // its own (x = col + 0.5 + d + sep +- 0.45 with d between 0 and divergence_px), so each lane counts inside that window.
 // NaN coordinates (a constant depth map: 0 / 0) compare false like in the reference's loop: such points stay where they are.
+// Round 5: the LDS image of a row is COMPACT -- the points in original order are not stored at all: x and |d| of point p are
+// recomputed from the column's coord_d (one double per column; the same three additions in the reference's order, so the same bits),
+// and the active set gets a bounded array instead of one slot per point (a segment in the set covers the current centre, and a
+// segment is at most |divergence_px| + 0.1 long: at most NP (3 |divergence_px| + 8) segments can be in the set, transient adds
+// included) -- 36 bytes per column instead of 68: a 3840-column row (Boost on a 4K image, BASELINE config 4) fits the CU's 160 KB,
+// where it used to fall back to the one-lane-per-row kernel above at 143 ms per launch (19 % of config 4's step).
 template <int DT, int SHARP>
-__global__ __launch_bounds__(64) void k_polylines_exact_lds(PolyParams P, int c, int win_pts)
+__global__ __launch_bounds__(64) void k_polylines_exact_lds(PolyParams P, int c, int win_pts, int csg_cap)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int NP = SHARP ? 2 : 1;
     const int lane = threadIdx.x;
     const int w = P.w;
     const int pt_end = NP * w + 2, sg_end = pt_end - 1;
-    double *ox = reinterpret_cast<double *>(smem);
-    double *od = ox + pt_end;
-    double *sx = od + pt_end;
-    int *sk = reinterpret_cast<int *>(sx + pt_end);
-    int *csg = sk + pt_end;
-    uint32_t *rgbx = reinterpret_cast<uint32_t *>(csg + pt_end);
+    double *cd = reinterpret_cast<double *>(smem);           // coord_d per column
+    double *sx = cd + w;                                     // sorted x
+    int *sk = reinterpret_cast<int *>(sx + pt_end);          // original index of the sorted point
+    uint32_t *rgbx = reinterpret_cast<uint32_t *>(sk + pt_end);
+    int *csg = reinterpret_cast<int *>(rgbx + w);            // the active set, csg_cap entries
     const int count = P.counters[0];
     for (int it = blockIdx.x; it < count; it += gridDim.x) {
         const int rowid = P.row_list[it];
@@ -1238,35 +1243,38 @@ __global__ __launch_bounds__(64) void k_polylines_exact_lds(PolyParams P, int c,
         typedef typename ds_depth_traits<DT>::T DTy;
         const DTy *depth_row = (const DTy *)P.depth + ((size_t)img * P.h + row) * (size_t)w;
         uint8_t *dst = P.out[eye] + (int64_t)img * P.ois[eye] + (int64_t)row * P.ors[eye];
+        // x and |d| of ORIGINAL point p (:179-191): point 0 and the last one are the sentinels, the others belong to column
+        // (p - 1) / NP; coord_x = col + 0.5 + coord_d + sep evaluated left to right like the reference's expression
+        auto OX = [&](const int p) -> double {
+            if (p == 0) return -1.0 * (double)w;
+            if (p == pt_end - 1) return 2.0 * (double)w;
+            const int col = SHARP ? (p - 1) >> 1 : p - 1;
+            const double coord_x = (double)col + 0.5 + cd[col] + sep_px;
+            if (!SHARP) return coord_x;
+            return ((p - 1) & 1) ? coord_x + 0.45 : coord_x - 0.45;
+        };
+        auto OD = [&](const int p) -> double {
+            if (p == 0 || p == pt_end - 1) return 0.0;
+            return fabs(cd[SHARP ? (p - 1) >> 1 : p - 1]);
+        };
         __syncthreads();                                     // the previous row's arrays are no longer read
-        // ---- points in original order (:179-191) and the row's colours, all lanes ----
+        // ---- coord_d and the colour of every column, all lanes ----
         for (int col = lane; col < w; col += 64) {
-            const double coord_d = pl_coord_d<DT>(P, img, depth_row, col, mn, mx, div_px);
-            const double coord_x = (double)col + 0.5 + coord_d + sep_px;
-            if (SHARP) {
-                ox[2 * col + 1] = coord_x - 0.45; od[2 * col + 1] = fabs(coord_d);
-                ox[2 * col + 2] = coord_x + 0.45; od[2 * col + 2] = fabs(coord_d);
-            } else {
-                ox[col + 1] = coord_x; od[col + 1] = fabs(coord_d);
-            }
+            cd[col] = pl_coord_d<DT>(P, img, depth_row, col, mn, mx, div_px);
             uint32_t px = 0;
             for (int q = 0; q < c; q++) px |= (uint32_t)src[(size_t)col * c + q] << (8 * q);
             rgbx[col] = px;
         }
-        if (lane == 0) {
-            ox[0] = -1.0 * (double)w; od[0] = 0.0;
-            ox[pt_end - 1] = 2.0 * (double)w; od[pt_end - 1] = 0.0;
-        }
         __syncthreads();
         // ---- stable sort of points 0 .. sg_end - 1 by x; the last point keeps its place (:214 sorts range(1, sg_end)) ----
         for (int i = lane; i < pt_end; i += 64) {
-            const double xi = ox[i];
+            const double xi = OX(i);
             int pos = i;
             if (i < sg_end && xi == xi) {
                 const int lo = max(0, i - win_pts), hi = min(sg_end - 1, i + win_pts);
                 int less = lo;                               // everything left of the window is smaller (or NaN: see below)
                 for (int j = lo; j <= hi; j++) {
-                    const double xj = ox[j];
+                    const double xj = OX(j);
                     less += (xj < xi || (xj == xi && j < i)) ? 1 : 0;
                 }
                 pos = less;
@@ -1291,14 +1299,15 @@ __global__ __launch_bounds__(64) void k_polylines_exact_lds(PolyParams P, int c,
                     const double significance = coord_to - coord_from;
                     const double coord_center = coord_from + 0.5 * significance;
                     while (sg_pointer < sg_end && sx[sg_pointer] < coord_center) {
-                        csg[csg_end] = sk[sg_pointer];
+                        if (csg_end < csg_cap) csg[csg_end] = sk[sg_pointer];      // (the host sized csg_cap above the bound: never clamps)
                         if (csg_end == 0) slot0_written = true;
                         sg_pointer++; csg_end++;
                     }
+                    if (csg_end > csg_cap) csg_end = csg_cap;
                     int csg_i = 0;
                     while (csg_i < csg_end) {
                         const int k = csg[csg_i];
-                        if (ox[k + 1] < coord_center) { csg[csg_i] = csg[csg_end - 1]; csg_end--; }
+                        if (OX(k + 1) < coord_center) { csg[csg_i] = csg[csg_end - 1]; csg_end--; }
                         else csg_i++;
                     }
                     int best = 0;
@@ -1306,9 +1315,9 @@ __global__ __launch_bounds__(64) void k_polylines_exact_lds(PolyParams P, int c,
                         double best_closeness = -PL_EPS;
                         for (csg_i = 0; csg_i < csg_end; csg_i++) {
                             const int k = csg[csg_i];
-                            const double x0 = ox[k], x1 = ox[k + 1];
+                            const double x0 = OX(k), x1 = OX(k + 1);
                             const double ip_k = (coord_center - x0) / (x1 - x0);
-                            const double closeness = (1.0 - ip_k) * od[k] + ip_k * od[k + 1];
+                            const double closeness = (1.0 - ip_k) * OD(k) + ip_k * OD(k + 1);
                             if (best_closeness < closeness && 0.0 < ip_k && ip_k < 1.0) { best_closeness = closeness; best = csg_i; }
                         }
                     }
@@ -1320,7 +1329,7 @@ __global__ __launch_bounds__(64) void k_polylines_exact_lds(PolyParams P, int c,
                             for (int q = 0; q < 4; q++) if (q < c) color[q] += (double)((pl >> (8 * q)) & 0xffu) * significance;
                         } else {
                             const uint32_t pr = rgbx[col_r];
-                            const double x0 = ox[k], x1 = ox[k + 1];
+                            const double x0 = OX(k), x1 = OX(k + 1);
                             const double ip_k = (coord_center - x0) / (x1 - x0);
                             for (int q = 0; q < 4; q++) if (q < c) {
                                 const double u = (double)((pl >> (8 * q)) & 0xffu) * (1.0 - ip_k);
@@ -1415,15 +1424,22 @@ static int pl_dispatch(int op, const PolyParams &P, int c, int ncu, long long nw
 #undef PL_CASE
 }
 
-// LDS of k_polylines_exact_lds for a row of w columns: 3 double + 2 int arrays of NP w + 2 points, one packed colour per column
-static size_t pl_exact_lds_bytes(int w, int sharp) { return (size_t)((sharp ? 2 : 1) * w + 2) * 32 + (size_t)w * 4 + 16; }
+// LDS of k_polylines_exact_lds for a row of w columns: coord_d (8 B) and a packed colour (4 B) per column, sorted x (8 B) and
+// original index (4 B) per point, + the bounded active set
+static size_t pl_exact_lds_fixed(int w, int sharp) { return (size_t)w * 12 + (size_t)((sharp ? 2 : 1) * w + 2) * 12 + 16; }
 
 template <int DT>
 static int pl_launch_exact(const PolyParams &P, int sharp, const ExactScratch &S, int exact_blocks, int c, double max_div_px, int device, hipStream_t st)
 {
-    const size_t lds = pl_exact_lds_bytes(P.w, sharp);
+    const size_t fixed = pl_exact_lds_fixed(P.w, sharp);
     const int force_global = getenv("DS_PL_EXACT_GLOBAL") ? atoi(getenv("DS_PL_EXACT_GLOBAL")) : 0;      // A/B switch (tests)
-    if (lds <= 160 * 1024 && !force_global) {
+    // the active set holds at most NP (3 |divergence_px| + 8) segments (see the kernel); whatever the CU's LDS leaves after the
+    // row's arrays, up to 8192 entries, is its capacity
+    const long long csg_need = (long long)(sharp ? 2 : 1) * (3 * (long long)ceil(fabs(max_div_px)) + 8);
+    long long csg_cap = fixed + 64 <= 160 * 1024 ? (long long)((160 * 1024 - fixed) / 4) : 0;
+    if (csg_cap > 8192) csg_cap = 8192;
+    if (csg_cap >= csg_need && csg_cap >= 64 && !force_global) {
+        const size_t lds = fixed + (size_t)csg_cap * 4;
         // one workgroup per flagged row, rows taken round-robin by a fixed grid (the count lives on the device)
         const int win_pts = (sharp ? 2 : 1) * ((int)ceil(fabs(max_div_px)) + 3);
         static std::atomic<uint64_t> attr_done{0};           // per device (bit) -- the limit is raised to the CU's whole LDS once
@@ -1433,8 +1449,8 @@ static int pl_launch_exact(const PolyParams &P, int sharp, const ExactScratch &S
             DS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_polylines_exact_lds<DT, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
             attr_done.fetch_or(bit, std::memory_order_relaxed);
         }
-        if (sharp) hipLaunchKernelGGL((k_polylines_exact_lds<DT, 1>), dim3(1024), dim3(64), lds, st, P, c, win_pts);
-        else hipLaunchKernelGGL((k_polylines_exact_lds<DT, 0>), dim3(1024), dim3(64), lds, st, P, c, win_pts);
+        if (sharp) hipLaunchKernelGGL((k_polylines_exact_lds<DT, 1>), dim3(1024), dim3(64), lds, st, P, c, win_pts, (int)csg_cap);
+        else hipLaunchKernelGGL((k_polylines_exact_lds<DT, 0>), dim3(1024), dim3(64), lds, st, P, c, win_pts, (int)csg_cap);
         return DS_OK;
     }
     if (sharp) hipLaunchKernelGGL((k_polylines_exact<DT, 1>), dim3(exact_blocks), dim3(64), 0, st, P, S);

@@ -608,7 +608,14 @@ def test_exact_fallback_lds_kernel_equals_global_kernel(sg, native, oracle, gpu)
     cases.append((img, np.full((6, 320), 1234, np.uint16), 5.0, 0.0, 'polylines_sharp'))                    # constant: NaN
     cases.append((img, (rng.integers(0, 3, (6, 320)) * 0.5).astype(np.float32), 10.0, 0.0, 'polylines_soft'))   # float32, 32 px
     wide = rng.integers(0, 256, (2, 5200, 3), dtype=np.uint8)
-    cases.append((wide, (rng.integers(0, 4, (2, 5200)) * 21845).astype(np.uint16), 100.0 * 32 / 5200, 0.0, 'polylines_sharp'))   # 332 KB of row arrays
+    cases.append((wide, (rng.integers(0, 4, (2, 5200)) * 21845).astype(np.uint16), 100.0 * 32 / 5200, 0.0, 'polylines_sharp'))   # 187 KB of row arrays: global
+    # round 5: the compact LDS image (36 bytes per column) takes a 3840-column row -- Boost on a 4K frame, BASELINE config 4, whose
+    # flagged rows cost 143 ms per launch in the one-lane-per-row kernel -- and a wide divergence (128 px: an active set of hundreds)
+    uhd = rng.integers(0, 256, (3, 3840, 3), dtype=np.uint8)
+    cases.append((uhd, (rng.integers(0, 4, (3, 3840)) * 21845).astype(np.uint16), 100.0 * 64 / 3840, 0.3, 'polylines_sharp'))
+    cases.append((uhd, (rng.integers(0, 5, (3, 3840)) * 16383).astype(np.uint16), 100.0 * 32 / 3840, 0.0, 'polylines_soft'))
+    img1k = rng.integers(0, 256, (4, 1024, 3), dtype=np.uint8)
+    cases.append((img1k, (rng.integers(0, 8, (4, 1024)) * 9362).astype(np.uint16), 12.5, -0.2, 'polylines_sharp'))
     flagged = 0
     old = os.environ.get("DS_PL_EXACT_GLOBAL")
     try:
