@@ -418,6 +418,22 @@ int ds_dpt_head_tail(ds_ctx *ctx, const void *x, int batch, int in_h, int in_w, 
                      int relu_out, void *out, int dtype, void *stream);
 
 /*
+ * ds_gconv3x3_nhwc_f32 -- the grouped 3x3 convolution of the ResNeXt-101 32x8d bottlenecks of LeReS, Boost's base estimator, in
+ * float32 with the folded BatchNorm's bias and the ReLU in the epilogue: `conv2` -> `bn2` -> `relu` of lib/Resnext_torch.py:104-110
+ * (groups = 32, stride 1, padding 1; the strided first block of a stage stays a library call).  Direct convolution on the float32
+ * vector pipe, input tile staged once in LDS, weights through the scalar path (csrc/ds_gconv.hip).
+ *   x, y    [batch, height, width, channels] float32, channels_last;  channels % 32 == 0
+ *   w_gtio  [channels / cpg groups][9 taps (ky * 3 + kx)][cpg in][cpg out] float32: torch's [out, in / groups, 3, 3] weight
+ *           (BatchNorm folded in) regrouped by the host;  bias [channels] or NULL
+ *   channels_per_group  8, 16 or 32
+ * ds_add_relu_f32 -- y = relu(a + b) over `count` float32 values (count % 4 == 0): `self.relu(out + identity)`, the tail of every
+ * bottleneck (lib/Resnext_torch.py:115-118), one pass instead of torch's add + clamp.
+ */
+int ds_gconv3x3_nhwc_f32(ds_ctx *ctx, const float *x, const float *w_gtio, const float *bias, float *y, int batch, int height, int width,
+                         int channels, int channels_per_group, int relu, void *stream);
+int ds_add_relu_f32(ds_ctx *ctx, const float *a, const float *b, float *y, int64_t count, void *stream);
+
+/*
  * ds_boost_blend -- the patch-merge step of Boost, all patches in one launch; replaces, per patch, np.polyval (:916),
  * cv2.resize INTER_CUBIC of the merged patch (:918), cv2.resize INTER_LINEAR of the Gaussian mask (:930) and the blend
  * `dst[rect] = dst[rect]*(1-mask) + merged*mask` (:936) of src/depthmap_generation.py:estimateboost.

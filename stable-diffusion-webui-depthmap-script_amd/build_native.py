@@ -18,7 +18,7 @@ EXPERIMENTS = bool(os.environ.get("DS_EXPERIMENTS"))
 # the experiments build is a SECOND library beside the product one (src/_native.py loads it only when DS_NATIVE_LIB names it)
 OUT = os.path.join(HERE, "libdepthstereo_hip_experiments.so" if EXPERIMENTS else "libdepthstereo_hip.so")
 OBJ_DIR = os.path.join(HERE, "build", "experiments") if EXPERIMENTS else os.path.join(HERE, "build")
-SOURCES = ["ds_api.hip", "ds_stereo.hip", "ds_stereo_polylines.hip", "ds_normalmap.hip", "ds_attention.hip", "ds_encoder_ops.hip", "ds_boost.hip", "ds_heatmap.hip", "ds_linear.hip"]
+SOURCES = ["ds_api.hip", "ds_stereo.hip", "ds_stereo_polylines.hip", "ds_normalmap.hip", "ds_attention.hip", "ds_encoder_ops.hip", "ds_boost.hip", "ds_heatmap.hip", "ds_linear.hip", "ds_gconv.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-fPIC",
          "-fvisibility=hidden", "-Wall", "-Wno-unused-function",
          # MFMA results land in ordinary VGPRs (gfx950 has one unified file): no v_accvgpr_read/write around the softmax

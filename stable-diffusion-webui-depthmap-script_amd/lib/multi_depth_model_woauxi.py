@@ -10,6 +10,8 @@ reference runs conv and BN as two passes over every activation: 104 BN layers in
 the library where it can; tensors stay channels_last.  Arithmetic stays float32 like the reference (Boost never uses
 half: src/depthmap_generation.py:271).
 """
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -38,9 +40,44 @@ def _folded(conv, bn, cache_holder):
     return wf, bf
 
 
+# Round 5: the grouped 3x3 convolutions of the bottlenecks (40 % of the encoder's convolution time in MIOpen for 7 % of its flops)
+# and the `relu(out + identity)` tails run in-tree on float32 channels_last CUDA tensors (csrc/ds_gconv.hip).  A/B switches:
+GCONV_HIP = os.environ.get("DS_GCONV", "1") != "0"
+ADD_RELU_HIP = os.environ.get("DS_ADD_RELU", "1") != "0"
+
+
+def _gconv_image(conv, wf):
+    """The folded grouped weight regrouped for ds_gconv3x3_nhwc_f32, cached beside the folded weight it was made from."""
+    from src import _native
+    c = getattr(conv, "_gconv_cache", None)
+    key = (wf.data_ptr(), wf._version)
+    if c is not None and c[0] == key:
+        return c[1]
+    img = _native.gconv_weight_image(wf, conv.groups)
+    if not torch.is_grad_enabled():
+        if c is not None:
+            vm.cache_evicted()
+        conv._gconv_cache = (key, img)
+    return img
+
+
+def add_relu(a, b):
+    """relu(a + b): one in-tree pass for float32 CUDA tensors of one dense layout, torch's two otherwise."""
+    if (ADD_RELU_HIP and a.is_cuda and a.dtype == torch.float32 and b.dtype == torch.float32 and a.shape == b.shape and a.stride() == b.stride()
+            and a.numel() % 4 == 0 and (a.is_contiguous() or a.is_contiguous(memory_format=torch.channels_last)) and not vm.STOCK[0]):
+        from src import _native
+        return _native.add_relu(a, b)
+    return F.relu(a + b)
+
+
 def conv_bn(x, conv, bn, relu=False):
     """BatchNorm(conv(x)) in inference mode as one convolution with folded weights."""
     w, b = _folded(conv, bn, conv)
+    if GCONV_HIP and conv.groups > 1 and conv.padding_mode == 'zeros' and x.is_cuda and not vm.STOCK[0]:
+        from src import _native
+        xc = x.contiguous(memory_format=torch.channels_last)
+        if _native.gconv3x3_supported(xc, w, conv.stride, conv.padding, conv.dilation, conv.groups):
+            return _native.gconv3x3(xc, _gconv_image(conv, w), b, relu, conv.in_channels // conv.groups)
     if conv.padding_mode != 'zeros':       # TILING_MODE (src/depthmap_generation.py:250-260): what nn.Conv2d._conv_forward does
         x = F.pad(x, conv._reversed_padding_repeated_twice, mode=conv.padding_mode)
         y = F.conv2d(x, w, b, conv.stride, 0, conv.dilation, conv.groups)
@@ -70,7 +107,7 @@ class Bottleneck(nn.Module):
         out = conv_bn(x, self.conv1, self.bn1, relu=True)
         out = conv_bn(out, self.conv2, self.bn2, relu=True)
         out = conv_bn(out, self.conv3, self.bn3)
-        return F.relu(out + identity)
+        return add_relu(out, identity)
 
 
 class ResNeXt101_32x8d(nn.Module):
@@ -121,7 +158,7 @@ class FTB(nn.Module):
         x = F.relu(self.conv1(x))
         b = conv_bn(x, self.conv_branch[1], self.conv_branch[2], relu=True)
         b = self.conv_branch[4](b)
-        return F.relu(x + b)
+        return add_relu(x, b)
 
 
 class FFM(nn.Module):

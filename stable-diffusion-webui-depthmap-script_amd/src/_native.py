@@ -24,7 +24,7 @@ EXPORTS = [
     "ds_stereo_last_exact_rows", "ds_copy_view", "ds_overlap_red_cyan", "ds_normalmap", "ds_depth_to_u16",
     "ds_convert_to_i16", "ds_profile_enable", "ds_profile_last_ms", "ds_stereo_last_stats", "ds_attention_fwd", "ds_attention_bias_pack", "ds_colorize_u16", "ds_residual_layernorm", "ds_boost_blend", "ds_upsample_bilinear_nhwc", "ds_dpt_head_tail", "ds_preprocess_bicubic", "ds_linear_reload_env",
     "ds_linear_shuffle", "ds_linear_readout", "ds_kernel_timer_enable", "ds_kernel_timer_read",
-    "ds_row_stats", "ds_linear_ln", "ds_linear_vt_ln",
+    "ds_row_stats", "ds_linear_ln", "ds_linear_vt_ln", "ds_gconv3x3_nhwc_f32", "ds_add_relu_f32",
 ]
 
 
@@ -91,6 +91,8 @@ def lib():
             L.ds_row_stats.argtypes = [vp, vp, vp, i64, ci, ctypes.c_float, ci, vp]
             L.ds_linear_ln.argtypes = [vp, vp, vp, vp, vp, vp, vp, i64, i64, i64, i64, ci, ci, vp]
             L.ds_linear_vt_ln.argtypes = [vp, vp, vp, vp, vp, vp, i64, i64, i64, i64, ci, vp]
+            L.ds_gconv3x3_nhwc_f32.argtypes = [vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, vp]
+            L.ds_add_relu_f32.argtypes = [vp, vp, vp, vp, i64, vp]
             L.ds_kernel_timer_enable.argtypes = [vp, ci]
             L.ds_kernel_timer_read.argtypes = [vp, ci, ctypes.POINTER(i64), ctypes.POINTER(cd)]
             L.ds_profile_enable.argtypes = [vp, ci]
@@ -518,6 +520,52 @@ def conv_transpose_shuffle(layer, x):
     _check(lib().ds_linear_shuffle(ctx_for(_dev_index(x)), xr.data_ptr(), wg.data_ptr(), None if bg is None else bg.data_ptr(), out.data_ptr(),
                                    b * h * w, c, w, s, co, 1 if x.dtype == torch.float16 else 2, _stream(x)))
     return out.permute(0, 3, 1, 2)               # logical NCHW, channels_last memory
+
+
+def gconv3x3_supported(x, weight, stride, padding, dilation, groups):
+    """What ds_gconv3x3_nhwc_f32 takes: a float32 channels_last activation, 3x3, stride 1, padding 1, no dilation, channels == out
+    channels, 8 / 16 / 32 channels per group, channels % 32 == 0."""
+    torch = _torch()
+    if not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and groups > 1 and tuple(weight.shape[2:]) == (3, 3)):
+        return False
+    c = x.shape[1]
+    cpg = c // groups
+    return (weight.shape[0] == c and weight.shape[1] == cpg and cpg in (8, 16, 32) and c % 32 == 0 and tuple(stride) == (1, 1)
+            and tuple(padding) == (1, 1) and tuple(dilation) == (1, 1) and x.is_contiguous(memory_format=torch.channels_last))
+
+
+def gconv_weight_image(weight, groups):
+    """torch's grouped weight [out, in / groups, 3, 3] -> [groups][9 taps][in / groups][out / groups] float32 (what the kernel's scalar
+    loads walk: the outputs of one (group, tap, input channel) are consecutive)."""
+    c, cpg = weight.shape[0], weight.shape[1]
+    w = weight.detach().float().reshape(groups, c // groups, cpg, 9)          # [g][co][ci][tap]
+    return w.permute(0, 3, 2, 1).contiguous()                                   # [g][tap][ci][co]
+
+
+def gconv3x3(x, w_gtio, bias, relu, cpg):
+    """[relu](grouped 3x3 convolution + bias) on a float32 channels_last activation (include/depthstereo.h: ds_gconv3x3_nhwc_f32)."""
+    torch = require_gpu()
+    b, c, h, w = x.shape
+    assert x.is_cuda and x.dtype == torch.float32 and x.is_contiguous(memory_format=torch.channels_last)
+    assert w_gtio.dtype == torch.float32 and w_gtio.is_contiguous() and w_gtio.numel() == (c // cpg) * 9 * cpg * cpg
+    bb = None if bias is None else bias.detach().float().contiguous()
+    out = torch.empty_like(x, memory_format=torch.channels_last)
+    CALLS["ds_gconv3x3_nhwc_f32"] += 1
+    _check(lib().ds_gconv3x3_nhwc_f32(ctx_for(_dev_index(x)), x.data_ptr(), w_gtio.data_ptr(), None if bb is None else bb.data_ptr(), out.data_ptr(),
+                                      b, h, w, c, cpg, 1 if relu else 0, _stream(x)))
+    return out
+
+
+def add_relu(a, b):
+    """relu(a + b) for two float32 CUDA tensors of one shape and one memory layout (include/depthstereo.h: ds_add_relu_f32)."""
+    torch = require_gpu()
+    assert a.is_cuda and a.dtype == torch.float32 and b.dtype == torch.float32 and a.shape == b.shape and a.stride() == b.stride()
+    assert a.numel() % 4 == 0 and (a.is_contiguous() or a.is_contiguous(memory_format=torch.channels_last))
+    out = torch.empty_like(a)                       # preserves the (dense) strides
+    assert out.stride() == a.stride()
+    CALLS["ds_add_relu_f32"] += 1
+    _check(lib().ds_add_relu_f32(ctx_for(_dev_index(a)), a.data_ptr(), b.data_ptr(), out.data_ptr(), a.numel(), _stream(a)))
+    return out
 
 
 KT_KINDS = {"linear_gelu": 0, "attention": 1, "linear_residual": 2, "linear": 3, "linear_vt": 4, "conv3x3": 5, "linear_readout": 6,

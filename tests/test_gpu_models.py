@@ -1598,3 +1598,58 @@ def test_ln_fold_route_equals_layernorm_route(gpu):
     e = ((y - y_ln).abs().flatten(1).max(1).values / y_ln.abs().flatten(1).max(1).values).max().item()
     e_mean = ((y - y_ln).abs().flatten(1).mean(1) / y_ln.abs().flatten(1).max(1).values).max().item()
     assert e < 2e-2 and e_mean < 2e-3, (e, e_mean)
+
+
+# ---- round 5: float32 kernels of Boost's base estimator ------------------------------------------------------------------------
+@pytest.mark.parametrize("b,c,cpg,h,w", [(8, 256, 8, 224, 224), (8, 512, 16, 112, 112), (8, 1024, 32, 56, 56), (2, 256, 8, 37, 53), (1, 64, 16, 9, 70),
+                                         (3, 96, 32, 8, 32)])
+def test_gconv3x3_matches_torch_grouped_convolution(gpu, b, c, cpg, h, w):
+    """ds_gconv3x3_nhwc_f32 (conv2 + folded bn2 + relu of the ResNeXt bottlenecks, lib/Resnext_torch.py:104-110) against torch's grouped
+    float32 convolution on the same operands: at the shapes a batch of eight 896^2 patches sends through layers 1-3, and on ragged
+    tiles (sizes that are not multiples of the 8 x 32 pixel tile, a single 32-channel block); with and without bias / ReLU."""
+    import torch.nn.functional as F
+    from src import _native
+    g = torch.Generator().manual_seed(40 + c + h)
+    x = torch.randn((b, c, h, w), generator=g).cuda().contiguous(memory_format=torch.channels_last)
+    wt = (torch.randn((c, cpg, 3, 3), generator=g) * (9 * cpg) ** -0.5).cuda()
+    bias = torch.randn((c,), generator=g).cuda()
+    assert _native.gconv3x3_supported(x, wt, (1, 1), (1, 1), (1, 1), c // cpg)
+    img = _native.gconv_weight_image(wt, c // cpg)
+    for use_bias, relu in ((True, True), (False, False)):
+        y = _native.gconv3x3(x, img, bias if use_bias else None, relu, cpg)
+        ref = F.conv2d(x, wt, bias if use_bias else None, 1, 1, 1, c // cpg)
+        if relu:
+            ref = F.relu(ref)
+        assert y.shape == ref.shape and y.is_contiguous(memory_format=torch.channels_last)
+        err = (y - ref).abs().max().item()
+        assert err < 2e-5 * (1 + ref.abs().max().item()), (use_bias, relu, err)
+        assert torch.equal(_native.gconv3x3(x, img, bias if use_bias else None, relu, cpg), y)
+    a, bb = torch.randn((b, c, h, w), generator=g).cuda().contiguous(memory_format=torch.channels_last), x
+    if a.numel() % 4 == 0:
+        assert torch.equal(_native.add_relu(a, bb), F.relu(a + bb))
+
+
+def test_leres_takes_the_in_tree_grouped_convolutions(gpu):
+    """RelDepthModel (LeReS res101) on the device: the 28 stride-1 grouped convolutions of layers 1-3 and the 33 bottleneck tails go
+    through ds_gconv3x3_nhwc_f32 / ds_add_relu_f32 (layer 4's 64-wide groups and the strided first blocks stay library calls), and the
+    output equals the library-only network (DS_GCONV=0, DS_ADD_RELU=0) at float32 summation-order level; 1e-4 against the reference's own
+    modules is held by test_leres_and_hybrid_gpu_fp32_vs_reference."""
+    import lib.multi_depth_model_woauxi as leres
+    from src import _native
+    m = leres.RelDepthModel(backbone='resnext101').eval()
+    m.load_state_dict(mw.fill_state_dict(m.state_dict()), strict=True)
+    m = m.cuda()
+    x = mw.synthetic_image((2, 3, 96, 160), seed=15).cuda()
+    before = dict(_native.CALLS)
+    with torch.no_grad():
+        y = m.depth_model(x)
+    assert _native.CALLS["ds_gconv3x3_nhwc_f32"] - before.get("ds_gconv3x3_nhwc_f32", 0) == 3 + 3 + 22
+    assert _native.CALLS["ds_add_relu_f32"] - before.get("ds_add_relu_f32", 0) == 33
+    saved = leres.GCONV_HIP, leres.ADD_RELU_HIP
+    try:
+        leres.GCONV_HIP = leres.ADD_RELU_HIP = False
+        with torch.no_grad():
+            y_lib = m.depth_model(x)
+    finally:
+        leres.GCONV_HIP, leres.ADD_RELU_HIP = saved
+    assert (y - y_lib).abs().max().item() < 2e-5 * (1 + y_lib.abs().max().item())

@@ -469,3 +469,29 @@ def test_standalone_harnesses_compile(tmp_path):
         for sym in re.findall(r'dlsym\(lib, "(\w+)"\)', text):
             assert sym == "ds_experiments_attention_profile" or re.search(r"\b%s\(" % sym, hdr), f"{name}: {sym} is not in the header"
         subprocess.check_call([hipcc, "-O1", "-std=c++17", src, "-o", str(tmp_path / name), "-ldl"])
+
+
+def test_gconv_weight_image_matches_the_grouped_convolution():
+    """_native.gconv_weight_image regroups torch's grouped weight [out, in / groups, 3, 3] into the [group][tap][in][out] image the HIP
+    kernel's scalar loads walk (csrc/ds_gconv.hip).  A numpy restatement of the kernel's index arithmetic -- input pixel (oy - 1 + tap / 3,
+    ox - 1 + tap % 3), channel g * cpg + ci, weight image[g][tap][ci][co] -- on that image must equal torch's grouped convolution."""
+    import torch
+    import torch.nn.functional as F
+    import src._native as nat
+    g = torch.Generator().manual_seed(5)
+    for cpg, groups, h, w in ((8, 4, 5, 7), (16, 2, 4, 6), (32, 1 + 1, 3, 5)):
+        c = cpg * groups
+        x = torch.randn((2, c, h, w), generator=g)
+        wt = torch.randn((c, cpg, 3, 3), generator=g)
+        b = torch.randn((c,), generator=g)
+        ref = F.conv2d(x, wt, b, 1, 1, 1, groups).permute(0, 2, 3, 1).numpy()
+        img = nat.gconv_weight_image(wt, groups).numpy()
+        assert img.shape == (groups, 9, cpg, cpg)
+        xp = np.pad(x.permute(0, 2, 3, 1).numpy(), ((0, 0), (1, 1), (1, 1), (0, 0)))
+        out = np.tile(b.numpy()[None, None, None, :], (2, h, w, 1)).astype(np.float64)
+        for gi in range(groups):
+            for tap in range(9):
+                dy, dx = tap // 3, tap % 3
+                patch = xp[:, dy:dy + h, dx:dx + w, gi * cpg:(gi + 1) * cpg].astype(np.float64)          # [b, h, w, ci]
+                out[..., gi * cpg:(gi + 1) * cpg] += patch @ img[gi, tap].astype(np.float64)              # [ci, co]
+        assert np.abs(out - ref).max() < 1e-4 * (1 + np.abs(ref).max())
