@@ -995,7 +995,8 @@ def run_c4(args):
         print(json.dumps({
             # the step is float32 convolutions of two library-backed networks (Boost never runs them in half: reference :271): the
             # roofline is the float32 MFMA peak (157.3 TF/s per GPU, MI355X_MICROARCH.md) against the convolutions' algorithmic flops
-            "roofline": {"bound": "mfma", "kernel": "MIOpen float32 convolutions of LeReS res101 + the pix2pix U-Net (library), whole step",
+            "roofline": {"bound": "mfma", "kernel": "float32 convolutions of LeReS res101 + the pix2pix U-Net, whole step (dense ones: MIOpen; the grouped 3x3 of the "
+                                                    "ResNeXt bottlenecks: ds_gconv3x3_nhwc_f32)",
                          "achieved": ach, "peak": 157.3 * world, "unit": "TFLOP/s", "frac": ach / (157.3 * world), "traffic": None,
                          "avg_kernel_ms": elapsed / args.steps * 1e3,
                          "algorithmic_flops_per_image": float(fl.item()), "source": "forward hooks on every convolution (priming step) / wall time of the timed steps"},

@@ -1218,7 +1218,21 @@ __global__ __launch_bounds__(64) void k_polylines_exact(PolyParams P, ExactScrat
 // segment is at most |divergence_px| + 0.1 long: at most NP (3 |divergence_px| + 8) segments can be in the set, transient adds
 // included) -- 36 bytes per column instead of 68: a 3840-column row (Boost on a 4K image, BASELINE config 4) fits the CU's 160 KB,
 // where it used to fall back to the one-lane-per-row kernel above at 143 ms per launch (19 % of config 4's step).
-template <int DT, int SHARP>
+//
+// COOP = 1 (round 5, the default): the sweep is run by the WHOLE wave instead of one lane.  Control flow and every double stay
+// uniform (all lanes compute the same values; lane 0 stores); the three scans over the active set -- the parts that made a row with a
+// wide divergence cost 12 us per column -- are spread over the lanes with the reference's sequential semantics restated exactly:
+//   * entering segments (:242-245): the sorted start points are appended in order -- a ballot finds how many consecutive ones lie left
+//     of the centre;
+//   * the swap-remove scan (:247-255: `csg[i] = csg[end - 1]; end -= 1` while scanning upwards) leaves, for K kept entries, the kept
+//     entries of positions < K in place and fills the removed positions < K (ascending) with the kept entries of positions >= K taken
+//     from the END downwards -- a permutation that only depends on the keep flags (checked against the sequential loop on 3 * 10^5
+//     random cases in tools, and by the byte-identity tests); if nothing is kept, slot 0 is left holding what the sequential loop
+//     leaves there (the old entry 1: the reference later reads that stale slot when the set is empty);
+//   * the winner (:259-267, strict `<` in index order = the FIRST index that attains the maximal closeness among valid candidates):
+//     per lane the first maximum of its strided candidates, across lanes the maximum with ties going to the lower index.
+#define PLX_SCR 512             // COOP: capacity of the hole / donor lists of one removal (more than that: the sequential loop, by lane 0)
+template <int DT, int SHARP, int COOP>
 __global__ __launch_bounds__(64) void k_polylines_exact_lds(PolyParams P, int c, int win_pts, int csg_cap)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1231,6 +1245,9 @@ __global__ __launch_bounds__(64) void k_polylines_exact_lds(PolyParams P, int c,
     int *sk = reinterpret_cast<int *>(sx + pt_end);          // original index of the sorted point
     uint32_t *rgbx = reinterpret_cast<uint32_t *>(sk + pt_end);
     int *csg = reinterpret_cast<int *>(rgbx + w);            // the active set, csg_cap entries
+    int *holes = csg + csg_cap;                              // COOP scratch: PLX_SCR + PLX_SCR positions, then the keep masks of the chunks
+    int *donors = holes + PLX_SCR;
+    unsigned long long *kmask = reinterpret_cast<unsigned long long *>((reinterpret_cast<uintptr_t>(donors + PLX_SCR) + 7) & ~(uintptr_t)7);   // (odd widths leave the lists 4-byte aligned)
     const int count = P.counters[0];
     for (int it = blockIdx.x; it < count; it += gridDim.x) {
         const int rowid = P.row_list[it];
@@ -1283,9 +1300,128 @@ __global__ __launch_bounds__(64) void k_polylines_exact_lds(PolyParams P, int c,
             sk[pos] = i;
         }
         __syncthreads();
-        if (lane == 0) {
-            // ---- the sweep (:228-282), statement by statement as in k_polylines_exact ----
 #define CI_(p) ((p) == 0 ? 0 : ((p) == pt_end - 1 ? (w - 1) : (SHARP ? ((p) - 1) >> 1 : (p) - 1)))
+        if (COOP) {
+            // ---- the sweep (:228-282) by the whole wave: uniform control flow, the active-set scans across the lanes ----
+            int csg_end = 0, sg_pointer = 0, pt_i = 0;
+            bool slot0_written = false;
+            for (int col = 0; col < w; col++) {
+                double color[4] = { 0.5, 0.5, 0.5, 0.5 };
+                while (sx[pt_i] < (double)col) pt_i++;
+                pt_i--;
+                while (sx[pt_i] < (double)(col + 1)) {
+                    const double pa = sx[pt_i], pb = sx[pt_i + 1];
+                    const double coord_from = (pa > (double)col ? pa : (double)col) + PL_EPS;
+                    const double coord_to = (pb < (double)(col + 1) ? pb : (double)(col + 1)) - PL_EPS;
+                    const double significance = coord_to - coord_from;
+                    const double coord_center = coord_from + 0.5 * significance;
+                    // (a) entering segments, in sorted order
+                    for (;;) {
+                        const int idx = sg_pointer + lane;
+                        const bool ok = idx < sg_end && sx[idx < sg_end ? idx : sg_end - 1] < coord_center;
+                        const unsigned long long m = __ballot(ok);
+                        const int nadd = m == ~0ull ? 64 : __builtin_ctzll(~m);
+                        if (lane < nadd && csg_end + lane < csg_cap) csg[csg_end + lane] = sk[idx];
+                        if (nadd > 0 && csg_end == 0) slot0_written = true;
+                        sg_pointer += nadd; csg_end += nadd;
+                        if (nadd < 64) break;
+                    }
+                    if (csg_end > csg_cap) csg_end = csg_cap;
+                    __syncthreads();
+                    // (b) leaving segments: the swap-remove scan as a permutation of the keep flags
+                    if (csg_end > 0) {
+                        const int n = csg_end, nch = (n + 63) >> 6;
+                        int K = 0;
+                        for (int ch = 0; ch < nch; ++ch) {
+                            const int p = 64 * ch + lane;
+                            bool keep = false;
+                            if (p < n) keep = !(OX(csg[p] + 1) < coord_center);
+                            const unsigned long long m = __ballot(keep);
+                            if (lane == 0) kmask[ch] = m;
+                            K += __builtin_popcountll(m);
+                        }
+                        __syncthreads();
+                        if (K == 0) {
+                            if (n >= 2 && lane == 0) csg[0] = csg[1];                // what the sequential scan leaves in the stale slot
+                        } else if (K < n) {
+                            const int nholes = K - [&] { int kept = 0; for (int ch = 0; ch <= (K - 1) >> 6; ++ch) { unsigned long long m = kmask[ch]; const int top = K - 64 * ch; if (top < 64) m &= (1ull << top) - 1ull; kept += __builtin_popcountll(m); } return kept; }();
+                            if (nholes > PLX_SCR) {
+                                if (lane == 0) {                                     // a removal larger than the scratch lists: the scan itself
+                                    int e = n, i = 0;
+                                    while (i < e) { const int k = csg[i]; if (OX(k + 1) < coord_center) { csg[i] = csg[e - 1]; e--; } else i++; }
+                                }
+                            } else if (nholes > 0) {
+                                int base = 0;
+                                for (int ch = 0; ch <= (K - 1) >> 6; ++ch) {         // removed positions below K, ascending
+                                    const int p = 64 * ch + lane;
+                                    unsigned long long hm = ~kmask[ch];
+                                    const int top = K - 64 * ch;
+                                    if (top < 64) hm &= (1ull << top) - 1ull;
+                                    if ((hm >> lane) & 1ull) holes[base + __builtin_popcountll(hm & ((1ull << lane) - 1ull))] = p;
+                                    base += __builtin_popcountll(hm);
+                                }
+                                base = 0;
+                                for (int ch = nch - 1; ch >= K >> 6; --ch) {         // kept positions from K up, descending
+                                    const int p = 64 * ch + lane;
+                                    unsigned long long dm = kmask[ch];
+                                    const int lo = K - 64 * ch;
+                                    if (lo > 0) dm &= ~((1ull << lo) - 1ull);
+                                    if ((dm >> lane) & 1ull) donors[base + __builtin_popcountll(lane == 63 ? 0ull : dm >> (lane + 1))] = p;
+                                    base += __builtin_popcountll(dm);
+                                }
+                                __syncthreads();
+                                for (int j = lane; j < nholes; j += 64) csg[holes[j]] = csg[donors[j]];      // disjoint: holes < K <= donors
+                            }
+                        }
+                        csg_end = K;
+                        __syncthreads();
+                    }
+                    // (c) the winner: the first index that attains the maximal closeness among the valid candidates
+                    int best = 0;
+                    if (csg_end != 1) {
+                        double bc = -PL_EPS;
+                        int bi = 0x7fffffff;
+                        for (int i = lane; i < csg_end; i += 64) {
+                            const int k = csg[i];
+                            const double x0 = OX(k), x1 = OX(k + 1);
+                            const double ip_k = (coord_center - x0) / (x1 - x0);
+                            const double closeness = (1.0 - ip_k) * OD(k) + ip_k * OD(k + 1);
+                            if (bc < closeness && 0.0 < ip_k && ip_k < 1.0) { bc = closeness; bi = i; }
+                        }
+#pragma unroll
+                        for (int sft = 32; sft > 0; sft >>= 1) {
+                            const double oc = __shfl_xor(bc, sft, 64);
+                            const int oi = __shfl_xor(bi, sft, 64);
+                            if (oi != 0x7fffffff && (bi == 0x7fffffff || oc > bc || (oc == bc && oi < bi))) { bc = oc; bi = oi; }
+                        }
+                        if (bi != 0x7fffffff) best = bi;
+                    }
+                    const int k = (csg_end > 0 || slot0_written) ? csg[best] : -1;
+                    if (k >= 0) {
+                        const int col_l = CI_(k), col_r = CI_(k + 1);
+                        const uint32_t pl = rgbx[col_l];
+                        if (col_l == col_r) {
+                            for (int q = 0; q < 4; q++) if (q < c) color[q] += (double)((pl >> (8 * q)) & 0xffu) * significance;
+                        } else {
+                            const uint32_t pr = rgbx[col_r];
+                            const double x0 = OX(k), x1 = OX(k + 1);
+                            const double ip_k = (coord_center - x0) / (x1 - x0);
+                            for (int q = 0; q < 4; q++) if (q < c) {
+                                const double u = (double)((pl >> (8 * q)) & 0xffu) * (1.0 - ip_k);
+                                const double v = (double)((pr >> (8 * q)) & 0xffu) * ip_k;
+                                color[q] += (u + v) * significance;
+                            }
+                        }
+                    } else {
+                        const uint32_t p0 = rgbx[0];
+                        for (int q = 0; q < 4; q++) if (q < c) color[q] += (double)((p0 >> (8 * q)) & 0xffu) * significance;
+                    }
+                    pt_i++;
+                }
+                if (lane == 0) for (int q = 0; q < 4; q++) if (q < c) dst[(size_t)col * c + q] = ds_f64_to_u8(color[q]);
+            }
+        } else if (lane == 0) {
+            // ---- the sweep (:228-282), statement by statement as in k_polylines_exact, by ONE lane (rounds 3-4; DS_PL_EXACT_COOP=0) ----
             int csg_end = 0, sg_pointer = 0, pt_i = 0;
             bool slot0_written = false;
             for (int col = 0; col < w; col++) {
@@ -1427,30 +1563,43 @@ static int pl_dispatch(int op, const PolyParams &P, int c, int ncu, long long nw
 // LDS of k_polylines_exact_lds for a row of w columns: coord_d (8 B) and a packed colour (4 B) per column, sorted x (8 B) and
 // original index (4 B) per point, + the bounded active set
 static size_t pl_exact_lds_fixed(int w, int sharp) { return (size_t)w * 12 + (size_t)((sharp ? 2 : 1) * w + 2) * 12 + 16; }
+// + the cooperative sweep's scratch behind the active set: two position lists of PLX_SCR entries and one keep mask per 64 entries
+static size_t pl_exact_lds_scratch(long long csg_cap) { return (size_t)2 * PLX_SCR * 4 + (size_t)((csg_cap + 63) / 64) * 8 + 16; }
 
 template <int DT>
 static int pl_launch_exact(const PolyParams &P, int sharp, const ExactScratch &S, int exact_blocks, int c, double max_div_px, int device, hipStream_t st)
 {
     const size_t fixed = pl_exact_lds_fixed(P.w, sharp);
     const int force_global = getenv("DS_PL_EXACT_GLOBAL") ? atoi(getenv("DS_PL_EXACT_GLOBAL")) : 0;      // A/B switch (tests)
+    const int coop = !(getenv("DS_PL_EXACT_COOP") && atoi(getenv("DS_PL_EXACT_COOP")) == 0);            // A/B switch: 0 = the one-lane sweep
     // the active set holds at most NP (3 |divergence_px| + 8) segments (see the kernel); whatever the CU's LDS leaves after the
-    // row's arrays, up to 8192 entries, is its capacity
+    // row's arrays (and the cooperative sweep's scratch), up to 8192 entries, is its capacity
     const long long csg_need = (long long)(sharp ? 2 : 1) * (3 * (long long)ceil(fabs(max_div_px)) + 8);
-    long long csg_cap = fixed + 64 <= 160 * 1024 ? (long long)((160 * 1024 - fixed) / 4) : 0;
-    if (csg_cap > 8192) csg_cap = 8192;
-    if (csg_cap >= csg_need && csg_cap >= 64 && !force_global) {
-        const size_t lds = fixed + (size_t)csg_cap * 4;
+    long long csg_cap = 0;
+    const size_t room = 160 * 1024;
+    if (fixed + pl_exact_lds_scratch(8192) + 8192 * 4 <= room) csg_cap = 8192;
+    else if (fixed + pl_exact_lds_scratch(64) + 64 * 4 <= room) {
+        csg_cap = (long long)((room - fixed - 2 * PLX_SCR * 4 - 32) / 4);
+        csg_cap = csg_cap * 64 / 66 / 64 * 64;               // leave 8 bytes of mask per 64 entries, whole chunks
+        if (csg_cap > 8192) csg_cap = 8192;
+    }
+    if (csg_cap >= csg_need && csg_cap >= 64 && !force_global && fixed + (size_t)csg_cap * 4 + pl_exact_lds_scratch(csg_cap) <= room) {
+        const size_t lds = fixed + (size_t)csg_cap * 4 + pl_exact_lds_scratch(csg_cap);
         // one workgroup per flagged row, rows taken round-robin by a fixed grid (the count lives on the device)
         const int win_pts = (sharp ? 2 : 1) * ((int)ceil(fabs(max_div_px)) + 3);
         static std::atomic<uint64_t> attr_done{0};           // per device (bit) -- the limit is raised to the CU's whole LDS once
         const uint64_t bit = 1ull << (device & 63);
         if (!(attr_done.load(std::memory_order_relaxed) & bit)) {
-            DS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_polylines_exact_lds<DT, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            DS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_polylines_exact_lds<DT, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            DS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_polylines_exact_lds<DT, 1, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            DS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_polylines_exact_lds<DT, 0, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            DS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_polylines_exact_lds<DT, 1, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            DS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_polylines_exact_lds<DT, 0, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
             attr_done.fetch_or(bit, std::memory_order_relaxed);
         }
-        if (sharp) hipLaunchKernelGGL((k_polylines_exact_lds<DT, 1>), dim3(1024), dim3(64), lds, st, P, c, win_pts, (int)csg_cap);
-        else hipLaunchKernelGGL((k_polylines_exact_lds<DT, 0>), dim3(1024), dim3(64), lds, st, P, c, win_pts, (int)csg_cap);
+        if (sharp && coop) hipLaunchKernelGGL((k_polylines_exact_lds<DT, 1, 1>), dim3(1024), dim3(64), lds, st, P, c, win_pts, (int)csg_cap);
+        else if (sharp) hipLaunchKernelGGL((k_polylines_exact_lds<DT, 1, 0>), dim3(1024), dim3(64), lds, st, P, c, win_pts, (int)csg_cap);
+        else if (coop) hipLaunchKernelGGL((k_polylines_exact_lds<DT, 0, 1>), dim3(1024), dim3(64), lds, st, P, c, win_pts, (int)csg_cap);
+        else hipLaunchKernelGGL((k_polylines_exact_lds<DT, 0, 0>), dim3(1024), dim3(64), lds, st, P, c, win_pts, (int)csg_cap);
         return DS_OK;
     }
     if (sharp) hipLaunchKernelGGL((k_polylines_exact<DT, 1>), dim3(exact_blocks), dim3(64), 0, st, P, S);

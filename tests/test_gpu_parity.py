@@ -616,6 +616,11 @@ def test_exact_fallback_lds_kernel_equals_global_kernel(sg, native, oracle, gpu)
     cases.append((uhd, (rng.integers(0, 5, (3, 3840)) * 16383).astype(np.uint16), 100.0 * 32 / 3840, 0.0, 'polylines_soft'))
     img1k = rng.integers(0, 256, (4, 1024, 3), dtype=np.uint8)
     cases.append((img1k, (rng.integers(0, 8, (4, 1024)) * 9362).astype(np.uint16), 12.5, -0.2, 'polylines_sharp'))
+    # active sets of several 64-entry chunks with removals all over them (the cooperative sweep's permutation of the keep flags)
+    img512 = rng.integers(0, 256, (6, 512, 3), dtype=np.uint8)
+    cases.append((img512, (rng.integers(0, 16, (6, 512)) * 4369).astype(np.uint16), 25.0, 0.0, 'polylines_sharp'))
+    cases.append((img512, (rng.integers(0, 16, (6, 512)) * 4369).astype(np.uint16), 25.0, 0.5, 'polylines_soft'))
+    cases.append((img512[:, :333], (rng.integers(0, 6, (6, 333)) * 13107).astype(np.uint16), -18.0, 0.0, 'polylines_sharp'))     # odd width, negative divergence
     flagged = 0
     old = os.environ.get("DS_PL_EXACT_GLOBAL")
     try:
@@ -623,13 +628,17 @@ def test_exact_fallback_lds_kernel_equals_global_kernel(sg, native, oracle, gpu)
             want = oracle.create_stereoimages_arrays(img, dep, div, 0.0, ['left-right'], bal, 1.0, fill)[0]
             it, dt = torch.from_numpy(img).cuda().unsqueeze(0), torch.from_numpy(dep).cuda().unsqueeze(0)
             outs = []
-            for force in ("0", "1"):
+            # the LDS kernel with the sweep run by the whole wave (round 5, the default), with the sweep on one lane, the global kernel
+            for force, coop in (("0", "1"), ("0", "0"), ("1", "1")):
                 os.environ["DS_PL_EXACT_GLOBAL"] = force
+                os.environ["DS_PL_EXACT_COOP"] = coop
                 outs.append(sg.create_stereoimages_batch(it, dt, div, 0.0, ['left-right'], bal, 1.0, fill)[0][0].cpu().numpy())
                 flagged += native.last_exact_rows(it)
-            assert np.array_equal(outs[0], outs[1]), (img.shape, fill, 'LDS and global exact kernels differ')
+            assert np.array_equal(outs[0], outs[1]), (img.shape, fill, 'cooperative and one-lane sweeps of the LDS exact kernel differ')
+            assert np.array_equal(outs[0], outs[2]), (img.shape, fill, 'LDS and global exact kernels differ')
             assert np.array_equal(outs[0], want), (img.shape, fill, int((outs[0] != want).sum()))
     finally:
+        os.environ.pop("DS_PL_EXACT_COOP", None)
         if old is None:
             os.environ.pop("DS_PL_EXACT_GLOBAL", None)
         else:
