@@ -1233,7 +1233,7 @@ __global__ __launch_bounds__(64) void k_polylines_exact(PolyParams P, ExactScrat
 //     per lane the first maximum of its strided candidates, across lanes the maximum with ties going to the lower index.
 #define PLX_SCR 512             // COOP: capacity of the hole / donor lists of one removal (more than that: the sequential loop, by lane 0)
 template <int DT, int SHARP, int COOP>
-__global__ __launch_bounds__(64) void k_polylines_exact_lds(PolyParams P, int c, int win_pts, int csg_cap)
+__global__ __launch_bounds__(64) void k_polylines_exact_lds(PolyParams P, int c, int win_pts, int csg_cap, int coop_min)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int NP = SHARP ? 2 : 1;
@@ -1328,6 +1328,27 @@ __global__ __launch_bounds__(64) void k_polylines_exact_lds(PolyParams P, int c,
                     }
                     if (csg_end > csg_cap) csg_end = csg_cap;
                     __syncthreads();
+                    int best = 0;
+                    if (csg_end < coop_min) {
+                        // a small active set: the two scans as the reference writes them, executed by every lane alike (the same
+                        // values into the same LDS words) -- ballots, list building and barriers cost more than they save here
+                        int csg_i = 0;
+                        while (csg_i < csg_end) {
+                            const int k = csg[csg_i];
+                            if (OX(k + 1) < coord_center) { csg[csg_i] = csg[csg_end - 1]; csg_end--; }
+                            else csg_i++;
+                        }
+                        if (csg_end != 1) {
+                            double best_closeness = -PL_EPS;
+                            for (csg_i = 0; csg_i < csg_end; csg_i++) {
+                                const int k = csg[csg_i];
+                                const double x0 = OX(k), x1 = OX(k + 1);
+                                const double ip_k = (coord_center - x0) / (x1 - x0);
+                                const double closeness = (1.0 - ip_k) * OD(k) + ip_k * OD(k + 1);
+                                if (best_closeness < closeness && 0.0 < ip_k && ip_k < 1.0) { best_closeness = closeness; best = csg_i; }
+                            }
+                        }
+                    } else {
                     // (b) leaving segments: the swap-remove scan as a permutation of the keep flags
                     if (csg_end > 0) {
                         const int n = csg_end, nch = (n + 63) >> 6;
@@ -1377,7 +1398,6 @@ __global__ __launch_bounds__(64) void k_polylines_exact_lds(PolyParams P, int c,
                         __syncthreads();
                     }
                     // (c) the winner: the first index that attains the maximal closeness among the valid candidates
-                    int best = 0;
                     if (csg_end != 1) {
                         double bc = -PL_EPS;
                         int bi = 0x7fffffff;
@@ -1395,6 +1415,7 @@ __global__ __launch_bounds__(64) void k_polylines_exact_lds(PolyParams P, int c,
                             if (oi != 0x7fffffff && (bi == 0x7fffffff || oc > bc || (oc == bc && oi < bi))) { bc = oc; bi = oi; }
                         }
                         if (bi != 0x7fffffff) best = bi;
+                    }
                     }
                     const int k = (csg_end > 0 || slot0_written) ? csg[best] : -1;
                     if (k >= 0) {
@@ -1572,6 +1593,8 @@ static int pl_launch_exact(const PolyParams &P, int sharp, const ExactScratch &S
     const size_t fixed = pl_exact_lds_fixed(P.w, sharp);
     const int force_global = getenv("DS_PL_EXACT_GLOBAL") ? atoi(getenv("DS_PL_EXACT_GLOBAL")) : 0;      // A/B switch (tests)
     const int coop = !(getenv("DS_PL_EXACT_COOP") && atoi(getenv("DS_PL_EXACT_COOP")) == 0);            // A/B switch: 0 = the one-lane sweep
+    // active-set size from which the cooperative sweep spreads its scans over the lanes (below it: the sequential scans, by every lane)
+    const int coop_min = getenv("DS_PL_EXACT_COOP_MIN") ? atoi(getenv("DS_PL_EXACT_COOP_MIN")) : 24;
     // the active set holds at most NP (3 |divergence_px| + 8) segments (see the kernel); whatever the CU's LDS leaves after the
     // row's arrays (and the cooperative sweep's scratch), up to 8192 entries, is its capacity
     const long long csg_need = (long long)(sharp ? 2 : 1) * (3 * (long long)ceil(fabs(max_div_px)) + 8);
@@ -1596,10 +1619,10 @@ static int pl_launch_exact(const PolyParams &P, int sharp, const ExactScratch &S
             DS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_polylines_exact_lds<DT, 0, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
             attr_done.fetch_or(bit, std::memory_order_relaxed);
         }
-        if (sharp && coop) hipLaunchKernelGGL((k_polylines_exact_lds<DT, 1, 1>), dim3(1024), dim3(64), lds, st, P, c, win_pts, (int)csg_cap);
-        else if (sharp) hipLaunchKernelGGL((k_polylines_exact_lds<DT, 1, 0>), dim3(1024), dim3(64), lds, st, P, c, win_pts, (int)csg_cap);
-        else if (coop) hipLaunchKernelGGL((k_polylines_exact_lds<DT, 0, 1>), dim3(1024), dim3(64), lds, st, P, c, win_pts, (int)csg_cap);
-        else hipLaunchKernelGGL((k_polylines_exact_lds<DT, 0, 0>), dim3(1024), dim3(64), lds, st, P, c, win_pts, (int)csg_cap);
+        if (sharp && coop) hipLaunchKernelGGL((k_polylines_exact_lds<DT, 1, 1>), dim3(1024), dim3(64), lds, st, P, c, win_pts, (int)csg_cap, coop_min);
+        else if (sharp) hipLaunchKernelGGL((k_polylines_exact_lds<DT, 1, 0>), dim3(1024), dim3(64), lds, st, P, c, win_pts, (int)csg_cap, coop_min);
+        else if (coop) hipLaunchKernelGGL((k_polylines_exact_lds<DT, 0, 1>), dim3(1024), dim3(64), lds, st, P, c, win_pts, (int)csg_cap, coop_min);
+        else hipLaunchKernelGGL((k_polylines_exact_lds<DT, 0, 0>), dim3(1024), dim3(64), lds, st, P, c, win_pts, (int)csg_cap, coop_min);
         return DS_OK;
     }
     if (sharp) hipLaunchKernelGGL((k_polylines_exact<DT, 1>), dim3(exact_blocks), dim3(64), 0, st, P, S);

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Shares of one bench step by kernel family, from a `rocprofv3 --kernel-trace --stats` summary (the figures DESIGN.md §5 quotes).
 
-    python tools/step_anatomy.py [profiles/round4_kernel_stats.csv] [--forwards 19]
+    python tools/step_anatomy.py [profiles/round5_kernel_stats.csv] [--forwards 19]
 
 `--forwards` = network forwards inside the profiled command (`bench.py --steps 10 --warmup 2` runs 19: seed probing, priming,
 warm-up, the timed steps and the per-kernel timing passes); it only scales the per-forward column."""
@@ -28,7 +28,7 @@ FAMILIES = [
 
 
 def main(argv):
-    path = "profiles/round4_kernel_stats.csv"
+    path = "profiles/round5_kernel_stats.csv"
     forwards = 19
     args = list(argv)
     while args:
