@@ -1593,8 +1593,11 @@ static int pl_launch_exact(const PolyParams &P, int sharp, const ExactScratch &S
     const size_t fixed = pl_exact_lds_fixed(P.w, sharp);
     const int force_global = getenv("DS_PL_EXACT_GLOBAL") ? atoi(getenv("DS_PL_EXACT_GLOBAL")) : 0;      // A/B switch (tests)
     const int coop = !(getenv("DS_PL_EXACT_COOP") && atoi(getenv("DS_PL_EXACT_COOP")) == 0);            // A/B switch: 0 = the one-lane sweep
-    // active-set size from which the cooperative sweep spreads its scans over the lanes (below it: the sequential scans, by every lane)
-    const int coop_min = getenv("DS_PL_EXACT_COOP_MIN") ? atoi(getenv("DS_PL_EXACT_COOP_MIN")) : 24;
+    // active-set size from which the cooperative sweep spreads its scans over the lanes (below it: the sequential scans, by every lane).
+    // Measured on 3840-column rows (tools/exact_sweep_probe.py, 80 flagged rows): always parallel 27.5 ms, parallel from 24 entries 70.0 ms,
+    // one lane 72.1 ms -- the parallel scans win on small sets too (one round trip instead of one per entry); sets of 0 / 1 entries have
+    // nothing to scan.  On config 5 (1080p, 0-2 flagged rows per launch) the choice is inside the run-to-run noise.
+    const int coop_min = getenv("DS_PL_EXACT_COOP_MIN") ? atoi(getenv("DS_PL_EXACT_COOP_MIN")) : 2;
     // the active set holds at most NP (3 |divergence_px| + 8) segments (see the kernel); whatever the CU's LDS leaves after the
     // row's arrays (and the cooperative sweep's scratch), up to 8192 entries, is its capacity
     const long long csg_need = (long long)(sharp ? 2 : 1) * (3 * (long long)ceil(fabs(max_div_px)) + 8);

@@ -629,9 +629,9 @@ def test_exact_fallback_lds_kernel_equals_global_kernel(sg, native, oracle, gpu)
             it, dt = torch.from_numpy(img).cuda().unsqueeze(0), torch.from_numpy(dep).cuda().unsqueeze(0)
             outs = []
             # the LDS kernel with the sweep run by the whole wave (round 5, the default), with the sweep on one lane, the global kernel
-            # (DS_PL_EXACT_COOP_MIN: the active-set size from which the cooperative sweep goes parallel -- default 24; 0 = always, so
-            # that the permutation logic also runs on sets of one or two entries)
-            for force, coop, cmin in (("0", "1", None), ("0", "1", "0"), ("0", "0", None), ("1", "1", None)):
+            # (DS_PL_EXACT_COOP_MIN: the active-set size from which the cooperative sweep goes parallel -- default 2; 24 mixes the
+            # sequential and the parallel scans inside one row)
+            for force, coop, cmin in (("0", "1", None), ("0", "1", "24"), ("0", "0", None), ("1", "1", None)):
                 os.environ["DS_PL_EXACT_GLOBAL"] = force
                 os.environ["DS_PL_EXACT_COOP"] = coop
                 if cmin is None:
@@ -640,7 +640,7 @@ def test_exact_fallback_lds_kernel_equals_global_kernel(sg, native, oracle, gpu)
                     os.environ["DS_PL_EXACT_COOP_MIN"] = cmin
                 outs.append(sg.create_stereoimages_batch(it, dt, div, 0.0, ['left-right'], bal, 1.0, fill)[0][0].cpu().numpy())
                 flagged += native.last_exact_rows(it)
-            assert np.array_equal(outs[0], outs[1]), (img.shape, fill, 'adaptive and always-parallel cooperative sweeps differ')
+            assert np.array_equal(outs[0], outs[1]), (img.shape, fill, 'cooperative sweeps with different parallel thresholds differ')
             assert np.array_equal(outs[0], outs[2]), (img.shape, fill, 'cooperative and one-lane sweeps of the LDS exact kernel differ')
             assert np.array_equal(outs[0], outs[3]), (img.shape, fill, 'LDS and global exact kernels differ')
             assert np.array_equal(outs[0], want), (img.shape, fill, int((outs[0] != want).sum()))
