@@ -518,3 +518,51 @@ def test_gconv_weight_image_matches_the_grouped_convolution():
                 patch = xp[:, dy:dy + h, dx:dx + w, gi * cpg:(gi + 1) * cpg].astype(np.float64)          # [b, h, w, ci]
                 out[..., gi * cpg:(gi + 1) * cpg] += patch @ img[gi, tap].astype(np.float64)              # [ci, co]
         assert np.abs(out - ref).max() < 1e-4 * (1 + np.abs(ref).max())
+
+
+def test_exact_sweep_parallel_removal_is_the_sequential_scan():
+    """The reference's active-set scan (src/stereoimage_generation.py:247-255: `if ...: csg[i] = csg[end - 1]; end -= 1 else: i += 1`)
+    restated as the permutation the wave-cooperative exact sweep applies (csrc/ds_stereo_polylines.hip, k_polylines_exact_lds<.., COOP>):
+    with K kept entries, the kept entries below position K stay, the removed positions below K (ascending) receive the kept entries
+    from K up taken from the END downwards; when nothing is kept, slot 0 holds the old entry 1 (what the sequential scan leaves in
+    the slot the reference later reads while the set is empty).  Everything the sweep can observe -- the active part in order, and
+    slot 0 of an emptied set -- must agree on random keep patterns, including 0, 1 and several 64-entry chunks of entries."""
+    import random
+
+    def sequential(csg, removable):
+        csg, end, i = list(csg), len(csg), 0
+        while i < end:
+            if csg[i] in removable:
+                csg[i] = csg[end - 1]
+                end -= 1
+            else:
+                i += 1
+        return end, csg
+
+    def permutation(csg, removable):
+        n = len(csg)
+        keep = [v not in removable for v in csg]
+        k = sum(keep)
+        out = list(csg)
+        if k == 0:
+            if n >= 2:
+                out[0] = csg[1]
+            return 0, out
+        holes = [p for p in range(k) if not keep[p]]
+        donors = [p for p in range(n - 1, k - 1, -1) if keep[p]]
+        assert len(holes) == len(donors)
+        for h, d in zip(holes, donors):
+            out[h] = csg[d]
+        return k, out
+
+    rnd = random.Random(7)
+    for _ in range(20000):
+        n = rnd.choice((0, 1, 2, 3, 5, 17, 63, 64, 65, 130, 200))
+        vals = rnd.sample(range(10000), n)
+        p = rnd.choice((0.0, 0.05, 0.5, 0.95, 1.0))
+        removable = {v for v in vals if rnd.random() < p}
+        ea, fa = sequential(vals, removable)
+        eb, fb = permutation(vals, removable)
+        assert ea == eb and fa[:ea] == fb[:eb], (vals, removable)
+        if ea == 0 and n > 0:
+            assert fa[0] == fb[0], (vals, removable)
