@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Time of the exact row sweep (k_polylines_exact_lds) on 3840-column rows that the main kernel flags, with the sweep run by the whole
+"""Time of the exact row sweep (k_polylines_exact_lds) on 3840-column rows (PROBE_W / PROBE_H: another frame size) that the main kernel flags, with the sweep run by the whole
 wave (default) and by one lane (DS_PL_EXACT_COOP=0), and by the global-scratch kernel (DS_PL_EXACT_GLOBAL=1): HIP events inside the C ABI
 (ds_profile_last_ms).  gpurun -- 'python tools/exact_sweep_probe.py'"""
 import os
@@ -14,7 +14,7 @@ import src._native as nat  # noqa: E402
 import src.stereoimage_generation as sg  # noqa: E402
 
 rng = np.random.default_rng(4)
-H, W = 2160, 3840
+H, W = int(os.environ.get("PROBE_H", 2160)), int(os.environ.get("PROBE_W", 3840))      # PROBE_H / PROBE_W: another frame size (1080 x 1920: config 5's)
 img = torch.from_numpy(rng.integers(0, 256, (1, H, W, 3), dtype=np.uint8)).cuda()
 yy, xx = np.mgrid[0:H, 0:W]
 smooth = 30000 + 20000 * np.sin(xx / 611.0) * np.cos(yy / 397.0)
