@@ -566,3 +566,36 @@ def test_exact_sweep_parallel_removal_is_the_sequential_scan():
         assert ea == eb and fa[:ea] == fb[:eb], (vals, removable)
         if ea == 0 and n > 0:
             assert fa[0] == fb[0], (vals, removable)
+
+
+def test_integration_md_binding_snippets_match_the_header():
+    """INTEGRATION.md shows the stub a maintainer of the reference would add: its Python blocks must be valid Python, every
+    `_L.ds_*` they call must be a symbol the header declares, the `ds_eye` structure must have the header's fields in the header's
+    order, and the argtypes it spells out for ds_linear must be the ones src/_native.py binds."""
+    import ast
+    text = open(os.path.join(conftest.ROOT, "INTEGRATION.md")).read()
+    blocks = re.findall(r"```python\n(.*?)```", text, flags=re.S)
+    assert len(blocks) >= 2
+    hdr = open(os.path.join(conftest.ROOT, "include", "depthstereo.h")).read()
+    declared = set(re.findall(r"\b(ds_[a-z0-9_]+)\s*\(", re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)))
+    called = set()
+    for b in blocks:
+        ast.parse(b)                                                  # a SyntaxError here is a broken document
+        called |= set(re.findall(r"_L\.(ds_[a-z0-9_]+)", b))
+    assert called and called <= declared, called - declared
+    fields = re.findall(r'\("([a-z_]+)", ctypes\.(c_[a-z0-9_]+)\)', blocks[0])
+    body = re.search(r"typedef struct ds_eye \{(.*?)\} ds_eye;", hdr, flags=re.S).group(1)
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    want = [(n, {"double": "c_double", "uint8_t *": "c_void_p", "int64_t": "c_int64"}[t.strip()])
+            for t, n in re.findall(r"(double|uint8_t \*|int64_t)\s*([a-z_]+);", body)]
+    assert fields == want, (fields, want)
+    # the argument list the stub passes to ds_stereo_warp has as many entries as the declaration has parameters
+    decl = re.search(r"int ds_stereo_warp\((.*?)\);", hdr, flags=re.S).group(1)
+    call = ast.parse(blocks[0])
+    n_args = [len(c.args) for c in ast.walk(call) if isinstance(c, ast.Call) and isinstance(c.func, ast.Attribute) and c.func.attr == "ds_stereo_warp"]
+    assert n_args == [len(decl.split(","))]
+    m = re.search(r"_L\.ds_linear\.argtypes = \[(.*?)\]", blocks[1])
+    spelled = [a.strip() for a in m.group(1).split(",")]
+    decl = re.search(r"int ds_linear\((.*?)\);", hdr, flags=re.S).group(1)
+    kinds = ["I64" if "int64_t" in p else ("P" if "*" in p else "ctypes.c_int") for p in decl.split(",")]
+    assert spelled == kinds, (spelled, kinds)
