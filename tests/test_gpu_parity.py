@@ -761,3 +761,31 @@ def test_normalmap_float32_gradient_is_the_reference_float32_evaluation(gpu, ora
         nm.create_normalmap(cases[0], 3, None, None, False)          # float32 + np.gradient + blur: cv2's float32 GaussianBlur, not built
     with pytest.raises(Exception):
         nm.create_normalmap(cases[0].astype(np.float16), None, None, None, False)
+
+
+@pytest.mark.gpu
+def test_integration_md_stub_runs_as_printed(gpu, oracle):
+    """The ctypes stub INTEGRATION.md shows to a maintainer of the reference (its replacement of apply_stereo_divergence,
+    src/stereoimage_generation.py:77-92) is executed exactly as printed -- only the library's file name is made absolute -- and
+    must give the oracle's bytes for every fill technique."""
+    import os
+    import re
+    import conftest
+    import src._native as nat
+    text = open(os.path.join(conftest.ROOT, "INTEGRATION.md")).read()
+    block = re.findall(r"```python\n(.*?)```", text, flags=re.S)[0]
+    assert 'ctypes.CDLL("libdepthstereo_hip.so")' in block
+    ns = {}
+    exec(compile(block.replace('"libdepthstereo_hip.so"', repr(nat.LIB_PATH)), "INTEGRATION.md", "exec"), ns)
+    rng = np.random.default_rng(77)
+    h, w = 48, 160
+    img = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+    xs = np.arange(w)[None, :]
+    ys = np.arange(h)[:, None]
+    dep = ((xs * 30000) // (w - 1) + ((xs // 8 + ys // 8) % 2) * 8000).astype(np.uint16)
+    dep[h // 4:h // 2, w // 3:2 * w // 3] = 60000
+    for fill in ("none", "naive", "naive_interpolating", "polylines_soft", "polylines_sharp"):
+        for div, sep in ((2.5, 0.0), (-4.0, 1.0)):
+            got = ns["apply_stereo_divergence"](img, dep, div, sep, 1.0, fill)
+            want = oracle.apply_stereo_divergence(img, dep, div, sep, 1.0, fill)
+            assert got.dtype == np.uint8 and np.array_equal(got, want), (fill, div, sep)
