@@ -789,3 +789,36 @@ def test_integration_md_stub_runs_as_printed(gpu, oracle):
             got = ns["apply_stereo_divergence"](img, dep, div, sep, 1.0, fill)
             want = oracle.apply_stereo_divergence(img, dep, div, sep, 1.0, fill)
             assert got.dtype == np.uint8 and np.array_equal(got, want), (fill, div, sep)
+
+
+@pytest.mark.gpu
+def test_integration_md_linear_snippet_runs_as_printed(gpu):
+    """The second block of INTEGRATION.md -- `self.act(self.fc1(x))` of the encoder's Mlp as one ds_linear call with the erf-GELU
+    in the epilogue -- is executed as printed (the names it uses are a float16 nn.Linear, its input, an output buffer and the
+    library handle of the first block) and held to x @ W.T + b -> GELU in float64 on the same rounded operands: 2e-3, the bar of the
+    kernel's own test (tests/test_gpu_models.py::test_linear_kernel_matches_float32_and_is_race_free)."""
+    import ctypes
+    import os
+    import re
+    import torch
+    import torch.nn.functional as F
+    import conftest
+    import src._native as nat
+    text = open(os.path.join(conftest.ROOT, "INTEGRATION.md")).read()
+    block = re.findall(r"```python\n(.*?)```", text, flags=re.S)[1]
+    L = ctypes.CDLL(nat.LIB_PATH)
+    ctx = ctypes.c_void_p()
+    assert L.ds_ctx_create(ctypes.byref(ctx), 0) == 0
+    torch.manual_seed(5)
+    fc1 = torch.nn.Linear(1024, 4096).half().cuda()
+    rows = 1032
+    x = torch.randn(rows, 1024).half().cuda()
+    y = torch.empty(rows, 4096, dtype=torch.float16, device="cuda")
+    ns = {"ctypes": ctypes, "torch": torch, "_L": L, "_ctx": ctx, "fc1": fc1, "x": x, "y": y, "rows": rows}
+    exec(compile(block, "INTEGRATION.md", "exec"), ns)
+    torch.cuda.synchronize()
+    assert ns["rc"] == 0
+    want = F.gelu(x.double() @ fc1.weight.double().T + fc1.bias.double())
+    err = (y.double() - want).abs().max().item()
+    assert err < 2e-3 * (1 + want.abs().max().item()), err
+    L.ds_ctx_destroy(ctx)
