@@ -232,6 +232,15 @@ int ds_attention_fwd(ds_ctx *ctx, const void *qk, const void *vt, const void *bi
 int ds_attention_bias_pack(ds_ctx *ctx, const float *bias, int H, int n, int Np, int dtype, void *packed, void *stream);
 
 /*
+ * ds_attention_reload_env -- ds_attention_fwd reads its A/B switches (DS_ATT_GEN = 2 / 4: kernel generation -- generation 4 runs
+ * one wave per SIMD with two query sub-blocks skewed inside the wave, generation 2, the default, two or three waves per SIMD;
+ * DS_ATT_TAIL = 0 / 1: query blocks with at most four live rows as GEMVs instead of tiles; DS_ATT_NQB, DS_ATT_LATE, DS_ATT_ORDER)
+ * once per process; this call reads them again.  Every setting computes the same function (dmidas/backbones/beit.py:65-91);
+ * generations 2 and 4 are bit-identical with DS_ATT_TAIL = 0.  Tests and A/B runs only.
+ */
+int ds_attention_reload_env(void);
+
+/*
  * ds_preprocess_bicubic -- image -> network input in one pass: the chain `cv2.cvtColor(.., COLOR_BGR2RGB) / 255.0`
  * (src/depthmap_generation.py:381) -> Resize(.., INTER_CUBIC) -> NormalizeImage -> PrepareForNet (:457-476, dmidas/transforms.py;
  * ddepth_anything_v2/depth_anything_v2/dpt.py:196-221) that estimatemidas / estimatedepthanything_v2 run on the host.

@@ -18,7 +18,7 @@ EXPERIMENTS = bool(os.environ.get("DS_EXPERIMENTS"))
 # the experiments build is a SECOND library beside the product one (src/_native.py loads it only when DS_NATIVE_LIB names it)
 OUT = os.path.join(HERE, "libdepthstereo_hip_experiments.so" if EXPERIMENTS else "libdepthstereo_hip.so")
 OBJ_DIR = os.path.join(HERE, "build", "experiments") if EXPERIMENTS else os.path.join(HERE, "build")
-SOURCES = ["ds_api.hip", "ds_stereo.hip", "ds_stereo_polylines.hip", "ds_normalmap.hip", "ds_attention.hip", "ds_encoder_ops.hip", "ds_boost.hip", "ds_heatmap.hip", "ds_linear.hip", "ds_gconv.hip"]
+SOURCES = ["ds_api.hip", "ds_stereo.hip", "ds_stereo_polylines.hip", "ds_normalmap.hip", "ds_attention.hip", "ds_attention4.hip", "ds_encoder_ops.hip", "ds_boost.hip", "ds_heatmap.hip", "ds_linear.hip", "ds_gconv.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-fPIC",
          "-fvisibility=hidden", "-Wall", "-Wno-unused-function",
          # MFMA results land in ordinary VGPRs (gfx950 has one unified file): no v_accvgpr_read/write around the softmax
@@ -30,6 +30,12 @@ if EXPERIMENTS:
     # DS_ATT_GEN=3, DS_LIN_ABLATE, DS_PL_DEBUG ...): some of them produce WRONG results by design, so they are compiled only on
     # request, into a library of their own, never into the default one
     FLAGS.append("-DDS_EXPERIMENTS")
+
+
+# per-file flags.  ds_attention4.hip: its phases are interleaved by hand (one MFMA, one fragment read, a share of the softmax per
+# step); the SLP vectoriser would pack the row-sum adds into v_pk_add_f32, which costs more than two plain adds beside MFMAs
+# (MI355X_MICROARCH.md, "price of one filler beside MFMAs").  Same values either way.
+EXTRA_FLAGS = {"ds_attention4.hip": ["-fno-slp-vectorize"]}
 
 
 def hipcc():
@@ -55,7 +61,7 @@ def build(force=False, verbose=True):
     os.makedirs(OBJ_DIR, exist_ok=True)
     for s in SOURCES:
         o = os.path.join(OBJ_DIR, s.replace(".hip", ".o"))
-        cmd = [hipcc()] + FLAGS + ["-c", os.path.join(CSRC, s), "-o", o]
+        cmd = [hipcc()] + FLAGS + EXTRA_FLAGS.get(s, []) + ["-c", os.path.join(CSRC, s), "-o", o]
         if verbose:
             print(" ".join(cmd), flush=True)
         procs.append((s, subprocess.Popen(cmd)))

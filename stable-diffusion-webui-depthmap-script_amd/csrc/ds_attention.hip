@@ -23,57 +23,7 @@
 // to 136 B (conflict-free ds_read_b64).  The next tile is fetched into registers (buffer loads through descriptors) while
 // the current one is computed and stashed into the other of two LDS buffers: one barrier per tile.  Workgroups are
 // ordered so that one XCD's L2 serves all query blocks of a (batch, head) and one head's bias (see the kernel).
-#include <type_traits>
-
-#include "ds_common.h"
-
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-
-#define AT_THREADS 256
-#define AT_QW 32                 // query rows per wave
-#define AT_QB (AT_QW * 4)        // query rows per workgroup
-#define AT_KB 64                 // keys per tile
-#define AT_D 64
-#define AT_VROW 136              // bytes per V^T row in LDS (128 + 8 pad)
-
-template <int BF16> struct at_traits;
-template <> struct at_traits<0> {
-    typedef _Float16 T; typedef f16x8 V8;
-    static __device__ __forceinline__ f32x16 mfma(V8 a, V8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
-    static __device__ __forceinline__ T from_f32(float x) { return (_Float16)x; }
-    static __device__ __forceinline__ float to_f32(T x) { return (float)x; }
-    // acc + a[i] + a[i+1]: v_dot2_f32_f16 against (1, 1)
-    static __device__ __forceinline__ float add2(V8 a, int i, float acc) {
-        typedef _Float16 h2 __attribute__((ext_vector_type(2)));
-        const h2 v = { a[i], a[i + 1] }, one = { (_Float16)1.0f, (_Float16)1.0f };
-        return __builtin_amdgcn_fdot2(v, one, acc, false);
-    }
-};
-template <> struct at_traits<1> {
-    typedef __bf16 T; typedef bf16x8 V8;
-    static __device__ __forceinline__ f32x16 mfma(V8 a, V8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
-    static __device__ __forceinline__ T from_f32(float x) { return (__bf16)x; }
-    static __device__ __forceinline__ float to_f32(T x) { return (float)x; }
-    static __device__ __forceinline__ float add2(V8 a, int i, float acc) { return acc + ((float)a[i] + (float)a[i + 1]); }
-};
-
-// row of the 32x32 accumulator held in register r of a lane with hi = lane >> 5 (cdna_hip_programming.md, 3. MFMA)
-__device__ __forceinline__ int at_crow(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }
-
-struct AttnParams {
-    const void *qk, *vt, *bias;
-    void *out;
-    int B, Np, H, n_valid;
-    int flags;                   // bit 0: raise the wave priority around the MFMA clusters (experiment switch)
-    int nq, total, chunk;        // query blocks per (b,h); B*H*nq; ceil(total / 8) (XCD-aware work order, see the kernel)
-    float k_logit;               // scale*log2(e): with a bias, the factor of the raw accumulator in  x = s*k_logit + bias
-    float c_exp;                 // factor inside the exponent, p = exp2((x - max x)*c_exp): scale*log2(e) without a bias,
-                                 // 1 with one (the packed bias is in log2 units)
-};
+#include "ds_attention.h"
 
 #ifdef DS_EXPERIMENTS          // the first kernel generation: A/B runs only (DS_ATT_V1=1), not in the shipped library
 template <int BF16, int HAS_BIAS>
@@ -332,19 +282,6 @@ __global__ __launch_bounds__(AT_THREADS, 3) void k_attention_fwd(AttnParams P)
 //   * K and V^T tiles use padded 144-byte rows (conflict-free ds_read_b128 for both; the XOR swizzle of version 1 left the
 //     K reads 2-way conflicted), and V^T is stored key-permuted so that a P.V fragment is ONE ds_read_b128: within every 16
 //     keys the order is [0-3, 8-11, 4-7, 12-15] -- the k-slot order the S^T accumulator hands to the P^T operand.
-// three-input maximum: IEEE-754 maximum (v_maximum3_f32 on gfx950) needs none of the canonicalising v_max instructions the
-// compiler puts in front of fmaxf() on MFMA results, and stays an ordinary VALU instruction for the scheduler
-__device__ __forceinline__ float at_max3(float a, float b, float c)
-{
-    return __builtin_elementwise_maximum(__builtin_elementwise_maximum(a, b), c);
-}
-
-#define AT2_ROW 144                     // bytes per LDS row: 64 halves + 16 pad
-#define AT2_TILE (64 * AT2_ROW)         // one K or V^T tile
-#define AT2_QW 64                       // query rows per wave
-#define AT2_QB 256                      // query rows per workgroup
-#define AT2_THR 6.0f                    // deferred-max threshold, log2 units
-
 // ABL bits below 256: the same kernel with parts compiled out (timing experiments, results are WRONG) -- instantiated only in
 // -DDS_EXPERIMENTS builds (DS_ATT_ABLATE); the shipped library has no switch that selects them.  A bit mask:
 //   1 softmax reduced to a conversion   2 no K / V^T / bias fetch, no stash after the first tile   4 no barrier in the loop
@@ -410,6 +347,16 @@ __global__ __launch_bounds__(AT_THREADS, NQB == 2 ? 2 : ((ABL & 4096) ? 4 : 3)) 
     const T *k_base = qk + (size_t)(H + h) * AT_D;
     const T *vt = (const T *)P.vt + ((size_t)b * H + h) * AT_D * (size_t)Np;
     T *out_base = (T *)P.out + (size_t)b * Np * (size_t)(H * AT_D) + (size_t)h * AT_D;
+    // a block with a handful of live rows (round 6): one GEMV per row instead of the tiled path (ds_attention.h: at_tail_rows)
+    if ((ABL & 0xff) == 0 && !(ABL & 8192)) {                   // (not in the timing ablations / the phase clock)
+        const int rows_live = P.n_valid - qblk * (128 * NQB);
+        if (rows_live > 0 && rows_live <= AT_TAIL_ROWS && Np64 <= AT_TAIL_MAXN && (P.flags & 4)) {
+            for (int row = qblk * (128 * NQB) + rows_live + (tid >> 3); row < min(Np, (qblk + 1) * (128 * NQB)); row += AT_THREADS / 8)
+                *reinterpret_cast<uint4 *>(out_base + (size_t)row * (H * AT_D) + 8 * (tid & 7)) = make_uint4(0, 0, 0, 0);
+            at_tail_rows<BF16, HAS_BIAS>(P, smem, b, h, qblk * (128 * NQB), rows_live);
+            return;
+        }
+    }
     // a wave whose rows are all padding only helps staging; its output rows are zeroed (they feed the next GEMM as ordinary
     // rows and must stay finite), rows >= Np do not exist
     const bool wave_live = q0 < P.n_valid;
@@ -1054,6 +1001,43 @@ __global__ void k_attention_bias_pack(const float *__restrict__ bias, typename a
 static constexpr int at_version() { return 2; }
 #endif
 
+// A/B switches of ds_attention_fwd, read once per process and again by ds_attention_reload_env (tests, A/B runs):
+//   DS_ATT_GEN    0 / unset: generation by shape; 2: generation 2 everywhere; 4: generation 4 everywhere
+//   DS_ATT_NQB    generation 2: 32-row query blocks per wave (1 or 2; unset: by sequence length)
+//   DS_ATT_LATE   generation 2, 32 rows per wave: late K / V^T fetch (0 / 1; unset: on without a bias)
+//   DS_ATT_ORDER  batch-fastest work order (0 / 1; unset: when one head's packed bias exceeds an L2)
+//   DS_ATT_TAIL   query blocks with <= 4 live rows as GEMVs (ds_attention.h: at_tail_rows; 0 / 1, default 1)
+struct AtEnv { int gen, nqb, late, order, tail; };
+static AtEnv g_at_env = { -1, 0, -1, -1, 1 };
+static void at_env_read()
+{
+    auto geti = [](const char *k, int d) { const char *v = getenv(k); return v && *v ? atoi(v) : d; };
+    AtEnv e;
+    e.gen = geti("DS_ATT_GEN", 0); e.nqb = geti("DS_ATT_NQB", 0); e.late = geti("DS_ATT_LATE", -1); e.order = geti("DS_ATT_ORDER", -1);
+    e.tail = geti("DS_ATT_TAIL", 1);
+    if (e.gen != 2 && e.gen != 4) e.gen = 0;
+    g_at_env = e;
+}
+static const AtEnv &at_env()
+{
+    if (g_at_env.gen < 0) at_env_read();
+    return g_at_env;
+}
+DS_API int ds_attention_reload_env(void)
+{
+    at_env_read();
+    return DS_OK;
+}
+
+// Where generation 4 is the default: nowhere.  Measured on the MI355X (profiles/round6_attention_gen4.txt, tools/att_ab.sh), f16, ms:
+//   (32, 1025, 16, bias) 0.283 generation 2 / 0.325 generation 4;  (8, 2443, 16) 0.282 / 0.281-0.303;  (8, 4097, 16, bias) 0.889 / 0.940;
+//   (32, 577, 12) 0.058 / 0.070;  (4, 1370, 16) 0.049 / 0.058.   DS_ATT_GEN=4 selects it (A/B runs, tests).
+static bool at4_wanted(int B, int Np, int H, int n_valid, bool with_bias)
+{
+    (void)B; (void)Np; (void)H; (void)n_valid; (void)with_bias;
+    return false;
+}
+
 DS_API int ds_attention_bias_pack(ds_ctx *ctx, const float *bias, int H, int n, int Np, int dtype, void *packed, void *stream)
 {
     DS_REQUIRE(ctx && bias && packed, DS_EINVAL, "ds_attention_bias_pack: null argument");
@@ -1119,18 +1103,20 @@ DS_API int ds_attention_fwd(ds_ctx *ctx, const void *qk, const void *vt, const v
         // Late fetch (option 4096: K / V^T of the next tile requested after S, 4 waves per SIMD) A/B on one box, 32 rows per
         // wave: N = 577: 0.064 -> 0.060, N = 1370: 0.404 -> 0.387, N = 2443: 0.272 -> 0.254 (vs 0.261 for 64 rows), no bias;
         // with bias it loses (N = 1025: 0.291 -> 0.300) and at N = 4097 64 rows per wave stay ahead (0.911 vs 0.946).
-        static const int nqb_env = getenv("DS_ATT_NQB") ? atoi(getenv("DS_ATT_NQB")) : 0;
-        const int nqb = (nqb_env == 1 || nqb_env == 2) ? nqb_env : (Np <= (bias ? 1280 : 2560) ? 1 : 2);
+        const AtEnv &E = at_env();
+        // Generation 4 (ds_attention4.hip: one wave per SIMD, two 32-query sub-blocks skewed inside the wave, 256 rows per
+        // workgroup) where its geometry fills the chip; DS_ATT_GEN=2 / 4 overrides (ds_attention_reload_env: A/B runs and tests).
+        // The two generations are bit-identical (same arithmetic per 32-query sub-block, another order of independent operations).
+        const bool gen4 = E.gen == 4 || (E.gen == 0 && at4_wanted(B, Np, H, n_valid, bias != nullptr));
+        const int nqb = gen4 ? 2 : ((E.nqb == 1 || E.nqb == 2) ? E.nqb : (Np <= (bias ? 1280 : 2560) ? 1 : 2));
         P.nq = (Np + 128 * nqb - 1) / (128 * nqb);
         P.total = P.nq * H * B;
         P.chunk = (P.total + 7) / 8;
         dim3 grid2(8 * P.chunk);
         hipStream_t st2 = (hipStream_t)stream;
-        static const int late_env = getenv("DS_ATT_LATE") ? atoi(getenv("DS_ATT_LATE")) : -1;        // A/B switch, see option 4096
-        const int late = late_env >= 0 ? late_env : (bias ? 0 : 1);
+        const int late = E.late >= 0 ? E.late : (bias ? 0 : 1);                 // A/B switch DS_ATT_LATE, see option 4096
         // batch-fastest work order when one head's packed bias exceeds an L2 (see the kernel); DS_ATT_ORDER=0/1 overrides
-        static const int order_env = getenv("DS_ATT_ORDER") ? atoi(getenv("DS_ATT_ORDER")) : -1;
-        const int batch_fastest = order_env >= 0 ? order_env : (bias && B > 1 && (size_t)Np * Np * 2 > (size_t)(3u << 20) ? 1 : 0);
+        const int batch_fastest = E.order >= 0 ? E.order : (bias && B > 1 && (size_t)Np * Np * 2 > (size_t)(3u << 20) ? 1 : 0);
 #ifdef DS_EXPERIMENTS
         static const int ablate = (getenv("DS_ATT_ABLATE") ? atoi(getenv("DS_ATT_ABLATE")) : 0)    // timing experiments, wrong results
                                   | (getenv("DS_ATT_OPT") ? atoi(getenv("DS_ATT_OPT")) : 0);        // options, correct results
@@ -1162,8 +1148,10 @@ DS_API int ds_attention_fwd(ds_ctx *ctx, const void *qk, const void *vt, const v
             else hipLaunchKernelGGL((k_attention_fwd2<BF_, BI_, 2, 256>), grid2, dim3(AT_THREADS), 0, st2, P);          \
         } while (0)
         if (batch_fastest) P.flags |= 2;
+        if (E.tail) P.flags |= 4;
         const int kt = ds_kt_begin(ctx, DS_KT_ATTENTION, st2);
-        if (dtype == DS_DTYPE_F16) { if (bias) A2_LAUNCH(0, 1); else A2_LAUNCH(0, 0); }
+        if (gen4) at4_launch(P, dtype == DS_DTYPE_BF16, bias != nullptr, grid2, st2);
+        else if (dtype == DS_DTYPE_F16) { if (bias) A2_LAUNCH(0, 1); else A2_LAUNCH(0, 0); }
         else { if (bias) A2_LAUNCH(1, 1); else A2_LAUNCH(1, 0); }
         ds_kt_end(ctx, DS_KT_ATTENTION, kt, st2);
         DS_HIP_CHECK(hipGetLastError());

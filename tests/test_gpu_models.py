@@ -104,6 +104,53 @@ def test_attention_tight_token_stride(gpu, b, n_valid, h, with_bias, stride):
     assert got.shape == (b, npad, h * 64) and torch.isfinite(got.float()).all()
 
 
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("b,n_valid,h,with_bias,stride", [
+    (2, 1025, 16, True, 1032),        # the metric's shape (one (batch, head) = 4 full workgroups + one with a single live row)
+    (1, 2443, 16, False, 2448),       # config 5: the last workgroup has three live waves, 11 keys in the last tile
+    (1, 4097, 4, True, 4104),         # NET_SIZE_MATCH: 65 tiles
+    (2, 577, 12, False, 584), (1, 1370, 16, False, 1376),
+    (3, 1, 1, True, 8), (2, 63, 2, False, 64), (1, 64, 3, True, 64), (2, 65, 2, True, 72), (2, 128, 1, False, 128),
+    (1, 129, 2, True, 136), (2, 256, 2, True, 256), (1, 257, 2, False, 264), (1, 300, 3, True, 304), (2, 191, 6, True, 192),
+])
+def test_attention_generation4_is_generation2_reordered(gpu, dtype, b, n_valid, h, with_bias, stride):
+    """Generation 4 of the attention kernel (csrc/ds_attention4.hip: one wave per SIMD, two query sub-blocks skewed by half a tile
+    inside the wave; opt-in, DS_ATT_GEN=4) restates generation 2's arithmetic in another order of INDEPENDENT operations: with
+    the tiled path on every block (DS_ATT_TAIL=0) the outputs are bit-identical, pad rows included, on every tile-count corner
+    (one tile, one key in the last tile, a full last tile, one live row in the last workgroup, dead waves), with keys far
+    above the rest in several tiles (the deferred maximum is raised mid-sequence) and junk in the pad rows.  With the GEMV
+    tail blocks (the default, ds_attention.h: at_tail_rows) both meet the float32 definition
+    (dmidas/backbones/beit.py:65-91)."""
+    from src import vit_mi355x as vm
+    from src import _native
+    qk, vt, bias, npad = _case(b, n_valid, h, dtype, 6000 + n_valid, with_bias, stride=stride)
+    packed, padded = None, None
+    if bias is not None:
+        packed = _native.attention_bias_pack(bias, npad, dtype)
+        padded = torch.zeros((h, npad, npad), device='cuda')
+        padded[:, :n_valid, :n_valid] = bias
+    if npad > n_valid:
+        qk[:, n_valid:, 1] = 300.0
+        vt[:, :, n_valid:] = -250.0
+    for t in range(0, n_valid, 97):
+        qk[:, t, 1] *= 3.0
+    out = {}
+    try:
+        for gen, tail in ((2, 0), (4, 0), (2, 1), (4, 1)):
+            # generation 2 with 32 rows per wave: the instantiation the metric's shape runs
+            _native.attention_env(DS_ATT_GEN=gen, DS_ATT_TAIL=tail, DS_ATT_NQB=1 if gen == 2 else None)
+            out[gen, tail] = _native.attention_fwd(qk, vt, n_valid, 0.125, packed).clone()
+    finally:
+        _native.attention_env(DS_ATT_GEN=None, DS_ATT_TAIL=None, DS_ATT_NQB=None)
+    assert torch.equal(out[2, 0].view(torch.int16), out[4, 0].view(torch.int16)), (out[2, 0].float() - out[4, 0].float()).abs().max().item()
+    want = vm.attention_reference(qk.float(), vt.float(), n_valid, 0.125, padded)
+    tol = (4e-3 if dtype == torch.float16 else 3e-2) if bias is None else (1e-2 if dtype == torch.float16 else 1e-1)
+    for key, got in out.items():
+        assert torch.isfinite(got.float()).all(), key
+        err = (got.float()[:, :n_valid] - want[:, :n_valid]).abs().max().item()
+        assert err < tol, (key, dtype, n_valid, err)
+
+
 def test_attention_masks_pad_keys(gpu):
     """Changing K / V^T of the pad keys must not change any real row."""
     from src import _native
