@@ -704,9 +704,15 @@ __global__ __launch_bounds__(LN_THREADS, S == 3 ? 4 : 2) void k_linear_ragged(Li
         offA[ks] = (unsigned)(br * 32 + l31) * 128u + sl;
         offB[ks] = 16384u + (unsigned)(bc * 32 + l31) * 128u + sl;
     }
-    lf32x16 mine, mine2;
+    // ONE accumulation chain, the 16-wide slices of K in ascending order: exactly the chain of k_linear256's accumulators (same
+    // instruction, same operand order).  Round 6: an output row's value must not depend on whether its tile falls into the main
+    // rounds or the ragged one -- the units of a batch are independent images (reference: batch 1, src/core.py:133), and the same
+    // image at units 0 and 31 of a batch of 32 has to come out bit-identical (rounds 3-5 ran two chains per K-tile here, even / odd
+    // slices summed at the end: another fp32 order, 3.2e-3 of the depth range after 24 blocks).  Price: the four MFMAs of a K-tile
+    // are dependent (~64 cycles each instead of two chains of two).
+    lf32x16 mine;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) mine[r] = mine2[r] = 0.f;
+    for (int r = 0; r < 16; ++r) mine[r] = 0.f;
 
     // epilogue operands of this wave's 32 x 32 block (see the epilogue below): with PIPE they are requested here, ahead of every
     // DMA (vmcnt retires in order: they are the oldest entries, the counted waits of the loop are unaffected)
@@ -747,9 +753,9 @@ __global__ __launch_bounds__(LN_THREADS, S == 3 ? 4 : 2) void k_linear_ragged(Li
             RG_READ(na_, nb_, (kt_) + 1);                                                                                \
             __builtin_amdgcn_sched_barrier(0);                                                                           \
             mine = TR::mfma(cb_[0], ca_[0], mine);                                                                       \
-            mine2 = TR::mfma(cb_[1], ca_[1], mine2);                                                                     \
+            mine = TR::mfma(cb_[1], ca_[1], mine);                                                                       \
             mine = TR::mfma(cb_[2], ca_[2], mine);                                                                       \
-            mine2 = TR::mfma(cb_[3], ca_[3], mine2);                                                                     \
+            mine = TR::mfma(cb_[3], ca_[3], mine);                                                                       \
             __builtin_amdgcn_sched_barrier(0);                                                                           \
             LN_WAIT_LGKM0();                                                                                             \
             __builtin_amdgcn_sched_barrier(0);                                                                           \
@@ -775,8 +781,8 @@ __global__ __launch_bounds__(LN_THREADS, S == 3 ? 4 : 2) void k_linear_ragged(Li
         LN_BARRIER();
         RG_STAGE(kt + S - 1);                            // into the slot of K-tile kt - 1
         const unsigned char *sb = lds + (kt % S) * RG_SLOT;
-        // all 8 fragment reads in flight at once, ONE wait, then two independent accumulation chains (a dependent MFMA
-        // costs its full 64-cycle latency; the first version -- read two, wait, one MFMA, four times -- spent 0.64 us per K-tile)
+        // all 8 fragment reads in flight at once, ONE wait, then the accumulation chain (the first version -- read two, wait,
+        // one MFMA, four times -- spent 0.64 us per K-tile)
         V8 fa[4], fb[4];
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
@@ -787,13 +793,11 @@ __global__ __launch_bounds__(LN_THREADS, S == 3 ? 4 : 2) void k_linear_ragged(Li
         LN_WAIT_LGKM0();
         __builtin_amdgcn_sched_barrier(0);
         mine = TR::mfma(fb[0], fa[0], mine);
-        mine2 = TR::mfma(fb[1], fa[1], mine2);
+        mine = TR::mfma(fb[1], fa[1], mine);
         mine = TR::mfma(fb[2], fa[2], mine);
-        mine2 = TR::mfma(fb[3], fa[3], mine2);
+        mine = TR::mfma(fb[3], fa[3], mine);
     }
     LN_WAIT_VM(0);                                       // the trailing re-loads: nothing may still be writing LDS at exit
-#pragma unroll
-    for (int r = 0; r < 16; ++r) mine[r] += mine2[r];
 #undef RG_STAGE
 
     // ---- K split: every workgroup of a piece leaves its fp32 partial in its own slot of the workspace ([wave][16][64 lanes]),
@@ -912,12 +916,13 @@ __global__ __launch_bounds__(LN_THREADS, S == 3 ? 4 : 2) void k_linear_ragged(Li
 
 // ---- C ABI -------------------------------------------------------------------------------------------------------------
 // A/B switches of the GEMM path, read from the environment ONCE (hundreds of launches per forward; ds_linear_reload_env re-reads
-// them: the tests flip them inside one process).  None of them changes a result.
+// them: the tests flip them inside one process).  None of them changes a result, except DS_LIN_RAGGED_KSPLIT > 1.
 //   DS_LIN_EARLY    1 (default) the next tile's prologue DMAs are issued before the epilogue, 0 after it
 //   DS_LIN_GRID     number of persistent workgroups (default: one per CU)
 //   DS_LIN_RAGGED / DS_LIN_RAGGED_DEN / DS_LIN_RAGGED_RING   the ragged round: on / "at most 1/DEN full" / ring depth 3 or 6
-//   DS_LIN_RAGGED_KSPLIT   the ragged round: at most this many workgroups share the K range of a piece (default 8, 1 = no split;
-//                          the values differ by the fp32 summation order, like every other split of a contraction), for
+//   DS_LIN_RAGGED_KSPLIT   the ragged round: at most this many workgroups share the K range of a piece.  Default 1 = no split since
+//                          round 6: a split sums in another fp32 order than the main rounds' single chain, so a row's value would
+//                          depend on where in the batch its image sits (8 = rounds 4-5: fc2 at batch 32 -16 us per launch), for
 //   DS_LIN_RAGGED_PIPE     the ragged round (deep ring): 1 (default) software-pipelined fragment reads + early epilogue operands
 //   DS_LIN_RAGGED_KSPLIT_MIN / _KEEP   contractions of at least MIN K-tiles (default 32), every workgroup keeping >= KEEP (default 8)
 struct LinOptions { int early, grid, ragged, ragged_den, ragged_ring, ragged_ksplit, ragged_ksplit_min, ragged_ksplit_keep, ragged_pipe; };
@@ -932,7 +937,7 @@ static void ln_read_options()
     o.ragged = geti("DS_LIN_RAGGED", 1);
     o.ragged_den = geti("DS_LIN_RAGGED_DEN", 4);
     o.ragged_ring = geti("DS_LIN_RAGGED_RING", 0);
-    o.ragged_ksplit = geti("DS_LIN_RAGGED_KSPLIT", 8);
+    o.ragged_ksplit = geti("DS_LIN_RAGGED_KSPLIT", 1);
     o.ragged_ksplit_min = geti("DS_LIN_RAGGED_KSPLIT_MIN", 32);
     o.ragged_ksplit_keep = geti("DS_LIN_RAGGED_KSPLIT_KEEP", 8);
     if (o.ragged_ksplit_keep < 1) o.ragged_ksplit_keep = 1;

@@ -57,6 +57,8 @@ class PatchEmbed(nn.Module):
         self.proj = nn.Conv2d(in_chans, embed_dim, kernel_size=patch_size, stride=patch_size)
 
     def forward(self, x):               # B C H W -> B HW C   (patch_embed.py:69-83)
+        if vm.patch_embed_hip_ok(self.proj, x):
+            return vm.patch_embed_tokens(self.proj, x)
         return self.proj(x).flatten(2).transpose(1, 2)
 
 

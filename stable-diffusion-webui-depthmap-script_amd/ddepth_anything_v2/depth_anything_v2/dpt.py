@@ -124,6 +124,7 @@ class DepthAnythingV2(nn.Module):
         self.pretrained = DINOv2(model_name=encoder)
         self.depth_head = DPTHead(self.pretrained.embed_dim, features, use_bn, out_channels=out_channels, use_clstoken=use_clstoken)
 
+    @vm.deterministic_forward
     def forward(self, x):               # dpt.py:176-184
         patch_h, patch_w = x.shape[-2] // 14, x.shape[-1] // 14
         features = self.pretrained.get_intermediate_layers(x, self.intermediate_layer_idx[self.encoder], return_class_token=True)

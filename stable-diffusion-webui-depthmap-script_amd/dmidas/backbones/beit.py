@@ -179,6 +179,8 @@ class PatchEmbed(nn.Module):
         self.proj = nn.Conv2d(3, embed_dim, kernel_size=patch_size, stride=patch_size)
 
     def forward(self, x):               # beit.py:18-27: any input size
+        if vm.patch_embed_hip_ok(self.proj, x):
+            return vm.patch_embed_tokens(self.proj, x)
         return self.proj(x).flatten(2).transpose(1, 2)
 
 
@@ -261,7 +263,13 @@ class ProjectReadout(nn.Module):       # utils.py:28-39
         w_tok, w_cls = self._split()
         if (self.start_index == 1 and vm.READOUT_HIP and vm.LINEAR_HIP == "all" and vm.half_on_gpu(xp) and xp.is_contiguous()
                 and _native.linear_readout_supported(xp, w_tok) and vm.hip_gemm_ok(xp.shape[0] * xp.shape[1], w_tok.shape[0])):
-            clsvec = F.linear(xp[:, 0], w_cls, self.project[0].bias)         # [B, C]: one small library GEMM
+            # [B, C]: the cls half of the projection.  In-tree as well (rows padded to one 256-row tile): a library GEMM picks its
+            # kernel -- and its summation order -- by the batch size, and the same image would come out differently at batch 8 and 32
+            x0 = xp[:, 0].contiguous()
+            if vm.INVARIANT and _native.linear_supported(x0, w_cls):
+                clsvec = _native.linear(x0, w_cls, self.project[0].bias)
+            else:
+                clsvec = F.linear(x0, w_cls, self.project[0].bias)
             return _native.linear_readout(xp, n_valid, w_tok, clsvec)
         return self.forward(xp[:, :n_valid])
 

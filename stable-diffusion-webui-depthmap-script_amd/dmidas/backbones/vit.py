@@ -225,10 +225,11 @@ class VisionTransformer(nn.Module):
         if self.hybrid:
             feats = self.patch_embed.backbone.forward_stages(x)
             stage_outs = feats[:n_stage_taps]
-            t = self.patch_embed.proj(feats[-1])
+            t = self.patch_embed.proj(feats[-1]).flatten(2).transpose(1, 2)
+        elif vm.patch_embed_hip_ok(self.patch_embed.proj, x):
+            t = vm.patch_embed_tokens(self.patch_embed.proj, x)
         else:
-            t = self.patch_embed.proj(x)
-        t = t.flatten(2).transpose(1, 2)
+            t = self.patch_embed.proj(x).flatten(2).transpose(1, 2)
         t = torch.cat((self.cls_token.expand(b, -1, -1).to(t.dtype), t), dim=1)
         t = t + self.resized_pos_embed(grid[0], grid[1], t.dtype)
         n_valid = t.shape[1]

@@ -163,6 +163,7 @@ class DPTDepthModel(DPT):
             parameters = parameters["model"]
         self.load_state_dict(parameters, strict=False)     # timm's non-persistent buffers may or may not be in the file
 
+    @vm.deterministic_forward
     def forward(self, x, features=None):
         return super().forward(x, features).squeeze(dim=1)
 

@@ -26,6 +26,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from dmidas.dpt_depth import DPTDepthModel, _constrain, midas_net_size
+from src import vit_mi355x as vm
 
 _MIDAS_BACKBONES = {"DPT_BEiT_L_384": "beitl16_384", "DPT_BEiT_L_512": "beitl16_512", "DPT_BEiT_B_384": "beitb16_384",
                     "DPT_Large": "vitl16_384", "DPT_Hybrid": "vitb_rn50_384"}
@@ -293,6 +294,7 @@ class ZoeDepth(_DepthModel):
         self.conditional_log_binomial = ConditionalLogBinomial(32 + 1, bin_embedding_dim, n_classes=n_bins, min_temp=min_temp,
                                                                max_temp=max_temp)
 
+    @vm.deterministic_forward
     def forward(self, x, return_final_centers=False, return_probs=False):
         rel_depth, feats = self.core(x)
         outconv, btlnck, blocks = feats[0], feats[1], feats[2:]
@@ -357,6 +359,7 @@ class ZoeDepthNK(_DepthModel):
             c['name']: ConditionalLogBinomial(32, bin_embedding_dim, c['n_bins'], bottleneck_factor=4, min_temp=min_temp,
                                               max_temp=max_temp) for c in self.bin_conf})
 
+    @vm.deterministic_forward
     def forward(self, x, return_final_centers=False, return_probs=False):
         rel_depth, feats = self.core(x)
         outconv, btlnck, blocks = feats[0], feats[1], feats[2:]

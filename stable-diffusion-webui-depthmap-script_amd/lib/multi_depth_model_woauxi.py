@@ -226,6 +226,7 @@ class DepthModel(nn.Module):
         self.encoder_modules = _Encoder()
         self.decoder_modules = Decoder()
 
+    @vm.deterministic_forward
     def forward(self, x):
         if x.is_cuda:
             x = x.contiguous(memory_format=torch.channels_last)

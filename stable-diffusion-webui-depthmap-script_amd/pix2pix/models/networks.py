@@ -13,6 +13,8 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from src import vit_mi355x as vm
+
 
 class _Identity(nn.Module):
     def forward(self, x):
@@ -75,6 +77,7 @@ class UnetGenerator(nn.Module):
             b = b.submodule
         return out
 
+    @vm.deterministic_forward
     def forward(self, x):
         lv = self.levels()
         if x.is_cuda:

@@ -1167,7 +1167,7 @@ def test_linear_vt_and_fused_fc2_at_benchmark_shapes(gpu, npad):
     w1, b1 = (torch.randn((4096, 1024), generator=g) / 32).half().cuda(), torch.randn(4096, generator=g).half().cuda()
     first = None
     try:
-        _native.linear_env(DS_LIN_RAGGED_KSPLIT_MIN="1", DS_LIN_RAGGED_KSPLIT_KEEP="2")  # split the K = 1024 launches too (8 / 8 / 4 / 2 ways)
+        _native.linear_env(DS_LIN_RAGGED_KSPLIT="8", DS_LIN_RAGGED_KSPLIT_MIN="1", DS_LIN_RAGGED_KSPLIT_KEEP="2")  # split the K = 1024 launches too (8 / 8 / 4 / 2 ways)
         for _ in range(3):
             outs = (_native.linear_residual(a, w2, b2, gam, res), _native.linear(x1, w1, b1, True), _native.linear_vt(wv, h),
                     _native.linear(x1, w1[:2048].contiguous(), b1[:2048].contiguous(), False))
@@ -1179,7 +1179,17 @@ def test_linear_vt_and_fused_fc2_at_benchmark_shapes(gpu, npad):
                  _native.linear(x1, w1[:2048].contiguous(), b1[:2048].contiguous(), False))
     finally:
         _native.linear_env(DS_LIN_RAGGED_KSPLIT=None, DS_LIN_RAGGED_KSPLIT_MIN=None, DS_LIN_RAGGED_KSPLIT_KEEP=None)
-    assert torch.equal(_native.linear_residual(a, w2, b2, gam, res), first[0])             # the default splits K = 4096 the same way
+    # the default (round 6): NO K split, and the ragged round runs the main rounds' accumulation chain -- a row's value does not depend
+    # on the round its tile falls into: bit-identical to the same launch with every tile sent through the main kernel
+    assert torch.equal(_native.linear_residual(a, w2, b2, gam, res), plain[0])
+    try:
+        _native.linear_env(DS_LIN_RAGGED="0")
+        main_only = (_native.linear_residual(a, w2, b2, gam, res), _native.linear(x1, w1, b1, True), _native.linear_vt(wv, h),
+                     _native.linear(x1, w1[:2048].contiguous(), b1[:2048].contiguous(), False))
+    finally:
+        _native.linear_env(DS_LIN_RAGGED=None)
+    for o, f in zip(plain, main_only):
+        assert torch.equal(o, f), "the ragged round and the main rounds sum in different orders"
     if npad == 1032:                                         # 516 / 1032 / 2064 tiles: ragged rounds of 4 / 8 / 16 tiles
         assert not all(torch.equal(o, f) for o, f in zip(plain, first)), "the K split was not taken at the benchmark shapes"
     for o, f in zip(plain, first):
@@ -1477,7 +1487,7 @@ def test_linear_ragged_ksplit_stress_small_grid(gpu):
         b = torch.randn((n,), generator=g).half().cuda()
         ops.append((x, w, b))
     try:
-        _native.linear_env(DS_LIN_GRID=64, DS_LIN_RAGGED_KSPLIT_MIN="1", DS_LIN_RAGGED_KSPLIT_KEEP="2", DS_LIN_RAGGED_DEN="2")
+        _native.linear_env(DS_LIN_GRID=64, DS_LIN_RAGGED_KSPLIT="8", DS_LIN_RAGGED_KSPLIT_MIN="1", DS_LIN_RAGGED_KSPLIT_KEEP="2", DS_LIN_RAGGED_DEN="2")
         first = [None, None]
         for it in range(60):
             i = it & 1
@@ -1502,8 +1512,8 @@ def test_dpt_beit_large_512_at_the_metrics_batch_is_pinned_on_three_units(gpu):
     only): dpt_beit_large_512 at 512^2, BATCH 32, float16 -- the launch shapes bench.py times (33 024 padded token rows: 129 row
     panels, fc1 2064 tiles with its ragged round, 4096 / 2048-tile transposed convolutions, the read-out on 129 x 4 tiles).  The
     golden image sits at units 0, 13 and 31 (first, middle, last: first / middle / last row panels and the shifted last panel),
-    the other units are flips / rolls of it: each of the three against the reference's own float32 output at 2e-2, bit-identical
-    to each other (the units of a batch are independent), every unit against library routing."""
+    the other units are flips / rolls of it: each of the three against the reference's own float32 output at 2e-2, BIT-IDENTICAL
+    to each other (the units of a batch are independent: asserted since round 6), every unit against library routing."""
     from dmidas.dpt_depth import DPTDepthModel
     from src import _native
     from src import vit_mi355x as vm
@@ -1526,12 +1536,22 @@ def test_dpt_beit_large_512_at_the_metrics_batch_is_pinned_on_three_units(gpu):
     for u in (0, 13, 31):
         e = np.abs(y[u:u + 1, ::2, ::2].cpu().numpy() - ref).max() / scale
         assert e < 2e-2, (u, e)
-    # the same image at three positions of the batch: units 0 and 13 sit in full rounds of every GEMM and come out bit-identical
-    # (measured: 0.0); unit 31's last tokens fall into the ragged round, whose K split sums in another fp32 order -- 3.2e-3 of the
-    # output range after 24 blocks, float16 noise (the two float16 routings of the whole network differ by more, below)
+    # the same image at three positions of the batch comes out BIT-IDENTICAL (round 6): units 0 and 13 sit in full rounds of every
+    # GEMM, unit 31's last tokens fall into the ragged round, which now runs the main rounds' accumulation chain (rounds 4-5: a K
+    # split and two chains per K-tile -- another fp32 order, 3.2e-3 of the output range after 24 blocks).  The reference processes
+    # one image at a time (src/core.py:133): an image's depth must not depend on its neighbours or its position.
     d13, d31 = (y[13] - y[0]).abs().max().item(), (y[31] - y[0]).abs().max().item()
     print(f"same image at units 0 / 13 / 31 of a batch of 32: max |difference| {d13:.3e} / {d31:.3e} of range {scale:.3f}")
-    assert d13 < 1e-2 * scale and d31 < 1e-2 * scale, (d13, d31)
+    assert d13 == 0.0 and d31 == 0.0, (d13, d31)
+    # ... nor on the SIZE of the batch (strong scaling: the same 32 units split over 1 / 2 / 4 / 8 ranks), nor on the
+    # launch: the forward of this network has no library convolution or GEMM left (vit_mi355x.INVARIANT: every convolution and the
+    # read-out's cls vector through the in-tree GEMM, one accumulation chain per output element) -- units 24..31 alone, as a batch
+    # of 8, and a second launch of the batch of 32, bit for bit
+    with torch.no_grad():
+        y8 = m(x[24:32].contiguous(memory_format=torch.channels_last)).float()
+        y_again = m(x).float()
+    assert torch.equal(y8, y[24:32]), (y8 - y[24:32]).abs().max().item()
+    assert torch.equal(y_again, y), (y_again - y).abs().max().item()
     with torch.no_grad(), vm.library_routing():
         y_lib = m(x[:8]).float()
     e_lib = ((y[:8] - y_lib).abs().flatten(1).max(1).values / y_lib.abs().flatten(1).max(1).values).max().item()
