@@ -213,13 +213,21 @@ def selftest_launch(args):
     import torch.distributed as dist
     from src import multigpu
     rank, world, _ = dist_setup("gloo")
-    batch = args.batch or 2
+    strong = args.scaling == "strong"
+    global_batch = args.batch or (12 if strong else 2)
+    if strong and global_batch % world:
+        raise SystemExit(f"--scaling strong: {global_batch} units do not split evenly over {world} ranks")
+    batch = global_batch // world if strong else global_batch
 
-    def render(r):
-        rng = np.random.default_rng(1000 + r)
-        sbs = torch.from_numpy(rng.integers(0, 256, (batch, 4, 16, 3), dtype=np.uint8))
-        d16 = torch.from_numpy(rng.integers(0, 65536, (batch, 4, 8), dtype=np.uint16))
-        return multigpu.pack_collated([sbs, d16])
+    def pattern(n, seed):
+        rng = np.random.default_rng(seed)
+        return (torch.from_numpy(rng.integers(0, 256, (n, 4, 16, 3), dtype=np.uint8)), torch.from_numpy(rng.integers(0, 65536, (n, 4, 8), dtype=np.uint16)))
+
+    def render(r):                                               # strong: the shard of ONE seeded job; weak: the rank's own units
+        if strong:
+            sbs, d16 = pattern(global_batch, 1000)
+            return multigpu.pack_collated([sbs[r * batch:(r + 1) * batch], d16[r * batch:(r + 1) * batch]])
+        return multigpu.pack_collated(list(pattern(batch, 1000 + r)))
     packed, layout = render(rank)
     gathered = [torch.empty_like(packed) for _ in range(world)] if rank == 0 else None
     if world > 1:
@@ -232,13 +240,19 @@ def selftest_launch(args):
         dist.barrier()
     elapsed = max_over_ranks(time.perf_counter() - t0, world)
     if rank == 0:
+        import hashlib
         check = None
         if world > 1:
             check = compare_gathered(gathered[world - 1], render(world - 1)[0], layout, exact=True)
             check["rank"] = world - 1
+        parts = gathered if (world > 1 and strong) else [packed]
+        hsh = hashlib.sha256()
+        for t in parts:
+            hsh.update(t.numpy().tobytes())
         print(json.dumps({"metric": "selftest: launcher + gather plumbing (no kernel)", "value": batch * world * args.steps / max(elapsed, 1e-9),
                           "unit": "units/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "selftest": True,
-                          "gather_check": check}))
+                          "scaling": args.scaling, "gather_check": check,
+                          "outputs_sha256": {"sha256": hsh.hexdigest(), "units": sum(int(t.shape[0]) for t in parts)}}))
     if world > 1:
         dist.destroy_process_group()
 
@@ -542,7 +556,11 @@ def parse_args(argv=None):
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--config", default="c3", choices=["c2", "c3", "c3match", "c4", "c5"], help="BASELINE.json config preset (see the header)")
-    ap.add_argument("--batch", type=int, default=None, help="units per GPU per step")
+    ap.add_argument("--batch", type=int, default=None, help="units per GPU per step (--scaling strong: units per step of the whole job)")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak (default): every rank renders its own --batch units; strong: the SAME --batch units (BASELINE.md 3: 'identical "
+                         "batch run on 1/2/4/8 GPUs') are split over the ranks in contiguous shards -- the gathered bytes do not depend on "
+                         "the number of ranks (outputs_sha256)")
     ap.add_argument("--model", default=None, choices=["dav2_vitl", "dpt_beit_large_512", "dpt_hybrid_384", "none"])
     ap.add_argument("--height", type=int, default=None)
     ap.add_argument("--width", type=int, default=None)
@@ -632,7 +650,18 @@ def run_pipeline(args):
     from src import multigpu
     from src import vit_mi355x as vm
 
-    img_np, pred_np = synth_batch(batch, seed=1000 + rank)
+    strong = args.scaling == "strong"
+    global_batch = batch
+    if strong:
+        # the same units whatever the number of ranks: rank r renders the contiguous shard [r * batch, (r + 1) * batch) of them
+        if global_batch % world:
+            raise SystemExit(f"--scaling strong: {global_batch} units do not split evenly over {world} ranks")
+        batch = global_batch // world
+        g_img, g_pred = synth_batch(global_batch, seed=1000)
+        shard = lambda r: (g_img[r * batch:(r + 1) * batch], g_pred[r * batch:(r + 1) * batch])      # noqa: E731
+    else:
+        shard = lambda r: synth_batch(batch, seed=1000 + r)                                          # noqa: E731
+    img_np, pred_np = shard(rank)
     img = torch.from_numpy(img_np).to(dev)
     pred_in = torch.from_numpy(pred_np).to(dev)
     nat.profile_enable(local_rank, True)
@@ -770,7 +799,7 @@ def run_pipeline(args):
     if gather_ok and rank == 0:
         torch.cuda.synchronize()
         side.synchronize()
-        o_img_np, o_pred_np = synth_batch(batch, seed=1000 + world - 1)
+        o_img_np, o_pred_np = shard(world - 1)
         o_img = torch.from_numpy(o_img_np).to(dev)
         with torch.no_grad():
             o_pred = render(o_img, torch.from_numpy(o_pred_np).to(dev), None)
@@ -789,6 +818,30 @@ def run_pipeline(args):
                                 + ("; identity asserted" if exact else "; DS_DETERMINISTIC=0: MIOpen's split-K solvers are not "
                                    "bit-reproducible between launches, fractions reported instead of asserting identity"))
         del o_img, o_pred, o_d16, o_sbs, o_parts, want
+
+    # outputs_sha256 (untimed): SHA-256 of the collated bytes (stereo pair | uint16 depth | normal map, unit by unit) of the last step
+    # -- strong scaling: of ALL units in rank order, i.e. the same digest on 1 / 2 / 4 / 8 GPUs ("outputs must be byte-identical
+    # across GPU counts"); weak scaling: of rank 0's units, whose inputs do not depend on the number of ranks either
+    outputs_sha256 = None
+    if rank == 0:
+        import hashlib
+        hsh = hashlib.sha256()
+        if gather_ok and strong:
+            for r in range(world):
+                hsh.update(gathered[r].cpu().numpy().tobytes())
+        else:
+            o_sbs, o_nmap, o_d16 = step()
+            torch.cuda.synchronize()
+            if side is not None:
+                side.synchronize()
+            own, _ = multigpu.pack_collated([o_sbs, o_d16] + ([o_nmap] if normalmap else []))
+            hsh.update(own.cpu().numpy().tobytes())
+            del o_sbs, o_nmap, o_d16, own
+        outputs_sha256 = {"sha256": hsh.hexdigest(), "of": ("all units of the job, rank order" if (gather_ok and strong) else "the units of rank 0"),
+                          "units": (global_batch if (gather_ok and strong) else batch)}
+    elif world > 1 and not (gather_ok and strong):
+        step()                                                  # (the ranks stay in step with rank 0's extra render: its gather is collective)
+        torch.cuda.synchronize()
 
     roofs, conv_roof = {}, None
     if model is not None:
@@ -848,13 +901,14 @@ def run_pipeline(args):
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": args.scaling,
             "vs_baseline": None,
             "dtype": "f16 (network) / f64 (stereo, normal map)" if model is not None else "f64",
             "data": "synthetic",
             "config": {"workload": f"BASELINE config {args.config}: {wl}depth->u16 + create_stereoimages({args.fill}, left-right, "
                                    f"divergence 2.5%)" + (" + create_normalmap (Sobel 3)" if normalmap else "")
-                                   + f" on {batch} x {W}x{H} RGB per GPU, inputs resident in HBM"
+                                   + (f" on the same {global_batch} x {W}x{H} RGB split over the GPUs ({batch} per GPU), inputs resident in HBM" if strong
+                                      else f" on {batch} x {W}x{H} RGB per GPU, inputs resident in HBM")
                                    + ("" if model is not None else "; float32 depth prediction is a synthetic input (--model none)"),
                        "depth_network": model_name, "units_per_step": batch * world, "height": H, "width": W,
                        "network_precision_vs_reference": "fp16 = the reference's GPU default; held to 2e-2 of its float32 output "
@@ -904,6 +958,7 @@ def run_pipeline(args):
                     r["frac_of_measured_copy_peak"] = r["achieved"] / HBM_COPY_GBPS
         if gather_check is not None:
             out["gather_check"] = gather_check
+        out["outputs_sha256"] = outputs_sha256
         if route is not None:
             out["route_check"] = route
         if funnel is not None:

@@ -399,6 +399,35 @@ def test_bench_gpus_n_launches_n_ranks_and_checks_the_gather(n):
     assert j["gather_check"]["identical"] and j["gather_check"]["rank"] == n - 1 and j["gather_check"]["units"] == 2
 
 
+def test_bench_strong_scaling_gathers_the_same_bytes_on_any_number_of_ranks():
+    """`bench.py --scaling strong` ("identical batch run on 1/2/4/8 GPUs ... outputs must be byte-identical across GPU
+    counts"): the same units are split over the ranks in contiguous shards and gathered in rank order -- the digest of the gathered
+    bytes (outputs_sha256) is the same on 1, 2, 3 and 4 ranks, the line says scaling = strong and counts the job's units once."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    digests = {}
+    for n in (1, 2, 3, 4):
+        p = subprocess.run([sys.executable, os.path.join(conftest.ROOT, "bench.py"), "--gpus", str(n), "--selftest-launch", "--steps", "2",
+                            "--scaling", "strong", "--batch", "12"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300, env=env)
+        assert p.returncode == 0, p.stderr[-2000:]
+        lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+        assert len(lines) == 1, p.stdout[-2000:]
+        j = json.loads(lines[0])
+        assert j["n_gpus"] == n and j["scaling"] == "strong" and j["outputs_sha256"]["units"] == 12
+        if n > 1:
+            assert j["gather_check"]["identical"] and j["gather_check"]["units"] == 12 // n
+        digests[n] = j["outputs_sha256"]["sha256"]
+    assert len(set(digests.values())) == 1, digests
+    # an uneven split is refused, not rounded
+    p = subprocess.run([sys.executable, os.path.join(conftest.ROOT, "bench.py"), "--gpus", "1", "--selftest-launch", "--scaling", "strong", "--batch", "12"],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=120, env=env)
+    assert p.returncode == 0
+    p = subprocess.run([sys.executable, os.path.join(conftest.ROOT, "bench.py"), "--gpus", "5", "--selftest-launch", "--scaling", "strong", "--batch", "12"],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300, env=env)
+    assert p.returncode != 0 and "do not split evenly" in (p.stderr + p.stdout)
+
+
 def test_bench_gather_check_catches_a_wrong_gather():
     b = _bench_module()
     from src import multigpu
