@@ -521,17 +521,30 @@ def route_check_leg(nat, vm, model, model_name, img, batch, net_size, net_h):
 
 def other_configs_leg(timeout_s):
     """Short legs of the other BASELINE configurations, each in a sub-process of its own after the timed region (a leg that fails or
-    hangs costs its timeout, never the line): c5 (3 steps), c2 (20 hipGraph replays), c4 (1 image).  A digest of each leg's own JSON
+    hangs costs its timeout, never the line): c5 (8 steps = 64 frames), c2 (20 hipGraph replays), c3match (3 steps), c4 (1 image, at
+    r_max 1600 and 3000).  A digest of each leg's own JSON
     line -- value, ms per step, workload, roofline -- goes under `other_configs`."""
-    legs = [("c5", ["--config", "c5", "--steps", "3", "--warmup", "1"], timeout_s),
-            ("c2", ["--config", "c2", "--steps", "20", "--warmup", "3"], timeout_s),
-            ("c4", ["--config", "c4", "--steps", "1", "--warmup", "0"], 2 * timeout_s)]
+    # c5 with --overlap: its per-pixel passes (the polylines fallbacks of a network's noisy 1080p prediction: one or two workgroups
+    # sweeping flagged rows for ~5 ms, a VALU-bound general pass) run on a second stream beside the next frames' forward (round 6:
+    # 190 -> 223 pairs/s on one box; on c3 the same switch buys nothing: 793 vs 781); 8 steps = 64 frames.  c3match = SURVEY 8(d)'s
+    # second form of the metric's network (NET_SIZE_MATCH: net 1024, 4097 tokens); c4 also at the paper's r_max 3000.
+    # The c4 legs run MIOpen's float32 convolutions on ~60 shapes nobody has searched on a fresh box: the default find mode costs
+    # ~330 s of wall there (kernel compilation) for 0.6 s of timed work, MIOPEN_FIND_MODE=FAST 9 s -- but FAST's immediate-mode
+    # choices run the image in 1156 ms instead of 607 (measured, round 6), so the search stays; the r_max 3000 leg comes second and
+    # finds most of its shapes (fixed patch sizes, pix2pix at 1024^2) in the user find-db the first leg left.
+    legs = [("c5", ["--config", "c5", "--steps", "8", "--warmup", "1", "--overlap"], timeout_s, None),
+            ("c2", ["--config", "c2", "--steps", "20", "--warmup", "3"], timeout_s, None),
+            ("c3match", ["--config", "c3match", "--steps", "3", "--warmup", "1"], timeout_s, None),
+            ("c4", ["--config", "c4", "--steps", "1", "--warmup", "0"], 2 * timeout_s, None),
+            ("c4_rmax3000", ["--config", "c4", "--steps", "1", "--warmup", "0", "--boost-rmax", "3000"], 2 * timeout_s, None)]
     out = {}
-    for name, extra, limit in legs:
+    for name, extra, limit, env_extra in legs:
         cmd = [sys.executable, os.path.abspath(__file__)] + extra + ["--no-cpu-baseline", "--no-route-check", "--no-funnel", "--no-other-configs"]
+        env = dict(os.environ)
+        env.update({k: v for k, v in (env_extra or {}).items() if k not in os.environ})          # (the caller's own setting wins)
         t0 = time.perf_counter()
         try:
-            p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=limit, text=True)
+            p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=limit, text=True, env=env)
             line = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
             if p.returncode != 0 or not line:
                 out[name] = {"error": f"exit code {p.returncode}", "stderr_tail": p.stderr[-400:], "seconds": time.perf_counter() - t0}
@@ -542,7 +555,9 @@ def other_configs_leg(timeout_s):
                          "steps": j.get("steps"), "warmup": j.get("warmup"), "n_gpus": j.get("n_gpus"), "dtype": j.get("dtype"),
                          "workload": (j.get("config") or {}).get("workload"), "forward_launch": (j.get("config") or {}).get("forward_launch"),
                          "roofline": {k: roof.get(k) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "avg_kernel_ms", "source")},
-                         "command": "python bench.py " + " ".join(extra), "seconds": time.perf_counter() - t0}
+                         "overlap": (j.get("config") or {}).get("overlap"),
+                         "command": " ".join(f"{k}={v}" for k, v in (env_extra or {}).items()) + (" " if env_extra else "") + "python bench.py " + " ".join(extra),
+                         "seconds": time.perf_counter() - t0}
         except subprocess.TimeoutExpired:
             out[name] = {"error": f"timed out after {limit} s", "seconds": time.perf_counter() - t0}
         except Exception as e:                                # a leg must never take the line down
