@@ -167,6 +167,15 @@ int ds_normalmap_f64(ds_ctx *ctx, const double *depth, int n, int h, int w, int 
 int ds_normalmap_gradient_f32(ds_ctx *ctx, const float *depth, int n, int h, int w, int invert, uint8_t *out, void *stream);
 
 /*
+ * ds_normalmap_selfcheck -- device self-test of the fused normal-map kernels' arithmetic (tests): their square root and reciprocal
+ * are the generic float64 expansions WITHOUT range scaling and special-case fix-ups (dead for n^2 = zx^2 + zy^2 + 1 in [1, 2^22],
+ * src/normalmap_generation.py:34-39); the kernel compares them with sqrt() and 1.0 / n on n^2 = K / 2^18, K = k0 + stride * i,
+ * i < count, K in [2^18, 2^40), and returns the number of operands on which they differ (must be 0).  Synchronises the stream.
+ */
+int ds_normalmap_selfcheck(ds_ctx *ctx, unsigned long long k0, unsigned long long stride, unsigned long long count,
+                           unsigned long long *mismatches, void *stream);
+
+/*
  * ds_depth_to_u16 -- replaces the depth post-processing of core_generation_funnel
  * (src/core.py:189-206, no-clip branch) followed by convert_to_i16 (src/core.py:44-50) for a batch
  * of float32 predictions: per image min/max, optional negate (models whose raw output is

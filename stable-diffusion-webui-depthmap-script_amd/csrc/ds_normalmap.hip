@@ -82,9 +82,71 @@ __global__ __launch_bounds__(NM_BX * NM_BY) void k_normalmap_fused(const uint16_
     nm_store(zx, zy, out + ((size_t)img * h * w + (size_t)y * w + x) * 3);
 }
 
+// ---- round 6: the fused kernel at ~60 instead of ~140 vector instructions per pixel ----------------------------------------------
+// The kernel is bound by float64 VALU issue (round 4: 62.8 M vector instructions per 32 x 1024^2 launch, 121-140 us against 35-40 us
+// of memory time).  What a pixel needs, and what the generic code spent on it:
+//   * the Sobel / np.gradient sums in INTEGERS.  The operands are uint16 / 256: every sum of the reference is exact in float64, so
+//     the same real number comes out of  Zx = (e02 - e00) + 2 (e12 - e10) + (e22 - e20)  in int32 and ONE conversion + ONE multiply
+//     by +-2^-8 (+-2^-9 for np.gradient's halved interior differences) -- instead of 18 conversions, 36 scalings and 10 float64
+//     adds per four pixels;
+//   * n^2 = fma(nx, nx, fma(ny, ny, 1)): exact (a multiple of 2^-18 below 2^22), so the two fused operations round nothing;
+//   * sqrt and 1 / n WITHOUT the range scaling and the special-case fix-ups of the generic expansions: n^2 lies in [1, 2^22], n in
+//     [1, 2^11] -- nm_sqrt / nm_rcp below are the compiler's own Newton / Goldschmidt sequences (AMDGPU lowering of llvm.sqrt.f64 and
+//     of the float64 division) minus v_div_scale / v_ldexp / v_div_fixup and their compares and selects: the same instructions on the
+//     same operands, bit for bit (tests/test_gpu_parity.py compares them with sqrt() and 1.0 / n on 2^27 operands of the domain);
+//   * (v + 1) * 128 as fma(v, 128, 128) (scaling by a power of two commutes with the rounding of v + 1), the upper clip as one
+//     v_min_f64 instead of compare + two 32-bit selects, and NO lower clip: |q| <= 1 because n >= |nx| (sqrt is monotonic and
+//     correctly rounded, |nx| is representable), so the value is never negative.
+__device__ __forceinline__ double nm_sqrt(double x)                 // x in [1, 2^22]: correctly rounded, as sqrt(x)
+{
+    const double y = __builtin_amdgcn_rsq(x);
+    double g = x * y, h = 0.5 * y;
+    const double r = __builtin_fma(-h, g, 0.5);
+    g = __builtin_fma(g, r, g);
+    h = __builtin_fma(h, r, h);
+    double d = __builtin_fma(-g, g, x);
+    g = __builtin_fma(d, h, g);
+    d = __builtin_fma(-g, g, x);
+    return __builtin_fma(d, h, g);
+}
+
+__device__ __forceinline__ double nm_rcp(double n)                  // n in [1, 2^11]: correctly rounded, as 1.0 / n
+{
+    double y = __builtin_amdgcn_rcp(n);
+    y = __builtin_fma(y, __builtin_fma(-n, y, 1.0), y);
+    y = __builtin_fma(y, __builtin_fma(-n, y, 1.0), y);
+    return __builtin_fma(__builtin_fma(-n, y, 1.0), y, y);
+}
+
+// one pixel: Zx, Zy = the integer gradient sums, kx, ky = their scales (sign of the inversion included; ky also carries the minus
+// sign of (zx, -zy, 1)); three bytes out
+__device__ __forceinline__ uint32_t nm_pixel(int Zx, int Zy, double kx, double ky)
+{
+    const double nx = (double)Zx * kx, ny = (double)Zy * ky;
+    const double n = nm_sqrt(__builtin_fma(nx, nx, __builtin_fma(ny, ny, 1.0)));
+    const double y = nm_rcp(n);
+    const double qx0 = nx * y, qy0 = ny * y;
+    const double v[3] = { __builtin_fma(__builtin_fma(-qx0, n, nx), y, qx0), __builtin_fma(__builtin_fma(-qy0, n, ny), y, qy0), y };
+    uint32_t o = 0;
+#pragma unroll
+    for (int k = 0; k < 3; k++) o |= (uint32_t)(int)__builtin_fmin(__builtin_fma(v[k], 128.0, 128.0), 256.0 - 0.1) << (8 * k);
+    return o;
+}
+
+// ds_normalmap_selfcheck: nm_sqrt / nm_rcp against the generic operations over a range of the operand domain, n^2 = K / 2^18 for
+// K = k0 + stride * i (every n^2 the kernels can form is such a value with K in [2^18, 2^40))
+__global__ void k_nm_check_sqrt_rcp(unsigned long long k0, unsigned long long stride, unsigned long long count, unsigned long long *bad)
+{
+    for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (unsigned long long)gridDim.x * blockDim.x) {
+        const double x = (double)(k0 + stride * i) * (1.0 / 262144.0);
+        const double a = nm_sqrt(x), b = sqrt(x);
+        if (a != b || nm_rcp(b) != 1.0 / b) atomicAdd(bad, 1ull);
+    }
+}
+
 // Four pixels per lane (w % 4 == 0): the three input rows arrive as one aligned 8-byte load each plus the two edge columns,
 // the 12 output bytes leave as three aligned 32-bit stores (round 1: one pixel per lane, three single-byte stores -- 0.20 ms
-// per 32 x 1024^2 = 10 % of the HBM roofline).  Same float64 arithmetic per pixel as k_normalmap_fused.
+// per 32 x 1024^2 = 10 % of the HBM roofline).
 template <int SOBEL3>
 __global__ __launch_bounds__(NM_BX * NM_BY) void k_normalmap_fused4(const uint16_t *__restrict__ depth, int h, int w, int invert,
                                                                     uint8_t *__restrict__ out)
@@ -94,7 +156,7 @@ __global__ __launch_bounds__(NM_BX * NM_BY) void k_normalmap_fused4(const uint16
     const int y = blockIdx.y * NM_BY + threadIdx.y;
     if (x0 >= w || y >= h) return;
     const uint16_t *d = depth + (size_t)img * h * w;
-    const double sgn = invert ? 1.0 : -1.0;
+    const double sgn = invert ? 1.0 : -1.0;                                                 /* :20: depthmap * (-1.0) unless inverted */
     // rows y-1, y, y+1 and columns x0-1 .. x0+4; outside the image: BORDER_REFLECT_101 for Sobel, clamped (unused) for gradient
     int ry[3], cl, cr;
     if (SOBEL3) {
@@ -105,37 +167,37 @@ __global__ __launch_bounds__(NM_BX * NM_BY) void k_normalmap_fused4(const uint16
         cl = x0 > 0 ? x0 - 1 : 0; cr = x0 + 4 < w ? x0 + 4 : w - 1;
     }
     ry[1] = y;
-    double v[3][6];
+    int e[3][6];                                                                            /* depth codes: value = sgn * e / 256 (:20-21) */
 #pragma unroll
     for (int r = 0; r < 3; r++) {
         const uint16_t *row = d + (size_t)ry[r] * w;
         const uint2 q = *reinterpret_cast<const uint2 *>(row + x0);
-        const uint32_t e[6] = { row[cl], q.x & 0xffffu, q.x >> 16, q.y & 0xffffu, q.y >> 16, row[cr] };
-#pragma unroll
-        for (int c = 0; c < 6; c++) v[r][c] = ((double)e[c] * sgn) / 256.0;                 /* :20-21 */
+        e[r][0] = row[cl]; e[r][1] = (int)(q.x & 0xffffu); e[r][2] = (int)(q.x >> 16);
+        e[r][3] = (int)(q.y & 0xffffu); e[r][4] = (int)(q.y >> 16); e[r][5] = row[cr];
     }
-    uint8_t o[12];
+    uint32_t o[4];
 #pragma unroll
     for (int i = 0; i < 4; i++) {
         const int x = x0 + i;
-        double zx, zy;
+        int Zx, Zy;
+        double kx = sgn * (1.0 / 256.0), ky = -kx;
         if (SOBEL3) {
-            zx = (v[0][i + 2] - v[0][i]) + 2.0 * (v[1][i + 2] - v[1][i]) + (v[2][i + 2] - v[2][i]);      /* cv2.Sobel dx, ksize 3 */
-            zy = (v[2][i] - v[0][i]) + 2.0 * (v[2][i + 1] - v[0][i + 1]) + (v[2][i + 2] - v[0][i + 2]);  /* cv2.Sobel dy, ksize 3 */
+            Zx = (e[0][i + 2] - e[0][i]) + 2 * (e[1][i + 2] - e[1][i]) + (e[2][i + 2] - e[2][i]);        /* cv2.Sobel dx, ksize 3 */
+            Zy = (e[2][i] - e[0][i]) + 2 * (e[2][i + 1] - e[0][i + 1]) + (e[2][i + 2] - e[0][i + 2]);    /* cv2.Sobel dy, ksize 3 */
         } else {                                                                                         /* np.gradient, :31 */
-            if (x == 0) zx = v[1][i + 2] - v[1][i + 1];
-            else if (x == w - 1) zx = v[1][i + 1] - v[1][i];
-            else zx = (v[1][i + 2] - v[1][i]) / 2.0;
-            if (y == 0) zy = v[2][i + 1] - v[1][i + 1];
-            else if (y == h - 1) zy = v[1][i + 1] - v[0][i + 1];
-            else zy = (v[2][i + 1] - v[0][i + 1]) / 2.0;
+            if (x == 0) Zx = e[1][i + 2] - e[1][i + 1];
+            else if (x == w - 1) Zx = e[1][i + 1] - e[1][i];
+            else { Zx = e[1][i + 2] - e[1][i]; kx *= 0.5; }
+            if (y == 0) Zy = e[2][i + 1] - e[1][i + 1];
+            else if (y == h - 1) Zy = e[1][i + 1] - e[0][i + 1];
+            else { Zy = e[2][i + 1] - e[0][i + 1]; ky *= 0.5; }
         }
-        nm_store(zx, zy, o + 3 * i);
+        o[i] = nm_pixel(Zx, Zy, kx, ky);
     }
     uint32_t *dst = reinterpret_cast<uint32_t *>(out + ((size_t)img * h * w + (size_t)y * w + x0) * 3);
-#pragma unroll
-    for (int k = 0; k < 3; k++)
-        dst[k] = (uint32_t)o[4 * k] | ((uint32_t)o[4 * k + 1] << 8) | ((uint32_t)o[4 * k + 2] << 16) | ((uint32_t)o[4 * k + 3] << 24);
+    dst[0] = o[0] | (o[1] << 24);
+    dst[1] = (o[1] >> 8) | (o[2] << 16);
+    dst[2] = (o[2] >> 16) | (o[3] << 8);
 }
 
 // ---- general path ---------------------------------------------------------------------------------
@@ -409,4 +471,23 @@ DS_API int ds_normalmap_f64(ds_ctx *ctx, const double *depth, int n, int h, int 
                             int sobel_ksize, int post_blur, int invert, uint8_t *out, void *stream)
 {
     return nm_run(ctx, depth, 1, n, h, w, pre_blur, sobel_ksize, post_blur, invert, out, stream);
+}
+
+DS_API int ds_normalmap_selfcheck(ds_ctx *ctx, unsigned long long k0, unsigned long long stride, unsigned long long count,
+                                  unsigned long long *mismatches, void *stream)
+{
+    DS_REQUIRE(ctx && mismatches, DS_EINVAL, "ds_normalmap_selfcheck: null argument");
+    DS_REQUIRE(k0 >= (1ull << 18) && stride >= 1 && count >= 1 && k0 + stride * (count - 1) < (1ull << 40), DS_EINVAL,
+               "ds_normalmap_selfcheck: K = k0 + stride * i must stay in [2^18, 2^40)");
+    DS_HIP_CHECK(hipSetDevice(ctx->device));
+    hipStream_t st = (hipStream_t)stream;
+    unsigned long long *d_bad = nullptr;
+    DS_HIP_CHECK(hipMalloc(&d_bad, sizeof(*d_bad)));
+    DS_HIP_CHECK(hipMemsetAsync(d_bad, 0, sizeof(*d_bad), st));
+    hipLaunchKernelGGL(k_nm_check_sqrt_rcp, dim3(4096), dim3(256), 0, st, k0, stride, count, d_bad);
+    hipError_t e = hipMemcpyAsync(mismatches, d_bad, sizeof(*d_bad), hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    (void)hipFree(d_bad);
+    DS_HIP_CHECK(e);
+    return DS_OK;
 }

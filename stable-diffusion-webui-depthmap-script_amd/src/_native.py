@@ -22,7 +22,7 @@ FILL_IDS = {"none": 0, "naive": 1, "naive_interpolating": 2, "polylines_soft": 3
 EXPORTS = [
     "ds_version", "ds_last_error", "ds_normalmap_f64", "ds_normalmap_gradient_f32", "ds_reassemble_readout", "ds_bias_act_nhwc", "ds_linear", "ds_linear_residual", "ds_linear_vt", "ds_conv3x3_nhwc", "ds_ctx_create", "ds_ctx_destroy", "ds_stereo_warp", "ds_depth_minmax",
     "ds_stereo_last_exact_rows", "ds_copy_view", "ds_overlap_red_cyan", "ds_normalmap", "ds_depth_to_u16",
-    "ds_convert_to_i16", "ds_profile_enable", "ds_profile_last_ms", "ds_stereo_last_stats", "ds_attention_fwd", "ds_attention_bias_pack", "ds_colorize_u16", "ds_residual_layernorm", "ds_boost_blend", "ds_upsample_bilinear_nhwc", "ds_dpt_head_tail", "ds_preprocess_bicubic", "ds_linear_reload_env", "ds_attention_reload_env",
+    "ds_convert_to_i16", "ds_profile_enable", "ds_profile_last_ms", "ds_stereo_last_stats", "ds_attention_fwd", "ds_attention_bias_pack", "ds_colorize_u16", "ds_residual_layernorm", "ds_boost_blend", "ds_upsample_bilinear_nhwc", "ds_dpt_head_tail", "ds_preprocess_bicubic", "ds_linear_reload_env", "ds_attention_reload_env", "ds_normalmap_selfcheck",
     "ds_linear_shuffle", "ds_linear_readout", "ds_kernel_timer_enable", "ds_kernel_timer_read",
     "ds_row_stats", "ds_linear_ln", "ds_linear_vt_ln", "ds_gconv3x3_nhwc_f32", "ds_add_relu_f32",
 ]
@@ -72,6 +72,7 @@ def lib():
             L.ds_convert_to_i16.argtypes = [vp, vp, ci, i64, vp, vp]
             L.ds_stereo_last_stats.argtypes = [vp, ctypes.POINTER(i64), vp]
             L.ds_attention_fwd.argtypes = [vp, vp, vp, vp, vp, ci, ci, ci, ci, ctypes.c_float, ci, vp]
+            L.ds_normalmap_selfcheck.argtypes = [vp, ctypes.c_ulonglong, ctypes.c_ulonglong, ctypes.c_ulonglong, ctypes.POINTER(ctypes.c_ulonglong), vp]
             L.ds_attention_bias_pack.argtypes = [vp, vp, ci, ci, ci, ci, vp, vp]
             L.ds_colorize_u16.argtypes = [vp, vp, ci, ci, ci, vp, vp, ci, vp, vp]
             L.ds_residual_layernorm.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, i64, ci, ctypes.c_float, ci, vp]
@@ -399,6 +400,16 @@ def linear_env(**switches):
         else:
             os.environ[k] = str(v)
     _check(lib().ds_linear_reload_env())
+
+
+def normalmap_selfcheck(k0, stride, count):
+    """Number of operands n^2 = (k0 + stride * i) / 2^18, i < count, on which the fused normal-map kernels' square root / reciprocal
+    differ from the generic float64 operations (include/depthstereo.h: ds_normalmap_selfcheck): must be 0."""
+    torch = require_gpu()
+    bad = ctypes.c_ulonglong(0)
+    _check(lib().ds_normalmap_selfcheck(ctx_for(torch.cuda.current_device()), ctypes.c_ulonglong(k0), ctypes.c_ulonglong(stride),
+                                        ctypes.c_ulonglong(count), ctypes.byref(bad), None))
+    return int(bad.value)
 
 
 def attention_env(**switches):

@@ -822,3 +822,19 @@ def test_integration_md_linear_snippet_runs_as_printed(gpu):
     err = (y.double() - want).abs().max().item()
     assert err < 2e-3 * (1 + want.abs().max().item()), err
     L.ds_ctx_destroy(ctx)
+
+
+def test_normalmap_fused_arithmetic_is_the_generic_one_on_its_domain(gpu):
+    """Round 6: the fused normal-map kernels take their square root and reciprocal from the compiler's own float64 expansions WITHOUT
+    the range scaling and special-case fix-ups (dead code for n^2 = zx^2 + zy^2 + 1 in [1, 2^22], src/normalmap_generation.py:34-39).
+    Every n^2 they can form is K / 2^18 with an integer K in [2^18, 2^40): the device compares nm_sqrt / nm_rcp with sqrt() and
+    1.0 / n on the 2^27 smallest K (flat and gently sloped surfaces: where real depth maps live), on the Sobel grid (K a multiple
+    of 4) above them, and on strided sweeps of the whole range -- 0 differences of ~10^9 operands."""
+    from src import _native
+    total = 0
+    for k0, stride, count in [(1 << 18, 1, 1 << 27), ((1 << 18) + (1 << 27), 4, 1 << 27), (1 << 18, 8191, 1 << 27), ((1 << 18) + 1, 7919, 1 << 27),
+                              ((1 << 39) - (1 << 28), 1, 1 << 27), ((1 << 30) + 3, 3, 1 << 27), ((1 << 35) + 1, 29, 1 << 27)]:
+        assert k0 + stride * (count - 1) < (1 << 40)
+        assert _native.normalmap_selfcheck(k0, stride, count) == 0, (k0, stride, count)
+        total += count
+    assert total > 9e8
