@@ -167,6 +167,25 @@ int ds_normalmap_f64(ds_ctx *ctx, const double *depth, int n, int h, int w, int 
 int ds_normalmap_gradient_f32(ds_ctx *ctx, const float *depth, int n, int h, int w, int invert, uint8_t *out, void *stream);
 
 /*
+ * ds_normalmap_gradient_f16 -- create_normalmap(float16 depth, sobel_gradient=None) without blurs: numpy keeps float16 from end to
+ * end (src/normalmap_generation.py:20-21 do not promote, :31 np.gradient returns the input's inexact dtype, :34-39 and :51-54 are
+ * float16 ufunc loops: each operation is computed in float32 and rounded to half; np.linalg.norm's add.reduce sums the squares in
+ * float32 and rounds once).  One fused pass with exactly those roundings: bit-identical.  depth n*h*w IEEE binary16 (2 bytes each),
+ * h, w >= 2; out n*h*w*3 uint8.
+ */
+int ds_normalmap_gradient_f16(ds_ctx *ctx, const void *depth, int n, int h, int w, int invert, uint8_t *out, void *stream);
+
+/*
+ * ds_normalmap_gradient_blur_f32 -- create_normalmap(float32 depth, sobel_gradient=None, pre_blur and / or post_blur): the reference
+ * runs cv2.GaussianBlur on float32 data (src/normalmap_generation.py:23-24 the depth plane, :42-48 the three-channel normal followed
+ * by the second normalisation) between numpy float32 steps.  CV_32F coefficients (getGaussianKernel's float rounding), float32
+ * accumulation, BORDER_REFLECT_101; OpenCV's summation order is unpinned (cv2 is absent), everything else is numpy's float32
+ * arithmetic.  Blur sizes odd, <= 63; 0 / negative = off (both off forwards to ds_normalmap_gradient_f32).
+ */
+int ds_normalmap_gradient_blur_f32(ds_ctx *ctx, const float *depth, int n, int h, int w, int pre_blur, int post_blur, int invert,
+                                   uint8_t *out, void *stream);
+
+/*
  * ds_normalmap_selfcheck -- device self-test of the fused normal-map kernels' arithmetic (tests): their square root and reciprocal
  * are the generic float64 expansions WITHOUT range scaling and special-case fix-ups (dead for n^2 = zx^2 + zy^2 + 1 in [1, 2^22],
  * src/normalmap_generation.py:34-39); the kernel compares them with sqrt() and 1.0 / n on n^2 = K / 2^18, K = k0 + stride * i,

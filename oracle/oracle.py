@@ -233,6 +233,21 @@ def gaussian_kernel(ksize, sigma):
     return np.array([t * inv for t in cf], dtype=np.float64)
 
 
+def gaussian_kernel_f32(ksize, sigma):
+    """cv2.getGaussianKernel(ksize, sigma>0, CV_32F): exp() rounded to float, the floats summed in double, scaled by the double
+    reciprocal and rounded to float again."""
+    import math
+    scale2x = -0.5 / (sigma * sigma)
+    cf, total = [], 0.0
+    for i in range(ksize):
+        x = i - (ksize - 1) * 0.5
+        t = float(np.float32(math.exp(scale2x * x * x)))
+        cf.append(t)
+        total += t
+    inv = 1.0 / total
+    return np.array([t * inv for t in cf], dtype=np.float32)
+
+
 def create_normalmap_array(depthmap, pre_blur=None, sobel_gradient=3, post_blur=None, invert=False):
     depthmap = np.asarray(depthmap)
     if (pre_blur is None or pre_blur <= 0) and (post_blur is None or post_blur <= 0) and depthmap.dtype == np.uint16:
@@ -247,24 +262,33 @@ def create_normalmap_array(depthmap, pre_blur=None, sobel_gradient=3, post_blur=
             return out
     normalmap = depthmap if invert else depthmap * (-1.0)
     normalmap = normalmap / 256.0
+    gradient = sobel_gradient is None or sobel_gradient <= 0
+    # float32 data on the np.gradient path stays float32 through cv2.GaussianBlur (CV_32F coefficients and accumulators); every other
+    # combination reaches the blurs as float64 (or is promoted for cv2.Sobel right behind the first one: restated in float64)
+    f32 = gradient and normalmap.dtype == np.float32
     if pre_blur is not None and pre_blur > 0:
-        g = gaussian_kernel(pre_blur, float(pre_blur))
-        normalmap = _sep_filter(np.float64(normalmap), g, g)
-    if sobel_gradient is not None and sobel_gradient > 0:
+        g = gaussian_kernel_f32(pre_blur, float(pre_blur)) if f32 else gaussian_kernel(pre_blur, float(pre_blur))
+        normalmap = _sep_filter(normalmap if f32 else np.float64(normalmap), g, g)
+    if not gradient:
         kd, ks = sobel_kernels(sobel_gradient, 1), sobel_kernels(sobel_gradient, 0)
         zx = _sep_filter(np.float64(normalmap), kd, ks)
         zy = _sep_filter(np.float64(normalmap), ks, kd)
     else:
         zy, zx = np.gradient(normalmap)
     normal = np.dstack((zx, -zy, np.ones_like(normalmap)))
-    n = np.sqrt(normal[:, :, 0] ** 2 + normal[:, :, 1] ** 2 + normal[:, :, 2] ** 2)
+
+    def _norm(v):
+        # np.linalg.norm(v, axis=2) (:34, :45): sqrt(add.reduce(v * v)) in the array's own dtype -- float16 reduces with a float32
+        # accumulator and one rounding, which the ufunc does by itself
+        return np.sqrt(np.add.reduce(v * v, axis=2))
+    n = _norm(normal)
     normal[:, :, 0] /= n
     normal[:, :, 1] /= n
     normal[:, :, 2] /= n
     if post_blur is not None and post_blur > 0:
-        g = gaussian_kernel(post_blur, float(post_blur))
+        g = gaussian_kernel_f32(post_blur, float(post_blur)) if f32 else gaussian_kernel(post_blur, float(post_blur))
         normal = np.dstack([_sep_filter(np.ascontiguousarray(normal[:, :, k]), g, g) for k in range(3)])
-        n = np.sqrt(normal[:, :, 0] ** 2 + normal[:, :, 1] ** 2 + normal[:, :, 2] ** 2)
+        n = _norm(normal)
         normal[:, :, 0] /= n
         normal[:, :, 1] /= n
         normal[:, :, 2] /= n

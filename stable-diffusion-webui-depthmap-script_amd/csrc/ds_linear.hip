@@ -90,6 +90,7 @@ struct LinParams {
     float *rg_ws;               // ragged round with K split over 2^rg_ksl workgroups per piece: one 32 KB fp32 partial per workgroup ...
     int *rg_cnt;                // ... and one arrival counter per piece (zero between launches)
     int rg_ksl;
+    int th_nrb;                 // k_linear_thin: the ragged row panel's new rows as 32-row blocks (the last th_nrb * 32 rows of x)
     int kt_kind;                // host side only: the in-step timer kind of this launch (DS_KT_*)
     // EPI 4 / 5 (LayerNorm folded into the GEMM): x is the UN-normalised residual stream, w holds W . diag(ln_weight); per token
     // {rstd, -mean * rstd} and per output feature colsum = sum_k w[n][k] (of the rounded weights) complete the affine map in the epilogue
@@ -914,6 +915,174 @@ __global__ __launch_bounds__(LN_THREADS, S == 3 ? 4 : 2) void k_linear_ragged(Li
     }
 }
 
+// ---- the thin ragged round (round 6) -----------------------------------------------------------------------------------------
+// The ragged round of the metric's encoder GEMMs is ONE row panel (32 images x 1032 token rows = 129 x 256: 4 / 8 / 16 tiles), and
+// since round 6 it runs one accumulation chain over the whole of K (no K split: a row's value must not depend on the round it falls
+// into).  k_linear_ragged stages 128 rows of x and 64 of W per K-tile, five K-tiles in flight: its loop is bound by the round trip
+// of its DMA chain, 0.30 us per K-tile -- 19 us for fc2 (K = 4096) behind a main kernel of 240 us, with 32 of 256 CUs at work.
+// This kernel renders the same rows as pieces of 32 rows x 64 columns -- four times as many workgroups -- and stages TWO K-tiles
+// per step into a slot of the same 24 KB (x: 2 x 32 rows x 128 B, W: 2 x 64 rows x 128 B): twice the K range in flight per round
+// trip, half the barriers, and the eight MFMAs of a step form the same chain (same instruction, same operand order, 16-wide slices
+// of K ascending) -- bit-identical to k_linear_ragged and to the main rounds.  Waves 0 and 1 own the two 32 x 32 blocks of the
+// piece; all eight waves stage (3 DMAs per wave and step, as in k_linear_ragged: its counted waits carry over).  The row blocks
+// are the last 32 * th_nrb rows of x: when the panel's new rows are not a multiple of 32 the first block reaches into rows of the
+// main rounds and writes them a second time with identical values (as the main kernel's shifted last panel does).  Taken when
+// all pieces run at once (one workgroup per CU: 144 KB of LDS).
+template <int BF16, int EPI, int RES>
+__global__ __launch_bounds__(LN_THREADS) void k_linear_thin(LinParams P)
+{
+    typedef ln_traits<BF16> TR;
+    typedef typename TR::T T;
+    typedef typename TR::V8 V8;
+    constexpr int S = 6;
+    extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
+    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ncb = P.N >> 6;                            // pieces per row block
+    const int rb = (int)blockIdx.x / ncb, cbk = (int)blockIdx.x - rb * ncb;
+    const int row0 = P.M - 32 * (P.th_nrb - rb), col0 = cbk * 64;
+    const int K = P.K, nst = K >> 7;                     // steps of two K-tiles
+    const unsigned rowbytes = (unsigned)K * (unsigned)sizeof(T);
+    // staging: a 1 KB chunk = 8 rows x 128 bytes of ONE K-tile, LDS row j = 8 c + (lane >> 3), LDS slot lane & 7 holds SOURCE slot
+    // (lane & 7) ^ ((j >> 1) & 7) (the swizzle of k_linear256).  Slot map: x K-tile 0 | x K-tile 1 (4 KB each) | W K-tile 0 | W K-tile 1
+    // (8 KB each).  Wave w stages x chunk w (K-tile w >> 2, rows 8 (w & 3) ..) and W chunks 2 w, 2 w + 1 (K-tile w >> 2, rows 16 (w & 3) ..)
+    unsigned srcA, srcB[2];
+    {
+        const int j = 8 * (wid & 3) + (lane >> 3);
+        srcA = (unsigned)j * rowbytes + (unsigned)(((lane & 7) ^ ((j >> 1) & 7)) << 4) + (unsigned)(wid >> 2) * 128u;
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int j = 8 * ((2 * wid + i) & 7) + (lane >> 3);
+        srcB[i] = (unsigned)j * rowbytes + (unsigned)(((lane & 7) ^ ((j >> 1) & 7)) << 4) + (unsigned)(wid >> 2) * 128u;
+    }
+    const unsigned char *xb = (const unsigned char *)P.x + (size_t)row0 * rowbytes;
+    const unsigned char *wb = (const unsigned char *)P.w + (size_t)col0 * rowbytes;
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) void *)lds;
+#define TH_STAGE(st_)                                                                                                    \
+    do {                                                                                                                 \
+        const int sc_ = min((st_), nst - 1);           /* past the end: a harmless re-load into a slot nobody reads */      \
+        const unsigned sl_ = lds0 + (unsigned)((st_) % S) * RG_SLOT;                                                      \
+        const unsigned char *xa_ = xb + (size_t)sc_ * 256, *wa_ = wb + (size_t)sc_ * 256;                                 \
+        ln_dma_s(xa_, srcA, sl_ + (unsigned)wid * 1024u);                                                                 \
+        ln_dma_s(wa_, srcB[0], sl_ + 8192u + (unsigned)(2 * wid) * 1024u);                                                \
+        ln_dma_s(wa_, srcB[1], sl_ + 8192u + (unsigned)(2 * wid + 1) * 1024u);                                            \
+    } while (0)
+    const bool mw = wid < 2;                             // the two waves that multiply: columns 32 wid .. 32 wid + 31 of the piece
+    unsigned offA[8], offB[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const int j = u >> 2, ks = u & 3;
+        const unsigned sl = (unsigned)((2 * ks + hi) ^ ((lane >> 1) & 7)) << 4;
+        offA[u] = (unsigned)j * 4096u + (unsigned)l31 * 128u + sl;
+        offB[u] = 8192u + (unsigned)j * 8192u + (unsigned)((wid & 1) * 32 + l31) * 128u + sl;
+    }
+    lf32x16 mine;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) mine[r] = 0.f;
+    // epilogue operands first (the oldest vmcnt entries: the counted waits of the loop are unaffected)
+    const int e_row = row0 + l31;
+    const int e_cb = col0 + (wid & 1) * 32 + 8 * hi;
+    V8 e_bv[2], e_gv[2], e_rv[2];
+    if (mw) {
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int col = e_cb + 16 * k;
+            if (P.bias) e_bv[k] = *(const V8 *)((const T *)P.bias + col);
+            if (EPI == 3) e_gv[k] = *(const V8 *)((const T *)P.gamma + col);
+            if (RES >= 1) e_rv[k] = *(const V8 *)((const T *)P.res1 + (size_t)e_row * P.ldy + col);
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < S - 1; ++t) TH_STAGE(t);
+    V8 fa0[8], fb0[8], fa1[8], fb1[8];
+#define TH_READ(fa_, fb_, st_)                                                                                           \
+    do {                                                                                                                 \
+        const unsigned char *sb_ = lds + ((st_) % S) * RG_SLOT;                                                          \
+        _Pragma("unroll") for (int u = 0; u < 8; ++u) {                                                                  \
+            fa_[u] = *(const V8 *)(sb_ + offA[u]);                                                                       \
+            fb_[u] = *(const V8 *)(sb_ + offB[u]);                                                                       \
+        }                                                                                                                \
+    } while (0)
+    // step st: wait for this wave's pieces of step st + 1 (three younger steps stay in flight) | barrier | stage step st + 5 into
+    // the slot of step st - 1 | request the fragments of step st + 1 | 8 MFMAs on step st | wait for the fragments
+#define TH_STEP(ca_, cb_, na_, nb_, st_)                                                                                 \
+    do {                                                                                                                 \
+        LN_WAIT_VM(9);                                                                                                   \
+        LN_BARRIER();                                                                                                    \
+        TH_STAGE((st_) + S - 1);                                                                                         \
+        if (mw) {                                                                                                        \
+            TH_READ(na_, nb_, (st_) + 1);                                                                                \
+            __builtin_amdgcn_sched_barrier(0);                                                                           \
+            _Pragma("unroll") for (int u = 0; u < 8; ++u) mine = TR::mfma(cb_[u], ca_[u], mine);                         \
+            __builtin_amdgcn_sched_barrier(0);                                                                           \
+            LN_WAIT_LGKM0();                                                                                             \
+            __builtin_amdgcn_sched_barrier(0);                                                                           \
+        }                                                                                                                \
+    } while (0)
+    LN_WAIT_VM(12);                                      // step 0 has landed (1 .. 4 in flight)
+    LN_BARRIER();
+    if (mw) {
+        TH_READ(fa0, fb0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        LN_WAIT_LGKM0();
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    int st = 0;
+    for (; st + 1 < nst; st += 2) {
+        TH_STEP(fa0, fb0, fa1, fb1, st);
+        TH_STEP(fa1, fb1, fa0, fb0, st + 1);
+    }
+    if (st < nst) TH_STEP(fa0, fb0, fa1, fb1, st);
+#undef TH_STEP
+#undef TH_READ
+#undef TH_STAGE
+    LN_WAIT_VM(0);                                       // the trailing re-loads: nothing may still be writing LDS at exit
+    if (!mw) return;
+
+    // ---- epilogue of this wave's 32 x 32 block, as in k_linear_ragged (VT 0)
+    const int row = e_row, cb = e_cb;
+    T *yb = (T *)P.y;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int col = cb + 16 * k;
+        const size_t off = (size_t)row * P.ldy + col;
+        V8 bv;
+        if (P.bias) bv = e_bv[k];
+        else {
+#pragma unroll
+            for (int t = 0; t < 8; ++t) bv[t] = (T)0.f;
+        }
+        float v[8];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const float fa = mine[8 * k + t], fb = mine[8 * k + 4 + t];
+            const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(fa), __float_as_uint(fb), false, false);
+            v[t] = __uint_as_float(sw[0]);
+            v[4 + t] = __uint_as_float(sw[1]);
+        }
+        if (EPI == 4 || EPI == 5) {                          // the folded LayerNorm, as in k_linear256
+            const float2 stt = P.ln_stats[row];
+            const float4 s0 = *(const float4 *)(P.ln_colsum + col), s1 = *(const float4 *)(P.ln_colsum + col + 4);
+            const float sc[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
+#pragma unroll
+            for (int t = 0; t < 8; ++t) v[t] = __builtin_fmaf(v[t], stt.x, stt.y * sc[t]);
+        }
+        V8 o;
+#pragma unroll
+        for (int t = 0; t < 8; t += 2) {
+            lf32x2 u = {v[t] + (float)bv[t], v[t + 1] + (float)bv[t + 1]};
+            if (EPI == 3) u *= (lf32x2){(float)e_gv[k][t], (float)e_gv[k][t + 1]};
+            if (RES >= 1) u += (lf32x2){(float)e_rv[k][t], (float)e_rv[k][t + 1]};
+            if (EPI == 1 || EPI == 5) u = ln_gelu2(u);
+            if (EPI == 2) u = (lf32x2){fmaxf(u[0], 0.f), fmaxf(u[1], 0.f)};
+            o[t] = (T)u[0];
+            o[t + 1] = (T)u[1];
+        }
+        *(V8 *)(yb + off) = o;
+    }
+}
+
 // ---- C ABI -------------------------------------------------------------------------------------------------------------
 // A/B switches of the GEMM path, read from the environment ONCE (hundreds of launches per forward; ds_linear_reload_env re-reads
 // them: the tests flip them inside one process).  None of them changes a result, except DS_LIN_RAGGED_KSPLIT > 1.
@@ -924,8 +1093,9 @@ __global__ __launch_bounds__(LN_THREADS, S == 3 ? 4 : 2) void k_linear_ragged(Li
 //                          round 6: a split sums in another fp32 order than the main rounds' single chain, so a row's value would
 //                          depend on where in the batch its image sits (8 = rounds 4-5: fc2 at batch 32 -16 us per launch), for
 //   DS_LIN_RAGGED_PIPE     the ragged round (deep ring): 1 (default) software-pipelined fragment reads + early epilogue operands
+//   DS_LIN_RAGGED_THIN     1 (default) a ragged round that is one row panel with at most 32 new rows runs k_linear_thin (same values)
 //   DS_LIN_RAGGED_KSPLIT_MIN / _KEEP   contractions of at least MIN K-tiles (default 32), every workgroup keeping >= KEEP (default 8)
-struct LinOptions { int early, grid, ragged, ragged_den, ragged_ring, ragged_ksplit, ragged_ksplit_min, ragged_ksplit_keep, ragged_pipe; };
+struct LinOptions { int early, grid, ragged, ragged_den, ragged_ring, ragged_ksplit, ragged_ksplit_min, ragged_ksplit_keep, ragged_pipe, ragged_thin; };
 static LinOptions g_lin_options;
 static std::atomic<int> g_lin_options_state{0};
 static void ln_read_options()
@@ -942,6 +1112,7 @@ static void ln_read_options()
     o.ragged_ksplit_keep = geti("DS_LIN_RAGGED_KSPLIT_KEEP", 8);
     if (o.ragged_ksplit_keep < 1) o.ragged_ksplit_keep = 1;
     o.ragged_pipe = geti("DS_LIN_RAGGED_PIPE", 1);
+    o.ragged_thin = geti("DS_LIN_RAGGED_THIN", 1);
     g_lin_options = o;
     g_lin_options_state.store(1, std::memory_order_release);
 }
@@ -1016,6 +1187,8 @@ static int ln_launch(ds_ctx *ctx, const LinParams &P0, hipStream_t stream)
             DS_HIP_CHECK(hipFuncSetAttribute((const void *)k_linear_ragged<BF16, EPI, RES, VT, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * RG_SLOT));
             DS_HIP_CHECK(hipFuncSetAttribute((const void *)k_linear_ragged<BF16, EPI, RES, VT, 6>, hipFuncAttributeMaxDynamicSharedMemorySize, 6 * RG_SLOT));
             DS_HIP_CHECK(hipFuncSetAttribute((const void *)k_linear_ragged<BF16, EPI, RES, VT, 6, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 6 * RG_SLOT));
+            if constexpr (VT == 0 && RES <= 1)
+                DS_HIP_CHECK(hipFuncSetAttribute((const void *)k_linear_thin<BF16, EPI, RES>, hipFuncAttributeMaxDynamicSharedMemorySize, 6 * RG_SLOT));
         }
         attr_done.fetch_or(bit, std::memory_order_relaxed);
     }
@@ -1048,8 +1221,18 @@ static int ln_launch(ds_ctx *ctx, const LinParams &P0, hipStream_t stream)
     // fc2 (K = 4096, 4 tiles) 270.1 -> 253.9 us; at K = 1024 the loop is 6 of the launch's 12 us and the split buys nothing
     // (fc1 274.4 / 275.0, qk 148.2 / 148.1, proj 85.9 / 87.6 with 2 K-tiles each), hence the lower bound of 32 K-tiles.
     const int deep = O.ragged_ring ? O.ragged_ring == 6 : 8 * ragged <= grid;
+    // the thin ragged round (k_linear_thin): the left-over tiles are exactly the last row panel (a group of its own in the tile
+    // list: (nbm - 1) % 8 == 0), and its 32 x 64 pieces all run at once (one workgroup per CU)
+    bool thin = false;
+    int th_nrb = 0;
+    if constexpr (CONV == 0 && VT == 0 && RES <= 1) {
+        th_nrb = (P.M - (P.nbm - 1) * 256 + 31) / 32;
+        thin = O.ragged_thin && ragged > 0 && ragged == P.nbn && P.nbm >= 2 && (P.nbm - 1) % 8 == 0 && P.K % 128 == 0 && P.N % 64 == 0 &&
+               O.ragged_ksplit <= 1 && th_nrb * (P.N / 64) <= ctx->ncu;
+    }
+    P.th_nrb = th_nrb;
     int ksl = 0;
-    if (CONV == 0 && ragged && deep && 8 * ragged * (int)sizeof(int) <= LN_RG_COUNTER_BYTES && ln_ksplit_arch_ok(ctx)) {
+    if (CONV == 0 && ragged && !thin && deep && 8 * ragged * (int)sizeof(int) <= LN_RG_COUNTER_BYTES && ln_ksplit_arch_ok(ctx)) {
         const int nt = P.K / 64;
         while (nt >= O.ragged_ksplit_min && (2 << ksl) <= O.ragged_ksplit && 8 * ragged * (2 << ksl) <= grid && nt % (2 << ksl) == 0 &&
                nt / (2 << ksl) >= O.ragged_ksplit_keep) ++ksl;
@@ -1066,7 +1249,9 @@ static int ln_launch(ds_ctx *ctx, const LinParams &P0, hipStream_t stream)
     ds_kt_end(ctx, P.kt_kind, kt0, stream);
     if constexpr (CONV == 0) {
         const int kt1 = ragged ? ds_kt_begin(ctx, P.kt_kind + DS_KT_RAGGED, stream) : -1;
-        if (ragged && deep && O.ragged_pipe) hipLaunchKernelGGL((k_linear_ragged<BF16, EPI, RES, VT, 6, 1>), dim3((8 * ragged) << ksl), dim3(LN_THREADS), 6 * RG_SLOT, stream, P);
+        if (thin) {
+            if constexpr (VT == 0 && RES <= 1) hipLaunchKernelGGL((k_linear_thin<BF16, EPI, RES>), dim3(th_nrb * (P.N / 64)), dim3(LN_THREADS), 6 * RG_SLOT, stream, P);
+        } else if (ragged && deep && O.ragged_pipe) hipLaunchKernelGGL((k_linear_ragged<BF16, EPI, RES, VT, 6, 1>), dim3((8 * ragged) << ksl), dim3(LN_THREADS), 6 * RG_SLOT, stream, P);
         else if (ragged && deep) hipLaunchKernelGGL((k_linear_ragged<BF16, EPI, RES, VT, 6>), dim3((8 * ragged) << ksl), dim3(LN_THREADS), 6 * RG_SLOT, stream, P);
         else if (ragged) hipLaunchKernelGGL((k_linear_ragged<BF16, EPI, RES, VT, 3>), dim3(8 * ragged), dim3(LN_THREADS), 3 * RG_SLOT, stream, P);
         ds_kt_end(ctx, P.kt_kind + DS_KT_RAGGED, kt1, stream);

@@ -465,6 +465,202 @@ DS_API int ds_normalmap_gradient_f32(ds_ctx *ctx, const float *depth, int n, int
     return DS_OK;
 }
 
+// float16 depth with sobel_gradient None / <= 0 and no blur (round 6): numpy keeps float16 from end to end (:20-21 `* (-1.0)` and
+// `/ 256.0` with Python scalars do not promote; np.gradient allocates its output in the input's inexact dtype; np.dstack,
+// np.linalg.norm, the in-place divisions and the quantisation stay float16).  numpy's float16 loops convert the operands to
+// float32, operate, and round the float32 result to half: that IS the correctly rounded half operation for + - * / sqrt
+// (24 >= 2 * 11 + 2 bits), and it is what this kernel does, operation by operation.  np.linalg.norm's add.reduce over the three
+// squares is the one multi-operand step: HALF_add's reduce loop keeps a FLOAT32 accumulator, adds the squares left to right and
+// rounds to half once (established on numpy 2.2 with operand triples on which (s0 + s1) + s2, s0 + (s1 + s2) and the
+// half-rounded chain differ: tests/test_oracle_golden.py).
+__device__ __forceinline__ float nm_r16(float x) { return (float)(_Float16)x; }
+
+__global__ __launch_bounds__(256) void k_nm_gradient_f16(const _Float16 *__restrict__ depth, int h, int w, int invert, uint8_t *__restrict__ out)
+{
+    const int img = blockIdx.z;
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= w || y >= h) return;
+    const _Float16 *p = depth + (size_t)img * h * w;
+    const float sgn = invert ? 1.0f : -1.0f;
+#define PV(yy, xx) nm_r16(nm_r16((float)p[(size_t)(yy) * w + (xx)] * sgn) / 256.0f)
+    float gx, gy;
+    if (x == 0) gx = nm_r16(nm_r16(PV(y, 1) - PV(y, 0)) / 1.0f);
+    else if (x == w - 1) gx = nm_r16(nm_r16(PV(y, w - 1) - PV(y, w - 2)) / 1.0f);
+    else gx = nm_r16(nm_r16(PV(y, x + 1) - PV(y, x - 1)) / 2.0f);
+    if (y == 0) gy = nm_r16(nm_r16(PV(1, x) - PV(0, x)) / 1.0f);
+    else if (y == h - 1) gy = nm_r16(nm_r16(PV(h - 1, x) - PV(h - 2, x)) / 1.0f);
+    else gy = nm_r16(nm_r16(PV(y + 1, x) - PV(y - 1, x)) / 2.0f);
+#undef PV
+    const float a = gx, b = -gy, c = 1.0f;
+    const float sa = nm_r16(a * a), sb = nm_r16(b * b), sc = nm_r16(c * c);
+    float sum = sa + sb;                                             // float32 accumulator, left to right, ONE rounding to half
+    sum = sum + sc;
+    const float n = nm_r16(__fsqrt_rn(nm_r16(sum)));
+    const float v[3] = { nm_r16(__fdiv_rn(a, n)), nm_r16(__fdiv_rn(b, n)), nm_r16(__fdiv_rn(c, n)) };
+    uint8_t *o = out + ((size_t)img * h * w + (size_t)y * w + x) * 3;
+    const float hi = (float)(_Float16)(256 - 0.1);                  // np.clip's bounds become float16 (NEP 50): 255.875
+    for (int k = 0; k < 3; k++) {
+        float t = nm_r16(v[k] + 1.0f);
+        t = nm_r16(t / 2.0f);
+        t = nm_r16(t * 256.0f);
+        t = t < 0.0f ? 0.0f : t;
+        t = t > hi ? hi : t;
+        o[k] = (t == t) ? (uint8_t)(int)t : (uint8_t)0;
+    }
+}
+
+DS_API int ds_normalmap_gradient_f16(ds_ctx *ctx, const void *depth, int n, int h, int w, int invert, uint8_t *out, void *stream)
+{
+    DS_REQUIRE(ctx && depth && out, DS_EINVAL, "ds_normalmap_gradient_f16: null argument");
+    DS_REQUIRE(n > 0 && n <= 65535 && h >= 2 && w >= 2, DS_EINVAL, "ds_normalmap_gradient_f16: np.gradient needs at least 2 samples per axis (n=%d h=%d w=%d)", n, h, w);
+    DS_HIP_CHECK(hipSetDevice(ctx->device));
+    dim3 g2((w + 63) / 64, (h + 3) / 4, n);
+    DS_REQUIRE(g2.y <= 65535, DS_EUNSUPPORTED, "ds_normalmap_gradient_f16: image too tall");
+    hipLaunchKernelGGL(k_nm_gradient_f16, g2, dim3(256), 0, (hipStream_t)stream, (const _Float16 *)depth, h, w, invert ? 1 : 0, out);
+    DS_HIP_CHECK(hipGetLastError());
+    return DS_OK;
+}
+
+// float32 depth with np.gradient AND a Gaussian blur in front of and / or behind it (round 6): the reference hands float32 arrays to
+// cv2.GaussianBlur (:24 the depth plane, :43 the three-channel normal), which filters CV_32F data with CV_32F coefficients
+// (createGaussianKernels takes max(depth, CV_32F); getGaussianKernel rounds exp() to float, sums the floats in double, scales by
+// the double reciprocal and rounds again) and float32 accumulators; everything around the blurs is numpy float32 as in
+// k_nm_gradient_f32.  OpenCV's own summation order inside the separable filter is not reproducible without the library (cv2 is
+// absent from the image: the blur arithmetic is a stand-in, tests hold it to one LSB); the structure is the reference's.
+struct NmKernelF { float cf[NM_MAXK]; int n; };
+
+__global__ __launch_bounds__(256) void k_nm_load_f32(const float *__restrict__ depth, int64_t count, int invert, float *__restrict__ plane)
+{
+    const float sgn = invert ? 1.0f : -1.0f;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (int64_t)gridDim.x * 256)
+        plane[i] = (depth[i] * sgn) / 256.0f;
+}
+
+template <int AXIS>
+__global__ __launch_bounds__(256) void k_nm_sep_f32(const float *__restrict__ in, float *__restrict__ out, int h, int w, NmKernelF K)
+{
+    const int img = blockIdx.z;
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= w || y >= h) return;
+    const float *p = in + (size_t)img * h * w;
+    const int r = K.n / 2;
+    float acc = 0.0f;
+    for (int k = 0; k < K.n; k++) {
+        float v;
+        if (AXIS == 0) v = p[(size_t)y * w + nm_reflect101(x + k - r, w)];
+        else v = p[(size_t)nm_reflect101(y + k - r, h) * w + x];
+        acc = acc + K.cf[k] * v;
+    }
+    out[(size_t)img * h * w + (size_t)y * w + x] = acc;
+}
+
+// np.gradient (:31) of the (blurred) plane and the first normalisation (:33-39), float32 like numpy: planes n0, n1, n2 out
+__global__ __launch_bounds__(256) void k_nm_gradnorm_f32(const float *__restrict__ in, float *__restrict__ n0, float *__restrict__ n1,
+                                                         float *__restrict__ n2, int h, int w)
+{
+    const int img = blockIdx.z;
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= w || y >= h) return;
+    const float *p = in + (size_t)img * h * w;
+#define PV(yy, xx) p[(size_t)(yy) * w + (xx)]
+    float gx, gy;
+    if (x == 0) gx = (PV(y, 1) - PV(y, 0)) / 1.0f;
+    else if (x == w - 1) gx = (PV(y, w - 1) - PV(y, w - 2)) / 1.0f;
+    else gx = (PV(y, x + 1) - PV(y, x - 1)) / 2.0f;
+    if (y == 0) gy = (PV(1, x) - PV(0, x)) / 1.0f;
+    else if (y == h - 1) gy = (PV(h - 1, x) - PV(h - 2, x)) / 1.0f;
+    else gy = (PV(y + 1, x) - PV(y - 1, x)) / 2.0f;
+#undef PV
+    const float a = gx, b = -gy, c = 1.0f;
+    float s = a * a;
+    s = s + b * b;
+    s = s + c * c;
+    const float n = __fsqrt_rn(s);
+    const size_t o = (size_t)img * h * w + (size_t)y * w + x;
+    n0[o] = __fdiv_rn(a, n); n1[o] = __fdiv_rn(b, n); n2[o] = __fdiv_rn(c, n);
+}
+
+__global__ __launch_bounds__(256) void k_nm_finish_f32(const float *__restrict__ n0, const float *__restrict__ n1, const float *__restrict__ n2,
+                                                       int64_t count, int renorm, uint8_t *__restrict__ out)
+{
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (int64_t)gridDim.x * 256) {
+        float v[3] = { n0[i], n1[i], n2[i] };
+        if (renorm) {                                               // :45-48
+            float s = v[0] * v[0];
+            s = s + v[1] * v[1];
+            s = s + v[2] * v[2];
+            const float n = __fsqrt_rn(s);
+            v[0] = __fdiv_rn(v[0], n); v[1] = __fdiv_rn(v[1], n); v[2] = __fdiv_rn(v[2], n);
+        }
+        for (int k = 0; k < 3; k++) {                               // :51-54
+            float t = v[k] + 1.0f;
+            t = t / 2.0f;
+            t = t * 256.0f;
+            t = t < 0.0f ? 0.0f : t;
+            t = t > (float)(256 - 0.1) ? (float)(256 - 0.1) : t;
+            out[i * 3 + k] = (t == t) ? (uint8_t)(int)t : (uint8_t)0;
+        }
+    }
+}
+
+static void nm_gaussian_f32(int ksize, double sigma, NmKernelF *K)   // getGaussianKernel(ksize, sigma > 0, CV_32F)
+{
+    K->n = ksize;
+    const double scale2x = -0.5 / (sigma * sigma);
+    double sum = 0.0;
+    for (int i = 0; i < ksize; i++) {
+        const double x = (double)i - (double)(ksize - 1) * 0.5;
+        K->cf[i] = (float)exp(scale2x * x * x);
+        sum += K->cf[i];
+    }
+    const double inv = 1.0 / sum;
+    for (int i = 0; i < ksize; i++) K->cf[i] = (float)(K->cf[i] * inv);
+}
+
+DS_API int ds_normalmap_gradient_blur_f32(ds_ctx *ctx, const float *depth, int n, int h, int w, int pre_blur, int post_blur, int invert,
+                                          uint8_t *out, void *stream)
+{
+    DS_REQUIRE(ctx && depth && out, DS_EINVAL, "ds_normalmap_gradient_blur_f32: null argument");
+    DS_REQUIRE(n > 0 && n <= 65535 && h >= 2 && w >= 2, DS_EINVAL, "ds_normalmap_gradient_blur_f32: np.gradient needs at least 2 samples per axis (n=%d h=%d w=%d)", n, h, w);
+    if (pre_blur < 0) pre_blur = 0;
+    if (post_blur < 0) post_blur = 0;
+    if (pre_blur == 0 && post_blur == 0) return ds_normalmap_gradient_f32(ctx, depth, n, h, w, invert, out, stream);
+    DS_REQUIRE((pre_blur == 0 || (pre_blur & 1)) && (post_blur == 0 || (post_blur & 1)), DS_EINVAL,
+               "ds_normalmap_gradient_blur_f32: Gaussian kernel sizes must be odd (cv2.GaussianBlur asserts)");
+    DS_REQUIRE(pre_blur <= NM_MAXK && post_blur <= NM_MAXK, DS_EUNSUPPORTED, "ds_normalmap_gradient_blur_f32: kernel sizes above %d are not supported", NM_MAXK);
+    DS_HIP_CHECK(hipSetDevice(ctx->device));
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t count = (int64_t)n * h * w;
+    int rc = ds_ctx_reserve(ctx, &ctx->tmp_a, &ctx->tmp_a_bytes, (size_t)count * sizeof(float) * 5);
+    if (rc) return rc;
+    float *A = (float *)ctx->tmp_a, *B = A + count, *C = B + count, *D = C + count, *E = D + count;
+    int nb = (int)((count + 1023) / 1024); if (nb > 4096) nb = 4096;
+    dim3 g2((w + 63) / 64, (h + 3) / 4, n);
+    DS_REQUIRE(g2.y <= 65535, DS_EUNSUPPORTED, "ds_normalmap_gradient_blur_f32: image too tall");
+    hipLaunchKernelGGL(k_nm_load_f32, dim3(nb), dim3(256), 0, st, depth, count, invert ? 1 : 0, A);
+    NmKernelF G;
+    if (pre_blur > 0) {                                            // :23-24
+        nm_gaussian_f32(pre_blur, (double)pre_blur, &G);
+        hipLaunchKernelGGL(k_nm_sep_f32<0>, g2, dim3(256), 0, st, A, B, h, w, G);
+        hipLaunchKernelGGL(k_nm_sep_f32<1>, g2, dim3(256), 0, st, B, A, h, w, G);
+    }
+    hipLaunchKernelGGL(k_nm_gradnorm_f32, g2, dim3(256), 0, st, A, C, D, E, h, w);
+    if (post_blur > 0) {                                           // :42-48
+        nm_gaussian_f32(post_blur, (double)post_blur, &G);
+        float *planes[3] = { C, D, E };
+        for (int k = 0; k < 3; k++) {
+            hipLaunchKernelGGL(k_nm_sep_f32<0>, g2, dim3(256), 0, st, planes[k], B, h, w, G);
+            hipLaunchKernelGGL(k_nm_sep_f32<1>, g2, dim3(256), 0, st, B, planes[k], h, w, G);
+        }
+    }
+    hipLaunchKernelGGL(k_nm_finish_f32, dim3(nb), dim3(256), 0, st, C, D, E, count, post_blur > 0 ? 1 : 0, out);
+    DS_HIP_CHECK(hipGetLastError());
+    return DS_OK;
+}
+
 // Any other real dtype of the reference's `depthmap` argument (:20-21 promote it to float64; the host casts): the separable
 // float64 passes for every kernel size (general float64 data has no exact 3x3 shortcut).
 DS_API int ds_normalmap_f64(ds_ctx *ctx, const double *depth, int n, int h, int w, int pre_blur,

@@ -22,7 +22,7 @@ FILL_IDS = {"none": 0, "naive": 1, "naive_interpolating": 2, "polylines_soft": 3
 EXPORTS = [
     "ds_version", "ds_last_error", "ds_normalmap_f64", "ds_normalmap_gradient_f32", "ds_reassemble_readout", "ds_bias_act_nhwc", "ds_linear", "ds_linear_residual", "ds_linear_vt", "ds_conv3x3_nhwc", "ds_ctx_create", "ds_ctx_destroy", "ds_stereo_warp", "ds_depth_minmax",
     "ds_stereo_last_exact_rows", "ds_copy_view", "ds_overlap_red_cyan", "ds_normalmap", "ds_depth_to_u16",
-    "ds_convert_to_i16", "ds_profile_enable", "ds_profile_last_ms", "ds_stereo_last_stats", "ds_attention_fwd", "ds_attention_bias_pack", "ds_colorize_u16", "ds_residual_layernorm", "ds_boost_blend", "ds_upsample_bilinear_nhwc", "ds_dpt_head_tail", "ds_preprocess_bicubic", "ds_linear_reload_env", "ds_attention_reload_env", "ds_normalmap_selfcheck",
+    "ds_convert_to_i16", "ds_profile_enable", "ds_profile_last_ms", "ds_stereo_last_stats", "ds_attention_fwd", "ds_attention_bias_pack", "ds_colorize_u16", "ds_residual_layernorm", "ds_boost_blend", "ds_upsample_bilinear_nhwc", "ds_dpt_head_tail", "ds_preprocess_bicubic", "ds_linear_reload_env", "ds_attention_reload_env", "ds_normalmap_selfcheck", "ds_normalmap_gradient_f16", "ds_normalmap_gradient_blur_f32",
     "ds_linear_shuffle", "ds_linear_readout", "ds_kernel_timer_enable", "ds_kernel_timer_read",
     "ds_row_stats", "ds_linear_ln", "ds_linear_vt_ln", "ds_gconv3x3_nhwc_f32", "ds_add_relu_f32",
 ]
@@ -68,6 +68,8 @@ def lib():
             L.ds_normalmap.argtypes = [vp, vp, ci, ci, ci, ci, ci, ci, ci, vp, vp]
             L.ds_normalmap_f64.argtypes = [vp, vp, ci, ci, ci, ci, ci, ci, ci, vp, vp]
             L.ds_normalmap_gradient_f32.argtypes = [vp, vp, ci, ci, ci, ci, vp, vp]
+            L.ds_normalmap_gradient_f16.argtypes = [vp, vp, ci, ci, ci, ci, vp, vp]
+            L.ds_normalmap_gradient_blur_f32.argtypes = [vp, vp, ci, ci, ci, ci, ci, ci, vp, vp]
             L.ds_depth_to_u16.argtypes = [vp, vp, ci, ci, ci, ci, vp, vp, vp]
             L.ds_convert_to_i16.argtypes = [vp, vp, ci, i64, vp, vp]
             L.ds_stereo_last_stats.argtypes = [vp, ctypes.POINTER(i64), vp]
@@ -245,17 +247,29 @@ def overlap_red_cyan(im1_ptr, r1, i1, im2_ptr, r2, i2, n, h, w, c, out):
 
 
 def normalmap(depth, pre_blur, sobel_ksize, post_blur, invert):
-    """depth [n,h,w]: uint16 (the funnel's depth maps; the fused kernel), float64 (any other dtype, cast by the caller), or
-    float32 with np.gradient and no blur (the reference's float32 evaluation: ds_normalmap_gradient_f32)."""
+    """depth [n,h,w]: uint16 (the funnel's depth maps; the fused kernel), float64 (any other dtype, cast by the caller), float32
+    with np.gradient (the reference's float32 evaluation: ds_normalmap_gradient_f32 / ds_normalmap_gradient_blur_f32) or float16
+    with np.gradient and no blur (numpy's float16 evaluation: ds_normalmap_gradient_f16)."""
     torch = require_gpu()
     n, h, w = depth.shape
-    assert depth.dtype in (torch.uint16, torch.float64, torch.float32) and depth.is_contiguous()
+    assert depth.dtype in (torch.uint16, torch.float64, torch.float32, torch.float16) and depth.is_contiguous()
     out = torch.empty((n, h, w, 3), dtype=torch.uint8, device=depth.device)
-    if depth.dtype == torch.float32:
-        assert int(pre_blur) == 0 and int(post_blur) == 0 and int(sobel_ksize) == 0, "float32 depth: np.gradient without blurs only"
-        CALLS["ds_normalmap_gradient_f32"] += 1
-        _check(lib().ds_normalmap_gradient_f32(ctx_for(_dev_index(depth)), depth.data_ptr(), n, h, w, 1 if invert else 0,
+    if depth.dtype == torch.float16:
+        assert int(pre_blur) == 0 and int(post_blur) == 0 and int(sobel_ksize) == 0, "float16 depth: np.gradient without blurs only"
+        CALLS["ds_normalmap_gradient_f16"] += 1
+        _check(lib().ds_normalmap_gradient_f16(ctx_for(_dev_index(depth)), depth.data_ptr(), n, h, w, 1 if invert else 0,
                                                out.data_ptr(), _stream(depth)))
+        return out
+    if depth.dtype == torch.float32:
+        assert int(sobel_ksize) == 0, "float32 depth: np.gradient only (cv2.Sobel is fed float64)"
+        if int(pre_blur) == 0 and int(post_blur) == 0:
+            CALLS["ds_normalmap_gradient_f32"] += 1
+            _check(lib().ds_normalmap_gradient_f32(ctx_for(_dev_index(depth)), depth.data_ptr(), n, h, w, 1 if invert else 0,
+                                                   out.data_ptr(), _stream(depth)))
+        else:
+            CALLS["ds_normalmap_gradient_blur_f32"] += 1
+            _check(lib().ds_normalmap_gradient_blur_f32(ctx_for(_dev_index(depth)), depth.data_ptr(), n, h, w, int(pre_blur), int(post_blur),
+                                                        1 if invert else 0, out.data_ptr(), _stream(depth)))
         return out
     fn = lib().ds_normalmap if depth.dtype == torch.uint16 else lib().ds_normalmap_f64
     CALLS["ds_normalmap" if depth.dtype == torch.uint16 else "ds_normalmap_f64"] += 1

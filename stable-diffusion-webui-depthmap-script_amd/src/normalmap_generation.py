@@ -22,19 +22,19 @@ def create_normalmap(depthmap, pre_blur=None, sobel_gradient=3, post_blur=None, 
     if depth.ndim != 2 or depth.dtype.kind not in 'buif':
         raise _native.DepthStereoError('create_normalmap: depthmap must be a 2-D real array, got %s %s' % (depth.dtype, depth.shape))
     if depth.dtype != np.uint16:
-        # :20-21: `depthmap * (-1.0) / 256.0` promotes integers to float64 and keeps float32 as float32; cv2.Sobel is fed
-        # np.float64(normalmap) (:28-29), which equals the float64 evaluation (negation and /256 are exact), but np.gradient
-        # (:31) and everything after it run in the array's own precision: float32 has a kernel of its own (every operation
-        # in binary32, numpy's order); a blur in front of / behind it would be cv2's float32 GaussianBlur (unpinned: not built),
-        # and float16 arithmetic (numpy rounds every operation to half) is not built either.
-        f32_gradient = depth.dtype == np.float32 and _ksize(sobel_gradient) == 0
-        if f32_gradient and (_ksize(pre_blur) or _ksize(post_blur)):
-            raise _native.DepthStereoError('create_normalmap: float32 depth with np.gradient AND a Gaussian blur runs through cv2\'s '
-                                           'float32 GaussianBlur in the reference and is not built; pass float64 or use a Sobel size')
-        if depth.dtype == np.float16 and _ksize(sobel_gradient) == 0:
-            raise _native.DepthStereoError('create_normalmap: float16 depth with np.gradient (sobel_gradient None) runs in float16 '
-                                           'in the reference and is not built; pass float32 / float64 or use a Sobel size')
-        if not f32_gradient:
+        # :20-21: `depthmap * (-1.0) / 256.0` promotes integers to float64 and keeps float32 / float16; cv2.Sobel is fed
+        # np.float64(normalmap) (:28-29), but np.gradient (:31) and everything after it run in the array's own precision:
+        # float32 and float16 have kernels of their own (every operation rounded like numpy's).  float16 cannot be blurred:
+        # cv2.GaussianBlur rejects CV_16F arrays in the reference too.
+        gradient = _ksize(sobel_gradient) == 0
+        if depth.dtype == np.float16 and (_ksize(pre_blur) or (gradient and _ksize(post_blur))):
+            raise _native.DepthStereoError('create_normalmap: float16 data cannot be blurred (cv2.GaussianBlur does not take CV_16F '
+                                           'arrays, the reference raises cv2.error here); pass float32 / float64')
+        if depth.dtype in (np.float16, np.float32) and not gradient:
+            # :20-21 scale in the array's own precision BEFORE the promotion to float64 at :28 (the quotient rounds when it is
+            # subnormal): hand the kernel 256 times that value, which its float64 `/ 256.0` undoes exactly
+            depth = (depth / 256.0).astype(np.float64) * 256.0
+        elif not (depth.dtype in (np.float16, np.float32) and gradient):
             depth = depth.astype(np.float64)
     dev = torch.device('cuda', torch.cuda.current_device())
     d = torch.from_numpy(np.array(depth, order='C')).to(dev).unsqueeze(0)
@@ -43,5 +43,5 @@ def create_normalmap(depthmap, pre_blur=None, sobel_gradient=3, post_blur=None, 
 
 
 def create_normalmap_batch(depth_u16, pre_blur=None, sobel_gradient=3, post_blur=None, invert=False):
-    """Device-resident batch: uint16 (or float64) cuda tensor [N,H,W] -> uint8 cuda tensor [N,H,W,3]."""
+    """Device-resident batch: uint16 (or float64 / float32 / float16, see _native.normalmap) cuda tensor [N,H,W] -> uint8 cuda tensor [N,H,W,3]."""
     return _native.normalmap(depth_u16.contiguous(), _ksize(pre_blur), _ksize(sobel_gradient), _ksize(post_blur), bool(invert))

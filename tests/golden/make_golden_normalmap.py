@@ -159,6 +159,32 @@ def main():
         for inv in (False, True):
             for sob in (None, 0):
                 add(nm_, arr, None, sob, None, inv)
+    # float16 depth with np.gradient (round 6): numpy stays in float16 from end to end (each ufunc loop computes in float32 and rounds
+    # to half; np.linalg.norm's add.reduce keeps a float32 accumulator) -- arbitrary values, no cv2 call: reference-exact
+    f16r = rng.normal(0.0, 3000.0, (31, 37)).astype(np.float16)
+    f16r[0:3, 0:5] = 60000.0
+    f16r[10, 10] = -60000.0
+    f16r[10, 11] = 60000.0                                                              # a step whose square overflows half: n = inf
+    out['f16normal31x37__depth'] = f16r
+    f16m = (rng.random((26, 41)) * 37.0 + 5.0).astype(np.float16)
+    f16m[5:11, 10:30] += np.float16(11.5)
+    out['f16midas26x41__depth'] = f16m
+    f16t = (rng.random((12, 14)) * 0.01).astype(np.float16)                             # quotients by 256 land in the subnormals
+    f16t[3:6, 4:9] = 0.0
+    out['f16tiny12x14__depth'] = f16t
+    with np.errstate(all='ignore'):
+        for nm_, arr in (('f16normal31x37', f16r), ('f16midas26x41', f16m), ('f16tiny12x14', f16t)):
+            for inv in (False, True):
+                for sob in (None, 0):
+                    add(nm_, arr, None, sob, None, inv)
+    f16i = rng.integers(0, 2048, (15, 22)).astype(np.float16)                           # integers: exact through / 256 and the Sobel stub
+    out['f16int15x22__depth'] = f16i
+    add('f16int15x22', f16i, None, 3, None, False)
+    add('f16int15x22', f16i, None, 5, None, True)
+    # float32 depth, np.gradient AND Gaussian blurs: cv2.GaussianBlur on CV_32F data (stand-in: float64 sums cast back to float32)
+    for args in ((3, None, None), (None, None, 3), (5, 0, 3)):
+        add('f32midas22x45', f32m, args[0], args[1], args[2], False, standin=1)
+        add('f32normal27x33', f32r, args[0], args[1], args[2], True, standin=1)
     # blur structure (stand-in arithmetic, see the module docstring)
     for args in ((3, 3, None), (None, 3, 3), (5, None, 3), (3, 5, 5)):
         add('survey48x64', deps['survey48x64'], args[0], args[1], args[2], False, standin=1)

@@ -1073,10 +1073,13 @@ def test_linear_ragged_round_vt_and_fused_residual(gpu, dtype, tol):
     from src import _native
     g = torch.Generator().manual_seed(77)
     mk = lambda *s: torch.randn(s, generator=g)  # noqa: E731
-    old = {k: os.environ.get(k) for k in ("DS_LIN_GRID", "DS_LIN_RAGGED", "DS_LIN_EARLY", "DS_LIN_RAGGED_RING", "DS_LIN_RAGGED_PIPE")}
+    old = {k: os.environ.get(k) for k in ("DS_LIN_GRID", "DS_LIN_RAGGED", "DS_LIN_EARLY", "DS_LIN_RAGGED_RING", "DS_LIN_RAGGED_PIPE", "DS_LIN_RAGGED_THIN")}
     try:
         # (rows, out, in, grid): tiles % grid <= grid / 4 -> a ragged round of 1 .. 4 tiles
-        for (m, n, k, grid) in [(4352, 256, 384, 8), (2304, 512, 1024, 8), (2637, 768, 640, 16), (4352, 256, 128, 8), (8448, 256, 256, 32)]:
+        # (2304, 512, ..) and (2100, 512, ..): the ragged round is the last row panel alone -> k_linear_thin (round 6: 32 x 64 pieces, two
+        # K-tiles per step; full panel / 52 new rows in two 32-row blocks, the first reaching into the main rounds' rows; odd step count)
+        for (m, n, k, grid) in [(4352, 256, 384, 8), (2304, 512, 1024, 8), (2637, 768, 640, 16), (4352, 256, 128, 8), (8448, 256, 256, 32),
+                                (2100, 512, 384, 8), (2304, 256, 128, 8)]:
             _native.linear_env(DS_LIN_GRID=str(grid))
             x, w, b = mk(m, k).to(dtype).cuda(), (mk(n, k) * k ** -0.5).to(dtype).cuda(), mk(n).to(dtype).cuda()
             gam, res = mk(n).to(dtype).cuda(), mk(m, n).to(dtype).cuda()
@@ -1091,12 +1094,19 @@ def test_linear_ragged_round_vt_and_fused_residual(gpu, dtype, tol):
                 assert (got.double() - off.double()).abs().max().item() < tol * (1 + want.abs().max().item())
                 # the two schedules differ only in the summation order of the ragged tiles: most outputs are bit-identical
                 assert (got != off).float().mean().item() < 0.2
+                assert torch.equal(got, off), "the ragged round and the main rounds sum in different orders"      # round 6: one chain
+                _native.linear_env(DS_LIN_RAGGED="1", DS_LIN_RAGGED_THIN="0")
+                assert torch.equal(_native.linear(x, w, b, gelu), got), "k_linear_thin differs from k_linear_ragged"
+                _native.linear_env(DS_LIN_RAGGED_THIN=None)
             _native.linear_env(DS_LIN_RAGGED="1")
             for gm in (gam, None):
                 want = _lin_ref(x, w, b, gamma=gm, res=res)
                 got = _native.linear_residual(x, w, b, gm, res)
                 assert (got.double() - want).abs().max().item() < tol * (1 + want.abs().max().item()), (m, n, k, gm is None)
                 assert torch.equal(_native.linear_residual(x, w, b, gm, res), got)
+                _native.linear_env(DS_LIN_RAGGED_THIN="0")
+                assert torch.equal(_native.linear_residual(x, w, b, gm, res), got), "k_linear_thin differs from k_linear_ragged"
+                _native.linear_env(DS_LIN_RAGGED_THIN=None)
         # schedule switches that must not change a single bit: the order of prologue DMAs and epilogue (DS_LIN_EARLY), the ring
         # depth of the ragged kernel -- on a many-tiles-per-workgroup walk with every epilogue variant
         _native.linear_env(DS_LIN_GRID="8")
@@ -1190,6 +1200,14 @@ def test_linear_vt_and_fused_fc2_at_benchmark_shapes(gpu, npad):
         _native.linear_env(DS_LIN_RAGGED=None)
     for o, f in zip(plain, main_only):
         assert torch.equal(o, f), "the ragged round and the main rounds sum in different orders"
+    try:                                                     # k_linear_thin (the default for proj / fc2 / qk here) against k_linear_ragged
+        _native.linear_env(DS_LIN_RAGGED_THIN="0")
+        wide = (_native.linear_residual(a, w2, b2, gam, res), _native.linear(x1, w1, b1, True), _native.linear_vt(wv, h),
+                _native.linear(x1, w1[:2048].contiguous(), b1[:2048].contiguous(), False))
+    finally:
+        _native.linear_env(DS_LIN_RAGGED_THIN=None)
+    for o, f in zip(plain, wide):
+        assert torch.equal(o, f), "k_linear_thin differs from k_linear_ragged"
     if npad == 1032:                                         # 516 / 1032 / 2064 tiles: ragged rounds of 4 / 8 / 16 tiles
         assert not all(torch.equal(o, f) for o, f in zip(plain, first)), "the K split was not taken at the benchmark shapes"
     for o, f in zip(plain, first):
@@ -1445,7 +1463,22 @@ def test_conv1x1_through_the_in_tree_gemm(gpu):
         assert y.shape == ref.shape and y.is_contiguous(memory_format=torch.channels_last)
         assert (y.float() - ref).abs().max().item() < 2e-3 * (1 + ref.abs().max().item())
     small = torch.randn((1, 256, 16, 16), generator=g).half().cuda().contiguous(memory_format=torch.channels_last)
-    assert not vm.conv1x1_hip_ok(nn.Conv2d(256, 256, 1).cuda().half(), small)       # one tile: the library's small kernels
+    # one tile: in-tree as well since round 6 (vm.INVARIANT: a unit's depth must not depend on which library solver a launch size
+    # picks); with DS_INVARIANT=0 the tile-count rule of rounds 4-5 hands it to the library's small kernels again
+    one = nn.Conv2d(256, 256, 1).cuda().half()
+    assert vm.conv1x1_hip_ok(one, small) == vm.INVARIANT
+    keep = vm.INVARIANT
+    try:
+        vm.INVARIANT = False
+        assert not vm.conv1x1_hip_ok(one, small)
+        vm.INVARIANT = True
+        assert vm.conv1x1_hip_ok(one, small)
+        with torch.no_grad():
+            y = vm.conv_module(one, small)
+            ref = torch.nn.functional.conv2d(small.float(), one.weight.float(), one.bias.float())
+        assert (y.float() - ref).abs().max().item() < 2e-3 * (1 + ref.abs().max().item())
+    finally:
+        vm.INVARIANT = keep
 
 
 def test_kernel_timers_bracket_the_launches(gpu):

@@ -757,10 +757,30 @@ def test_normalmap_float32_gradient_is_the_reference_float32_evaluation(gpu, ora
                 want = oracle.create_normalmap_array(d, None, sob, None, inv)
                 got = np.asarray(nm.create_normalmap(d, None, sob, None, inv))
                 assert got.dtype == np.uint8 and np.array_equal(got, want), (d.shape, inv, sob, int((got != want).sum()))
-    with pytest.raises(Exception):
-        nm.create_normalmap(cases[0], 3, None, None, False)          # float32 + np.gradient + blur: cv2's float32 GaussianBlur, not built
-    with pytest.raises(Exception):
-        nm.create_normalmap(cases[0].astype(np.float16), None, None, None, False)
+    # round 6: float32 + np.gradient + Gaussian blurs (cv2.GaussianBlur on CV_32F data: float32 coefficients and sums; the oracle's
+    # restatement of the stand-in arithmetic, bit for bit) and float16 + np.gradient (numpy's float16 evaluation, pinned by the
+    # reference-made f16* goldens) -- every input combination the reference accepts now has a device path
+    for d in cases[:2]:
+        for args in ((3, None, None), (None, 0, 5), (5, None, 3), (7, -1, 7)):
+            for inv in (False, True):
+                want = oracle.create_normalmap_array(d, args[0], args[1], args[2], inv)
+                got = np.asarray(nm.create_normalmap(d, args[0], args[1], args[2], inv))
+                assert np.array_equal(got, want), (d.shape, args, inv, int((got != want).sum()))
+    with np.errstate(all='ignore'):
+        for d in cases:
+            d16 = d.astype(np.float16)
+            for inv in (False, True):
+                want = oracle.create_normalmap_array(d16, None, None, None, inv)
+                got = np.asarray(nm.create_normalmap(d16, None, None, None, inv))
+                assert np.array_equal(got, want), (d.shape, inv, int((got != want).sum()))
+        d16 = rng.integers(0, 2048, (33, 47)).astype(np.float16)        # float16 through cv2.Sobel: float64 behind the float16 scaling
+        for args in ((None, 3, None), (None, 5, 3)):
+            want = oracle.create_normalmap_array(d16, *args, False)
+            got = np.asarray(nm.create_normalmap(d16, *args, False))
+            assert np.array_equal(got, want), args
+    for args in ((3, None, None), (None, None, 3), (3, 3, None)):       # cv2.GaussianBlur rejects CV_16F: the reference raises too
+        with pytest.raises(Exception):
+            nm.create_normalmap(cases[0].astype(np.float16), args[0], args[1], args[2], False)
 
 
 @pytest.mark.gpu

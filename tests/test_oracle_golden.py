@@ -148,3 +148,66 @@ def test_python_port_reproduces_reference_goldens(oracle):
         a = oracle_py.create_stereoimages_arrays(img[0], dep[0], 4.0, 0.5, ['left-right'], 0.2, 1.0, fill)[0]
         b = oracle.create_stereoimages_arrays(img[0], dep[0], 4.0, 0.5, ['left-right'], 0.2, 1.0, fill)[0]
         assert np.array_equal(a, b), fill
+
+
+def _f16_kernel_model(depth, invert):
+    """k_nm_gradient_f16 (csrc/ds_normalmap.hip) written out in numpy float32 with an explicit rounding to half behind every
+    operation -- the arithmetic the device kernel performs, operation by operation."""
+    f, hf = np.float32, np.float16
+
+    def r(x):
+        return x.astype(hf).astype(f)
+    with np.errstate(all='ignore'):
+        p = r(r(depth.astype(f) * f(1.0 if invert else -1.0)) / f(256))
+        gx, gy = np.empty_like(p), np.empty_like(p)
+        gx[:, 1:-1] = r(r(p[:, 2:] - p[:, :-2]) / f(2)); gx[:, 0] = r(p[:, 1] - p[:, 0]); gx[:, -1] = r(p[:, -1] - p[:, -2])
+        gy[1:-1] = r(r(p[2:] - p[:-2]) / f(2)); gy[0] = r(p[1] - p[0]); gy[-1] = r(p[-1] - p[-2])
+        a, b, c = gx, -gy, np.ones_like(p)
+        n = r(np.sqrt(r((r(a * a) + r(b * b)) + r(c * c))))
+        out = []
+        for v in (a, b, c):
+            t = r(r(r(r(v / n) + f(1)) / f(2)) * f(256))
+            t = np.where(t < 0, f(0), t)
+            t = np.where(t > f(hf(256 - 0.1)), f(hf(256 - 0.1)), t)
+            out.append(np.where(np.isnan(t), f(0), t).astype(np.uint8))
+    return np.dstack(out)
+
+
+def test_float16_normalmap_kernel_arithmetic_matches_reference_golden():
+    """Round 6: the float16 + np.gradient kernel's arithmetic (float32 operation, then one rounding to half, per numpy ufunc) restated
+    in numpy and held to the reference-made float16 goldens bit for bit -- the GPU test then only has to show that the device
+    executes this arithmetic."""
+    z, index = util.load_normalmap_golden()
+    seen = 0
+    for c in index:
+        d = z[c['depth'] + '__depth']
+        if d.dtype != np.float16 or (c['sobel'] is not None and c['sobel'] > 0):
+            continue
+        got = _f16_kernel_model(d, c['invert'])
+        want = z[c['key'] + '__out']
+        assert np.array_equal(got, want), (c['key'], int((got != want).sum()))
+        seen += 1
+    assert seen == 12
+
+
+def test_numpy_half_add_reduce_is_a_float32_chain_rounded_once():
+    """np.linalg.norm(float16, axis=2) = sqrt(add.reduce(x * x)): the reduce adds the three squares left to right in a float32
+    accumulator and rounds to half once.  Operand triples on which (s0 + s1) + s2, s0 + (s1 + s2) and the half-rounded chain all
+    differ (found by search; s2 = 1 as in the normal's third component) pin which one numpy computes."""
+    f, hf = np.float32, np.float16
+    rng = np.random.default_rng(1)
+    n = 4_000_000
+    s0 = rng.integers(0x0400, 0x7bff, n, dtype=np.uint16).view(hf)
+    s1 = rng.integers(0x0001, 0x7bff, n, dtype=np.uint16).view(hf)
+    with np.errstate(all='ignore'):
+        left = ((s0.astype(f) + s1.astype(f)) + f(1)).astype(hf)
+        right = (s0.astype(f) + (s1.astype(f) + f(1))).astype(hf)
+        chain = (s0 + s1) + hf(1)
+        idx = np.nonzero((left != right) | (left != chain))[0]
+        assert len(idx) > 100
+        x = np.ones((3, len(idx), 3), hf)
+        x[:, :, 0] = s0[idx]
+        x[:, :, 1] = s1[idx]
+        got = np.add.reduce(x, axis=2)
+    assert np.array_equal(got, np.broadcast_to(left[idx], got.shape))
+    assert (left[idx] != chain[idx]).sum() > 50
