@@ -444,12 +444,14 @@ def mfma_roofline(kernel, flops, ms, launches_per_step, source, shape, **extra):
     return out
 
 
-IN_STEP = ("in-step: HIP events recorded by the C ABI around every launch of this kernel on the launch stream, INSIDE the timed region "
-           "(ds_kernel_timer_enable, include/depthstereo.h); average over {n} launches")
+IN_STEP = ("in-step: HIP events recorded by the C ABI around every launch of this kernel on the launch stream (ds_kernel_timer_enable, "
+           "include/depthstereo.h) in an instrumented repeat of the timed steps right behind the timed region -- same process, tensors and "
+           "launches; the event records cost ~2 ms per step, so the timed region runs without them (--timers-in-region: inside it); "
+           "average over {n} launches")
 MICRO = "microbenchmark: separate launches at the in-step shape on randn operands, HIP events on the launch stream"
 
 
-def encoder_rooflines(nat, vm, dev, local_rank, batch, minfo, config, timed):
+def encoder_rooflines(nat, vm, dev, local_rank, batch, minfo, config, timed, timed_each=None):
     """Roofline objects of the encoder's three big kernels.  `timed`: {kind: (launches, total ms)} read from the C ABI's in-step
     timers after the timed region -- the figure of each object when present; the microbenchmark of the same launch shape on randn
     operands is the side note.  Algorithmic flops use the VALID tokens (batch x n), not the padded rows the kernels walk."""
@@ -489,6 +491,22 @@ def encoder_rooflines(nat, vm, dev, local_rank, batch, minfo, config, timed):
             r = mfma_roofline(label, flops, micro_ms, per_step, MICRO, shape, operands="random (randn)")
         else:
             continue
+        each = (timed_each or {}).get(kind)
+        if kind == "linear_residual" and each and len(each) % 2 == 0:
+            # the two launches of a block alternate: projection (K = dim) first, fc2 (K = 4 dim) second -- one roofline entry each
+            rag_each = (timed_each or {}).get(kind + "+ragged") or []
+            by_shape = {}
+            for idx, (nm_, kk) in enumerate((("projection", dim), ("fc2", 4 * dim))):
+                d = each[idx::2]
+                fl = 2.0 * rows * dim * kk
+                avg = sum(d) / len(d)
+                e = {"kernel": "k_linear256<EPI 3, RES 1> (%s + LayerScale + residual)" % nm_, "in_features": kk, "launches": len(d),
+                     "avg_kernel_ms": avg, "algorithmic_flops_per_launch": fl, "achieved": fl / (avg * 1e-3) / 1e12,
+                     "frac": fl / (avg * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS, "unit": "TFLOP/s"}
+                if len(rag_each) == len(each):
+                    e["ragged_round_avg_ms"] = sum(rag_each[idx::2]) / len(d)
+                by_shape[nm_] = e
+            r["by_shape"] = by_shape
         if c3:
             r["traffic_from_profile"] = traffic_from_profile(prof_name, batch)
             r["profile_avg"] = stats_from_profile(prof_name)
@@ -595,6 +613,7 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-route-check", action="store_true", help="leave out the untimed route check (profile runs: its library-routed "
                                                                   "forward would show up in the kernel statistics of the step)")
+    ap.add_argument("--timers-in-region", action="store_true", help="record the kernel timers' events inside the timed region (rounds 3-5; costs ~2 ms per step)")
     ap.add_argument("--no-kernel-timers", action="store_true", help="do not bracket the kernels with events inside the timed region (A/B of the "
                                                                     "timers' own cost; the rooflines then fall back to the microbenchmarks)")
     ap.add_argument("--no-other-configs", action="store_true", help="default invocation only: skip the short c5 / c2 / c4 legs behind the metric's line")
@@ -765,10 +784,14 @@ def run_pipeline(args):
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
-    # in-step kernel timers: event pairs around the launches of the big in-tree kernels, recorded INSIDE the timed region (an event
-    # record is a marker on the stream: ~100 per step; --no-kernel-timers measures what they cost: nothing outside the noise)
+    # kernel timers: event pairs around the launches of the big in-tree kernels (ds_kernel_timer_enable).  Rounds 3-5 recorded them
+    # INSIDE the timed region on the belief that a record is a free marker; round 6 measured it: ~250 pairs per step cost 2.2 ms of a
+    # 39 ms step (eager 818.7 pairs/s with them, 868.8 without, 867.3 as a hipGraph replay, which skips them: profiles/
+    # round6_timers_ab.txt) -- every record is a barrier packet between two kernels.  So the timed region runs WITHOUT them, and the
+    # roofline durations come from an instrumented repeat of the same steps right behind it (same process, tensors, launches and
+    # clocks; its own step time is reported as instrumented_ms_per_step).  --timers-in-region restores the old arrangement (A/B).
     timers_on = model is not None and not args.no_kernel_timers
-    if timers_on:
+    if timers_on and args.timers_in_region:
         nat.kernel_timer_enable(local_rank, True)
     if world > 1:
         dist.barrier()
@@ -781,8 +804,22 @@ def run_pipeline(args):
         dist.barrier()
         torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    timed = {}
+    instrumented_ms = None
+    if timers_on and not args.timers_in_region:
+        n_inst = min(args.steps, 20)                             # the event rings hold 1024 launches per kernel kind
+        nat.kernel_timer_enable(local_rank, True)
+        ti = time.perf_counter()
+        for _ in range(n_inst):
+            step()
+        torch.cuda.synchronize()
+        instrumented_ms = (time.perf_counter() - ti) / n_inst * 1e3
+        if world > 1:
+            dist.barrier()
+    timed, timed_each = {}, {}
+    timer_steps = args.steps if args.timers_in_region else min(args.steps, 20)
     if timers_on:
+        for kind in ("linear_residual", "linear_residual+ragged"):
+            timed_each[kind] = nat.kernel_timer_read_each(local_rank, kind)
         for kind in ("linear_gelu", "linear_residual", "attention", "linear", "linear_vt", "conv3x3", "linear_readout", "linear_shuffle", "normalmap"):
             timed[kind] = nat.kernel_timer_read(local_rank, kind)
             if kind.startswith("linear"):
@@ -866,7 +903,7 @@ def run_pipeline(args):
                 if n > 0 and "+" not in kind:
                     roofs[kind] = {"kernel": kind, "avg_kernel_ms": ms / n, "launches": n, "source": IN_STEP.format(n=n)}
         else:
-            roofs = encoder_rooflines(nat, vm, dev, local_rank, batch, minfo, args.config, timed)
+            roofs = encoder_rooflines(nat, vm, dev, local_rank, batch, minfo, args.config, timed, timed_each)
             if vm.CONV_HIP and model_name.startswith("dpt_"):
                 cv_ms, hw = microbench_conv(nat, vm, dev, batch, net_size, net_h)
                 if cv_ms is not None:
@@ -952,7 +989,8 @@ def run_pipeline(args):
         elif roofs:
             out["in_step_kernel_ms"] = roofs
         if timed:
-            out["in_step_kernel_time_ms_per_step"] = {k: v[1] / args.steps for k, v in timed.items() if v[0] > 0}
+            out["in_step_kernel_time_ms_per_step"] = {k: v[1] / timer_steps for k, v in timed.items() if v[0] > 0}
+            out["instrumented_ms_per_step"] = instrumented_ms
         if normalmap and nm_ms:
             a = batch * algo_bytes_normalmap() / (float(np.mean(nm_ms)) * 1e-3) / 1e9
             out["roofline_normalmap"] = {"bound": "hbm", "kernel": "k_normalmap_fused", "achieved": a, "peak": HBM_PEAK_GBPS,

@@ -114,6 +114,9 @@ int ds_profile_last_ms(ds_ctx *ctx, float *render_ms, float *exact_ms);
 #define DS_KT_RAGGED          12   /* + kind: the ragged round (k_linear_ragged) of that GEMM kind */
 int ds_kernel_timer_enable(ds_ctx *ctx, int enable);
 int ds_kernel_timer_read(ds_ctx *ctx, int kind, int64_t *launches, double *total_ms);
+/* the same, launch by launch in launch order: the first min(*launches, capacity) durations (ms) go to ms_out (bench.py tells the
+ * projection launches of ds_linear_residual from the fc2 launches: they alternate) */
+int ds_kernel_timer_read_each(ds_ctx *ctx, int kind, float *ms_out, int64_t capacity, int64_t *launches);
 
 /* Number of image rows the last ds_stereo_warp on this ctx re-rendered with the exact sequential
  * sweep (polylines only; see DESIGN.md "exact fallback").  Synchronises the stream. */

@@ -130,6 +130,18 @@ DS_API int ds_kernel_timer_read(ds_ctx *ctx, int kind, int64_t *launches, double
     return DS_OK;
 }
 
+DS_API int ds_kernel_timer_read_each(ds_ctx *ctx, int kind, float *ms_out, int64_t capacity, int64_t *launches)
+{
+    DS_REQUIRE(ctx && launches && (ms_out || capacity == 0), DS_EINVAL, "ds_kernel_timer_read_each: null argument");
+    DS_REQUIRE(kind >= 0 && kind < DS_KT_KINDS, DS_EINVAL, "ds_kernel_timer_read_each: kind %d outside 0..%d", kind, DS_KT_KINDS - 1);
+    DS_HIP_CHECK(hipSetDevice(ctx->device));
+    const int n = ctx->kt_n[kind];
+    if (n > 0) DS_HIP_CHECK(hipEventSynchronize(ctx->kt_ev[kind][n - 1][1]));
+    for (int i = 0; i < n && i < capacity; i++) DS_HIP_CHECK(hipEventElapsedTime(&ms_out[i], ctx->kt_ev[kind][i][0], ctx->kt_ev[kind][i][1]));
+    *launches = n;
+    return DS_OK;
+}
+
 int ds_ctx_reserve(ds_ctx *ctx, void **slot, size_t *cur, size_t need)
 {
     if (*cur >= need && *slot) return DS_OK;

@@ -23,7 +23,7 @@ EXPORTS = [
     "ds_version", "ds_last_error", "ds_normalmap_f64", "ds_normalmap_gradient_f32", "ds_reassemble_readout", "ds_bias_act_nhwc", "ds_linear", "ds_linear_residual", "ds_linear_vt", "ds_conv3x3_nhwc", "ds_ctx_create", "ds_ctx_destroy", "ds_stereo_warp", "ds_depth_minmax",
     "ds_stereo_last_exact_rows", "ds_copy_view", "ds_overlap_red_cyan", "ds_normalmap", "ds_depth_to_u16",
     "ds_convert_to_i16", "ds_profile_enable", "ds_profile_last_ms", "ds_stereo_last_stats", "ds_attention_fwd", "ds_attention_bias_pack", "ds_colorize_u16", "ds_residual_layernorm", "ds_boost_blend", "ds_upsample_bilinear_nhwc", "ds_dpt_head_tail", "ds_preprocess_bicubic", "ds_linear_reload_env", "ds_attention_reload_env", "ds_normalmap_selfcheck", "ds_normalmap_gradient_f16", "ds_normalmap_gradient_blur_f32",
-    "ds_linear_shuffle", "ds_linear_readout", "ds_kernel_timer_enable", "ds_kernel_timer_read",
+    "ds_linear_shuffle", "ds_linear_readout", "ds_kernel_timer_enable", "ds_kernel_timer_read", "ds_kernel_timer_read_each",
     "ds_row_stats", "ds_linear_ln", "ds_linear_vt_ln", "ds_gconv3x3_nhwc_f32", "ds_add_relu_f32",
 ]
 
@@ -98,6 +98,7 @@ def lib():
             L.ds_add_relu_f32.argtypes = [vp, vp, vp, vp, i64, vp]
             L.ds_kernel_timer_enable.argtypes = [vp, ci]
             L.ds_kernel_timer_read.argtypes = [vp, ci, ctypes.POINTER(i64), ctypes.POINTER(cd)]
+            L.ds_kernel_timer_read_each.argtypes = [vp, ci, ctypes.POINTER(ctypes.c_float), i64, ctypes.POINTER(i64)]
             L.ds_profile_enable.argtypes = [vp, ci]
             L.ds_profile_last_ms.argtypes = [vp, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float)]
             for name in EXPORTS:          # fail at load time, not at first use, if a symbol is missing
@@ -622,6 +623,16 @@ def kernel_timer_read(device_index, kind):
     n, ms = ctypes.c_int64(), ctypes.c_double()
     _check(lib().ds_kernel_timer_read(ctx_for(device_index), k, ctypes.byref(n), ctypes.byref(ms)))
     return int(n.value), float(ms.value)
+
+
+def kernel_timer_read_each(device_index, kind):
+    """Durations (ms) of the timed launches of one kind in launch order (include/depthstereo.h: ds_kernel_timer_read_each)."""
+    base, _, rag = kind.partition("+")
+    k = KT_KINDS[base] + (KT_RAGGED if rag == "ragged" else 0)
+    buf = (ctypes.c_float * 1024)()
+    n = ctypes.c_int64()
+    _check(lib().ds_kernel_timer_read_each(ctx_for(device_index), k, buf, 1024, ctypes.byref(n)))
+    return [float(buf[i]) for i in range(min(int(n.value), 1024))]
 
 
 def row_stats(x, eps):
