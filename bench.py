@@ -1148,15 +1148,15 @@ def funnel_leg(model, model_name, img_np, net_size, net_h, normalmap):
             return run_forward(model, model_name, t, net_size, net_h)
 
     graphed = None
-    if os.environ.get("DS_FUNNEL_GRAPH", "0") != "0":        # the group's forward as ONE hipGraph replay (src/hip_graph.py)
-        from src.hip_graph import GraphedForward
-        graphed = GraphedForward(lambda x: run_forward(model, model_name, x, net_size, net_h))
+    if os.environ.get("DS_FUNNEL_GRAPH", "1") != "0":        # the group's forward as ONE hipGraph replay (src/hip_graph.py), captured on
+        from src.hip_graph import GraphedForward             # the third use of a shape like the product's own predictor ("auto")
+        graphed = GraphedForward(lambda x: run_forward(model, model_name, x, net_size, net_h), lazy=2)
 
     core.model_holder.register_predictor(mt, _Pred())
     pils = [Image.fromarray(a) for a in img_np]
     opts = {"model_type": mt, "gen_stereo": True, "stereo_modes": ["left-right"], "gen_normalmap": normalmap,
             "net_width": net_size, "net_height": net_size if net_h is None else net_h}
-    for _ in range(2):
+    for _ in range(3):                                       # warm-up calls (the second one's groups are captured into hipGraphs)
         n_out = sum(1 for _ in core.core_generation_funnel(None, list(pils), None, None, opts))
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -1165,6 +1165,7 @@ def funnel_leg(model, model_name, img_np, net_size, net_h, normalmap):
     dt = time.perf_counter() - t0
     st = dict(core.FUNNEL_STATS)
     return {"value": len(pils) / dt, "unit": "pairs/s", "results": n_out, "seconds": dt,
+            "forward_launch": ("hipGraph replay" if (graphed is not None and graphed.graphs) else "eager"),
             "host_seconds": {"enqueue (decode + stage + launch)": st.get("launch"), "enqueue: decode + upload": st.get("launch_decode"),
                              "enqueue: network forward": st.get("launch_forward"), "enqueue: post-processing + downloads": st.get("launch_post"),
                              "blocked on device results": st.get("wait"),

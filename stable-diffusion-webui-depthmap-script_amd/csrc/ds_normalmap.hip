@@ -472,7 +472,7 @@ DS_API int ds_normalmap_gradient_f32(ds_ctx *ctx, const float *depth, int n, int
 // (24 >= 2 * 11 + 2 bits), and it is what this kernel does, operation by operation.  np.linalg.norm's add.reduce over the three
 // squares is the one multi-operand step: HALF_add's reduce loop keeps a FLOAT32 accumulator, adds the squares left to right and
 // rounds to half once (established on numpy 2.2 with operand triples on which (s0 + s1) + s2, s0 + (s1 + s2) and the
-// half-rounded chain differ: tests/test_oracle_golden.py).
+// half-rounded chain differ: a CPU test holds numpy to it).
 __device__ __forceinline__ float nm_r16(float x) { return (float)(_Float16)x; }
 
 __global__ __launch_bounds__(256) void k_nm_gradient_f16(const _Float16 *__restrict__ depth, int h, int w, int invert, uint8_t *__restrict__ out)

@@ -443,6 +443,14 @@ def _launch_group(gen, idxs, inputimages, inputdepthmaps, inp, device, stats=Non
     ready = torch.cuda.Event()
     ready.record()                                            # everything the copies read has been enqueued on the main stream
     cs = _copy_stream(device)
+    # round 6: the copies go out in CHUNKS of units with an event behind each, and the conversion of every unit to PIL is handed to
+    # the render pool right here: a unit is converted as soon as ITS chunk has landed -- beside the copies of the later chunks and
+    # the enqueueing of the next group -- instead of after the whole group (the last group's conversion used to be a tail of
+    # ~10 ms per 16 units with the device idle)
+    nchunks = min(b, max(1, int(_os.environ.get("DS_FUNNEL_CHUNKS", 4))))
+    bounds = [(b * c) // nchunks for c in range(nchunks + 1)]
+    g["chunk_of"] = [next(c for c in range(nchunks) if bounds[c] <= j < bounds[c + 1]) for j in range(b)]
+    g["chunk_done"] = []
     with torch.cuda.stream(cs):
         cs.wait_event(ready)
         if g["pred_host"] is not None:
@@ -450,13 +458,19 @@ def _launch_group(gen, idxs, inputimages, inputdepthmaps, inp, device, stats=Non
             ph.copy_(src, non_blocking=True)
             src.record_stream(cs)
             g["pred_host"] = ph
-        for t, tag in pending_downloads:
-            hbuf = _staging.get(gen, tag, tuple(t.shape), t.dtype)
-            hbuf.copy_(t, non_blocking=True)
-            t.record_stream(cs)                               # the allocator must not hand t's memory out while the copy runs
+        hbufs = [(t, tag, _staging.get(gen, tag, tuple(t.shape), t.dtype)) for t, tag in pending_downloads]
+        for c in range(nchunks):
+            for t, tag, hbuf in hbufs:
+                hbuf[bounds[c]:bounds[c + 1]].copy_(t[bounds[c]:bounds[c + 1]], non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+            g["chunk_done"].append(ev)
+        for t, tag, hbuf in hbufs:
+            t.record_stream(cs)                               # the allocator must not hand t's memory out while the copies run
             g["host"][tag] = hbuf
-        g["done"] = torch.cuda.Event()
-        g["done"].record()
+        g["done"] = g["chunk_done"][-1]
+    g["inp"] = inp
+    g["futures"] = [_render_pool().submit(_render_unit, g, j) for j in range(b)] if b > 1 else None
     lap("launch_post")
     return g
 
@@ -545,50 +559,68 @@ def _to_pil(a):
     return Image.fromarray(a.copy())
 
 
+_rpool = None
+
+
+def _render_pool():
+    """Threads that turn pinned result buffers into PIL images (a pool of its own: its workers also WAIT for their chunk's copy
+    event, and must not starve the decode / upload work _host_pool does for the next group)."""
+    global _rpool
+    if _rpool is None:
+        from concurrent.futures import ThreadPoolExecutor
+        _rpool = ThreadPoolExecutor(max_workers=min(32, (_os.cpu_count() or 4)), thread_name_prefix="ds-funnel-render")
+    return _rpool
+
+
+def _render_unit(g, j):
+    """Results of unit j of a launched group in the reference's order (:208-274), as soon as the unit's chunk of copies has landed."""
+    inp = g["inp"]
+    g["chunk_done"][g["chunk_of"][j]].synchronize()          # (the prediction buffer, one copy for the whole group, went first)
+    host = g["host"]
+    image = g["images"][j]
+    out = []
+    if g["pred_host"] is not None and not g["broken"][j]:
+        out.append(('depth_prediction', g["pred_host"].numpy()[j].copy()))
+    if inp[go.DO_OUTPUT_DEPTH]:                                                              # :240-249
+        img_output = host["depth"].numpy()[j]
+        img_depth = np.bitwise_not(img_output) if inp[go.OUTPUT_DEPTH_INVERT] else img_output   # cv2.bitwise_not
+        if inp[go.OUTPUT_DEPTH_COMBINE]:
+            axis = 1 if inp[go.OUTPUT_DEPTH_COMBINE_AXIS] == 'Horizontal' else 0
+            out.append(('concat_depth', Image.fromarray(np.concatenate(
+                (image, convert_i16_to_rgb(img_depth, np.asarray(image))), axis=axis))))
+        else:
+            out.append(('depth', Image.fromarray(img_depth.copy())))
+    if g.get("stereo_error") is not None:
+        return out                                       # the reference raised here, inside create_stereoimages
+    if inp[go.GEN_STEREO]:
+        for c in range(g["n_stereo"]):
+            out.append((inp[go.STEREO_MODES][c], _to_pil(host["stereo%d" % c].numpy()[j])))
+    if inp[go.GEN_NORMALMAP]:
+        out.append(('normalmap', _to_pil(host["normalmap"].numpy()[j])))
+    if inp[go.GEN_HEATMAP]:
+        out.append(('heatmap', _to_pil(host["heatmap"].numpy()[j])))
+    return out
+
+
 def _emit_group(g, outpath, inp, device, stats):
     """Yield a finished group's results image by image in the reference's order (:208-306).  The pinned buffers are reused
-    two groups later, so every result is copied out of them (PIL owns its pixels); the copies of a group run on a small
-    thread pool while the generator hands out what is already done."""
+    two groups later, so every result is copied out of them (PIL owns its pixels); the conversions were handed to the render
+    pool when the group was launched (_render_unit: each waits for its own chunk of copies), the generator hands out what is done."""
     torch = _native._torch()
     if g.get("skip"):
         return
-    _t0 = _time.perf_counter()
-    g["done"].synchronize()
-    stats["wait"] = stats.get("wait", 0.0) + (_time.perf_counter() - _t0)
-    host = {k: v.numpy() for k, v in g["host"].items()}
-    pred_host = None if g["pred_host"] is None else g["pred_host"].numpy()
+    futures = g.get("futures")
 
-    def render(j):
-        image = g["images"][j]
-        out = []
-        if pred_host is not None and not g["broken"][j]:
-            out.append(('depth_prediction', pred_host[j].copy()))
-        if inp[go.DO_OUTPUT_DEPTH]:                                                              # :240-249
-            img_output = host["depth"][j]
-            img_depth = np.bitwise_not(img_output) if inp[go.OUTPUT_DEPTH_INVERT] else img_output   # cv2.bitwise_not
-            if inp[go.OUTPUT_DEPTH_COMBINE]:
-                axis = 1 if inp[go.OUTPUT_DEPTH_COMBINE_AXIS] == 'Horizontal' else 0
-                out.append(('concat_depth', Image.fromarray(np.concatenate(
-                    (image, convert_i16_to_rgb(img_depth, np.asarray(image))), axis=axis))))
-            else:
-                out.append(('depth', Image.fromarray(img_depth.copy())))
-        if g.get("stereo_error") is not None:
-            return out                                       # the reference raised here, inside create_stereoimages
-        if inp[go.GEN_STEREO]:
-            for c in range(g["n_stereo"]):
-                out.append((inp[go.STEREO_MODES][c], _to_pil(host["stereo%d" % c][j])))
-        if inp[go.GEN_NORMALMAP]:
-            out.append(('normalmap', _to_pil(host["normalmap"][j])))
-        if inp[go.GEN_HEATMAP]:
-            out.append(('heatmap', _to_pil(host["heatmap"][j])))
-        return out
+    def result_of(j):
+        _t0 = _time.perf_counter()
+        r = futures[j].result() if futures is not None else _render_unit(g, j)
+        stats["wait"] = stats.get("wait", 0.0) + (_time.perf_counter() - _t0)
+        return r
 
-    n = len(g["idxs"])
-    futures = [_host_pool().submit(render, j) for j in range(n)] if n > 1 else None
     try:
         for j, count in enumerate(g["idxs"]):
             image = g["images"][j]
-            for kind, res in (futures[j].result() if futures is not None else render(j)):
+            for kind, res in result_of(j):
                 yield count, kind, res
             if g.get("stereo_error") is not None:
                 raise g["stereo_error"]
@@ -636,6 +668,7 @@ def core_generation_funnel(outpath, inputimages, inputdepthmaps, inputnames, inp
     stats = {"finished": False}
     FUNNEL_STATS.clear()                   # a reader never sees the PREVIOUS call's numbers while (or after) this one runs
     _t_start = _time.perf_counter()
+    pending = launched = None
 
     try:
         if not inputdepthmaps_complete:
@@ -646,7 +679,7 @@ def core_generation_funnel(outpath, inputimages, inputdepthmaps, inputnames, inp
                 inputimages[count] = inputimages[count].convert('RGB')
         # Boost renders one image at a time by construction (its own patch batches inside estimateboost)
         groups = _plan_groups(inputimages, inputdepthmaps, batchable=not inp[go.BOOST])
-        pending = None
+        pending = launched = None
         for gi, idxs in enumerate(groups):
             # group k+1 is enqueued before group k is handed out (host conversion overlaps device work); whatever goes wrong
             # while enqueueing it (a bad image, out of memory) must not swallow the finished results of group k: the
@@ -678,6 +711,12 @@ def core_generation_funnel(outpath, inputimages, inputdepthmaps, inputnames, inp
         raise e
     finally:
         # published whether the generator ran to completion, was closed early or raised ('finished' says which)
+        for g_ in (pending, launched):       # closed early or raised: conversions already handed to the render pool must be done with
+            for f in ((g_ or {}).get("futures") or []):          # the pinned buffers before a later call reuses them
+                try:
+                    f.result()
+                except Exception:            # noqa: BLE001
+                    pass
         stats["total"] = _time.perf_counter() - _t_start
         FUNNEL_STATS.clear()
         FUNNEL_STATS.update(stats)

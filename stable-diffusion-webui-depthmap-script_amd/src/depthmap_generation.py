@@ -125,7 +125,7 @@ class _NetPredictor:
                                     "Place the checkpoint there or set ModelHolder.allow_random_init for a dry run")
         self.model_type = model_type
         self.no_half = bool(no_half)
-        self.hip_graphs = False
+        self.hip_graphs = "auto"
         self._graphed = {}
         self.net = net.eval().to(device)
         dev = torch.device(device)
@@ -145,14 +145,18 @@ class _NetPredictor:
 
     def predict_batch(self, batch, net_width, net_height):
         """uint8 RGB [B,H,W,3] on the network's device -> float32 [B,H,W] raw predictions: ONE forward for the batch.
-        With ModelHolder's `hip_graphs` setting the launches of that forward are captured once per (shape, net size) into a
-        hipGraph and replayed (src/hip_graph.py): what a launch-bound batch-1 forward needs."""
-        if getattr(self, "hip_graphs", False) and batch.is_cuda:
+        The launches of that forward are captured once per (shape, net size) into a hipGraph and replayed (src/hip_graph.py) --
+        ModelHolder's `hip_graphs` setting: "auto" (default: from the third use of a shape), True (from the first), False (never)."""
+        mode = getattr(self, "hip_graphs", False)
+        if mode and batch.is_cuda:
             from .hip_graph import GraphedForward
             key = (int(net_width), int(net_height))
             gf = self._graphed.get(key)
             if gf is None:
-                gf = self._graphed[key] = GraphedForward(lambda b: self._predict_batch_eager(b, net_width, net_height))
+                # "auto" (the default since round 6): a (shape, net size) runs eager twice, is captured on its third use and
+                # replayed from then on, when the replay reproduces the eager result; True: captured on first use
+                gf = self._graphed[key] = GraphedForward(lambda b: self._predict_batch_eager(b, net_width, net_height),
+                                                         lazy=2 if mode == "auto" else 0)
             return gf(batch)
         return self._predict_batch_eager(batch, net_width, net_height)
 
@@ -212,7 +216,7 @@ class ModelHolder:
             if (self.depth_model is None or self.depth_model_type != model_type or not isinstance(self.depth_model, _NetPredictor)
                     or self.depth_model.no_half != no_half or self.depth_model.tiling_mode != bool(tiling_mode)):
                 self.depth_model = _NetPredictor(model_type, device, self.model_dir, self.allow_random_init, no_half, tiling_mode)
-            self.depth_model.hip_graphs = bool(getattr(self, "hip_graphs", False))
+            self.depth_model.hip_graphs = getattr(self, "hip_graphs", "auto")      # "auto" | True | False (see predict_batch)
         else:
             raise NotImplementedError(
                 f"depth model {model_type!r} is not available in this build (built: ids {sorted(_BUILDERS)}); register a "

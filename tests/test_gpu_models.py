@@ -613,6 +613,32 @@ def test_dpt_beit_large_512_forward_vs_reference(gpu):
     assert np.abs(y16 - ref).max() / scale < 2e-2, np.abs(y16 - ref).max() / scale
 
 
+def test_dpt_beit_large_512_net1024_forward_vs_reference(gpu):
+    """The metric's network in its second form (NET_SIZE_MATCH on a 1024 x 1024 frame, net 1024, 4097 tokens; reference
+    src/core.py:177-181, dmidas/backbones/beit.py:38-63 interpolate the relative-position tables to the 64 x 64 window) against the
+    float32 output of the reference's own dmidas code at that size (tests/golden/make_golden_models_net1024.py): float32 at 1e-4,
+    float16 -- what bench.py's c3match leg runs -- at 2e-2, plus the reassembled tap of block 23."""
+    from dmidas.dpt_depth import DPTDepthModel
+    gold = np.load(os.path.join(os.path.dirname(GOLD_LARGE), "model_cases_net1024.npz"))
+    m = DPTDepthModel(path=None, backbone="beitl16_512", non_negative=True).eval()
+    m.load_state_dict(mw.fill_state_dict_beit(m.state_dict()), strict=True)
+    x = mw.synthetic_image((1, 3, 1024, 1024), seed=33).cuda()
+    ref = gold["dpt_beitl512_1024x1024_out_s4"]
+    m = m.cuda()
+    with torch.no_grad():
+        y32 = m(x)[:, ::4, ::4].cpu().numpy()
+        taps = m.pretrained(x)
+    scale = np.abs(ref).max()
+    assert np.abs(y32 - ref).max() / scale < 1e-4, np.abs(y32 - ref).max() / scale
+    t4 = taps[3][:, ::4].float().cpu().numpy()
+    g4 = gold["dpt_beitl512_1024x1024_layer4_s"]
+    assert t4.shape == g4.shape and np.abs(t4 - g4).max() / np.abs(g4).max() < 1e-4
+    del taps
+    with torch.no_grad():
+        y16 = m.half()(x.half().contiguous(memory_format=torch.channels_last))[:, ::4, ::4].float().cpu().numpy()
+    assert np.abs(y16 - ref).max() / scale < 2e-2, np.abs(y16 - ref).max() / scale
+
+
 def test_dav2_vitl_1080p_forward_vs_reference(gpu):
     """Depth-Anything-V2 ViT-L at 518 x 924 (a 1080p frame at input_size 518: 2443 tokens, BASELINE config 5) against the
     float32 outputs of the reference's own modules: encoder taps and depth, float32 at 1e-4 and float16 at 2e-2."""
@@ -786,6 +812,14 @@ def test_hip_graph_replay_equals_eager_forward(gpu):
             assert (got2 - got).abs().mean().item() > 0
         # every shape was either captured (and validated at capture) or, if the library misbehaved inside the capture, left eager
         assert len(gf.graphs) + len(gf.failed) == 2
+        # lazy = 2 (ModelHolder.hip_graphs = "auto", the default): a shape runs eager twice and is captured on its third use
+        gl = GraphedForward(lambda x, net=net, call=call: call(net, x), lazy=2)
+        x = torch.randint(0, 256, (1, 96, 128, 3), generator=g, dtype=torch.uint8).cuda()
+        want = call(net, x)
+        for i in range(4):
+            got = gl(x)
+            assert len(gl.graphs) + len(gl.failed) == (1 if i >= 2 else 0), i
+            assert (got - want).abs().max().item() <= 5 * noise + 2e-2 * want.abs().max().item()
 
 
 @pytest.mark.parametrize("dtype,tol", [(torch.float16, 1.5e-3), (torch.bfloat16, 1.2e-2)])
