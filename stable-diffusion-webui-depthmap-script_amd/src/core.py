@@ -304,6 +304,21 @@ def _plan_groups(inputimages, inputdepthmaps, batchable):
     return groups
 
 
+# DS_FUNNEL_TRACE=1 (tools/funnel_timeline.py): device timestamps of every group's stages (events with timing on the streams that
+# carry them) and host timestamps of every unit's conversion, collected per funnel call in FUNNEL_TRACE.  Off: plain events.
+_TRACE = bool(_os.environ.get("DS_FUNNEL_TRACE"))
+FUNNEL_TRACE = {}
+
+
+def _mark(g, name, stream=None):
+    if not _TRACE:
+        return
+    torch = _native._torch()
+    ev = torch.cuda.Event(enable_timing=True)
+    ev.record(stream) if stream is not None else ev.record()
+    g.setdefault("trace", []).append((name, ev, _time.perf_counter()))
+
+
 def _launch_group(gen, idxs, inputimages, inputdepthmaps, inp, device, stats=None):
     """Enqueue everything a group needs on the current stream -- H2D, network, post-processing, stereo, normal map, heat
     map, D2H into pinned buffers -- and return the handles; nothing here waits for the device except the post-processing
@@ -323,12 +338,34 @@ def _launch_group(gen, idxs, inputimages, inputdepthmaps, inp, device, stats=Non
     custom = inputdepthmaps[idxs[0]] is not None
     want_stereo = inp[go.GEN_STEREO]
 
+    def h2d(st):
+        """Pinned staging -> device on the UPLOAD streams (round 6): the inputs of group k+1 cross the link beside the kernels of
+        group k instead of in front of its own forward on the compute stream, which waits for the copies' events only.  Two halves
+        on two streams: one hipMemcpyAsync runs on one SDMA engine at about half the link's rate."""
+        main = torch.cuda.current_stream(device)
+        up0 = _copy_stream(device, "up0")
+        with torch.cuda.stream(up0):
+            t = torch.empty(st.shape, dtype=st.dtype, device=device)
+        n = st.shape[0]
+        cuts = [0, n] if n < 2 else [0, n // 2, n]
+        for i in range(len(cuts) - 1):
+            up = _copy_stream(device, "up%d" % i)
+            with torch.cuda.stream(up):
+                t[cuts[i]:cuts[i + 1]].copy_(st[cuts[i]:cuts[i + 1]], non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record()
+            main.wait_event(ev)
+            if i > 0:
+                t.record_stream(up)
+        t.record_stream(main)
+        return t
+
     def upload(arrays, tag, dtype):
         st = _staging.get(gen, tag, (b,) + arrays[0].shape, dtype)
         stn = st.numpy()
         for j, a in enumerate(arrays):
             np.copyto(stn[j], a)
-        return st.to(device, non_blocking=True)
+        return h2d(st)
 
     def upload_pixels(tag, to_array, rgb=False):
         """PIL -> uint8 array -> pinned staging (decoded and copied on the host thread pool) -> device.
@@ -343,14 +380,14 @@ def _launch_group(gen, idxs, inputimages, inputdepthmaps, inp, device, stats=Non
                 else:
                     _ctypes.memmove(base, srcs[0][0], nbytes)
                 del srcs
-                return st.to(device, non_blocking=True)[..., :3].contiguous()
+                return h2d(st)[..., :3].contiguous()
         first = to_array(images[0])
         st = _staging.get(gen, tag, (b,) + first.shape, torch.uint8)
         stn = st.numpy()
         np.copyto(stn[0], first)
         if b > 1:
             list(_host_pool().map(lambda j: np.copyto(stn[j], to_array(images[j])), range(1, b)))
-        return st.to(device, non_blocking=True)
+        return h2d(st)
 
     img_t = None
     ndim0 = 3 if len(images[0].getbands()) > 1 else 2                                            # np.array(image).ndim
@@ -379,7 +416,9 @@ def _launch_group(gen, idxs, inputimages, inputdepthmaps, inp, device, stats=Non
         else:
             rgb_t = upload_pixels("rgb", lambda im: np.asarray(im.convert("RGB"), dtype=np.uint8), rgb=images[0].mode == "RGB")
         lap("launch_decode")
+        _mark(g, "inputs on the device")
         pred, invert = model_holder.get_raw_prediction_batch(images, rgb_t, net_width, net_height)
+        _mark(g, "forward done")
         lap("launch_forward")
         if pred is None:                 # Boost sharded over ranks (ModelHolder.boost_group): only the group's rank 0 renders
             g["skip"] = True
@@ -440,6 +479,7 @@ def _launch_group(gen, idxs, inputimages, inputdepthmaps, inp, device, stats=Non
     if inp[go.GEN_HEATMAP]:                                                                      # :271-274
         from .heatmap import colorize_batch
         download(colorize_batch(d16), "heatmap")
+    _mark(g, "per-pixel kernels done")
     ready = torch.cuda.Event()
     ready.record()                                            # everything the copies read has been enqueued on the main stream
     cs = _copy_stream(device)
@@ -451,6 +491,10 @@ def _launch_group(gen, idxs, inputimages, inputdepthmaps, inp, device, stats=Non
     bounds = [(b * c) // nchunks for c in range(nchunks + 1)]
     g["chunk_of"] = [next(c for c in range(nchunks) if bounds[c] <= j < bounds[c + 1]) for j in range(b)]
     g["chunk_done"] = []
+    # ONE copy stream: the device-to-host copies of a group already run at the link's rate on it (176 MB in 3.4 ms), and HIP maps its
+    # streams onto four hardware queues -- with four copy streams the compute stream shared a queue with one of them and the next
+    # group's forward waited 3.8 ms for copies it does not depend on (tools/funnel_timeline.py; DS_FUNNEL_COPY_STREAMS for A/B runs)
+    nstreams = max(1, min(nchunks, int(_os.environ.get("DS_FUNNEL_COPY_STREAMS", 1))))
     with torch.cuda.stream(cs):
         cs.wait_event(ready)
         if g["pred_host"] is not None:
@@ -458,19 +502,36 @@ def _launch_group(gen, idxs, inputimages, inputdepthmaps, inp, device, stats=Non
             ph.copy_(src, non_blocking=True)
             src.record_stream(cs)
             g["pred_host"] = ph
-        hbufs = [(t, tag, _staging.get(gen, tag, tuple(t.shape), t.dtype)) for t, tag in pending_downloads]
-        for c in range(nchunks):
+        pred_done = torch.cuda.Event()
+        pred_done.record()
+    # largest results first inside a chunk, an event behind every (chunk, result): the pair's conversion (the longest) starts while
+    # the chunk's smaller results are still crossing the link
+    hbufs = sorted(((t, tag, _staging.get(gen, tag, tuple(t.shape), t.dtype)) for t, tag in pending_downloads),
+                   key=lambda e: -e[0][0].numel() * e[0].element_size())
+    g["landed"] = {}
+    for c in range(nchunks):
+        cs_c = _copy_stream(device, c % nstreams)
+        with torch.cuda.stream(cs_c):
+            if c < nstreams:
+                cs_c.wait_event(ready)
+                if c > 0 and g["pred_host"] is not None:
+                    cs_c.wait_event(pred_done)                # (every chunk's event also covers the group's prediction copy)
             for t, tag, hbuf in hbufs:
                 hbuf[bounds[c]:bounds[c + 1]].copy_(t[bounds[c]:bounds[c + 1]], non_blocking=True)
-            ev = torch.cuda.Event()
-            ev.record()
+                ev = torch.cuda.Event()
+                ev.record()
+                g["landed"][(c, tag)] = ev
+            if not hbufs:                                     # (nothing to copy: mesh-only calls)
+                ev = torch.cuda.Event()
+                ev.record()
             g["chunk_done"].append(ev)
-        for t, tag, hbuf in hbufs:
-            t.record_stream(cs)                               # the allocator must not hand t's memory out while the copies run
-            g["host"][tag] = hbuf
-        g["done"] = g["chunk_done"][-1]
+            _mark(g, "chunk %d on the host" % c)
+    for t, tag, hbuf in hbufs:
+        for i in range(nstreams):
+            t.record_stream(_copy_stream(device, i))          # the allocator must not hand t's memory out while the copies run
+        g["host"][tag] = hbuf
     g["inp"] = inp
-    g["futures"] = [_render_pool().submit(_render_unit, g, j) for j in range(b)] if b > 1 else None
+    g["futures"] = [[_render_pool().submit(_run_task, g, j, t) for t in _unit_tasks(g, j)] for j in range(b)] if b > 1 else None
     lap("launch_post")
     return g
 
@@ -483,9 +544,11 @@ _copy_streams = {}
 FUNNEL_STATS = {}
 
 
-def _copy_stream(device):
+def _copy_stream(device, index=0):
+    """Copy streams of a device: 0 .. for the results (device to host), "up" for the inputs.  One hipMemcpyAsync runs on ONE SDMA
+    engine (~25 GB/s of the link's ~55): the chunks of a group's results go out on several streams side by side."""
     torch = _native._torch()
-    key = str(device)
+    key = (str(device), index)
     st = _copy_streams.get(key)
     if st is None:
         st = _copy_streams[key] = torch.cuda.Stream(device=device)
@@ -572,40 +635,57 @@ def _render_pool():
     return _rpool
 
 
-def _render_unit(g, j):
-    """Results of unit j of a launched group in the reference's order (:208-274), as soon as the unit's chunk of copies has landed."""
+def _unit_tasks(g, j):
+    """The conversions of unit j of a launched group as independent tasks, in the reference's output order (:208-274): (result buffer
+    the task reads, callable returning (kind, result)).  One task per OUTPUT, not per unit: a 1024 x 2048 pair takes ~2 ms to unpack
+    into PIL's pixel store, the normal map ~1 ms -- side by side the last unit of a group is out ~3 ms after its bytes landed
+    instead of ~5 (tools/funnel_timeline.py)."""
     inp = g["inp"]
-    g["chunk_done"][g["chunk_of"][j]].synchronize()          # (the prediction buffer, one copy for the whole group, went first)
     host = g["host"]
     image = g["images"][j]
-    out = []
+    tasks = []
     if g["pred_host"] is not None and not g["broken"][j]:
-        out.append(('depth_prediction', g["pred_host"].numpy()[j].copy()))
+        tasks.append((None, lambda: ('depth_prediction', g["pred_host"].numpy()[j].copy())))
     if inp[go.DO_OUTPUT_DEPTH]:                                                              # :240-249
-        img_output = host["depth"].numpy()[j]
-        img_depth = np.bitwise_not(img_output) if inp[go.OUTPUT_DEPTH_INVERT] else img_output   # cv2.bitwise_not
-        if inp[go.OUTPUT_DEPTH_COMBINE]:
-            axis = 1 if inp[go.OUTPUT_DEPTH_COMBINE_AXIS] == 'Horizontal' else 0
-            out.append(('concat_depth', Image.fromarray(np.concatenate(
-                (image, convert_i16_to_rgb(img_depth, np.asarray(image))), axis=axis))))
-        else:
-            out.append(('depth', Image.fromarray(img_depth.copy())))
+        def depth():
+            img_output = host["depth"].numpy()[j]
+            img_depth = np.bitwise_not(img_output) if inp[go.OUTPUT_DEPTH_INVERT] else img_output   # cv2.bitwise_not
+            if inp[go.OUTPUT_DEPTH_COMBINE]:
+                axis = 1 if inp[go.OUTPUT_DEPTH_COMBINE_AXIS] == 'Horizontal' else 0
+                return ('concat_depth', Image.fromarray(np.concatenate((image, convert_i16_to_rgb(img_depth, np.asarray(image))), axis=axis)))
+            return ('depth', Image.fromarray(img_depth.copy()))
+        tasks.append(("depth", depth))
     if g.get("stereo_error") is not None:
-        return out                                       # the reference raised here, inside create_stereoimages
+        return tasks                                     # the reference raised here, inside create_stereoimages
     if inp[go.GEN_STEREO]:
         for c in range(g["n_stereo"]):
-            out.append((inp[go.STEREO_MODES][c], _to_pil(host["stereo%d" % c].numpy()[j])))
+            tasks.append(("stereo%d" % c, lambda c=c: (inp[go.STEREO_MODES][c], _to_pil(host["stereo%d" % c].numpy()[j]))))
     if inp[go.GEN_NORMALMAP]:
-        out.append(('normalmap', _to_pil(host["normalmap"].numpy()[j])))
+        tasks.append(("normalmap", lambda: ('normalmap', _to_pil(host["normalmap"].numpy()[j]))))
     if inp[go.GEN_HEATMAP]:
-        out.append(('heatmap', _to_pil(host["heatmap"].numpy()[j])))
-    return out
+        tasks.append(("heatmap", lambda: ('heatmap', _to_pil(host["heatmap"].numpy()[j]))))
+    return tasks
+
+
+def _run_task(g, j, task):
+    tag, fn = task
+    c = g["chunk_of"][j]
+    # the task's own result of the unit's chunk has landed (the prediction buffer, one copy for the whole group, went first)
+    (g["landed"].get((c, tag)) or g["chunk_done"][c]).synchronize()
+    r = fn()
+    if _TRACE:
+        g.setdefault("converted", {})[j] = _time.perf_counter()
+    return r
+
+
+def _render_unit(g, j):
+    return [_run_task(g, j, t) for t in _unit_tasks(g, j)]
 
 
 def _emit_group(g, outpath, inp, device, stats):
     """Yield a finished group's results image by image in the reference's order (:208-306).  The pinned buffers are reused
     two groups later, so every result is copied out of them (PIL owns its pixels); the conversions were handed to the render
-    pool when the group was launched (_render_unit: each waits for its own chunk of copies), the generator hands out what is done."""
+    pool when the group was launched (_unit_tasks: each waits for its own chunk of copies), the generator hands out what is done."""
     torch = _native._torch()
     if g.get("skip"):
         return
@@ -613,10 +693,12 @@ def _emit_group(g, outpath, inp, device, stats):
 
     def result_of(j):
         _t0 = _time.perf_counter()
-        r = futures[j].result() if futures is not None else _render_unit(g, j)
+        r = [f.result() for f in futures[j]] if futures is not None else _render_unit(g, j)
         stats["wait"] = stats.get("wait", 0.0) + (_time.perf_counter() - _t0)
         return r
 
+    if _TRACE:
+        FUNNEL_TRACE.setdefault("groups", []).append(g)
     try:
         for j, count in enumerate(g["idxs"]):
             image = g["images"][j]
@@ -635,7 +717,7 @@ def _emit_group(g, outpath, inp, device, stats):
                 yield count, 'simple_mesh', mg.write_obj(fn, verts.cpu().numpy(), faces.cpu().numpy(), colors.cpu().numpy())
     finally:
         if futures is not None:
-            for f in futures:                                # (also when the consumer stops early) the buffers must be
+            for f in (f_ for fs in futures for f_ in fs):    # (also when the consumer stops early) the buffers must be
                 f.result()                                   # free before the next group reuses them
 
 
@@ -669,6 +751,9 @@ def core_generation_funnel(outpath, inputimages, inputdepthmaps, inputnames, inp
     FUNNEL_STATS.clear()                   # a reader never sees the PREVIOUS call's numbers while (or after) this one runs
     _t_start = _time.perf_counter()
     pending = launched = None
+    if _TRACE:
+        FUNNEL_TRACE.clear()
+        _mark(FUNNEL_TRACE, "call")
 
     try:
         if not inputdepthmaps_complete:
@@ -712,7 +797,7 @@ def core_generation_funnel(outpath, inputimages, inputdepthmaps, inputnames, inp
     finally:
         # published whether the generator ran to completion, was closed early or raised ('finished' says which)
         for g_ in (pending, launched):       # closed early or raised: conversions already handed to the render pool must be done with
-            for f in ((g_ or {}).get("futures") or []):          # the pinned buffers before a later call reuses them
+            for f in (f_ for fs in ((g_ or {}).get("futures") or []) for f_ in fs):      # the pinned buffers before a later call reuses them
                 try:
                     f.result()
                 except Exception:            # noqa: BLE001
