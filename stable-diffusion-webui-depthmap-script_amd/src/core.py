@@ -14,6 +14,7 @@ video assembly.  Asking for them raises NotImplementedError instead of silently 
 import gc
 
 import numpy as np
+from contextlib import nullcontext as _nullcontext
 from PIL import Image
 
 from . import _native
@@ -462,26 +463,37 @@ def _launch_group(gen, idxs, inputimages, inputdepthmaps, inp, device, stats=Non
 
     if inp[go.DO_OUTPUT_DEPTH]:
         download(d16, "depth")
-    if want_stereo:                                                                              # :251-259
-        modes = inp[go.STEREO_MODES]
-        stereo = create_stereoimages_batch(img_t, d16, inp[go.STEREO_DIVERGENCE], inp[go.STEREO_SEPARATION], modes,
-                                           inp[go.STEREO_BALANCE], inp[go.STEREO_OFFSET_EXPONENT], inp[go.STEREO_FILL_ALGO])
-        for c in range(len(stereo)):
-            download(stereo[c], "stereo%d" % c)
-        g["n_stereo"] = len(stereo)
-    if inp[go.GEN_NORMALMAP]:                                                                    # :261-269
-        download(create_normalmap_batch(
-            d16,
-            inp[go.NORMALMAP_PRE_BLUR_KERNEL] if inp[go.NORMALMAP_PRE_BLUR] else None,
-            inp[go.NORMALMAP_SOBEL_KERNEL] if inp[go.NORMALMAP_SOBEL] else None,
-            inp[go.NORMALMAP_POST_BLUR_KERNEL] if inp[go.NORMALMAP_POST_BLUR] else None,
-            inp[go.NORMALMAP_INVERT]), "normalmap")
-    if inp[go.GEN_HEATMAP]:                                                                      # :271-274
-        from .heatmap import colorize_batch
-        download(colorize_batch(d16), "heatmap")
-    _mark(g, "per-pixel kernels done")
-    ready = torch.cuda.Event()
-    ready.record()                                            # everything the copies read has been enqueued on the main stream
+    # DS_FUNNEL_POST_STREAM=1: the per-pixel kernels of the group (float64 VALU / LDS bound) on a stream of their own, beside the next
+    # group's forward (MFMA bound) -- what bench.py --overlap does for the resident loop.  Off by default: see DESIGN.md (hardware queues)
+    post = _copy_stream(device, "post") if _os.environ.get("DS_FUNNEL_POST_STREAM", "0") != "0" else None
+    if post is not None:
+        fwd_done = torch.cuda.Event()
+        fwd_done.record()
+        post.wait_event(fwd_done)
+        for t in (d16, img_t):
+            if t is not None:
+                t.record_stream(post)
+    with (torch.cuda.stream(post) if post is not None else _nullcontext()):
+        if want_stereo:                                                                              # :251-259
+            modes = inp[go.STEREO_MODES]
+            stereo = create_stereoimages_batch(img_t, d16, inp[go.STEREO_DIVERGENCE], inp[go.STEREO_SEPARATION], modes,
+                                               inp[go.STEREO_BALANCE], inp[go.STEREO_OFFSET_EXPONENT], inp[go.STEREO_FILL_ALGO])
+            for c in range(len(stereo)):
+                download(stereo[c], "stereo%d" % c)
+            g["n_stereo"] = len(stereo)
+        if inp[go.GEN_NORMALMAP]:                                                                    # :261-269
+            download(create_normalmap_batch(
+                d16,
+                inp[go.NORMALMAP_PRE_BLUR_KERNEL] if inp[go.NORMALMAP_PRE_BLUR] else None,
+                inp[go.NORMALMAP_SOBEL_KERNEL] if inp[go.NORMALMAP_SOBEL] else None,
+                inp[go.NORMALMAP_POST_BLUR_KERNEL] if inp[go.NORMALMAP_POST_BLUR] else None,
+                inp[go.NORMALMAP_INVERT]), "normalmap")
+        if inp[go.GEN_HEATMAP]:                                                                      # :271-274
+            from .heatmap import colorize_batch
+            download(colorize_batch(d16), "heatmap")
+        _mark(g, "per-pixel kernels done")
+        ready = torch.cuda.Event()
+        ready.record()                                        # everything the copies read has been enqueued (main or post stream)
     cs = _copy_stream(device)
     # round 6: the copies go out in CHUNKS of units with an event behind each, and the conversion of every unit to PIL is handed to
     # the render pool right here: a unit is converted as soon as ITS chunk has landed -- beside the copies of the later chunks and

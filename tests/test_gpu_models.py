@@ -1352,6 +1352,40 @@ def test_dpt_beit_large_512_batch8_takes_the_benchmarked_route(gpu):
     assert (y[1] - y[0]).abs().max().item() > 1e-3 * scale
 
 
+def test_full_1080p_frame_on_the_networks_own_prediction_vs_oracle(gpu, oracle):
+    """BASELINE config 5's per-pixel leg on what actually feeds it in bench.py: the float16 prediction of a random-initialised
+    Depth-Anything-V2 ViT-L on a 1920 x 1080 frame -- noise at every scale: a quarter of the pixel-eyes take the general pass, a row
+    or two the exact sweep -- through depth -> uint16 -> create_stereoimages(polylines_sharp, left-right, 2.5 %) and create_normalmap:
+    EVERY row of both eyes and the normal map bit for bit against the CPU oracle on the same uint16 depth
+    (reference: src/core.py:189-211, src/stereoimage_generation.py:162-283, src/normalmap_generation.py:5-56)."""
+    orc = oracle
+    from ddepth_anything_v2 import DepthAnythingV2
+    from src import _native
+    import src.stereoimage_generation as sg
+    import src.normalmap_generation as nmg
+    torch.manual_seed(1)                                      # bench.py's c5 network: seed 1
+    net = DepthAnythingV2(encoder='vitl', features=256, out_channels=[256, 512, 1024, 1024]).eval().cuda().half()
+    rng = np.random.default_rng(5)
+    img = rng.integers(0, 256, (1, 1080, 1920, 3), dtype=np.uint8)
+    it = torch.from_numpy(img).cuda()
+    with torch.no_grad():
+        pred = net.infer_batch(it, 518).float()
+    assert pred.shape == (1, 1080, 1920) and float(pred.max() - pred.min()) > 0
+    d16 = _native.depth_to_u16(pred, False)
+    sbs = sg.create_stereoimages_batch(it, d16, 2.5, 0.0, ['left-right'], 0.0, 1.0, 'polylines_sharp')[0]
+    exact_rows, general = _native.last_stats(it)
+    nmap = nmg.create_normalmap_batch(d16)
+    torch.cuda.synchronize()
+    d16_np = d16[0].cpu().numpy()
+    assert np.array_equal(d16_np, orc.convert_to_i16(orc.depth_normalize01(pred[0].cpu().numpy(), False)))
+    want = orc.create_stereoimages_arrays(img[0], d16_np, 2.5, 0.0, ['left-right'], 0.0, 1.0, 'polylines_sharp')[0]
+    got = sbs[0].cpu().numpy()
+    bad = int((want != got).sum())
+    assert bad == 0, (bad, np.argwhere((want != got).any(axis=2))[:5].tolist())
+    assert np.array_equal(nmap[0].cpu().numpy(), orc.create_normalmap_array(d16_np))
+    assert general > 100000, general                          # the regime the bench's c5 leg is in: a large general pass
+
+
 def test_dav2_vitl_1080p_batch4_takes_the_benchmarked_route(gpu):
     """Depth-Anything-V2 ViT-L at 518 x 924 (2443 tokens, BASELINE config 5), batch 4, float16: the block route of
     ddepth_anything_v2/depth_anything_v2/dinov2_layers/block.py:82-107 as in-tree GEMMs (156 tiles at 1024 columns).
