@@ -27,6 +27,7 @@ def main():
     from oracle import oracle as orc
     from oracle import oracle_py
     bench.H = bench.W = 512
+    bench.wl.configure(512, 512)
     img, pred = bench.synth_batch(1, 1000)
     d16 = orc.convert_to_i16(orc.depth_normalize01(pred[0], False))
     out = {"host": platform.processor() or platform.machine(), "cores_used": 1, "unit": "512x512, polylines_sharp, left-right, divergence 2.5"}
