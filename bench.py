@@ -430,7 +430,7 @@ def run_pipeline(args):
                        # what actually bounds it: float64 VALU issue (bit-exactness forces binary64 in the reference's order)
                        "fp64_valu": {"peak_tflops": 78.6, "note": "see DESIGN.md 3.1: instruction count per 64 pixel-eyes from "
                                                                   "the committed PMC profile"}}
-        wl = (f"{minfo['name']} forward (fp16, random-init weights seed {minfo['init_seed']}, net {minfo['net']}, "
+        wl_text = (f"{minfo['name']} forward (fp16, random-init weights seed {minfo['init_seed']}, net {minfo['net']}, "
               f"{minfo['tokens']} tokens) + " if model is not None else "")
         out = {
             "metric": "depth+stereo pairs/sec @1024x1024" if (H, W) == (1024, 1024) else f"depth+stereo pairs/sec @{W}x{H}",
@@ -445,7 +445,7 @@ def run_pipeline(args):
             "vs_baseline": None,
             "dtype": "f16 (network) / f64 (stereo, normal map)" if model is not None else "f64",
             "data": "synthetic",
-            "config": {"workload": f"BASELINE config {args.config}: {wl}depth->u16 + create_stereoimages({args.fill}, left-right, "
+            "config": {"workload": f"BASELINE config {args.config}: {wl_text}depth->u16 + create_stereoimages({args.fill}, left-right, "
                                    f"divergence 2.5%)" + (" + create_normalmap (Sobel 3)" if normalmap else "")
                                    + (f" on the same {global_batch} x {W}x{H} RGB split over the GPUs ({batch} per GPU), inputs resident in HBM" if strong
                                       else f" on {batch} x {W}x{H} RGB per GPU, inputs resident in HBM")
