@@ -4,8 +4,8 @@ import json
 import os
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-PMC_SUMMARY = "profiles/round5_pmc_summary.json"      # tools/pmc_summary.py over rocprofv3 --pmc passes of the default command
-KERNEL_STATS = "profiles/round5_kernel_stats.csv"     # rocprofv3 --kernel-trace --stats of the default command
+PMC_SUMMARY = "profiles/round6_pmc_summary.json"      # tools/pmc_summary.py over rocprofv3 --pmc passes of the default command
+KERNEL_STATS = "profiles/round6_kernel_stats.csv"     # rocprofv3 --kernel-trace --stats of the default command
 
 
 # ---- figures out of the committed profiles (labelled as such) --------------------------------------------------------------
