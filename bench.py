@@ -117,6 +117,12 @@ def parse_args(argv=None):
     return ap.parse_args(argv)
 
 
+def seed_miopen():
+    """The shipped MIOpen find-db (src/miopen_db.py): without it the c4 legs spend 334 s of wall searching float32 solvers on a fresh box."""
+    from src import miopen_db
+    return miopen_db.seed()
+
+
 def main(argv=None):
     argv = list(sys.argv[1:] if argv is None else argv)
     args = parse_args(argv)
@@ -125,6 +131,7 @@ def main(argv=None):
         sys.exit(self_launch(args, argv))
     if args.selftest_launch:
         return selftest_launch(args)
+    seed_miopen()
     if args.config == "c4":
         return run_c4(args)
     return run_pipeline(args)

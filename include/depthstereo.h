@@ -101,6 +101,7 @@ int ds_profile_last_ms(ds_ctx *ctx, float *render_ms, float *exact_ms);
  * a pair of HIP events out of a ring of 1024 pairs per kind (launches beyond the ring, and launches made while the stream is
  * being captured into a graph, are not timed); nothing synchronises until ds_kernel_timer_read, which waits for the last pair of
  * the kind and returns how many launches were timed and the sum of their durations.  Enabling (or disabling) resets every ring.
+ * One thread at a time may launch on a context while its timers are on (the slot counters are not atomic).
  * A GEMM kind that hands its last tiles to the ragged round has a second timer, kind + DS_KT_RAGGED, around that launch. */
 #define DS_KT_LINEAR_GELU      0   /* ds_linear, act = 1 (fc1 + GELU of an encoder block) */
 #define DS_KT_ATTENTION        1   /* ds_attention_fwd */

@@ -78,7 +78,9 @@ DS_API int ds_profile_last_ms(ds_ctx *ctx, float *render_ms, float *exact_ms)
 // ---- in-step kernel timers ---------------------------------------------------------------------------------------------------
 // bench.py's `roofline` wants the average duration of a kernel INSIDE the timed step, on the stream it is launched on: the entry
 // points bracket their launch with an event pair out of a per-kind ring (no synchronisation; an event record is a marker packet
-// on the stream), ds_kernel_timer_read synchronises once and adds the pairs up.
+// on the stream), ds_kernel_timer_read synchronises once and adds the pairs up.  SINGLE-THREADED by contract: the slot counters are
+// plain ints (bench.py's instrumented repeat drives one context from one thread; the funnel, which drives a context from several
+// threads, never enables the timers).  Launches beyond the ring are not timed: ds_kernel_timer_read's count is the TIMED launches.
 int ds_kt_begin(ds_ctx *ctx, int kind, hipStream_t st)
 {
     if (!ctx->ktimer || kind < 0 || kind >= DS_KT_KINDS || ctx->kt_n[kind] >= DS_KT_RING) return -1;
@@ -86,9 +88,20 @@ int ds_kt_begin(ds_ctx *ctx, int kind, hipStream_t st)
     if (hipStreamIsCapturing(st, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) { (void)hipGetLastError(); return -1; }
     if (!ctx->kt_ev[kind]) {
         hipEvent_t (*ring)[2] = new (std::nothrow) hipEvent_t[DS_KT_RING][2];
-        if (!ring) return -1;
-        for (int i = 0; i < DS_KT_RING; i++)
-            if (hipEventCreate(&ring[i][0]) != hipSuccess || hipEventCreate(&ring[i][1]) != hipSuccess) { (void)hipGetLastError(); return -1; }
+        if (!ring) { ctx->ktimer = 0; return -1; }
+        int made = 0;                                        // events created so far (two per slot)
+        bool ok = true;
+        for (int i = 0; i < DS_KT_RING && ok; i++)
+            for (int j = 0; j < 2 && ok; j++) {
+                if (hipEventCreate(&ring[i][j]) == hipSuccess) made++;
+                else { (void)hipGetLastError(); ok = false; }
+            }
+        if (!ok) {                                           // nothing leaks, and the timers switch themselves off instead of retrying
+            for (int e = 0; e < made; e++) (void)hipEventDestroy(ring[e >> 1][e & 1]);      // the whole allocation on every launch
+            delete[] ring;
+            ctx->ktimer = 0;
+            return -1;
+        }
         ctx->kt_ev[kind] = ring;
     }
     const int slot = ctx->kt_n[kind];

@@ -23,6 +23,9 @@
 #define GC_IH (GC_TH + 2)
 #define GC_IW (GC_TW + 2)
 
+// ReLU as torch computes it: a NaN activation stays NaN (fmaxf(v, 0) would turn it into 0 and hide it from the output)
+__device__ __forceinline__ float gc_relu(float v) { return v < 0.f ? 0.f : v; }
+
 // x [batch, H, W, C] float32 NHWC; wt [C / CPG groups][9 taps][CPG in][CPG out]; bias [C] or null; y [batch, H, W, C]
 template <int CPG>
 __global__ __launch_bounds__(256) void k_gconv3x3_nhwc_f32(const float *__restrict__ x, const float *__restrict__ wt, const float *__restrict__ bias,
@@ -84,7 +87,7 @@ __global__ __launch_bounds__(256) void k_gconv3x3_nhwc_f32(const float *__restri
 #pragma unroll
                 for (int co = 0; co < COT; co += 4) {
                     float4 o = make_float4(acc[co], acc[co + 1], acc[co + 2], acc[co + 3]);
-                    if (relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
+                    if (relu) { o.x = gc_relu(o.x); o.y = gc_relu(o.y); o.z = gc_relu(o.z); o.w = gc_relu(o.w); }
                     *(float4 *)(yp + g * CPG + half * COT + co) = o;
                 }
             }
@@ -124,7 +127,7 @@ __global__ __launch_bounds__(256) void k_add_relu_f32(const float4 *__restrict__
 {
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
         const float4 p = a[i], q = b[i];
-        y[i] = make_float4(fmaxf(p.x + q.x, 0.f), fmaxf(p.y + q.y, 0.f), fmaxf(p.z + q.z, 0.f), fmaxf(p.w + q.w, 0.f));
+        y[i] = make_float4(gc_relu(p.x + q.x), gc_relu(p.y + q.y), gc_relu(p.z + q.z), gc_relu(p.w + q.w));
     }
 }
 

@@ -1507,6 +1507,341 @@ __global__ __launch_bounds__(64) void k_polylines_exact_lds(PolyParams P, int c,
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Exact fallback, LDS resident, SPECULATIVE CHUNKS (round 6).  The sweep of a flagged row is a chain of dependent LDS round
+// trips -- ~5 us per column on one wave: 9.5 ms for one 1920-column row of a 1080p batch, with one or two workgroups at work and the
+// stream waiting.  What is history in the reference's sweep (:228-281) is the ORDER of the active set (the swap-remove scan) and the
+// two pointers; WHICH segments are in the set at a centre is a local property (start < centre <= end), and where the set holds exactly
+// ONE segment its order is trivial.  So NW waves of the workgroup sweep NW chunks of the row side by side: wave k > 0 looks for a
+// column near its nominal start whose first sub-interval has, computed locally, exactly one covering segment, ASSUMES the state
+// {pt_i, sg_pointer, csg = [that segment]} there and sweeps from it; every wave, at the end of its chunk, runs the first
+// sub-interval of the next chunk's start column up to the removal step ("peek": adding and removing are idempotent at one centre) and
+// compares its TRUE state with what the successor assumed.  A chunk is valid when its predecessor is valid and the hand-over matches
+// -- from identical state the same deterministic code produces the same bytes.  After a barrier wave 0 walks the chain and re-sweeps,
+// from the true state, every chunk whose assumption did not hold (anomalies of the history -- non-monotone centres, a set emptied
+// and refilled -- can reach at most one segment length ahead, so this is rare; correctness never depends on the speculation).
+// Rows with NaN coordinates (a constant depth map) and rows whose LDS image leaves no room for NW active sets take one chunk.
+// The sweep itself is k_polylines_exact_lds's cooperative one, statement for statement, with its workgroup barriers replaced by
+// wavefront fences (one wave's LDS operations execute in order).
+struct PlxState { int pt_i, sg_pointer, csg_end, slot0; };
+#define PLX_MAXW 16
+#define PLX_WSYNC() __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront")
+template <int DT, int SHARP>
+__global__ __launch_bounds__(512) void k_polylines_exact_chunked(PolyParams P, int c, int win_pts, int csg_cap, int coop_min, int scan_pts, int break_spec)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int NP = SHARP ? 2 : 1;
+    const int tid = threadIdx.x, lane = tid & 63, nthr = blockDim.x;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), nw = nthr >> 6;
+    const int w = P.w;
+    const int pt_end = NP * w + 2, sg_end = pt_end - 1;
+    double *cd = reinterpret_cast<double *>(smem);           // coord_d per column
+    double *sx = cd + w;                                     // sorted x
+    int *sk = reinterpret_cast<int *>(sx + pt_end);          // original index of the sorted point
+    uint32_t *rgbx = reinterpret_cast<uint32_t *>(sk + pt_end);
+    int *shared_i = reinterpret_cast<int *>(rgbx + w);       // per-row control block
+    int *start_col = shared_i;                               // [PLX_MAXW + 1]: start column of every wave's chunk (-1: none), then w
+    int *a_pt = start_col + PLX_MAXW + 1, *a_sgp = a_pt + PLX_MAXW, *a_seg = a_sgp + PLX_MAXW;      // assumed state at the chunk's start
+    int *match = a_seg + PLX_MAXW;                           // [k]: the predecessor's true state equals chunk k's assumption
+    int *fin = match + PLX_MAXW;                             // [4 k ..]: pt_i, sg_pointer, csg_end, slot0 of wave k after its peek
+    int *s_nan = fin + 4 * PLX_MAXW;
+    // per-wave arrays: active set, hole / donor lists, keep masks
+    const int per_wave_ints = csg_cap + 2 * PLX_SCR + 2 * ((csg_cap + 63) / 64) + 2;
+    int *wave_base = reinterpret_cast<int *>((reinterpret_cast<uintptr_t>(s_nan + 2) + 7) & ~(uintptr_t)7);
+    auto CSG = [&](int k) -> int * { return wave_base + (size_t)k * per_wave_ints; };
+    const int count = P.counters[0];
+    for (int it = blockIdx.x; it < count; it += gridDim.x) {
+        const int rowid = P.row_list[it];
+        const int row = rowid % P.h;
+        const int ie = rowid / P.h;
+        const int eye = ie % P.n_eyes, img = ie / P.n_eyes;
+        const double div_px = P.div_px[eye], sep_px = P.sep_px[eye];
+        const double mn = P.minmax[img * 2], mx = P.minmax[img * 2 + 1];
+        const uint8_t *src = P.img + ((size_t)img * P.h + row) * (size_t)w * c;
+        typedef typename ds_depth_traits<DT>::T DTy;
+        const DTy *depth_row = (const DTy *)P.depth + ((size_t)img * P.h + row) * (size_t)w;
+        uint8_t *dst = P.out[eye] + (int64_t)img * P.ois[eye] + (int64_t)row * P.ors[eye];
+        auto OX = [&](const int p) -> double {
+            if (p == 0) return -1.0 * (double)w;
+            if (p == pt_end - 1) return 2.0 * (double)w;
+            const int col = SHARP ? (p - 1) >> 1 : p - 1;
+            const double coord_x = (double)col + 0.5 + cd[col] + sep_px;
+            if (!SHARP) return coord_x;
+            return ((p - 1) & 1) ? coord_x + 0.45 : coord_x - 0.45;
+        };
+        auto OD = [&](const int p) -> double {
+            if (p == 0 || p == pt_end - 1) return 0.0;
+            return fabs(cd[SHARP ? (p - 1) >> 1 : p - 1]);
+        };
+        __syncthreads();                                     // the previous row's arrays are no longer read
+        if (tid == 0) s_nan[0] = 0;
+        __syncthreads();
+        // ---- coord_d and the colour of every column, all threads ----
+        bool nan_here = false;
+        for (int col = tid; col < w; col += nthr) {
+            const double v = pl_coord_d<DT>(P, img, depth_row, col, mn, mx, div_px);
+            cd[col] = v;
+            nan_here |= !(v == v);
+            uint32_t px = 0;
+            for (int q = 0; q < c; q++) px |= (uint32_t)src[(size_t)col * c + q] << (8 * q);
+            rgbx[col] = px;
+        }
+        if (nan_here) s_nan[0] = 1;
+        __syncthreads();
+        // ---- stable sort of points 0 .. sg_end - 1 by x (as in k_polylines_exact_lds) ----
+        for (int i = tid; i < pt_end; i += nthr) {
+            const double xi = OX(i);
+            int pos = i;
+            if (i < sg_end && xi == xi) {
+                const int lo = max(0, i - win_pts), hi = min(sg_end - 1, i + win_pts);
+                int less = lo;
+                for (int j = lo; j <= hi; j++) {
+                    const double xj = OX(j);
+                    less += (xj < xi || (xj == xi && j < i)) ? 1 : 0;
+                }
+                pos = less;
+            }
+            sx[pos] = xi;
+            sk[pos] = i;
+        }
+        __syncthreads();
+        const bool one_chunk = s_nan[0] != 0 || nw == 1;
+#define CI_(p) ((p) == 0 ? 0 : ((p) == pt_end - 1 ? (w - 1) : (SHARP ? ((p) - 1) >> 1 : (p) - 1)))
+        // first index in [lo, hi) whose sorted x is not below v (the sorted array has no NaN here)
+        auto lower_bound = [&](int lo, int hi, const double v) -> int {
+            while (lo < hi) { const int mid = (lo + hi) >> 1; if (sx[mid] < v) lo = mid + 1; else hi = mid; }
+            return lo;
+        };
+        // ---- the sweep (:228-282) of columns [cb, ce) by ONE wave on the active set `csg`; peek: only the first sub-interval of column
+        // cb up to the removal step (state after it in st, nothing written) ----
+        auto sweep = [&](int *csg, const int cb, const int ce, PlxState &st, const bool peek) {
+            int *holes = csg + csg_cap, *donors = holes + PLX_SCR;
+            unsigned long long *kmask = reinterpret_cast<unsigned long long *>((reinterpret_cast<uintptr_t>(donors + PLX_SCR) + 7) & ~(uintptr_t)7);
+            int csg_end = st.csg_end, sg_pointer = st.sg_pointer, pt_i = st.pt_i;
+            bool slot0_written = st.slot0 != 0;
+            for (int col = cb; col < (peek ? cb + 1 : ce); col++) {
+                double color[4] = { 0.5, 0.5, 0.5, 0.5 };
+                while (sx[pt_i] < (double)col) pt_i++;
+                pt_i--;
+                while (sx[pt_i] < (double)(col + 1)) {
+                    const double pa = sx[pt_i], pb = sx[pt_i + 1];
+                    const double coord_from = (pa > (double)col ? pa : (double)col) + PL_EPS;
+                    const double coord_to = (pb < (double)(col + 1) ? pb : (double)(col + 1)) - PL_EPS;
+                    const double significance = coord_to - coord_from;
+                    const double coord_center = coord_from + 0.5 * significance;
+                    // (a) entering segments, in sorted order
+                    for (;;) {
+                        const int idx = sg_pointer + lane;
+                        const bool ok = idx < sg_end && sx[idx < sg_end ? idx : sg_end - 1] < coord_center;
+                        const unsigned long long m = __ballot(ok);
+                        const int nadd = m == ~0ull ? 64 : __builtin_ctzll(~m);
+                        if (lane < nadd && csg_end + lane < csg_cap) csg[csg_end + lane] = sk[idx];
+                        if (nadd > 0 && csg_end == 0) slot0_written = true;
+                        sg_pointer += nadd; csg_end += nadd;
+                        if (nadd < 64) break;
+                    }
+                    if (csg_end > csg_cap) csg_end = csg_cap;
+                    PLX_WSYNC();
+                    int best = 0;
+                    if (csg_end < coop_min) {
+                        int csg_i = 0;
+                        while (csg_i < csg_end) {
+                            const int k = csg[csg_i];
+                            if (OX(k + 1) < coord_center) { csg[csg_i] = csg[csg_end - 1]; csg_end--; }
+                            else csg_i++;
+                        }
+                        if (peek) break;
+                        if (csg_end != 1) {
+                            double best_closeness = -PL_EPS;
+                            for (csg_i = 0; csg_i < csg_end; csg_i++) {
+                                const int k = csg[csg_i];
+                                const double x0 = OX(k), x1 = OX(k + 1);
+                                const double ip_k = (coord_center - x0) / (x1 - x0);
+                                const double closeness = (1.0 - ip_k) * OD(k) + ip_k * OD(k + 1);
+                                if (best_closeness < closeness && 0.0 < ip_k && ip_k < 1.0) { best_closeness = closeness; best = csg_i; }
+                            }
+                        }
+                    } else {
+                    // (b) leaving segments: the swap-remove scan as a permutation of the keep flags
+                    if (csg_end > 0) {
+                        const int n = csg_end, nch = (n + 63) >> 6;
+                        int K = 0;
+                        for (int ch = 0; ch < nch; ++ch) {
+                            const int p = 64 * ch + lane;
+                            bool keep = false;
+                            if (p < n) keep = !(OX(csg[p] + 1) < coord_center);
+                            const unsigned long long m = __ballot(keep);
+                            if (lane == 0) kmask[ch] = m;
+                            K += __builtin_popcountll(m);
+                        }
+                        PLX_WSYNC();
+                        if (K == 0) {
+                            if (n >= 2 && lane == 0) csg[0] = csg[1];                // what the sequential scan leaves in the stale slot
+                        } else if (K < n) {
+                            const int nholes = K - [&] { int kept = 0; for (int ch = 0; ch <= (K - 1) >> 6; ++ch) { unsigned long long m = kmask[ch]; const int top = K - 64 * ch; if (top < 64) m &= (1ull << top) - 1ull; kept += __builtin_popcountll(m); } return kept; }();
+                            if (nholes > PLX_SCR) {
+                                if (lane == 0) {
+                                    int e = n, i = 0;
+                                    while (i < e) { const int k = csg[i]; if (OX(k + 1) < coord_center) { csg[i] = csg[e - 1]; e--; } else i++; }
+                                }
+                            } else if (nholes > 0) {
+                                int base = 0;
+                                for (int ch = 0; ch <= (K - 1) >> 6; ++ch) {         // removed positions below K, ascending
+                                    const int p = 64 * ch + lane;
+                                    unsigned long long hm = ~kmask[ch];
+                                    const int top = K - 64 * ch;
+                                    if (top < 64) hm &= (1ull << top) - 1ull;
+                                    if ((hm >> lane) & 1ull) holes[base + __builtin_popcountll(hm & ((1ull << lane) - 1ull))] = p;
+                                    base += __builtin_popcountll(hm);
+                                }
+                                base = 0;
+                                for (int ch = nch - 1; ch >= K >> 6; --ch) {         // kept positions from K up, descending
+                                    const int p = 64 * ch + lane;
+                                    unsigned long long dm = kmask[ch];
+                                    const int lo = K - 64 * ch;
+                                    if (lo > 0) dm &= ~((1ull << lo) - 1ull);
+                                    if ((dm >> lane) & 1ull) donors[base + __builtin_popcountll(lane == 63 ? 0ull : dm >> (lane + 1))] = p;
+                                    base += __builtin_popcountll(dm);
+                                }
+                                PLX_WSYNC();
+                                for (int j = lane; j < nholes; j += 64) csg[holes[j]] = csg[donors[j]];      // disjoint: holes < K <= donors
+                            }
+                        }
+                        csg_end = K;
+                        PLX_WSYNC();
+                    }
+                    if (peek) break;
+                    // (c) the winner: the first index that attains the maximal closeness among the valid candidates
+                    if (csg_end != 1) {
+                        double bc = -PL_EPS;
+                        int bi = 0x7fffffff;
+                        for (int i = lane; i < csg_end; i += 64) {
+                            const int k = csg[i];
+                            const double x0 = OX(k), x1 = OX(k + 1);
+                            const double ip_k = (coord_center - x0) / (x1 - x0);
+                            const double closeness = (1.0 - ip_k) * OD(k) + ip_k * OD(k + 1);
+                            if (bc < closeness && 0.0 < ip_k && ip_k < 1.0) { bc = closeness; bi = i; }
+                        }
+#pragma unroll
+                        for (int sft = 32; sft > 0; sft >>= 1) {
+                            const double oc = __shfl_xor(bc, sft, 64);
+                            const int oi = __shfl_xor(bi, sft, 64);
+                            if (oi != 0x7fffffff && (bi == 0x7fffffff || oc > bc || (oc == bc && oi < bi))) { bc = oc; bi = oi; }
+                        }
+                        if (bi != 0x7fffffff) best = bi;
+                    }
+                    }
+                    const int k = (csg_end > 0 || slot0_written) ? csg[best] : -1;
+                    if (k >= 0) {
+                        const int col_l = CI_(k), col_r = CI_(k + 1);
+                        const uint32_t pl = rgbx[col_l];
+                        if (col_l == col_r) {
+                            for (int q = 0; q < 4; q++) if (q < c) color[q] += (double)((pl >> (8 * q)) & 0xffu) * significance;
+                        } else {
+                            const uint32_t pr = rgbx[col_r];
+                            const double x0 = OX(k), x1 = OX(k + 1);
+                            const double ip_k = (coord_center - x0) / (x1 - x0);
+                            for (int q = 0; q < 4; q++) if (q < c) {
+                                const double u = (double)((pl >> (8 * q)) & 0xffu) * (1.0 - ip_k);
+                                const double v = (double)((pr >> (8 * q)) & 0xffu) * ip_k;
+                                color[q] += (u + v) * significance;
+                            }
+                        }
+                    } else {
+                        const uint32_t p0 = rgbx[0];
+                        for (int q = 0; q < 4; q++) if (q < c) color[q] += (double)((p0 >> (8 * q)) & 0xffu) * significance;
+                    }
+                    pt_i++;
+                }
+                if (!peek && lane == 0) for (int q = 0; q < 4; q++) if (q < c) dst[(size_t)col * c + q] = ds_f64_to_u8(color[q]);
+            }
+            st.csg_end = csg_end; st.sg_pointer = sg_pointer; st.pt_i = pt_i; st.slot0 = slot0_written ? 1 : 0;
+        };
+        if (one_chunk) {
+            if (wv == 0) { PlxState st = { 0, 0, 0, 0 }; sweep(CSG(0), 0, w, st, false); }
+            continue;
+        }
+        // ---- where every wave starts: wave 0 at column 0 with the empty state, wave k at the first column at or behind k w / nw whose
+        // first sub-interval is covered by exactly one segment (set membership computed locally) ----
+        if (lane == 0) { start_col[wv] = wv == 0 ? 0 : -1; match[wv] = 0; if (wv == 0) start_col[nw] = w; }
+        if (wv > 0) {
+            const int nominal = (int)(((long long)wv * w) / nw), limit = min((int)(((long long)(wv + 1) * w) / nw), nominal + 96);
+            for (int col = nominal; col < limit; col++) {
+                const int lb = lower_bound(0, pt_end, (double)col);
+                if (lb < 1 || lb >= pt_end) continue;
+                const int pt_i = lb - 1;
+                const double pa = sx[pt_i], pb = sx[pt_i + 1];
+                const double coord_from = (pa > (double)col ? pa : (double)col) + PL_EPS;
+                const double coord_to = (pb < (double)(col + 1) ? pb : (double)(col + 1)) - PL_EPS;
+                const double significance = coord_to - coord_from;
+                if (!(significance > 1.0e-3)) continue;      // a sliver: its neighbourhood is where centres may stop being monotone
+                const double coord_center = coord_from + 0.5 * significance;
+                const int sgp0 = lower_bound(0, sg_end, coord_center);
+                int covering = 0, seg = -1;
+                for (int base = max(0, sgp0 - scan_pts); base < sgp0; base += 64) {
+                    const int idx = base + lane;
+                    bool in = false;
+                    int k = -1;
+                    if (idx < sgp0) { k = sk[idx]; in = !(OX(k + 1) < coord_center); }
+                    const unsigned long long m = __ballot(in);
+                    covering += __builtin_popcountll(m);
+                    if (m != 0ull) seg = __shfl(k, __builtin_ctzll(m), 64);
+                }
+                if (covering == 1) {
+                    if (lane == 0) { start_col[wv] = col; a_pt[wv] = pt_i; a_sgp[wv] = sgp0 + (break_spec ? -1 : 0); a_seg[wv] = seg; }
+                    break;
+                }
+            }
+        }
+        __syncthreads();
+        // ---- every wave with a start sweeps its chunk, peeks into the next one and compares ----
+        int my_start = start_col[wv], nxt = -1, my_end = w;
+        for (int k = wv + 1; k < nw; k++) if (start_col[k] >= 0) { nxt = k; my_end = start_col[k]; break; }
+        if (my_start >= 0) {
+            int *csg = CSG(wv);
+            PlxState st = { 0, 0, 0, 0 };
+            if (wv > 0) {
+                st.pt_i = a_pt[wv]; st.sg_pointer = a_sgp[wv]; st.csg_end = 1; st.slot0 = 1;
+                if (lane == 0) csg[0] = a_seg[wv];
+                PLX_WSYNC();
+            }
+            sweep(csg, my_start, my_end, st, false);
+            if (nxt >= 0) {
+                sweep(csg, my_end, my_end + 1, st, true);
+                PLX_WSYNC();
+                const bool ok = st.pt_i == a_pt[nxt] && st.sg_pointer == a_sgp[nxt] && st.csg_end == 1 && csg[0] == a_seg[nxt];
+                if (lane == 0) match[nxt] = ok ? 1 : 0;
+            }
+            if (lane == 0) { fin[4 * wv] = st.pt_i; fin[4 * wv + 1] = st.sg_pointer; fin[4 * wv + 2] = st.csg_end; fin[4 * wv + 3] = st.slot0; }
+        }
+        __syncthreads();
+        // ---- wave 0 walks the chain: a chunk whose assumption did not hold is swept again from the true state, which lives in the
+        // active-set array (and the saved scalars) of the wave that swept up to it ----
+        if (wv == 0) {
+            int holder = 0;                                  // its array + fin hold the TRUE state at the start of the next chunk
+            for (int k = 1; k < nw; k++) {
+                if (start_col[k] < 0) continue;
+                if (match[k]) { holder = k; continue; }
+                int ke = w, kn = -1;
+                for (int j = k + 1; j < nw; j++) if (start_col[j] >= 0) { kn = j; ke = start_col[j]; break; }
+                int *csg = CSG(holder);
+                PlxState st = { fin[4 * holder], fin[4 * holder + 1], fin[4 * holder + 2], fin[4 * holder + 3] };
+                sweep(csg, start_col[k], ke, st, false);
+                if (kn >= 0) {
+                    sweep(csg, ke, ke + 1, st, true);
+                    PLX_WSYNC();
+                    const bool ok = st.pt_i == a_pt[kn] && st.sg_pointer == a_sgp[kn] && st.csg_end == 1 && csg[0] == a_seg[kn];
+                    if (lane == 0) match[kn] = ok ? 1 : 0;
+                    PLX_WSYNC();
+                }
+                if (lane == 0) { fin[4 * holder] = st.pt_i; fin[4 * holder + 1] = st.sg_pointer; fin[4 * holder + 2] = st.csg_end; fin[4 * holder + 3] = st.slot0; }
+                PLX_WSYNC();
+            }
+        }
+#undef CI_
+    }
+}
+
 template <int C, int SHARP, int NE>
 static int pl_main_blocks(int ncu, long long nwork, size_t lds, long long *nblocks_out)
 {
@@ -1608,6 +1943,36 @@ static int pl_launch_exact(const PolyParams &P, int sharp, const ExactScratch &S
         csg_cap = (long long)((room - fixed - 2 * PLX_SCR * 4 - 32) / 4);
         csg_cap = csg_cap * 64 / 66 / 64 * 64;               // leave 8 bytes of mask per 64 entries, whole chunks
         if (csg_cap > 8192) csg_cap = 8192;
+    }
+    // round 6: speculative chunks (k_polylines_exact_chunked) -- NW waves sweep NW chunks of the row side by side, each with an active set
+    // of its own: as many as the CU's LDS leaves room for behind the row's arrays (8 at 1920 columns, one or two at 3840: then the
+    // single-chunk kernel below).  DS_PL_EXACT_CHUNKS=<n> caps the count (1 = off), DS_PL_EXACT_BREAK=1 makes every assumption wrong
+    // (tests: every chunk is then swept again from the true state and the bytes must not change).
+    {
+        const int want = getenv("DS_PL_EXACT_CHUNKS") ? atoi(getenv("DS_PL_EXACT_CHUNKS")) : 8;
+        const long long cap_w = (csg_need + 64 + 63) / 64 * 64;
+        const size_t per_wave = (size_t)(cap_w + 2 * PLX_SCR + 2 * ((cap_w + 63) / 64) + 2) * 4;
+        const size_t ctrl = (size_t)(PLX_MAXW + 1 + 4 * PLX_MAXW + 4 * PLX_MAXW + 2) * 4 + 16;
+        int nw = 0;
+        if (fixed + ctrl + 2 * per_wave <= room) nw = (int)((room - fixed - ctrl) / per_wave);
+        if (nw > 8) nw = 8;
+        if (nw > want) nw = want;
+        if (coop && !force_global && nw >= 2 && cap_w <= 8192 && P.w >= 64 * nw) {
+            static std::atomic<uint64_t> attr2_done{0};
+            const uint64_t bit2 = 1ull << (device & 63);
+            if (!(attr2_done.load(std::memory_order_relaxed) & bit2)) {
+                DS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_polylines_exact_chunked<DT, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                DS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_polylines_exact_chunked<DT, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                attr2_done.fetch_or(bit2, std::memory_order_relaxed);
+            }
+            const int win_pts2 = (sharp ? 2 : 1) * ((int)ceil(fabs(max_div_px)) + 3);
+            const int scan_pts = (sharp ? 2 : 1) * (2 * (int)ceil(fabs(max_div_px)) + 6);
+            const int break_spec = getenv("DS_PL_EXACT_BREAK") ? atoi(getenv("DS_PL_EXACT_BREAK")) : 0;
+            const size_t lds2 = fixed + ctrl + (size_t)nw * per_wave;
+            if (sharp) hipLaunchKernelGGL((k_polylines_exact_chunked<DT, 1>), dim3(1024), dim3(64 * nw), lds2, st, P, c, win_pts2, (int)cap_w, coop_min, scan_pts, break_spec);
+            else hipLaunchKernelGGL((k_polylines_exact_chunked<DT, 0>), dim3(1024), dim3(64 * nw), lds2, st, P, c, win_pts2, (int)cap_w, coop_min, scan_pts, break_spec);
+            return DS_OK;
+        }
     }
     if (csg_cap >= csg_need && csg_cap >= 64 && !force_global && fixed + (size_t)csg_cap * 4 + pl_exact_lds_scratch(csg_cap) <= room) {
         const size_t lds = fixed + (size_t)csg_cap * 4 + pl_exact_lds_scratch(csg_cap);

@@ -61,9 +61,14 @@ def _gconv_image(conv, wf):
     return img
 
 
+def _wants_grad(*tensors):
+    """The in-tree kernels are raw launches outside autograd: a caller that backpropagates through the network keeps torch's ops."""
+    return torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors)
+
+
 def add_relu(a, b):
     """relu(a + b): one in-tree pass for float32 CUDA tensors of one dense layout, torch's two otherwise."""
-    if (ADD_RELU_HIP and a.is_cuda and a.dtype == torch.float32 and b.dtype == torch.float32 and a.shape == b.shape and a.stride() == b.stride()
+    if (ADD_RELU_HIP and not _wants_grad(a, b) and a.is_cuda and a.dtype == torch.float32 and b.dtype == torch.float32 and a.shape == b.shape and a.stride() == b.stride()
             and a.numel() % 4 == 0 and (a.is_contiguous() or a.is_contiguous(memory_format=torch.channels_last)) and not vm.STOCK[0]):
         from src import _native
         return _native.add_relu(a, b)
@@ -73,7 +78,9 @@ def add_relu(a, b):
 def conv_bn(x, conv, bn, relu=False):
     """BatchNorm(conv(x)) in inference mode as one convolution with folded weights."""
     w, b = _folded(conv, bn, conv)
-    if GCONV_HIP and conv.groups > 1 and conv.padding_mode == 'zeros' and x.is_cuda and not vm.STOCK[0]:
+    cpg = conv.in_channels // max(conv.groups, 1)
+    if (GCONV_HIP and conv.groups > 1 and conv.padding_mode == 'zeros' and x.is_cuda and x.dtype == torch.float32 and not vm.STOCK[0]
+            and not _wants_grad(x, w) and tuple(conv.stride) == (1, 1) and cpg in (8, 16, 32)):     # (checked BEFORE the layout copy)
         from src import _native
         xc = x.contiguous(memory_format=torch.channels_last)
         if _native.gconv3x3_supported(xc, w, conv.stride, conv.padding, conv.dilation, conv.groups):

@@ -197,6 +197,8 @@ class ModelHolder:
 
     def ensure_models(self, model_type, device, boost: bool, tiling_mode: bool = False):
         """reference :60-74."""
+        from . import miopen_db
+        miopen_db.seed()                 # the package's MIOpen find results, before the first library convolution (src/miopen_db.py)
         if boost:
             if model_type not in (0, 1, 2, 3, 4, 7, 8, 9, 12, 13, 14):
                 raise NotImplementedError(f"Boost with depth model id {model_type!r} is not built (built: 0 LeReS, 1-4 MiDaS "

@@ -1795,6 +1795,16 @@ def test_gconv3x3_matches_torch_grouped_convolution(gpu, b, c, cpg, h, w):
     a, bb = torch.randn((b, c, h, w), generator=g).cuda().contiguous(memory_format=torch.channels_last), x
     if a.numel() % 4 == 0:
         assert torch.equal(_native.add_relu(a, bb), F.relu(a + bb))
+        # NaN / Inf activations propagate like torch's ReLU (a NaN must reach the output, not become 0)
+        a2 = a.clone()
+        a2.view(-1)[:4] = torch.tensor([float("nan"), float("inf"), float("-inf"), -0.0]).cuda()
+        got, want = _native.add_relu(a2, torch.zeros_like(a2)), F.relu(a2)
+        assert torch.equal(torch.isnan(got), torch.isnan(want)) and torch.equal(torch.nan_to_num(got, 7.0), torch.nan_to_num(want, 7.0))
+        xn = x.clone()
+        xn[0, :, 0, 0] = float("nan")
+        yn = _native.gconv3x3(xn, img, None, True, cpg)
+        rn = F.relu(F.conv2d(xn, wt, None, 1, 1, 1, c // cpg))
+        assert torch.equal(torch.isnan(yn), torch.isnan(rn)) and bool(torch.isnan(yn).any())
 
 
 def test_leres_takes_the_in_tree_grouped_convolutions(gpu):

@@ -621,6 +621,14 @@ def test_exact_fallback_lds_kernel_equals_global_kernel(sg, native, oracle, gpu)
     cases.append((img512, (rng.integers(0, 16, (6, 512)) * 4369).astype(np.uint16), 25.0, 0.0, 'polylines_sharp'))
     cases.append((img512, (rng.integers(0, 16, (6, 512)) * 4369).astype(np.uint16), 25.0, 0.5, 'polylines_soft'))
     cases.append((img512[:, :333], (rng.integers(0, 6, (6, 333)) * 13107).astype(np.uint16), -18.0, 0.0, 'polylines_sharp'))     # odd width, negative divergence
+    # round 6 (speculative chunks): rows that are smooth almost everywhere -- every chunk finds a column covered by one segment and its
+    # assumption holds -- with a few quantised stretches that flag them; 1080p width at config 5's divergence, and a 1024-column frame
+    for (h, w, div) in ((4, 1920, 2.5), (4, 1024, 3.125)):
+        yy, xx = np.mgrid[0:h, 0:w]
+        smooth = (30000 + 20000 * np.sin(xx / 97.0 + yy) + rng.integers(0, 40, (h, w))).astype(np.uint16)
+        for x0 in (w // 7, w // 2, (5 * w) // 6):
+            smooth[:, x0:x0 + 48] = (rng.integers(0, 4, (h, 48)) * 21845).astype(np.uint16)
+        cases.append((rng.integers(0, 256, (h, w, 3), dtype=np.uint8), smooth, div, 0.0, 'polylines_sharp'))
     flagged = 0
     old = os.environ.get("DS_PL_EXACT_GLOBAL")
     try:
@@ -640,6 +648,20 @@ def test_exact_fallback_lds_kernel_equals_global_kernel(sg, native, oracle, gpu)
                     os.environ["DS_PL_EXACT_COOP_MIN"] = cmin
                 outs.append(sg.create_stereoimages_batch(it, dt, div, 0.0, ['left-right'], bal, 1.0, fill)[0][0].cpu().numpy())
                 flagged += native.last_exact_rows(it)
+            # round 6: the default runs the row as speculative chunks (k_polylines_exact_chunked); one chunk, three chunks, and every
+            # assumption made wrong on purpose (DS_PL_EXACT_BREAK: each chunk is swept again from the true state) give the same bytes
+            os.environ["DS_PL_EXACT_GLOBAL"], os.environ["DS_PL_EXACT_COOP"] = "0", "1"
+            os.environ.pop("DS_PL_EXACT_COOP_MIN", None)
+            for chunks, brk in (("1", None), ("3", None), ("8", "1")):
+                os.environ["DS_PL_EXACT_CHUNKS"] = chunks
+                if brk is None:
+                    os.environ.pop("DS_PL_EXACT_BREAK", None)
+                else:
+                    os.environ["DS_PL_EXACT_BREAK"] = brk
+                got = sg.create_stereoimages_batch(it, dt, div, 0.0, ['left-right'], bal, 1.0, fill)[0][0].cpu().numpy()
+                assert np.array_equal(outs[0], got), (img.shape, fill, chunks, brk, 'chunked exact sweep differs', int((outs[0] != got).sum()))
+            os.environ.pop("DS_PL_EXACT_CHUNKS", None)
+            os.environ.pop("DS_PL_EXACT_BREAK", None)
             assert np.array_equal(outs[0], outs[1]), (img.shape, fill, 'cooperative sweeps with different parallel thresholds differ')
             assert np.array_equal(outs[0], outs[2]), (img.shape, fill, 'cooperative and one-lane sweeps of the LDS exact kernel differ')
             assert np.array_equal(outs[0], outs[3]), (img.shape, fill, 'LDS and global exact kernels differ')
@@ -647,6 +669,8 @@ def test_exact_fallback_lds_kernel_equals_global_kernel(sg, native, oracle, gpu)
     finally:
         os.environ.pop("DS_PL_EXACT_COOP", None)
         os.environ.pop("DS_PL_EXACT_COOP_MIN", None)
+        os.environ.pop("DS_PL_EXACT_CHUNKS", None)
+        os.environ.pop("DS_PL_EXACT_BREAK", None)
         if old is None:
             os.environ.pop("DS_PL_EXACT_GLOBAL", None)
         else:
