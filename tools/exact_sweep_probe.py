@@ -19,7 +19,14 @@ img = torch.from_numpy(rng.integers(0, 256, (1, H, W, 3), dtype=np.uint8)).cuda(
 yy, xx = np.mgrid[0:H, 0:W]
 smooth = 30000 + 20000 * np.sin(xx / 611.0) * np.cos(yy / 397.0)
 dep = smooth.astype(np.uint16)
-dep[100:140] = (rng.integers(0, 4, (40, W)) * 21845).astype(np.uint16)          # 40 rows of quantised depth: ties -> flagged rows
+if os.environ.get("PROBE_KIND", "quantised") == "quantised":
+    dep[100:140] = (rng.integers(0, 4, (40, W)) * 21845).astype(np.uint16)          # 40 rows of quantised depth: ties -> flagged rows
+else:
+    # PROBE_KIND=noisy: the regime of a network's prediction -- smooth with small noise, a few short quantised stretches per row that flag
+    # it: the speculative chunks of round 6 find their restart columns (rows fully quantised leave them none)
+    dep[100:140] = (dep[100:140].astype(np.int64) + rng.integers(0, 40, (40, W))).astype(np.uint16)
+    for x0 in (W // 7, W // 2, (5 * W) // 6):
+        dep[100:140, x0:x0 + 48] = (rng.integers(0, 4, (40, 48)) * 21845).astype(np.uint16)
 dep_t = torch.from_numpy(dep).cuda().unsqueeze(0)
 nat.profile_enable(0, True)
 for name, env in (("wave (default)", {}), ("one lane", {"DS_PL_EXACT_COOP": "0"}), ("global scratch", {"DS_PL_EXACT_GLOBAL": "1"})):
