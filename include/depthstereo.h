@@ -320,6 +320,17 @@ int ds_bias_act_nhwc(ds_ctx *ctx, const void *x, const void *bias, const void *r
                      int64_t elements, int channels, int relu, int dtype, void *stream);
 
 /*
+ * ds_group_norm_nchw -- GroupNorm [+ residual] [+ ReLU] of an NCHW activation in two launches (no counterpart function in the
+ * reference: it is timm's GroupNormAct inside the ResNetV2-50 stem of dpt_hybrid_384, which the reference obtains through
+ * timm.create_model in dmidas/backbones/vit.py:_make_pretrained_vitb_rn50_384; torch spends three launches + a ReLU + an add on it):
+ *     out = [relu]( (x - mean_g) * rstd_g * gamma[c] + beta[c] [+ res] ),   mean / biased variance over the group's channels x pixels
+ * x, res, out [n, channels, hw] contiguous (res may be NULL, out may alias x), gamma / beta [channels] in the activation's type;
+ * f16 / bf16, hw % 8 == 0, n * groups <= 4096.  Moments in float32 per slice, combined in float64; the affine map in float32.
+ */
+int ds_group_norm_nchw(ds_ctx *ctx, const void *x, const void *gamma, const void *beta, const void *res, void *out, int n, int channels,
+                       int hw, int groups, float eps, int relu, int dtype, void *stream);
+
+/*
  * ds_linear -- y = act(x . W^T + bias), the token GEMMs of the ViT encoders with the epilogue fused (csrc/ds_linear.hip):
  * `fc1 -> nn.GELU` of the encoder MLP (timm Mlp as run by dmidas/backbones/beit.py:93-107; ddepth_anything_v2/
  * depth_anything_v2/dinov2_layers/mlp.py:33-39) is ONE kernel (act = 1: erf-GELU evaluated on the fp32 accumulator, see

@@ -39,7 +39,7 @@ DS_API int ds_ctx_destroy(ds_ctx *ctx)
     int prev = 0;
     (void)hipGetDevice(&prev);
     (void)hipSetDevice(ctx->device);
-    void *blocks[] = { ctx->minmax, ctx->partials, ctx->row_flags, ctx->row_list, ctx->exact_ws, ctx->tmp_a, ctx->tmp_b, ctx->zero_line, ctx->lin_ws };
+    void *blocks[] = { ctx->minmax, ctx->partials, ctx->row_flags, ctx->row_list, ctx->exact_ws, ctx->tmp_a, ctx->tmp_b, ctx->zero_line, ctx->lin_ws, ctx->gn_ws };
     for (void *b : blocks) if (b) (void)hipFree(b);
     if (ctx->ev_created) for (int i = 0; i < 4; i++) (void)hipEventDestroy(ctx->ev[i]);
     for (int k = 0; k < DS_KT_KINDS; k++)

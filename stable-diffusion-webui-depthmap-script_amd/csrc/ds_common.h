@@ -46,6 +46,7 @@ struct ds_ctx {
     int zero_line_cleared;
     void *lin_ws;      size_t lin_ws_bytes;      // ds_linear's ragged round with a K split: arrival counters + fp32 partials
     void *lin_ws_cleared;                        // the block whose counters have been zeroed
+    void *gn_ws;       size_t gn_ws_bytes;       // ds_group_norm_nchw: float32 moments per (image, group, slice); ONE size (graphs hold it)
     int ncu;                                     // CU count of `device` rounded down to a multiple of 8 (0 = not read yet)
     int64_t last_exact_rows_valid;
     // optional kernel timing (ds_profile_enable)

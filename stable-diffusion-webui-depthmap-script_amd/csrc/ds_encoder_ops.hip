@@ -1052,3 +1052,117 @@ DS_API int ds_bias_act_nhwc(ds_ctx *ctx, const void *x, const void *bias, const 
     DS_HIP_CHECK(hipGetLastError());
     return DS_OK;
 }
+
+// ---- GroupNorm (+ residual) (+ ReLU) on an NCHW activation (round 6) ------------------------------------------------------------
+// The ResNetV2-50 stem of dpt_hybrid_384 (timm's GroupNormAct, 32 groups: dmidas/backbones/vit.py of the reference's timm model) runs
+// 52 GroupNorms per image, and at batch 1 -- BASELINE config 2, a latency line -- torch spends three launches on each: RowwiseMoments
+// (one workgroup per group = 32 workgroups on 256 CUs: 15.5 us), ComputeFusedParams, the element-wise kernel, then a separate ReLU
+// and, behind norm3, a separate add + ReLU: 1.3 ms of a 4.8 ms image.  Here: one launch for the moments -- every (image, group) split
+// over up to 32 workgroups, float32 sum / sum of squares per slice -- and one that combines the slices in float64 (mean, var =
+// E[x^2] - mean^2 with the population variance, rstd = 1 / sqrt(var + eps) as torch), and applies y = x * (rstd gamma_c) + (beta_c -
+// mean rstd gamma_c) [+ res] [relu] in float32, rounded once to the activation's type.
+#define GN_MAX_SPLIT 32
+#define GN_MAX_NG 4096           // (images x groups) of one call: the moments block is allocated once at this size -- captured graphs hold its address
+template <int BF16>
+__global__ __launch_bounds__(256) void k_gn_moments(const void *x_, float2 *partial, int group_len, int splits)
+{
+    typedef typename eo_traits<BF16>::T T;
+    const int sp = blockIdx.x, ng = blockIdx.y;              // slice of the group, (image * groups + group)
+    const T *x = (const T *)x_ + (size_t)ng * group_len;
+    const int vecs = group_len >> 3;
+    const int per = (vecs + splits - 1) / splits;
+    const int v0 = sp * per, v1 = min(vecs, v0 + per);
+    float s = 0.f, q = 0.f;
+    for (int v = v0 + threadIdx.x; v < v1; v += 256) {
+        T xv[8];
+        __builtin_memcpy(xv, x + (size_t)v * 8, 16);
+#pragma unroll
+        for (int t = 0; t < 8; t++) { const float f = (float)xv[t]; s += f; q = __builtin_fmaf(f, f, q); }
+    }
+#pragma unroll
+    for (int sft = 32; sft > 0; sft >>= 1) { s += __shfl_xor(s, sft, 64); q += __shfl_xor(q, sft, 64); }
+    __shared__ float2 red[4];
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = make_float2(s, q);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float2 r = red[0];
+        for (int k = 1; k < 4; k++) { r.x += red[k].x; r.y += red[k].y; }
+        partial[(size_t)ng * GN_MAX_SPLIT + sp] = r;
+    }
+}
+
+template <int BF16>
+__global__ __launch_bounds__(256) void k_gn_apply(const void *x_, const float2 *partial, const void *gamma_, const void *beta_, const void *res_,
+                                                  void *out_, int group_len, int splits, int hw, int cpg, int groups, float eps, int relu, int chunks)
+{
+    typedef typename eo_traits<BF16>::T T;
+    const int ck = blockIdx.x, ng = blockIdx.y, g = ng % groups;
+    __shared__ float s_stat[2];
+    if (threadIdx.x < 64) {
+        double s = 0.0, q = 0.0;
+        if ((int)threadIdx.x < splits) { const float2 p = partial[(size_t)ng * GN_MAX_SPLIT + threadIdx.x]; s = p.x; q = p.y; }
+#pragma unroll
+        for (int sft = 32; sft > 0; sft >>= 1) { s += __shfl_xor(s, sft, 64); q += __shfl_xor(q, sft, 64); }
+        if (threadIdx.x == 0) {
+            const double mean = s / (double)group_len;
+            double var = q / (double)group_len - mean * mean;
+            if (var < 0.0) var = 0.0;
+            s_stat[0] = (float)mean;
+            s_stat[1] = (float)(1.0 / sqrt(var + (double)eps));
+        }
+    }
+    __syncthreads();
+    const float mean = s_stat[0], rstd = s_stat[1];
+    const T *x = (const T *)x_ + (size_t)ng * group_len, *res = res_ ? (const T *)res_ + (size_t)ng * group_len : nullptr;
+    const T *gamma = (const T *)gamma_, *beta = (const T *)beta_;
+    T *out = (T *)out_ + (size_t)ng * group_len;
+    const int vecs = group_len >> 3;
+    const int per = (vecs + chunks - 1) / chunks;
+    const int v0 = ck * per, v1 = min(vecs, v0 + per);
+    for (int v = v0 + threadIdx.x; v < v1; v += 256) {
+        const int c = g * cpg + (v * 8) / hw;                // hw % 8 == 0: the 8 values belong to one channel
+        const float a = rstd * (float)gamma[c], b = (float)beta[c] - mean * a;
+        T xv[8], rv[8], ov[8];
+        __builtin_memcpy(xv, x + (size_t)v * 8, 16);
+        if (res) __builtin_memcpy(rv, res + (size_t)v * 8, 16);
+#pragma unroll
+        for (int t = 0; t < 8; t++) {
+            float f = __builtin_fmaf((float)xv[t], a, b);
+            if (res) f += (float)rv[t];
+            if (relu) f = f < 0.f ? 0.f : f;
+            ov[t] = (T)f;
+        }
+        __builtin_memcpy(out + (size_t)v * 8, ov, 16);
+    }
+}
+
+DS_API int ds_group_norm_nchw(ds_ctx *ctx, const void *x, const void *gamma, const void *beta, const void *res, void *out, int n, int channels,
+                              int hw, int groups, float eps, int relu, int dtype, void *stream)
+{
+    DS_REQUIRE(ctx && x && gamma && beta && out, DS_EINVAL, "ds_group_norm_nchw: null argument");
+    DS_REQUIRE(n > 0 && channels > 0 && hw > 0 && groups > 0 && channels % groups == 0, DS_EINVAL, "ds_group_norm_nchw: bad shape n=%d c=%d hw=%d groups=%d", n, channels, hw, groups);
+    DS_REQUIRE(hw % 8 == 0, DS_EUNSUPPORTED, "ds_group_norm_nchw: pixels per channel plane must be a multiple of 8 (got %d)", hw);
+    DS_REQUIRE(dtype == DS_DTYPE_F16 || dtype == DS_DTYPE_BF16, DS_EINVAL, "ds_group_norm_nchw: dtype must be f16 or bf16");
+    DS_REQUIRE((((uintptr_t)x | (uintptr_t)res | (uintptr_t)out) & 15) == 0, DS_EINVAL, "ds_group_norm_nchw: x, res and out must be 16-byte aligned");
+    DS_REQUIRE((long long)n * groups <= GN_MAX_NG, DS_EUNSUPPORTED, "ds_group_norm_nchw: n * groups must be <= %d", GN_MAX_NG);
+    DS_HIP_CHECK(hipSetDevice(ctx->device));
+    const int cpg = channels / groups;
+    const long long group_len_ll = (long long)cpg * hw;
+    DS_REQUIRE(group_len_ll < (1ll << 30), DS_EUNSUPPORTED, "ds_group_norm_nchw: a group of %lld values is too large", group_len_ll);
+    const int group_len = (int)group_len_ll;
+    int splits = group_len / 4096; if (splits < 1) splits = 1; if (splits > GN_MAX_SPLIT) splits = GN_MAX_SPLIT;
+    int chunks = group_len / 8192; if (chunks < 1) chunks = 1; if (chunks > 64) chunks = 64;
+    const int rc = ds_ctx_reserve(ctx, &ctx->gn_ws, &ctx->gn_ws_bytes, (size_t)GN_MAX_NG * GN_MAX_SPLIT * sizeof(float2));
+    if (rc) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    float2 *partial = (float2 *)ctx->gn_ws;
+    if (dtype == DS_DTYPE_F16) {
+        hipLaunchKernelGGL((k_gn_moments<0>), dim3(splits, n * groups), dim3(256), 0, st, x, partial, group_len, splits);
+        hipLaunchKernelGGL((k_gn_apply<0>), dim3(chunks, n * groups), dim3(256), 0, st, x, partial, gamma, beta, res, out, group_len, splits, hw, cpg, groups, eps, relu, chunks);
+    } else {
+        hipLaunchKernelGGL((k_gn_moments<1>), dim3(splits, n * groups), dim3(256), 0, st, x, partial, group_len, splits);
+        hipLaunchKernelGGL((k_gn_apply<1>), dim3(chunks, n * groups), dim3(256), 0, st, x, partial, gamma, beta, res, out, group_len, splits, hw, cpg, groups, eps, relu, chunks);
+    }
+    DS_HIP_CHECK(hipGetLastError());
+    return DS_OK;
+}

@@ -13,6 +13,7 @@ the stem's StdConv layers is computed once per weight version instead of in ever
 embedding is cached per grid; hooks/global activations dict replaced by returned taps.
 """
 import math
+import os
 
 import torch
 import torch.nn as nn
@@ -61,13 +62,31 @@ class StdConv2dSame(nn.Conv2d):
         return F.conv2d(x, self.std_weight(), None, self.stride, 0)
 
 
+GROUPNORM_HIP = os.environ.get("DS_GROUPNORM", "1") != "0"        # A/B switch: 0 = torch's F.group_norm + separate ReLU / add
+
+
 class GroupNormAct(nn.GroupNorm):
     def __init__(self, ch, apply_act=True):
         super().__init__(32, ch, eps=1e-5)
         self.apply_act = apply_act
 
-    def forward(self, x):
+    def forward(self, x, res=None, relu_after_res=False):
+        """GroupNorm [+ ReLU]; with `res`: relu(group_norm(x) + res), the tail of a bottleneck (norm3, the add and the ReLU in one
+        pass).  Half-precision CUDA activations take the in-tree two-launch kernel (csrc/ds_encoder_ops.hip: ds_group_norm_nchw --
+        torch spends three launches, 15 us of them on 32 workgroups, plus a ReLU and an add per norm at batch 1)."""
+        if GROUPNORM_HIP and vm.half_on_gpu(x) and not vm.STOCK[0] and not (torch.is_grad_enabled() and x.requires_grad):
+            from src import _native
+            if not x.is_contiguous():
+                x = x.contiguous()
+            if res is not None and not res.is_contiguous():
+                res = res.contiguous()
+            if _native.group_norm_supported(x, self.num_groups):
+                return _native.group_norm(x, self.num_groups, self.weight, self.bias, self.eps,
+                                          relu=self.apply_act or (res is not None and relu_after_res), res=res)
         x = F.group_norm(x, self.num_groups, self.weight, self.bias, self.eps)
+        if res is not None:
+            x = x + res
+            return F.relu(x) if relu_after_res else x
         return F.relu(x) if self.apply_act else x
 
 
@@ -100,8 +119,7 @@ class _Bottleneck(nn.Module):
         shortcut = x if self.downsample is None else self.downsample(x)
         x = self.norm1(self.conv1(x))
         x = self.norm2(self.conv2(x))
-        x = self.norm3(self.conv3(x))
-        return F.relu(x + shortcut)
+        return self.norm3(self.conv3(x), res=shortcut, relu_after_res=True)       # relu(norm3(conv3(x)) + shortcut)
 
 
 class _Stage(nn.Module):

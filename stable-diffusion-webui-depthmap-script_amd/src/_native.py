@@ -23,7 +23,7 @@ EXPORTS = [
     "ds_version", "ds_last_error", "ds_normalmap_f64", "ds_normalmap_gradient_f32", "ds_reassemble_readout", "ds_bias_act_nhwc", "ds_linear", "ds_linear_residual", "ds_linear_vt", "ds_conv3x3_nhwc", "ds_ctx_create", "ds_ctx_destroy", "ds_stereo_warp", "ds_depth_minmax",
     "ds_stereo_last_exact_rows", "ds_copy_view", "ds_overlap_red_cyan", "ds_normalmap", "ds_depth_to_u16",
     "ds_convert_to_i16", "ds_profile_enable", "ds_profile_last_ms", "ds_stereo_last_stats", "ds_attention_fwd", "ds_attention_bias_pack", "ds_colorize_u16", "ds_residual_layernorm", "ds_boost_blend", "ds_upsample_bilinear_nhwc", "ds_dpt_head_tail", "ds_preprocess_bicubic", "ds_linear_reload_env", "ds_attention_reload_env", "ds_normalmap_selfcheck", "ds_normalmap_gradient_f16", "ds_normalmap_gradient_blur_f32",
-    "ds_linear_shuffle", "ds_linear_readout", "ds_kernel_timer_enable", "ds_kernel_timer_read", "ds_kernel_timer_read_each",
+    "ds_linear_shuffle", "ds_linear_readout", "ds_kernel_timer_enable", "ds_kernel_timer_read", "ds_kernel_timer_read_each", "ds_group_norm_nchw",
     "ds_row_stats", "ds_linear_ln", "ds_linear_vt_ln", "ds_gconv3x3_nhwc_f32", "ds_add_relu_f32",
 ]
 
@@ -85,6 +85,7 @@ def lib():
                                                 ctypes.POINTER(ctypes.c_float), ci, vp]
             L.ds_reassemble_readout.argtypes = [vp, vp, vp, vp, ci, ci, ci, ci, vp]
             L.ds_bias_act_nhwc.argtypes = [vp, vp, vp, vp, vp, vp, i64, ci, ci, ci, vp]
+            L.ds_group_norm_nchw.argtypes = [vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ctypes.c_float, ci, ci, vp]
             L.ds_linear.argtypes = [vp, vp, vp, vp, vp, i64, i64, i64, i64, ci, ci, vp]
             L.ds_linear_residual.argtypes = [vp, vp, vp, vp, vp, vp, vp, i64, i64, i64, ci, vp]
             L.ds_linear_vt.argtypes = [vp, vp, vp, vp, i64, i64, i64, i64, ci, vp]
@@ -756,6 +757,27 @@ def bias_act(x, bias, relu=False, res1=None, res2=None, inplace=True):
     _check(lib().ds_bias_act_nhwc(ctx_for(_dev_index(x)), x.data_ptr(), b.data_ptr(), None if res1 is None else res1.data_ptr(),
                                   None if res2 is None else res2.data_ptr(), out.data_ptr(), x.numel(), x.shape[1], 1 if relu else 0,
                                   1 if x.dtype == torch.float16 else 2, _stream(x)))
+    return out
+
+
+def group_norm_supported(x, groups):
+    """What ds_group_norm_nchw takes: a contiguous NCHW float16 / bfloat16 CUDA activation whose planes hold a multiple of 8 pixels."""
+    torch = _torch()
+    return (x.is_cuda and x.dtype in (torch.float16, torch.bfloat16) and x.dim() == 4 and x.is_contiguous() and x.shape[1] % groups == 0
+            and (x.shape[2] * x.shape[3]) % 8 == 0 and x.shape[0] * groups <= 4096 and x.data_ptr() % 16 == 0)
+
+
+def group_norm(x, groups, weight, bias, eps, relu=False, res=None):
+    """[relu](group_norm(x) [+ res]) (include/depthstereo.h: ds_group_norm_nchw); weight / bias in any float type (cast to x's)."""
+    torch = require_gpu()
+    assert group_norm_supported(x, groups)
+    assert res is None or (res.shape == x.shape and res.dtype == x.dtype and res.is_contiguous() and res.data_ptr() % 16 == 0)
+    out = torch.empty_like(x)
+    g, b = weight.detach().to(x.dtype).contiguous(), bias.detach().to(x.dtype).contiguous()
+    CALLS["ds_group_norm_nchw"] += 1
+    _check(lib().ds_group_norm_nchw(ctx_for(_dev_index(x)), x.data_ptr(), g.data_ptr(), b.data_ptr(), None if res is None else res.data_ptr(),
+                                    out.data_ptr(), x.shape[0], x.shape[1], x.shape[2] * x.shape[3], int(groups), float(eps), 1 if relu else 0,
+                                    1 if x.dtype == torch.float16 else 2, _stream(x)))
     return out
 
 

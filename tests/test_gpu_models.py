@@ -1831,3 +1831,66 @@ def test_leres_takes_the_in_tree_grouped_convolutions(gpu):
     finally:
         leres.GCONV_HIP, leres.ADD_RELU_HIP = saved
     assert (y - y_lib).abs().max().item() < 2e-5 * (1 + y_lib.abs().max().item())
+
+
+# ---- round 6: GroupNorm of the ResNetV2-50 stem (dpt_hybrid_384, BASELINE config 2) ----------------------------------------------------
+@pytest.mark.parametrize("dtype,tol", [(torch.float16, 2e-3), (torch.bfloat16, 1.6e-2)])
+def test_group_norm_kernel_matches_float32_group_norm(gpu, dtype, tol):
+    """ds_group_norm_nchw (two launches: float32 moments per slice, float64 combine, float32 affine map [+ residual] [+ ReLU]) against
+    torch's F.group_norm in float32 on the same rounded operands -- the shapes of the stem at 384 x 384 (64 x 192^2 with 2 channels per
+    group ... 1024 x 24^2 with 32), a batch, a plane that is a bare multiple of 8, an offset distribution (mean >> spread: the
+    E[x^2] - mean^2 form must survive it), and the routing rule for what it does not take."""
+    import torch.nn.functional as F
+    from src import _native
+    g = torch.Generator().manual_seed(61)
+    for (n, c, h, w, shift) in [(1, 64, 192, 192, 0.0), (1, 256, 96, 96, 0.0), (1, 128, 48, 48, 3.0), (2, 1024, 24, 24, 0.0), (3, 64, 4, 6, 0.0),
+                                (1, 512, 48, 48, 40.0)]:
+        x = (torch.randn((n, c, h, w), generator=g) * 1.7 + shift).to(dtype).cuda()
+        res = torch.randn((n, c, h, w), generator=g).to(dtype).cuda()
+        wt, bs = (torch.randn(c, generator=g) * 0.5 + 1.0).cuda(), torch.randn(c, generator=g).cuda()
+        assert _native.group_norm_supported(x, 32)
+        for relu, use_res in ((True, False), (False, False), (True, True)):
+            want = F.group_norm(x.float(), 32, wt.to(dtype).float(), bs.to(dtype).float(), 1e-5)
+            if use_res:
+                want = want + res.float()
+            if relu:
+                want = F.relu(want)
+            got = _native.group_norm(x, 32, wt, bs, 1e-5, relu=relu, res=res if use_res else None)
+            assert got.shape == x.shape and got.dtype == dtype
+            err = (got.float() - want).abs().max().item()
+            assert err < tol * (1 + want.abs().max().item()), (n, c, h, w, shift, relu, use_res, err)
+            assert torch.equal(_native.group_norm(x, 32, wt, bs, 1e-5, relu=relu, res=res if use_res else None), got)
+    assert not _native.group_norm_supported(torch.randn((1, 64, 5, 5)).half().cuda(), 32)            # 25 pixels per plane: torch's kernel
+    assert not _native.group_norm_supported(torch.randn((1, 64, 8, 8)).cuda(), 32)                   # float32: torch's kernel
+
+
+def test_hybrid_stem_takes_the_in_tree_group_norm(gpu):
+    """The ResNetV2-50 stem of dpt_hybrid_384 in half precision: 52 GroupNorms per image through ds_group_norm_nchw (the 16 behind
+    conv3 with the shortcut add and the ReLU folded in); against the float32 stem it loses no more than the same half-precision stem with
+    DS_GROUPNORM off (torch's group_norm + ReLU + add) does."""
+    from dmidas.backbones import vit as hv
+    from src import _native
+    torch.manual_seed(3)
+    stem = hv.ResNetV2Stem().eval().cuda().half()
+    x = torch.randn((1, 3, 384, 384)).half().cuda()
+    before = _native.CALLS["ds_group_norm_nchw"]
+    with torch.no_grad():
+        got = stem.forward_stages(x)
+    assert _native.CALLS["ds_group_norm_nchw"] - before == 1 + 16 * 3 + 3          # stem + three per bottleneck + three downsamples
+    keep = hv.GROUPNORM_HIP
+    try:
+        hv.GROUPNORM_HIP = False
+        with torch.no_grad():
+            half_torch = stem.forward_stages(x)
+    finally:
+        hv.GROUPNORM_HIP = keep
+    with torch.no_grad():
+        want = stem.float().forward_stages(x.float())
+    # a random-initialised stem amplifies half-precision rounding stage by stage (16 bottlenecks, no trained scales): the yardstick is the
+    # float32 stem, and the in-tree GroupNorm must not lose more against it than torch's own half-precision group_norm does
+    for a, b, ref in zip(got, half_torch, want):
+        assert a.shape == ref.shape
+        scale = ref.abs().max().item()
+        e_tree, e_torch = (a.float() - ref).abs().max().item() / scale, (b.float() - ref).abs().max().item() / scale
+        e_tree_mean, e_torch_mean = (a.float() - ref).abs().mean().item() / scale, (b.float() - ref).abs().mean().item() / scale
+        assert e_tree < 1.5 * e_torch + 5e-3 and e_tree_mean < 1.5 * e_torch_mean + 5e-4, (e_tree, e_torch, e_tree_mean, e_torch_mean)
