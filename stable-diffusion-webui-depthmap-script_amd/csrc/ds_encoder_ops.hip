@@ -1136,6 +1136,76 @@ __global__ __launch_bounds__(256) void k_gn_apply(const void *x_, const float2 *
     }
 }
 
+// One launch when a group fits the registers of one workgroup (1024 threads x up to 10 vectors of 8 values = 81.9 k values: every
+// GroupNorm of the ResNetV2 stem at 384 x 384 -- at most 73.7 k): the values are read ONCE, kept packed while the workgroup reduces the
+// moments, and written once.  Same arithmetic as the two-launch pair (float32 partial sums per thread and per wave, float64 combine).
+#define GN_FUSED_THREADS 1024
+#define GN_FUSED_VECS 10
+template <int BF16>
+__global__ __launch_bounds__(GN_FUSED_THREADS) void k_gn_fused(const void *x_, const void *gamma_, const void *beta_, const void *res_, void *out_,
+                                                               int group_len, int hw, int cpg, int groups, float eps, int relu)
+{
+    typedef typename eo_traits<BF16>::T T;
+    const int ng = blockIdx.x, g = ng % groups, tid = threadIdx.x;
+    const T *x = (const T *)x_ + (size_t)ng * group_len, *res = res_ ? (const T *)res_ + (size_t)ng * group_len : nullptr;
+    const T *gamma = (const T *)gamma_, *beta = (const T *)beta_;
+    T *out = (T *)out_ + (size_t)ng * group_len;
+    const int vecs = group_len >> 3;
+    uint4 keep[GN_FUSED_VECS];
+    float s = 0.f, q = 0.f;
+#pragma unroll
+    for (int k = 0; k < GN_FUSED_VECS; k++) {
+        const int v = tid + k * GN_FUSED_THREADS;
+        if (v < vecs) {
+            keep[k] = *(const uint4 *)(x + (size_t)v * 8);
+            T xv[8];
+            __builtin_memcpy(xv, &keep[k], 16);
+#pragma unroll
+            for (int t = 0; t < 8; t++) { const float f = (float)xv[t]; s += f; q = __builtin_fmaf(f, f, q); }
+        }
+    }
+#pragma unroll
+    for (int sft = 32; sft > 0; sft >>= 1) { s += __shfl_xor(s, sft, 64); q += __shfl_xor(q, sft, 64); }
+    __shared__ float2 red[GN_FUSED_THREADS / 64];
+    __shared__ float s_stat[2];
+    if ((tid & 63) == 0) red[tid >> 6] = make_float2(s, q);
+    __syncthreads();
+    if (tid < 64) {
+        double ds = 0.0, dq = 0.0;
+        if (tid < GN_FUSED_THREADS / 64) { ds = red[tid].x; dq = red[tid].y; }
+#pragma unroll
+        for (int sft = 32; sft > 0; sft >>= 1) { ds += __shfl_xor(ds, sft, 64); dq += __shfl_xor(dq, sft, 64); }
+        if (tid == 0) {
+            const double mean = ds / (double)group_len;
+            double var = dq / (double)group_len - mean * mean;
+            if (var < 0.0) var = 0.0;
+            s_stat[0] = (float)mean;
+            s_stat[1] = (float)(1.0 / sqrt(var + (double)eps));
+        }
+    }
+    __syncthreads();
+    const float mean = s_stat[0], rstd = s_stat[1];
+#pragma unroll
+    for (int k = 0; k < GN_FUSED_VECS; k++) {
+        const int v = tid + k * GN_FUSED_THREADS;
+        if (v < vecs) {
+            const int c = g * cpg + (v * 8) / hw;
+            const float a = rstd * (float)gamma[c], b = (float)beta[c] - mean * a;
+            T xv[8], rv[8], ov[8];
+            __builtin_memcpy(xv, &keep[k], 16);
+            if (res) __builtin_memcpy(rv, res + (size_t)v * 8, 16);
+#pragma unroll
+            for (int t = 0; t < 8; t++) {
+                float f = __builtin_fmaf((float)xv[t], a, b);
+                if (res) f += (float)rv[t];
+                if (relu) f = f < 0.f ? 0.f : f;
+                ov[t] = (T)f;
+            }
+            __builtin_memcpy(out + (size_t)v * 8, ov, 16);
+        }
+    }
+}
+
 DS_API int ds_group_norm_nchw(ds_ctx *ctx, const void *x, const void *gamma, const void *beta, const void *res, void *out, int n, int channels,
                               int hw, int groups, float eps, int relu, int dtype, void *stream)
 {
@@ -1156,6 +1226,15 @@ DS_API int ds_group_norm_nchw(ds_ctx *ctx, const void *x, const void *gamma, con
     if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;
     float2 *partial = (float2 *)ctx->gn_ws;
+    // few groups of a size one workgroup holds in registers (the batch-1 stem): ONE launch; many or larger groups: moments + apply,
+    // every group spread over several workgroups.  DS_GN_FUSED=0: always the pair (A/B runs)
+    static const int s_fused = getenv("DS_GN_FUSED") ? atoi(getenv("DS_GN_FUSED")) : 1;
+    if (s_fused && (group_len >> 3) <= GN_FUSED_THREADS * GN_FUSED_VECS && n * groups <= 512) {
+        if (dtype == DS_DTYPE_F16) hipLaunchKernelGGL((k_gn_fused<0>), dim3(n * groups), dim3(GN_FUSED_THREADS), 0, st, x, gamma, beta, res, out, group_len, hw, cpg, groups, eps, relu);
+        else hipLaunchKernelGGL((k_gn_fused<1>), dim3(n * groups), dim3(GN_FUSED_THREADS), 0, st, x, gamma, beta, res, out, group_len, hw, cpg, groups, eps, relu);
+        DS_HIP_CHECK(hipGetLastError());
+        return DS_OK;
+    }
     if (dtype == DS_DTYPE_F16) {
         hipLaunchKernelGGL((k_gn_moments<0>), dim3(splits, n * groups), dim3(256), 0, st, x, partial, group_len, splits);
         hipLaunchKernelGGL((k_gn_apply<0>), dim3(chunks, n * groups), dim3(256), 0, st, x, partial, gamma, beta, res, out, group_len, splits, hw, cpg, groups, eps, relu, chunks);

@@ -58,7 +58,15 @@ class StdConv2dSame(nn.Conv2d):
         return ws
 
     def forward(self, x):
-        x = _pad_same(x, self.kernel_size[0], self.stride[0])
+        k, st = self.kernel_size[0], self.stride[0]
+        ih, iw = x.shape[-2:]
+        ph = max((math.ceil(ih / st) - 1) * st + (k - 1) + 1 - ih, 0)
+        pw = max((math.ceil(iw / st) - 1) * st + (k - 1) + 1 - iw, 0)
+        if ph % 2 == 0 and pw % 2 == 0:
+            # TF 'SAME' padding that happens to be symmetric (every stride-1 3x3 of the stem): the convolution's own zero padding -- the
+            # same values without the fill + copy of a padded tensor in front of every such layer
+            return F.conv2d(x, self.std_weight(), None, self.stride, (ph // 2, pw // 2))
+        x = _pad_same(x, k, st)
         return F.conv2d(x, self.std_weight(), None, self.stride, 0)
 
 

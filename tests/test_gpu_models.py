@@ -1860,6 +1860,13 @@ def test_group_norm_kernel_matches_float32_group_norm(gpu, dtype, tol):
             err = (got.float() - want).abs().max().item()
             assert err < tol * (1 + want.abs().max().item()), (n, c, h, w, shift, relu, use_res, err)
             assert torch.equal(_native.group_norm(x, 32, wt, bs, 1e-5, relu=relu, res=res if use_res else None), got)
+    # (the batch of 3 x 32 groups and every group above fit one workgroup's registers: the single-launch kernel; 20 images x 32 groups of
+    # 96^2 x 8 values = the moments + apply pair)
+    xb = torch.randn((20, 256, 96, 96), generator=g).to(dtype).cuda()
+    wt, bs = torch.ones(256).cuda(), torch.zeros(256).cuda()
+    got = _native.group_norm(xb, 32, wt, bs, 1e-5, relu=True)
+    want = F.relu(F.group_norm(xb.float(), 32, wt, bs, 1e-5))
+    assert (got.float() - want).abs().max().item() < tol * (1 + want.abs().max().item())
     assert not _native.group_norm_supported(torch.randn((1, 64, 5, 5)).half().cuda(), 32)            # 25 pixels per plane: torch's kernel
     assert not _native.group_norm_supported(torch.randn((1, 64, 8, 8)).cuda(), 32)                   # float32: torch's kernel
 
