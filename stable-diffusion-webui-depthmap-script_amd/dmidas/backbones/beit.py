@@ -266,7 +266,7 @@ class ProjectReadout(nn.Module):       # utils.py:28-39
             # [B, C]: the cls half of the projection.  In-tree as well (rows padded to one 256-row tile): a library GEMM picks its
             # kernel -- and its summation order -- by the batch size, and the same image would come out differently at batch 8 and 32
             x0 = xp[:, 0].contiguous()
-            if vm.INVARIANT and _native.linear_supported(x0, w_cls):
+            if vm.invariant() and _native.linear_supported(x0, w_cls):
                 clsvec = _native.linear(x0, w_cls, self.project[0].bias)
             else:
                 clsvec = F.linear(x0, w_cls, self.project[0].bias)

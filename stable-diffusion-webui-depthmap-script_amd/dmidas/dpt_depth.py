@@ -67,6 +67,7 @@ class DPT(nn.Module):
         if readout != "project" or use_bn:
             raise NotImplementedError("only readout='project', use_bn=False (what src/depthmap_generation.py:129-176 uses)")
         self.channels_last = channels_last
+        self.size_routed = backbone == "vitb_rn50_384"     # its ResNetV2 stem is library code: see vm.size_routed
         make = make_beit if backbone.startswith("beit") else make_vit
         self.pretrained, in_shape = make(backbone, _HOOKS[backbone])
         scratch = nn.Module()
@@ -81,6 +82,12 @@ class DPT(nn.Module):
         """features: None, or a dict that receives what ZoeDepth's MidasCore taps with forward hooks
         (dzoedepth/models/base_models/midas.py:307-331): 'l4_rn', 'r4'..'r1' and 'out_conv' (the 32-channel activation
         after the head's second convolution + ReLU)."""
+        if getattr(self, "size_routed", False):
+            with vm.size_routed():
+                return self._forward(x, features)
+        return self._forward(x, features)
+
+    def _forward(self, x, features=None):
         l1, l2, l3, l4 = self.pretrained(x)
         s = self.scratch
         l1, l2, l3, l4 = vm.conv2d(s.layer1_rn, l1), vm.conv2d(s.layer2_rn, l2), vm.conv2d(s.layer3_rn, l3), vm.conv2d(s.layer4_rn, l4)

@@ -225,6 +225,26 @@ DETERMINISTIC_LIBRARY = os.environ.get("DS_DETERMINISTIC", "0") == "1"
 # the shapes allow -- an image's depth does not depend on its position in the batch, on its neighbours or on the launch
 # (tests/test_gpu_models.py: the metric's batch, the same image at units 0 / 13 / 31, bit-identical).
 INVARIANT = os.environ.get("DS_INVARIANT", "1") != "0"
+_size_routed = threading.local()
+
+
+def invariant():
+    """INVARIANT, unless the calling thread is inside size_routed()."""
+    return INVARIANT and not getattr(_size_routed, "depth", 0)
+
+
+@contextlib.contextmanager
+def size_routed():
+    """Inside the block the tile-count thresholds decide again whether a convolution goes in-tree (what DS_INVARIANT=0 selects for the
+    process).  For networks whose forward calls library kernels anyway -- dpt_hybrid_384's ResNetV2 stem is MIOpen -- sending every
+    tiny launch through the in-tree GEMM buys no invariance and costs latency: BASELINE config 2 (one 512^2 image) 3.73 ms with the
+    rule, 3.30 ms with the thresholds (a 3x3 convolution of 9 tiles is a chain of 36 K-tiles on nine CUs in k_linear256, MIOpen
+    splits it)."""
+    _size_routed.depth = getattr(_size_routed, "depth", 0) + 1
+    try:
+        yield
+    finally:
+        _size_routed.depth -= 1
 _det_lock = threading.Lock()
 _det_state = [0, False]                      # forwards inside, the caller's torch.backends.cudnn.deterministic
 
@@ -498,7 +518,7 @@ def conv3x3_hip_ok(conv, x):
     if conv.out_channels % 256 != 0 and not CONV_HEAD_HIP:
         return False
     tiles = (x.shape[0] * x.shape[2] * x.shape[3] + 255) // 256 * ((conv.out_channels + 255) // 256)
-    return _native.conv3x3_supported(conv, x) and tiles >= (1 if INVARIANT else CONV_HIP_MIN_TILES)
+    return _native.conv3x3_supported(conv, x) and tiles >= (1 if invariant() else CONV_HIP_MIN_TILES)
 
 
 def conv2d(conv, x):
@@ -527,7 +547,7 @@ def conv1x1_hip_ok(layer, x):
         return False
     pixels = x.shape[0] * x.shape[2] * x.shape[3]
     return (layer.out_channels % 256 == 0 and layer.in_channels % 128 == 0 and 128 <= layer.in_channels <= 16384 and pixels >= 256
-            and ((pixels + 255) // 256) * (layer.out_channels // 256) >= (1 if INVARIANT else CONV1X1_MIN_TILES)
+            and ((pixels + 255) // 256) * (layer.out_channels // 256) >= (1 if invariant() else CONV1X1_MIN_TILES)
             and x.is_contiguous(memory_format=torch.channels_last))
 
 
@@ -547,7 +567,7 @@ def conv_transpose_hip_ok(layer, x):
         return False
     pixels = x.shape[0] * x.shape[2] * x.shape[3]
     n = layer.stride[0] * layer.stride[0] * layer.out_channels
-    return ((pixels + 255) // 256) * (n // 256) >= (1 if INVARIANT else CONV1X1_MIN_TILES)
+    return ((pixels + 255) // 256) * (n // 256) >= (1 if invariant() else CONV1X1_MIN_TILES)
 
 
 # ---- round 6: the last library convolutions of the DPT networks as in-tree GEMMs (INVARIANT above) -------------------------------
@@ -569,7 +589,7 @@ def _gemm_weight(layer, x, kpad):
 def patch_embed_hip_ok(conv, x):
     """A patch embedding -- Conv2d with kernel == stride, no padding -- on a half-precision channels_last image: non-overlapping
     patches, i.e. a GEMM on [patches, kh * kw * in] (dmidas/backbones/beit.py:18-27, vit.py, dinov2_layers/patch_embed.py)."""
-    if not (INVARIANT and LINEAR_HIP == "all" and half_on_gpu(x) and x.dim() == 4 and type(conv) is nn.Conv2d):
+    if not (invariant() and LINEAR_HIP == "all" and half_on_gpu(x) and x.dim() == 4 and type(conv) is nn.Conv2d):
         return False
     k = conv.kernel_size
     return (k[0] == k[1] and tuple(conv.stride) == tuple(k) and tuple(conv.padding) == (0, 0) and conv.groups == 1
@@ -598,7 +618,7 @@ def patch_embed_tokens(conv, x):
 
 def strided3x3_hip_ok(layer, x):
     """The strided 3x3 of the reassemble stage (act_postprocess4 / resize_layers[3]: Conv2d(C, C, 3, stride 2, padding 1))."""
-    if not (INVARIANT and LINEAR_HIP == "all" and half_on_gpu(x) and x.dim() == 4 and type(layer) is nn.Conv2d):
+    if not (invariant() and LINEAR_HIP == "all" and half_on_gpu(x) and x.dim() == 4 and type(layer) is nn.Conv2d):
         return False
     return (tuple(layer.kernel_size) == (3, 3) and tuple(layer.stride) == (2, 2) and tuple(layer.padding) == (1, 1) and layer.groups == 1
             and tuple(layer.dilation) == (1, 1) and layer.padding_mode == "zeros" and layer.out_channels % 256 == 0
