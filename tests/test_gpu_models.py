@@ -1797,7 +1797,7 @@ def test_gconv3x3_matches_torch_grouped_convolution(gpu, b, c, cpg, h, w):
         assert torch.equal(_native.add_relu(a, bb), F.relu(a + bb))
         # NaN / Inf activations propagate like torch's ReLU (a NaN must reach the output, not become 0)
         a2 = a.clone()
-        a2.view(-1)[:4] = torch.tensor([float("nan"), float("inf"), float("-inf"), -0.0]).cuda()
+        a2[0, 0, 0, :4] = torch.tensor([float("nan"), float("inf"), float("-inf"), -0.0]).cuda()
         got, want = _native.add_relu(a2, torch.zeros_like(a2)), F.relu(a2)
         assert torch.equal(torch.isnan(got), torch.isnan(want)) and torch.equal(torch.nan_to_num(got, 7.0), torch.nan_to_num(want, 7.0))
         xn = x.clone()
