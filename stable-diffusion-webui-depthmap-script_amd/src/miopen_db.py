@@ -27,7 +27,9 @@ def seed():
             dst = os.path.join(dst_dir, os.path.basename(f))
             if not os.path.exists(dst):
                 os.makedirs(dst_dir, exist_ok=True)
-                shutil.copyfile(f, dst)
+                tmp = "%s.seed.%d" % (dst, os.getpid())      # several ranks may seed at once: the file appears whole or not at all
+                shutil.copyfile(f, tmp)
+                os.replace(tmp, dst)
                 copied.append(dst)
     except OSError:            # a read-only home: MIOpen searches as before
         pass
