@@ -599,3 +599,24 @@ def test_integration_md_binding_snippets_match_the_header():
     decl = re.search(r"int ds_linear\((.*?)\);", hdr, flags=re.S).group(1)
     kinds = ["I64" if "int64_t" in p else ("P" if "*" in p else "ctypes.c_int") for p in decl.split(",")]
     assert spelled == kinds, (spelled, kinds)
+
+
+def test_miopen_find_db_seeding_never_overwrites(tmp_path, monkeypatch):
+    """src/miopen_db.seed: the shipped MIOpen find results are copied into the user db directory when no file of that name exists
+    there, never over an existing one, atomically; DS_MIOPEN_SEED=0 switches it off."""
+    from src import miopen_db
+    shipped = sorted(os.listdir(os.path.join(conftest.PKG, "miopen_db")))
+    assert shipped and all(f.endswith(".ufdb.txt") for f in shipped)
+    monkeypatch.setenv("MIOPEN_USER_DB_PATH", str(tmp_path / "db"))
+    monkeypatch.setattr(miopen_db, "_done", [False])
+    monkeypatch.setenv("DS_MIOPEN_SEED", "0")
+    assert miopen_db.seed() == [] and not (tmp_path / "db").exists()
+    monkeypatch.setenv("DS_MIOPEN_SEED", "1")
+    monkeypatch.setattr(miopen_db, "_done", [False])
+    copied = miopen_db.seed()
+    assert sorted(os.path.basename(c) for c in copied) == shipped
+    assert sorted(os.listdir(tmp_path / "db")) == shipped                        # no temporary left behind
+    mine = tmp_path / "db" / shipped[0]
+    mine.write_text("the user's own find results\n")
+    monkeypatch.setattr(miopen_db, "_done", [False])
+    assert miopen_db.seed() == [] and mine.read_text() == "the user's own find results\n"
