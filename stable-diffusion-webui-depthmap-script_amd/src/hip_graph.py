@@ -28,8 +28,10 @@ from . import vit_mi355x as vm
 
 
 class GraphedForward:
-    def __init__(self, fn, warmup=2, accept=3e-2, lazy=0):
+    def __init__(self, fn, warmup=2, accept=3e-2, lazy=0, max_graphs=4):
         self.fn = fn
+        self.max_graphs = int(max_graphs)    # a graph keeps its activations' memory pool: a folder of many image sizes must not pile
+                                             # them up -- beyond this many shapes the least recently used graph is dropped
         self.warmup = warmup
         self.lazy = int(lazy)            # a shape is captured on its (lazy + 1)-th use: the first `lazy` calls run eager (a one-off call
         self.seen = {}                   # never pays for a capture; a caller that keeps coming back with one shape gets the replay)
@@ -64,6 +66,8 @@ class GraphedForward:
                     if attempt == 1:
                         self.failed.add(key)
                         return self.fn(x)
+        if key in self.graphs and len(self.graphs) > 1:      # most recently used last (dicts keep insertion order)
+            self.graphs[key] = self.graphs.pop(key)
         g, static_in, static_out = hit
         static_in.copy_(x)
         g.replay()
@@ -96,5 +100,10 @@ class GraphedForward:
         if self.epoch != vm.CACHE_EPOCH[0]:                  # the warm-up itself evicted entries older graphs may read
             self.graphs.clear()
             self.epoch = vm.CACHE_EPOCH[0]
+        while self.max_graphs > 0 and len(self.graphs) >= self.max_graphs:
+            oldest = next(iter(self.graphs))
+            torch.cuda.synchronize()                         # nothing of the dropped graph may still be running
+            del self.graphs[oldest]
+            self.seen.pop(oldest, None)                      # (it earns its graph again by being used)
         self.graphs[key] = (g, static_in, static_out)
         return self.graphs[key]

@@ -812,6 +812,12 @@ def test_hip_graph_replay_equals_eager_forward(gpu):
             assert (got2 - got).abs().mean().item() > 0
         # every shape was either captured (and validated at capture) or, if the library misbehaved inside the capture, left eager
         assert len(gf.graphs) + len(gf.failed) == 2
+        # at most max_graphs shapes keep a graph (each holds its activations' memory pool): the least recently used one is dropped
+        gm = GraphedForward(lambda x, net=net, call=call: call(net, x), max_graphs=2)
+        for shape in ((1, 96, 128, 3), (1, 64, 96, 3), (1, 96, 128, 3), (1, 128, 160, 3)):
+            gm(torch.randint(0, 256, shape, generator=g, dtype=torch.uint8).cuda())
+            assert len(gm.graphs) <= 2
+        assert (1, 64, 96, 3) not in [k[0] for k in gm.graphs] or len(gm.failed) > 0
         # lazy = 2 (ModelHolder.hip_graphs = "auto", the default): a shape runs eager twice and is captured on its third use
         gl = GraphedForward(lambda x, net=net, call=call: call(net, x), lazy=2)
         x = torch.randint(0, 256, (1, 96, 128, 3), generator=g, dtype=torch.uint8).cuda()
