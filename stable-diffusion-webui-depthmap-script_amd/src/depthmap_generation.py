@@ -153,6 +153,8 @@ class _NetPredictor:
             key = (int(net_width), int(net_height))
             gf = self._graphed.get(key)
             if gf is None:
+                while len(self._graphed) >= 4:               # NET_SIZE_MATCH makes the net size follow the images: bounded like the shapes
+                    self._graphed.pop(next(iter(self._graphed)))
                 # "auto" (the default since round 6): a (shape, net size) runs eager twice, is captured on its third use and
                 # replayed from then on, when the replay reproduces the eager result; True: captured on first use
                 gf = self._graphed[key] = GraphedForward(lambda b: self._predict_batch_eager(b, net_width, net_height),
