@@ -1527,7 +1527,7 @@ struct PlxState { int pt_i, sg_pointer, csg_end, slot0; };
 #define PLX_MAXW 16
 #define PLX_WSYNC() __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront")
 template <int DT, int SHARP>
-__global__ __launch_bounds__(512) void k_polylines_exact_chunked(PolyParams P, int c, int win_pts, int csg_cap, int coop_min, int scan_pts, int break_spec)
+__global__ __launch_bounds__(512) void k_polylines_exact_chunked(PolyParams P, int c, int win_pts, int csg_cap, int coop_min, int scan_pts, int break_spec, int scr)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int NP = SHARP ? 2 : 1;
@@ -1546,7 +1546,7 @@ __global__ __launch_bounds__(512) void k_polylines_exact_chunked(PolyParams P, i
     int *fin = match + PLX_MAXW;                             // [4 k ..]: pt_i, sg_pointer, csg_end, slot0 of wave k after its peek
     int *s_nan = fin + 4 * PLX_MAXW;
     // per-wave arrays: active set, hole / donor lists, keep masks
-    const int per_wave_ints = csg_cap + 2 * PLX_SCR + 2 * ((csg_cap + 63) / 64) + 2;
+    const int per_wave_ints = csg_cap + 2 * scr + 2 * ((csg_cap + 63) / 64) + 2;   // scr: capacity of the hole / donor lists (PLX_SCR, or less on wide rows)
     int *wave_base = reinterpret_cast<int *>((reinterpret_cast<uintptr_t>(s_nan + 2) + 7) & ~(uintptr_t)7);
     auto CSG = [&](int k) -> int * { return wave_base + (size_t)k * per_wave_ints; };
     const int count = P.counters[0];
@@ -1615,8 +1615,8 @@ __global__ __launch_bounds__(512) void k_polylines_exact_chunked(PolyParams P, i
         // ---- the sweep (:228-282) of columns [cb, ce) by ONE wave on the active set `csg`; peek: only the first sub-interval of column
         // cb up to the removal step (state after it in st, nothing written) ----
         auto sweep = [&](int *csg, const int cb, const int ce, PlxState &st, const bool peek) {
-            int *holes = csg + csg_cap, *donors = holes + PLX_SCR;
-            unsigned long long *kmask = reinterpret_cast<unsigned long long *>((reinterpret_cast<uintptr_t>(donors + PLX_SCR) + 7) & ~(uintptr_t)7);
+            int *holes = csg + csg_cap, *donors = holes + scr;
+            unsigned long long *kmask = reinterpret_cast<unsigned long long *>((reinterpret_cast<uintptr_t>(donors + scr) + 7) & ~(uintptr_t)7);
             int csg_end = st.csg_end, sg_pointer = st.sg_pointer, pt_i = st.pt_i;
             bool slot0_written = st.slot0 != 0;
             for (int col = cb; col < (peek ? cb + 1 : ce); col++) {
@@ -1679,7 +1679,7 @@ __global__ __launch_bounds__(512) void k_polylines_exact_chunked(PolyParams P, i
                             if (n >= 2 && lane == 0) csg[0] = csg[1];                // what the sequential scan leaves in the stale slot
                         } else if (K < n) {
                             const int nholes = K - [&] { int kept = 0; for (int ch = 0; ch <= (K - 1) >> 6; ++ch) { unsigned long long m = kmask[ch]; const int top = K - 64 * ch; if (top < 64) m &= (1ull << top) - 1ull; kept += __builtin_popcountll(m); } return kept; }();
-                            if (nholes > PLX_SCR) {
+                            if (nholes > scr) {
                                 if (lane == 0) {
                                     int e = n, i = 0;
                                     while (i < e) { const int k = csg[i]; if (OX(k + 1) < coord_center) { csg[i] = csg[e - 1]; e--; } else i++; }
@@ -1951,8 +1951,12 @@ static int pl_launch_exact(const PolyParams &P, int sharp, const ExactScratch &S
     {
         const int want = getenv("DS_PL_EXACT_CHUNKS") ? atoi(getenv("DS_PL_EXACT_CHUNKS")) : 8;
         const long long cap_w = (csg_need + 64 + 63) / 64 * 64;
-        const size_t per_wave = (size_t)(cap_w + 2 * PLX_SCR + 2 * ((cap_w + 63) / 64) + 2) * 4;
         const size_t ctrl = (size_t)(PLX_MAXW + 1 + 4 * PLX_MAXW + 4 * PLX_MAXW + 2) * 4 + 16;
+        // the hole / donor lists of the cooperative removal: PLX_SCR entries each where the LDS allows eight chunks with them, 128 on
+        // wide rows (3840 columns: six chunks instead of three; a removal of more holes than that takes the sequential scan)
+        int scr = PLX_SCR;
+        size_t per_wave = (size_t)(cap_w + 2 * scr + 2 * ((cap_w + 63) / 64) + 2) * 4;
+        if (fixed + ctrl + 8 * per_wave > room) { scr = 128; per_wave = (size_t)(cap_w + 2 * scr + 2 * ((cap_w + 63) / 64) + 2) * 4; }
         int nw = 0;
         if (fixed + ctrl + 2 * per_wave <= room) nw = (int)((room - fixed - ctrl) / per_wave);
         if (nw > 8) nw = 8;
@@ -1969,8 +1973,8 @@ static int pl_launch_exact(const PolyParams &P, int sharp, const ExactScratch &S
             const int scan_pts = (sharp ? 2 : 1) * (2 * (int)ceil(fabs(max_div_px)) + 6);
             const int break_spec = getenv("DS_PL_EXACT_BREAK") ? atoi(getenv("DS_PL_EXACT_BREAK")) : 0;
             const size_t lds2 = fixed + ctrl + (size_t)nw * per_wave;
-            if (sharp) hipLaunchKernelGGL((k_polylines_exact_chunked<DT, 1>), dim3(1024), dim3(64 * nw), lds2, st, P, c, win_pts2, (int)cap_w, coop_min, scan_pts, break_spec);
-            else hipLaunchKernelGGL((k_polylines_exact_chunked<DT, 0>), dim3(1024), dim3(64 * nw), lds2, st, P, c, win_pts2, (int)cap_w, coop_min, scan_pts, break_spec);
+            if (sharp) hipLaunchKernelGGL((k_polylines_exact_chunked<DT, 1>), dim3(1024), dim3(64 * nw), lds2, st, P, c, win_pts2, (int)cap_w, coop_min, scan_pts, break_spec, scr);
+            else hipLaunchKernelGGL((k_polylines_exact_chunked<DT, 0>), dim3(1024), dim3(64 * nw), lds2, st, P, c, win_pts2, (int)cap_w, coop_min, scan_pts, break_spec, scr);
             return DS_OK;
         }
     }

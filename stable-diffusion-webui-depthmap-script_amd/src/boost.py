@@ -75,8 +75,10 @@ def resizewithpool(img, size):
     n = int(math.floor(img.shape[0] / size))
     h, w = img.shape
     ph, pw = (-h) % n, (-w) % n
-    p = F.pad(img[None, None], (0, pw, 0, ph), value=0.0)
-    return F.max_pool2d(p, kernel_size=n, stride=n)[0, 0]
+    p = F.pad(img, (0, pw, 0, ph), value=0.0)
+    # the maximum of every n x n block as a reduction over a [H/n, n, W/n, n] view (exact: a maximum rounds nothing) -- torch's float64
+    # max_pool2d on a single-channel 2160 x 3840 plane took 1 ms per call, 13 calls per image of BASELINE config 4
+    return p.view(p.shape[0] // n, n, p.shape[1] // n, n).amax(dim=(1, 3))
 
 
 def generatemask(size, device):
