@@ -24,7 +24,7 @@ def main():
     model = model.to(dev).half()
     img, _ = bench.synth_batch(batch, 0)
     img = torch.from_numpy(img).to(dev)
-    size = bench.model_input_size(name)
+    size = bench.default_net_size(name)
     for _ in range(2):
         model.infer_batch(img, size)
     torch.cuda.synchronize()
