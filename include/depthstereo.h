@@ -439,7 +439,10 @@ int ds_linear_reload_env(void);
  * scratch.layerN_rn (dmidas/blocks.py:64-80, no bias); ddepth_anything_v2/depth_anything_v2/util/blocks.py:56-85.
  * x [batch, height, width, in_channels] (channels_last), W [out_channels, 3, 3, in_channels] (the channels_last memory of
  * torch's [out, in, 3, 3] weight), bias [out_channels] or NULL, res1 / res2 / y [batch, height, width, out_channels].
- * act: 0 none, 2 ReLU (applied after the adds).  f16/bf16, fp32 accumulation.  in_channels % 128 == 0,
+ * act: 0 none, 2 ReLU (applied after the adds), 6 = 2 | 4: ReLU on the output AND on x itself -- conv(relu(x)), the first
+ * convolution of a residual unit (dmidas/blocks.py:361-363: `out = self.activation(x); out = self.conv1(out)`), the maximum
+ * taken on the MFMA fragments inside the K loop instead of in a pass over x (no residual operands, out_channels % 256 == 0;
+ * a NaN in x becomes 0 there, as it does in the ReLU of the epilogue).  f16/bf16, fp32 accumulation.  in_channels % 128 == 0,
  * out_channels % 128 == 0 (a multiple of 256 runs 256 x 256 tiles; otherwise 256 x 128 tiles, without residual operands:
  * the head's 256 -> 128 convolution, dmidas/dpt_depth.py:150), batch * height * width >= 256.  y must not alias x, res1 or res2.
  */

@@ -56,10 +56,35 @@ template <int BF16> struct ln_traits;
 template <> struct ln_traits<0> {
     typedef _Float16 T; typedef lf16x8 V8; typedef lf16x4 V4;
     static __device__ __forceinline__ lf32x16 mfma(V8 a, V8 b, lf32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
+    // max(v, 0) on the 8 packed halves of a fragment: 4 v_pk_max_f16 (inline asm: the builtin puts a canonicalising v_pk_max in
+    // front of every one of them)
+    static __device__ __forceinline__ V8 relu(V8 v)
+    {
+        typedef unsigned lu32x4 __attribute__((ext_vector_type(4)));
+        const lu32x4 x = __builtin_bit_cast(lu32x4, v);
+        unsigned r0, r1, r2, r3;
+        asm("v_pk_max_f16 %0, %1, 0" : "=v"(r0) : "v"(x[0]));
+        asm("v_pk_max_f16 %0, %1, 0" : "=v"(r1) : "v"(x[1]));
+        asm("v_pk_max_f16 %0, %1, 0" : "=v"(r2) : "v"(x[2]));
+        asm("v_pk_max_f16 %0, %1, 0" : "=v"(r3) : "v"(x[3]));
+        return __builtin_bit_cast(V8, (lu32x4){r0, r1, r2, r3});
+    }
 };
 template <> struct ln_traits<1> {
     typedef __bf16 T; typedef lbf16x8 V8; typedef lbf16x4 V4;
     static __device__ __forceinline__ lf32x16 mfma(V8 a, V8 b, lf32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+    // max(v, 0) on 8 packed bfloat16 (no packed bfloat16 maximum on gfx950): clear every half whose sign bit is set
+    static __device__ __forceinline__ V8 relu(V8 v)
+    {
+        typedef unsigned lu32x4 __attribute__((ext_vector_type(4)));
+        lu32x4 x = __builtin_bit_cast(lu32x4, v);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const unsigned neg = (x[i] >> 15) & 0x00010001u;
+            x[i] &= ~(neg * 0xffffu);
+        }
+        return __builtin_bit_cast(V8, x);
+    }
 };
 
 struct LinParams {
@@ -350,6 +375,16 @@ __global__ __launch_bounds__(LN_THREADS) void k_linear256(LinParams P)
 #define LN_READ_A(h, s)                                                                                                  \
     _Pragma("unroll") for (int rb_ = 0; rb_ < 2; ++rb_) _Pragma("unroll") for (int ks_ = 0; ks_ < 4; ++ks_)              \
         fa[h][rb_][ks_] = *(const V8 *)(lds + offA[ks_] + ((h) * 2 * LN_HALF + (s) * LN_HALF + rb_ * 4096))
+    // CONV 2: ReLU on the x operand (the `conv1(relu(x))` of a residual unit, dmidas/blocks.py:361-363): applied to the fragments
+    // in the MEMORY part of the phase that read them -- 32 packed maxima per wave, issued as the reads return, beside the other
+    // wave-row's MFMAs -- instead of a pass over the activation in front of the launch
+#define LN_RELU_A(h)                                                                                                     \
+    do {                                                                                                                 \
+        if constexpr (CONV == 2) {                                                                                       \
+            _Pragma("unroll") for (int rb_ = 0; rb_ < 2; ++rb_) _Pragma("unroll") for (int ks_ = 0; ks_ < 4; ++ks_)      \
+                fa[h][rb_][ks_] = TR::relu(fa[h][rb_][ks_]);                                                             \
+        }                                                                                                                \
+    } while (0)
 #define LN_READ_B(h, s)                                                                                                  \
     _Pragma("unroll") for (int ks_ = 0; ks_ < 4; ++ks_)                                                                  \
         if (!(NH && (h) == 1)) fb[h][ks_] = *(const V8 *)(lds + offB[ks_] + ((h) * 2 * LN_HALF + (s) * LN_HALF))
@@ -433,10 +468,10 @@ __global__ __launch_bounds__(LN_THREADS) void k_linear256(LinParams P)
         if constexpr (!LAST) { LN_MEM(LN_READ_B(1, 0), LN_STAGE(0, e2, 0)); LN_WAIT_HEAD(); } else { LN_READ_B(1, 0); LN_WAIT_VM(12); }
         LN_PHASE_END(0, 1);
         // phase 2
-        if constexpr (!LAST) { LN_MEM(LN_READ_A(1, 0), LN_STAGE(2, e2, 0)); LN_WAIT_HEAD(); } else { LN_READ_A(1, 0); LN_WAIT_VM(10); }
+        if constexpr (!LAST) { LN_MEM(LN_READ_A(1, 0), LN_STAGE(2, e2, 0)); LN_RELU_A(1); LN_WAIT_HEAD(); } else { LN_READ_A(1, 0); LN_RELU_A(1); LN_WAIT_VM(10); }
         LN_PHASE_END(1, 1);
         // phase 3
-        if constexpr (!LAST) { LN_MEM(LN_READ_A(0, 1), LN_STAGE(3, e2, 0)); LN_WAIT_HEAD(); } else { LN_READ_A(0, 1); LN_WAIT_VM(8); }
+        if constexpr (!LAST) { LN_MEM(LN_READ_A(0, 1), LN_STAGE(3, e2, 0)); LN_RELU_A(0); LN_WAIT_HEAD(); } else { LN_READ_A(0, 1); LN_RELU_A(0); LN_WAIT_VM(8); }
         LN_PHASE_END(1, 0);
         // phase 4
         if constexpr (!LAST) { LN_MEM(LN_READ_B(0, 1), LN_STAGE(1, e2, 0)); LN_WAIT_HEAD(); } else { LN_READ_B(0, 1); LN_WAIT_VM(6); }
@@ -446,10 +481,10 @@ __global__ __launch_bounds__(LN_THREADS) void k_linear256(LinParams P)
         if constexpr (!LAST) { LN_MEM(LN_READ_B(1, 1), LN_STAGE(0, o2, 1)); LN_WAIT_VM(10); } else { LN_READ_B(1, 1); LN_WAIT_VM(0); }
         LN_PHASE_END(0, 1);
         // phase 6
-        if constexpr (!LAST) { LN_MEM(LN_READ_A(1, 1), LN_STAGE(2, o2, 1)); LN_WAIT_VM(10); } else { LN_READ_A(1, 1); }
+        if constexpr (!LAST) { LN_MEM(LN_READ_A(1, 1), LN_STAGE(2, o2, 1)); LN_RELU_A(1); LN_WAIT_VM(10); } else { LN_READ_A(1, 1); LN_RELU_A(1); }
         LN_PHASE_END(1, 1);
         // phase 7
-        if constexpr (!LAST) { LN_MEM(LN_READ_A(0, 0), LN_STAGE(3, o2, 1)); LN_WAIT_VM(10); }
+        if constexpr (!LAST) { LN_MEM(LN_READ_A(0, 0), LN_STAGE(3, o2, 1)); LN_RELU_A(0); LN_WAIT_VM(10); }
         LN_PHASE_END(1, 0);
     };
     if (LN_STAGGER() > 0 && ((blockIdx.x >> 3) & 1)) {
@@ -487,6 +522,7 @@ __global__ __launch_bounds__(LN_THREADS) void k_linear256(LinParams P)
     LN_BARRIER();
     LN_READ_A(0, 0);
     LN_WAIT_LGKM0();                      // retired here: A0 of buffer 0 is re-staged in phase 1
+    LN_RELU_A(0);
     if (wr == 1) LN_BARRIER();            // the stagger
     if (LN_ABLATE(2)) {
         LN_LOAD_BIAS();
@@ -1272,6 +1308,11 @@ template <int BF16>
 static int ln_dispatch_conv(ds_ctx *ctx, const LinParams &P, int act, hipStream_t st)
 {
     const int res = P.res1 ? (P.res2 ? 2 : 1) : 0;
+    if (act & 4) {                           // ReLU on x (CONV 2): the first convolution of a residual unit -- ReLU out, no addends
+        if (P.N % 256 == 0 && (act & 3) == 2 && res == 0) return ln_launch<BF16, 2, 2, 0>(ctx, P, st);
+        ds_set_error("ds_conv3x3_nhwc: act 4 (ReLU on x) is built for act 2 | 4 without residual operands and out_channels %% 256 == 0");
+        return DS_EUNSUPPORTED;
+    }
     if (P.N % 256 != 0) {                    // 128-column tiles (NH = 1): the head convolution, no residual operands
         if (act == 2) return ln_launch<BF16, 2, 1, 0, 0, 1>(ctx, P, st);
         return ln_launch<BF16, 0, 1, 0, 0, 1>(ctx, P, st);
@@ -1351,7 +1392,7 @@ DS_API int ds_conv3x3_nhwc(ds_ctx *ctx, const void *x, const void *w, const void
     DS_REQUIRE(out_channels > 0 && out_channels % 128 == 0, DS_EINVAL, "ds_conv3x3_nhwc: out_channels must be a multiple of 128");
     DS_REQUIRE(out_channels % 256 == 0 || (!res1 && !res2), DS_EUNSUPPORTED,
                "ds_conv3x3_nhwc: residual operands need out_channels to be a multiple of 256 (the 128-column tiles have no residual epilogue)");
-    DS_REQUIRE(act == 0 || act == 2, DS_EINVAL, "ds_conv3x3_nhwc: act must be 0 (none) or 2 (ReLU)");
+    DS_REQUIRE(act == 0 || act == 2 || act == 6, DS_EINVAL, "ds_conv3x3_nhwc: act must be 0 (none), 2 (ReLU) or 6 (ReLU, and ReLU on x)");
     DS_REQUIRE(dtype == DS_DTYPE_F16 || dtype == DS_DTYPE_BF16, DS_EINVAL, "ds_conv3x3_nhwc: dtype must be f16 or bf16");
     DS_REQUIRE(((uintptr_t)x & 15) == 0 && ((uintptr_t)w & 15) == 0 && ((uintptr_t)y & 15) == 0 && (!bias || ((uintptr_t)bias & 15) == 0) &&
                ((uintptr_t)res1 & 15) == 0 && ((uintptr_t)res2 & 15) == 0,

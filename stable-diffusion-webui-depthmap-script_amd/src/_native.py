@@ -715,9 +715,10 @@ def conv3x3_supported(conv, x):
             and x.shape[0] * x.shape[2] * x.shape[3] >= 256)
 
 
-def conv3x3(conv, x, relu=False, res1=None, res2=None):
+def conv3x3(conv, x, relu=False, res1=None, res2=None, relu_in=False):
     """[relu](conv(x) + bias [+ res1] [+ res2]) for a 3x3 nn.Conv2d on a float16 / bfloat16 CUDA activation, channels_last
-    in and out (include/depthstereo.h: ds_conv3x3_nhwc).  The [out, 3, 3, in] weight image is cached on the module."""
+    in and out (include/depthstereo.h: ds_conv3x3_nhwc).  The [out, 3, 3, in] weight image is cached on the module.
+    relu_in: conv(relu(x)) with the maximum taken inside the kernel (needs relu, no residual operands, out % 256 == 0)."""
     torch = require_gpu()
     assert x.is_cuda and x.dtype in (torch.float16, torch.bfloat16) and conv3x3_supported(conv, x)
     x = x.contiguous(memory_format=torch.channels_last)
@@ -738,7 +739,7 @@ def conv3x3(conv, x, relu=False, res1=None, res2=None):
     CALLS["ds_conv3x3_nhwc"] += 1
     _check(lib().ds_conv3x3_nhwc(ctx_for(_dev_index(x)), x.data_ptr(), wk.data_ptr(), None if bk is None else bk.data_ptr(),
                                  None if res1 is None else res1.data_ptr(), None if res2 is None else res2.data_ptr(),
-                                 out.data_ptr(), b, h, w, c, conv.out_channels, 2 if relu else 0,
+                                 out.data_ptr(), b, h, w, c, conv.out_channels, (2 if relu else 0) | (4 if relu_in else 0),
                                  1 if x.dtype == torch.float16 else 2, _stream(x)))
     return out
 

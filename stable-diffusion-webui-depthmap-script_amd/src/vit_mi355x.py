@@ -509,6 +509,7 @@ def interpolate_bilinear(x, size=None, scale_factor=None, align_corners=True):
 CONV_HIP = os.environ.get("DS_CONV", "1") != "0"
 CONV_HIP_MIN_TILES = int(os.environ.get("DS_CONV_MIN_TILES", 48))
 CONV_HEAD_HIP = os.environ.get("DS_CONV_HEAD", "1") != "0"      # A/B switch: the 256 x 128 tiles (out_channels % 256 == 128)
+CONV_RELU_IN = os.environ.get("DS_CONV_RELU_IN", "1") != "0"    # A/B switch: conv1(relu(x)) of a residual unit with the ReLU inside the kernel
 
 
 def conv3x3_hip_ok(conv, x):
@@ -681,8 +682,12 @@ def residual_conv_unit(conv1, conv2, x, skip=None):
         if (conv3x3_hip_ok(conv1, xc) and conv3x3_hip_ok(conv2, xc) and conv1.out_channels == conv2.in_channels
                 and conv2.out_channels % 256 == 0):
             # both convolutions as in-tree implicit GEMMs, the element-wise tails in their epilogues: 3 launches per unit
+            # (round 6: the ReLU in front of conv1 is taken on the MFMA fragments inside the kernel: no clamp pass over x)
             sk = None if skip is None else skip.contiguous(memory_format=torch.channels_last)
-            a = _native.conv3x3(conv1, F.relu(xc), relu=True)
+            if CONV_RELU_IN and conv1.out_channels % 256 == 0:
+                a = _native.conv3x3(conv1, xc, relu=True, relu_in=True)
+            else:
+                a = _native.conv3x3(conv1, F.relu(xc), relu=True)
             return _native.conv3x3(conv2, a, relu=False, res1=xc, res2=sk)
         c1 = conv1._conv_forward(F.relu(xc), conv1.weight, None)          # honours padding_mode (TILING_MODE: circular)
         if c1.is_contiguous(memory_format=torch.channels_last):

@@ -943,10 +943,23 @@ def test_conv3x3_kernel_matches_float32_convolution(gpu, dtype, tol):
             err = (got.float() - want).abs().max().item()
             assert err < tol * (1 + want.abs().max().item()), (b, h, w, cin, cout, relu, err)
             assert torch.equal(_native.conv3x3(conv, x, relu=relu, res1=a, res2=bb), got)
+        if cout % 256 == 0:
+            # round 6: conv(relu(x)) with the maximum taken on the MFMA fragments inside the K loop (act 6) -- the same bits as
+            # the convolution of a rectified copy of x, signed zeros and the zero padding ring included
+            xz = x.clone()
+            flat = xz.permute(0, 2, 3, 1).reshape(-1)           # a view of the channels_last memory
+            flat[::7] = -0.0
+            flat[3::11] = 0.0
+            got = _native.conv3x3(conv, xz, relu=True, relu_in=True)
+            assert torch.equal(got, _native.conv3x3(conv, F.relu(xz), relu=True)), (b, h, w, cin, cout)
+            want = F.relu(F.conv2d(F.relu(xz.float()), wq, bq, padding=1))
+            assert (got.float() - want).abs().max().item() < tol * (1 + want.abs().max().item())
     import os
     _native.linear_env(DS_LIN_GRID="8")                 # persistent workgroups walking many tiles (see the linear test)
     try:
         conv = nn.Conv2d(256, 256, 3, padding=1).cuda()
+        xr = torch.randn((2, 256, 37, 41), generator=g).to(dtype).cuda().contiguous(memory_format=torch.channels_last)
+        assert torch.equal(_native.conv3x3(conv, xr, relu=True, relu_in=True), _native.conv3x3(conv, F.relu(xr), relu=True))
         x = torch.randn((2, 256, 37, 41), generator=g).to(dtype).cuda().contiguous(memory_format=torch.channels_last)
         r1 = torch.randn((2, 256, 37, 41), generator=g).to(dtype).cuda().contiguous(memory_format=torch.channels_last)
         want = F.relu(F.conv2d(x.float(), conv.weight.detach().to(dtype).float(), conv.bias.detach().to(dtype).float(), padding=1) + r1.float())
