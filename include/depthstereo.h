@@ -489,6 +489,23 @@ int ds_gconv3x3_nhwc_f32(ds_ctx *ctx, const float *x, const float *w_gtio, const
 int ds_add_relu_f32(ds_ctx *ctx, const float *a, const float *b, float *y, int64_t count, void *stream);
 
 /*
+ * ds_bias_act_f32 -- y = [relu]((x + bias[c]) [+ res]) on float32 rows of `channels` values (channels_last activations; y may be x):
+ * the element-wise tail of a LIBRARY convolution of LeReS in the reference's own order -- the BatchNorm that follows the
+ * convolution (folded into weight and bias here; torch adds a convolution's bias in a separate pass on ROCm), the ReLU
+ * (lib/Resnext_torch.py:100-102,104-110), for conv3 the shortcut add and its ReLU (:112-118), and the decoder's conv -> bias ->
+ * ReLU / conv -> bias -> + x -> ReLU pairs (lib/network_auxi.py:116-121).  channels % 4 == 0; res NULL or laid out like x.
+ * ds_relu_cat_f32 -- y[p] = relu(cat(a[p], b[p])) on float32 rows: the skip concatenation of the pix2pix U-Net's up path together
+ * with the ReLU the parent level applies to it (pix2pix/models/networks.py:545-550 and :519); the concatenated tensor has no other
+ * reader.  layout 0: a, b, y channels_last ([batch, plane, channels] rows; channel counts % 4 == 0).  layout 1: a channels_last, b and y
+ * NCHW -- what the up path runs in (MIOpen computes the float32 transposed convolutions on NCHW tensors, the down path's skips are
+ * channels_last; torch.cat of the two is NCHW); layout 2: all NCHW.  Layouts 1 / 2: channel counts % 32 == 0.  y must not alias an input.
+ */
+int ds_bias_act_f32(ds_ctx *ctx, const float *x, const float *bias, const float *res, float *y, int64_t pixels, int channels, int relu,
+                    void *stream);
+int ds_relu_cat_f32(ds_ctx *ctx, const float *a, const float *b, float *y, int batch, int64_t plane, int channels_a, int channels_b, int layout,
+                    void *stream);
+
+/*
  * ds_boost_blend -- the patch-merge step of Boost, all patches in one launch; replaces, per patch, np.polyval (:916),
  * cv2.resize INTER_CUBIC of the merged patch (:918), cv2.resize INTER_LINEAR of the Gaussian mask (:930) and the blend
  * `dst[rect] = dst[rect]*(1-mask) + merged*mask` (:936) of src/depthmap_generation.py:estimateboost.

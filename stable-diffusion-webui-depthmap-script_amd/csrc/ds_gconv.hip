@@ -144,3 +144,139 @@ DS_API int ds_add_relu_f32(ds_ctx *ctx, const float *a, const float *b, float *y
     DS_HIP_CHECK(hipGetLastError());
     return DS_OK;
 }
+
+// y = [relu]((x + bias[c]) [+ res]) on float32 NHWC rows (in place when y == x): what follows a LIBRARY convolution of LeReS in the
+// reference's order -- the folded BatchNorm's bias (torch adds a convolution's bias in a pass of its own on ROCm), the ReLU
+// (lib/Resnext_torch.py:100-102: conv1 -> bn1 -> relu), and for conv3 the shortcut add with its ReLU (:112-118); the decoder's
+// conv -> bias -> ReLU / + x pairs (lib/network_auxi.py:116-121).  One pass instead of two or three.  c4 = channels / 4.
+template <int RELU, int RES>
+__global__ __launch_bounds__(256) void k_bias_act_f32(const float4 *__restrict__ x, const float4 *__restrict__ bias, const float4 *__restrict__ res,
+                                                       float4 *__restrict__ y, long long n4, int c4)
+{
+    // (the channel group of element i is carried along the grid stride: no 64-bit division per element)
+    const long long i0 = (long long)blockIdx.x * 256 + threadIdx.x;
+    const int step = (int)(((long long)gridDim.x * 256) % c4);
+    int c = (int)(i0 % c4);
+    for (long long i = i0; i < n4; i += (long long)gridDim.x * 256, c = c + step >= c4 ? c + step - c4 : c + step) {
+        const float4 p = x[i], b = bias[c];
+        float4 v = make_float4(p.x + b.x, p.y + b.y, p.z + b.z, p.w + b.w);
+        if (RES) {
+            const float4 q = res[i];
+            v = make_float4(v.x + q.x, v.y + q.y, v.z + q.z, v.w + q.w);
+        }
+        if (RELU) v = make_float4(gc_relu(v.x), gc_relu(v.y), gc_relu(v.z), gc_relu(v.w));
+        y[i] = v;
+    }
+}
+
+DS_API int ds_bias_act_f32(ds_ctx *ctx, const float *x, const float *bias, const float *res, float *y, int64_t pixels, int channels, int relu,
+                           void *stream)
+{
+    DS_REQUIRE(ctx && x && bias && y, DS_EINVAL, "ds_bias_act_f32: null argument");
+    DS_REQUIRE(pixels > 0 && channels > 0 && channels % 4 == 0, DS_EINVAL, "ds_bias_act_f32: channels must be a positive multiple of 4");
+    DS_REQUIRE(((uintptr_t)x & 15) == 0 && ((uintptr_t)bias & 15) == 0 && ((uintptr_t)res & 15) == 0 && ((uintptr_t)y & 15) == 0, DS_EINVAL,
+               "ds_bias_act_f32: 16-byte alignment");
+    DS_HIP_CHECK(hipSetDevice(ctx->device));
+    const long long n4 = (long long)pixels * (channels / 4);
+    long long blocks = (n4 + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    const dim3 g((unsigned)blocks), b(256);
+    hipStream_t st = (hipStream_t)stream;
+    const float4 *x4 = (const float4 *)x, *b4 = (const float4 *)bias, *r4 = (const float4 *)res;
+    if (relu && res) hipLaunchKernelGGL((k_bias_act_f32<1, 1>), g, b, 0, st, x4, b4, r4, (float4 *)y, n4, channels / 4);
+    else if (relu) hipLaunchKernelGGL((k_bias_act_f32<1, 0>), g, b, 0, st, x4, b4, r4, (float4 *)y, n4, channels / 4);
+    else if (res) hipLaunchKernelGGL((k_bias_act_f32<0, 1>), g, b, 0, st, x4, b4, r4, (float4 *)y, n4, channels / 4);
+    else hipLaunchKernelGGL((k_bias_act_f32<0, 0>), g, b, 0, st, x4, b4, r4, (float4 *)y, n4, channels / 4);
+    DS_HIP_CHECK(hipGetLastError());
+    return DS_OK;
+}
+
+// y[p] = relu(cat(a[p], b[p])) on float32 NHWC rows: the skip concatenation of the pix2pix U-Net's up path and the ReLU the next
+// level applies to it (pix2pix/models/networks.py:545-550 `torch.cat([x, self.model(x)], 1)` followed by the parent's `uprelu`, :519):
+// the concatenated tensor is read by nothing else, so it is written rectified -- one pass instead of a copy pass and a clamp pass.
+__global__ __launch_bounds__(256) void k_relu_cat_f32(const float4 *__restrict__ a, const float4 *__restrict__ b, float4 *__restrict__ y, long long n4,
+                                                       int ca4, int cb4)
+{
+    const int ct4 = ca4 + cb4;
+    const long long i0 = (long long)blockIdx.x * 256 + threadIdx.x, stride = (long long)gridDim.x * 256;
+    const long long pstep = stride / ct4;
+    const int cstep = (int)(stride - pstep * ct4);
+    long long p = i0 / ct4;
+    int c = (int)(i0 - p * ct4);
+    for (long long i = i0; i < n4; i += stride) {
+        const float4 v = c < ca4 ? a[p * ca4 + c] : b[p * cb4 + (c - ca4)];
+        p += pstep; c += cstep;
+        if (c >= ct4) { c -= ct4; ++p; }
+        y[i] = make_float4(gc_relu(v.x), gc_relu(v.y), gc_relu(v.z), gc_relu(v.w));
+    }
+}
+
+// The same with the result in NCHW (what the U-Net's up path runs in: MIOpen computes the float32 transposed convolutions as GEMM +
+// col2im on NCHW tensors, and torch.cat of a channels_last skip and an NCHW up-convolution is an NCHW tensor): b is NCHW, a is NHWC
+// (A_NHWC: the skip, produced by the down path's NHWC convolutions -- transposed through LDS, 64 pixels x 32 channels per workgroup)
+// or NCHW.  Grid: (pixel tiles of 64, channel tiles of 32 over a then b, batch).
+template <int A_NHWC>
+__global__ __launch_bounds__(256) void k_relu_cat_nchw_f32(const float *__restrict__ a, const float *__restrict__ b, float *__restrict__ y,
+                                                            long long plane, int ca, int cb)
+{
+    __shared__ float tile[64][33];
+    const int t = threadIdx.x, n = blockIdx.z;
+    const long long p0 = (long long)blockIdx.x * 64;
+    const int c0 = blockIdx.y * 32, ct = ca + cb;
+    float *yo = y + ((long long)n * ct + c0) * plane;
+    if (A_NHWC && c0 < ca) {
+        const int ci = t & 31;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int pi = (t >> 5) + 8 * k;
+            if (p0 + pi < plane) tile[pi][ci] = a[((long long)n * plane + p0 + pi) * ca + c0 + ci];
+        }
+        __syncthreads();
+        const int po = t & 63;
+        if (p0 + po < plane) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int co = (t >> 6) + 4 * k;
+                yo[(long long)co * plane + p0 + po] = gc_relu(tile[po][co]);
+            }
+        }
+        return;
+    }
+    const float *src = c0 < ca ? a + ((long long)n * ca + c0) * plane : b + ((long long)n * cb + (c0 - ca)) * plane;
+    const int po = t & 63;
+    if (p0 + po < plane) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int co = (t >> 6) + 4 * k;
+            yo[(long long)co * plane + p0 + po] = gc_relu(src[(long long)co * plane + p0 + po]);
+        }
+    }
+}
+
+DS_API int ds_relu_cat_f32(ds_ctx *ctx, const float *a, const float *b, float *y, int batch, int64_t plane, int channels_a, int channels_b,
+                           int layout, void *stream)
+{
+    DS_REQUIRE(ctx && a && b && y, DS_EINVAL, "ds_relu_cat_f32: null argument");
+    DS_REQUIRE(batch > 0 && plane > 0 && channels_a > 0 && channels_b > 0, DS_EINVAL, "ds_relu_cat_f32: bad shape");
+    DS_REQUIRE(layout >= 0 && layout <= 2, DS_EINVAL, "ds_relu_cat_f32: layout must be 0 (all NHWC), 1 (a NHWC; b, y NCHW) or 2 (all NCHW)");
+    DS_REQUIRE(y != a && y != b, DS_EINVAL, "ds_relu_cat_f32: y must not alias an input");
+    DS_HIP_CHECK(hipSetDevice(ctx->device));
+    hipStream_t st = (hipStream_t)stream;
+    if (layout == 0) {
+        DS_REQUIRE(channels_a % 4 == 0 && channels_b % 4 == 0, DS_EINVAL, "ds_relu_cat_f32: NHWC channel counts must be multiples of 4");
+        DS_REQUIRE(((uintptr_t)a & 15) == 0 && ((uintptr_t)b & 15) == 0 && ((uintptr_t)y & 15) == 0, DS_EINVAL, "ds_relu_cat_f32: 16-byte alignment");
+        const long long n4 = (long long)batch * plane * ((channels_a + channels_b) / 4);
+        long long blocks = (n4 + 255) / 256;
+        if (blocks > 8192) blocks = 8192;
+        hipLaunchKernelGGL(k_relu_cat_f32, dim3((unsigned)blocks), dim3(256), 0, st, (const float4 *)a, (const float4 *)b, (float4 *)y, n4, channels_a / 4,
+                           channels_b / 4);
+    } else {
+        DS_REQUIRE(channels_a % 32 == 0 && channels_b % 32 == 0, DS_EUNSUPPORTED, "ds_relu_cat_f32: NCHW output needs channel counts that are multiples of 32");
+        DS_REQUIRE((channels_a + channels_b) / 32 <= 65535 && batch <= 65535 && (plane + 63) / 64 < (1ll << 31), DS_EUNSUPPORTED, "ds_relu_cat_f32: grid too large");
+        const dim3 grid((unsigned)((plane + 63) / 64), (unsigned)((channels_a + channels_b) / 32), (unsigned)batch);
+        if (layout == 1) hipLaunchKernelGGL((k_relu_cat_nchw_f32<1>), grid, dim3(256), 0, st, a, b, y, (long long)plane, channels_a, channels_b);
+        else hipLaunchKernelGGL((k_relu_cat_nchw_f32<0>), grid, dim3(256), 0, st, a, b, y, (long long)plane, channels_a, channels_b);
+    }
+    DS_HIP_CHECK(hipGetLastError());
+    return DS_OK;
+}

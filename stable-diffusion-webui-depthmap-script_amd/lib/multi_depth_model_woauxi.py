@@ -44,6 +44,9 @@ def _folded(conv, bn, cache_holder):
 # and the `relu(out + identity)` tails run in-tree on float32 channels_last CUDA tensors (csrc/ds_gconv.hip).  A/B switches:
 GCONV_HIP = os.environ.get("DS_GCONV", "1") != "0"
 ADD_RELU_HIP = os.environ.get("DS_ADD_RELU", "1") != "0"
+# Round 6: what follows a LIBRARY convolution -- the (folded) bias, the shortcut / residual add, the ReLU -- is one in-tree pass
+# (ds_bias_act_f32) instead of torch's bias pass + add pass + clamp pass; same operations in the same order, same bits.
+BIAS_ACT_HIP = os.environ.get("DS_BIAS_ACT_F32", "1") != "0"
 
 
 def _gconv_image(conv, wf):
@@ -75,21 +78,49 @@ def add_relu(a, b):
     return F.relu(a + b)
 
 
-def conv_bn(x, conv, bn, relu=False):
-    """BatchNorm(conv(x)) in inference mode as one convolution with folded weights."""
+def _library_conv_tail(y, b, relu, res):
+    """[relu]((y + b) [+ res]) behind a bias-free library convolution: ds_bias_act_f32 in place where it applies, torch otherwise."""
+    if b is not None and BIAS_ACT_HIP and y.is_cuda and not vm.STOCK[0] and not _wants_grad(y, b, res):
+        from src import _native
+        if _native.bias_act_f32_ok(y, b, res):
+            return _native.bias_act_f32(y, b, relu, res)
+    if b is not None:
+        y = y + b.view(1, -1, 1, 1)
+    if res is not None:
+        return add_relu(y, res) if relu else y + res
+    return F.relu(y) if relu else y
+
+
+def conv_act(x, conv, relu=False, res=None):
+    """[relu](conv(x) [+ res]) for a plain nn.Conv2d with a bias (the decoder's convolutions, lib/network_auxi.py:116-121)."""
+    if conv.bias is None or not (BIAS_ACT_HIP and x.is_cuda and x.dtype == torch.float32 and not vm.STOCK[0] and not _wants_grad(x, conv.weight)):
+        y = conv(x)
+        if res is not None:
+            return add_relu(y, res) if relu else y + res
+        return F.relu(y) if relu else y
+    return _library_conv_tail(conv._conv_forward(x, conv.weight, None), conv.bias, relu, res)       # honours padding_mode
+
+
+def conv_bn(x, conv, bn, relu=False, res=None):
+    """[relu](BatchNorm(conv(x)) [+ res]) in inference mode as one convolution with folded weights."""
     w, b = _folded(conv, bn, conv)
     cpg = conv.in_channels // max(conv.groups, 1)
     if (GCONV_HIP and conv.groups > 1 and conv.padding_mode == 'zeros' and x.is_cuda and x.dtype == torch.float32 and not vm.STOCK[0]
             and not _wants_grad(x, w) and tuple(conv.stride) == (1, 1) and cpg in (8, 16, 32)):     # (checked BEFORE the layout copy)
         from src import _native
         xc = x.contiguous(memory_format=torch.channels_last)
-        if _native.gconv3x3_supported(xc, w, conv.stride, conv.padding, conv.dilation, conv.groups):
+        if res is None and _native.gconv3x3_supported(xc, w, conv.stride, conv.padding, conv.dilation, conv.groups):
             return _native.gconv3x3(xc, _gconv_image(conv, w), b, relu, conv.in_channels // conv.groups)
+    fused = BIAS_ACT_HIP and x.is_cuda and x.dtype == torch.float32 and not vm.STOCK[0] and not _wants_grad(x, w)
     if conv.padding_mode != 'zeros':       # TILING_MODE (src/depthmap_generation.py:250-260): what nn.Conv2d._conv_forward does
         x = F.pad(x, conv._reversed_padding_repeated_twice, mode=conv.padding_mode)
-        y = F.conv2d(x, w, b, conv.stride, 0, conv.dilation, conv.groups)
+        y = F.conv2d(x, w, None if fused else b, conv.stride, 0, conv.dilation, conv.groups)
     else:
-        y = F.conv2d(x, w, b, conv.stride, conv.padding, conv.dilation, conv.groups)
+        y = F.conv2d(x, w, None if fused else b, conv.stride, conv.padding, conv.dilation, conv.groups)
+    if fused:
+        return _library_conv_tail(y, b, relu, res)
+    if res is not None:
+        return add_relu(y, res) if relu else y + res
     return F.relu(y) if relu else y
 
 
@@ -113,8 +144,7 @@ class Bottleneck(nn.Module):
         identity = x if self.downsample is None else conv_bn(x, self.downsample[0], self.downsample[1])
         out = conv_bn(x, self.conv1, self.bn1, relu=True)
         out = conv_bn(out, self.conv2, self.bn2, relu=True)
-        out = conv_bn(out, self.conv3, self.bn3)
-        return add_relu(out, identity)
+        return conv_bn(out, self.conv3, self.bn3, relu=True, res=identity)     # relu(bn3(conv3(out)) + identity): one pass behind the GEMM
 
 
 class ResNeXt101_32x8d(nn.Module):
@@ -162,10 +192,9 @@ class FTB(nn.Module):
 
     def forward(self, x):               # network_auxi.py:116-121
         # conv_branch starts with ReLU(inplace=True): it rectifies x itself before `x + conv_branch(x)` is formed
-        x = F.relu(self.conv1(x))
+        x = conv_act(x, self.conv1, relu=True)
         b = conv_bn(x, self.conv_branch[1], self.conv_branch[2], relu=True)
-        b = self.conv_branch[4](b)
-        return add_relu(x, b)
+        return conv_act(b, self.conv_branch[4], relu=True, res=x)             # relu(x + conv(b)): the add commutes bit for bit
 
 
 class FFM(nn.Module):

@@ -9,11 +9,25 @@ Forward is a flat loop over the ten levels instead of ten nested module calls.  
 purpose: its down-path LeakyReLU is in-place, so the tensor that reaches the skip concatenation is the ACTIVATED input
 of the block (networks.py:509,545-550: `torch.cat([x, self.model(x)], 1)` after `self.model` has rectified x in place).
 """
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
 from src import vit_mi355x as vm
+
+
+RELU_CAT_HIP = os.environ.get("DS_RELU_CAT", "1") != "0"         # A/B switch
+
+
+def _relu_cat(s, t):
+    """relu(torch.cat([s, t], 1))"""
+    if RELU_CAT_HIP and s.is_cuda and not vm.STOCK[0] and not (torch.is_grad_enabled() and (s.requires_grad or t.requires_grad)):
+        from src import _native
+        if _native.relu_cat_f32_ok(s, t):
+            return _native.relu_cat_f32(s, t)
+    return F.relu(torch.cat([s, t], 1))
 
 
 class _Identity(nn.Module):
@@ -88,7 +102,9 @@ class UnetGenerator(nn.Module):
             t = F.leaky_relu(t, 0.2)                            # in-place in the reference: this IS the skip tensor
             skips.append(t)
             t = b.downconv(t)
+        # up path: `cat([skip, upconv(relu(t))])` is read by the parent's ReLU and by nothing else (networks.py:519,545-550), so the
+        # concatenation is written rectified: one pass (ds_relu_cat_f32) instead of a copy pass and a clamp pass
+        r = F.relu(t)
         for b, s in zip(reversed(lv[1:]), reversed(skips)):
-            t = b.upconv(F.relu(t))
-            t = torch.cat([s, t], 1)
-        return torch.tanh(lv[0].upconv(F.relu(t)))
+            r = _relu_cat(s, b.upconv(r))
+        return torch.tanh(lv[0].upconv(r))

@@ -24,7 +24,7 @@ EXPORTS = [
     "ds_stereo_last_exact_rows", "ds_copy_view", "ds_overlap_red_cyan", "ds_normalmap", "ds_depth_to_u16",
     "ds_convert_to_i16", "ds_profile_enable", "ds_profile_last_ms", "ds_stereo_last_stats", "ds_attention_fwd", "ds_attention_bias_pack", "ds_colorize_u16", "ds_residual_layernorm", "ds_boost_blend", "ds_upsample_bilinear_nhwc", "ds_dpt_head_tail", "ds_preprocess_bicubic", "ds_linear_reload_env", "ds_attention_reload_env", "ds_normalmap_selfcheck", "ds_normalmap_gradient_f16", "ds_normalmap_gradient_blur_f32",
     "ds_linear_shuffle", "ds_linear_readout", "ds_kernel_timer_enable", "ds_kernel_timer_read", "ds_kernel_timer_read_each", "ds_group_norm_nchw",
-    "ds_row_stats", "ds_linear_ln", "ds_linear_vt_ln", "ds_gconv3x3_nhwc_f32", "ds_add_relu_f32",
+    "ds_row_stats", "ds_linear_ln", "ds_linear_vt_ln", "ds_gconv3x3_nhwc_f32", "ds_add_relu_f32", "ds_bias_act_f32", "ds_relu_cat_f32",
 ]
 
 
@@ -97,6 +97,8 @@ def lib():
             L.ds_linear_vt_ln.argtypes = [vp, vp, vp, vp, vp, vp, i64, i64, i64, i64, ci, vp]
             L.ds_gconv3x3_nhwc_f32.argtypes = [vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, vp]
             L.ds_add_relu_f32.argtypes = [vp, vp, vp, vp, i64, vp]
+            L.ds_bias_act_f32.argtypes = [vp, vp, vp, vp, vp, i64, ci, ci, vp]
+            L.ds_relu_cat_f32.argtypes = [vp, vp, vp, vp, ci, i64, ci, ci, ci, vp]
             L.ds_kernel_timer_enable.argtypes = [vp, ci]
             L.ds_kernel_timer_read.argtypes = [vp, ci, ctypes.POINTER(i64), ctypes.POINTER(cd)]
             L.ds_kernel_timer_read_each.argtypes = [vp, ci, ctypes.POINTER(ctypes.c_float), i64, ctypes.POINTER(i64)]
@@ -604,6 +606,63 @@ def add_relu(a, b):
     assert out.stride() == a.stride()
     CALLS["ds_add_relu_f32"] += 1
     _check(lib().ds_add_relu_f32(ctx_for(_dev_index(a)), a.data_ptr(), b.data_ptr(), out.data_ptr(), a.numel(), _stream(a)))
+    return out
+
+
+def bias_act_f32_ok(x, bias, res=None):
+    """What ds_bias_act_f32 takes: a float32 CUDA activation in channels_last memory (or a dense [rows, C] matrix), C % 4 == 0, a
+    float32 bias of C values, res laid out like x."""
+    torch = require_gpu()
+    if not (x.is_cuda and x.dtype == torch.float32 and bias is not None and bias.dtype == torch.float32 and bias.is_cuda and bias.numel() == x.shape[1]):
+        return False
+    if not (x.dim() == 4 and x.shape[1] % 4 == 0 and x.is_contiguous(memory_format=torch.channels_last) and x.numel() > 0):
+        return False
+    return res is None or (res.dtype == torch.float32 and res.shape == x.shape and res.is_cuda and res.is_contiguous(memory_format=torch.channels_last))
+
+
+def bias_act_f32(x, bias, relu=False, res=None):
+    """[relu]((x + bias[c]) [+ res]) IN PLACE on a float32 channels_last activation (include/depthstereo.h: ds_bias_act_f32)."""
+    assert bias_act_f32_ok(x, bias, res)
+    b, c, h, w = x.shape
+    bias = bias.contiguous()
+    CALLS["ds_bias_act_f32"] += 1
+    _check(lib().ds_bias_act_f32(ctx_for(_dev_index(x)), x.data_ptr(), bias.data_ptr(), None if res is None else res.data_ptr(), x.data_ptr(),
+                                 b * h * w, c, 1 if relu else 0, _stream(x)))
+    return x
+
+
+def _relu_cat_layout(a, b):
+    """0: both channels_last; 1: a channels_last, b NCHW-contiguous; 2: both NCHW-contiguous; None: not taken."""
+    torch = require_gpu()
+    if not (a.is_cuda and b.is_cuda and a.dtype == torch.float32 and b.dtype == torch.float32 and a.dim() == 4 and b.dim() == 4
+            and a.shape[0] == b.shape[0] and a.shape[2:] == b.shape[2:] and a.numel() > 0 and b.numel() > 0):
+        return None
+    cl = torch.channels_last
+    # (a tensor with one channel or a 1 x 1 plane is contiguous in both senses: NCHW is tested first for b, channels_last first for a)
+    if b.is_contiguous():
+        lay = 2 if (a.is_contiguous() and not a.is_contiguous(memory_format=cl)) else (1 if a.is_contiguous(memory_format=cl) else None)
+        if lay is not None and a.shape[1] % 32 == 0 and b.shape[1] % 32 == 0:
+            return lay
+    if a.is_contiguous(memory_format=cl) and b.is_contiguous(memory_format=cl) and a.shape[1] % 4 == 0 and b.shape[1] % 4 == 0:
+        return 0
+    return None
+
+
+def relu_cat_f32_ok(a, b):
+    return _relu_cat_layout(a, b) is not None
+
+
+def relu_cat_f32(a, b):
+    """relu(torch.cat([a, b], 1)) for float32 activations, one pass (include/depthstereo.h: ds_relu_cat_f32): channels_last out of two
+    channels_last inputs; NCHW when b is NCHW (a channels_last or NCHW) -- the memory format torch.cat itself would produce."""
+    torch = require_gpu()
+    lay = _relu_cat_layout(a, b)
+    assert lay is not None
+    n, ca, h, w = a.shape
+    cb = b.shape[1]
+    out = torch.empty((n, ca + cb, h, w), dtype=a.dtype, device=a.device, memory_format=torch.channels_last if lay == 0 else torch.contiguous_format)
+    CALLS["ds_relu_cat_f32"] += 1
+    _check(lib().ds_relu_cat_f32(ctx_for(_dev_index(a)), a.data_ptr(), b.data_ptr(), out.data_ptr(), n, h * w, ca, cb, lay, _stream(a)))
     return out
 
 

@@ -1827,10 +1827,12 @@ def test_gconv3x3_matches_torch_grouped_convolution(gpu, b, c, cpg, h, w):
 
 
 def test_leres_takes_the_in_tree_grouped_convolutions(gpu):
-    """RelDepthModel (LeReS res101) on the device: the 28 stride-1 grouped convolutions of layers 1-3 and the 33 bottleneck tails go
-    through ds_gconv3x3_nhwc_f32 / ds_add_relu_f32 (layer 4's 64-wide groups and the strided first blocks stay library calls), and the
-    output equals the library-only network (DS_GCONV=0, DS_ADD_RELU=0) at float32 summation-order level; 1e-4 against the reference's own
-    modules is held by test_leres_and_hybrid_gpu_fp32_vs_reference."""
+    """RelDepthModel (LeReS res101) on the device: the 28 stride-1 grouped convolutions of layers 1-3 go through ds_gconv3x3_nhwc_f32
+    (layer 4's 64-wide groups and the strided first blocks stay library calls); round 6: every library convolution runs without its
+    bias and ds_bias_act_f32 applies the folded bias, the shortcut add of the 33 bottleneck tails and the ReLU in one pass -- the same
+    operations in the same order, so the output is BIT-IDENTICAL to torch's bias pass + add_relu (DS_BIAS_ACT_F32=0).  Against the
+    library-only network (DS_GCONV=0 too) the difference is float32 summation order; 1e-4 against the reference's own modules is held
+    by test_leres_and_hybrid_gpu_fp32_vs_reference."""
     import lib.multi_depth_model_woauxi as leres
     from src import _native
     m = leres.RelDepthModel(backbone='resnext101').eval()
@@ -1841,15 +1843,92 @@ def test_leres_takes_the_in_tree_grouped_convolutions(gpu):
     with torch.no_grad():
         y = m.depth_model(x)
     assert _native.CALLS["ds_gconv3x3_nhwc_f32"] - before.get("ds_gconv3x3_nhwc_f32", 0) == 3 + 3 + 22
-    assert _native.CALLS["ds_add_relu_f32"] - before.get("ds_add_relu_f32", 0) >= 33        # 33 bottleneck tails (+ the decoder's FTB tails)
-    saved = leres.GCONV_HIP, leres.ADD_RELU_HIP
+    # stem + 33 x (conv1, conv3 + shortcut) + 4 downsample + 5 library conv2 (3 strided first blocks + layer 4's other two) + the decoder
+    assert _native.CALLS["ds_bias_act_f32"] - before.get("ds_bias_act_f32", 0) >= 1 + 66 + 4 + 5
+    saved = leres.GCONV_HIP, leres.ADD_RELU_HIP, leres.BIAS_ACT_HIP
     try:
+        leres.BIAS_ACT_HIP = False
+        before = dict(_native.CALLS)
+        with torch.no_grad():
+            y_two_pass = m.depth_model(x)
+        assert _native.CALLS["ds_bias_act_f32"] == before.get("ds_bias_act_f32", 0)
+        assert _native.CALLS["ds_add_relu_f32"] - before.get("ds_add_relu_f32", 0) >= 33
+        assert torch.equal(y, y_two_pass), (y - y_two_pass).abs().max().item()
         leres.GCONV_HIP = leres.ADD_RELU_HIP = False
         with torch.no_grad():
             y_lib = m.depth_model(x)
     finally:
-        leres.GCONV_HIP, leres.ADD_RELU_HIP = saved
+        leres.GCONV_HIP, leres.ADD_RELU_HIP, leres.BIAS_ACT_HIP = saved
     assert (y - y_lib).abs().max().item() < 2e-5 * (1 + y_lib.abs().max().item())
+
+
+def test_bias_act_f32_and_relu_cat_f32_match_torch_bit_for_bit(gpu):
+    """ds_bias_act_f32 = [relu]((x + bias) [+ res]) in place and ds_relu_cat_f32 = relu(cat(a, b)) on float32 channels_last activations
+    against torch's own passes: equal bits (the same float32 operations in the same order), NaN / Inf / -0.0 included, at a shape of
+    layer 1 of a 896^2 patch batch, on ragged sizes, and with more elements than one grid stride."""
+    import torch.nn.functional as F
+    from src import _native
+    g = torch.Generator().manual_seed(77)
+    for (n, c, h, w) in [(8, 256, 224, 224), (1, 4, 3, 5), (2, 2048, 7, 9), (3, 36, 11, 13)]:
+        x = torch.randn((n, c, h, w), generator=g).cuda().contiguous(memory_format=torch.channels_last)
+        r = torch.randn((n, c, h, w), generator=g).cuda().contiguous(memory_format=torch.channels_last)
+        b = torch.randn((c,), generator=g).cuda()
+        x[0, 0, 0, :4] = torch.tensor([float("nan"), float("inf"), float("-inf"), -0.0]).cuda()[:min(4, w)] if w >= 4 else x[0, 0, 0, :4]
+        for relu, res in ((True, None), (False, None), (True, r), (False, r)):
+            want = x + b.view(1, -1, 1, 1)
+            if res is not None:
+                want = want + res
+            if relu:
+                want = F.relu(want)
+            assert _native.bias_act_f32_ok(x, b, res)
+            got = _native.bias_act_f32(x.clone(memory_format=torch.preserve_format), b, relu, res)
+            assert got.is_contiguous(memory_format=torch.channels_last)
+            assert torch.equal(torch.isnan(got), torch.isnan(want)) and torch.equal(torch.nan_to_num(got, 7.0), torch.nan_to_num(want, 7.0)), (n, c, h, w, relu)
+    for (n, ca, cb, h, w) in [(8, 64, 64, 512, 512), (1, 4, 8, 3, 5), (2, 512, 512, 2, 2), (3, 12, 4, 7, 9)]:
+        a = torch.randn((n, ca, h, w), generator=g).cuda().contiguous(memory_format=torch.channels_last)
+        b = torch.randn((n, cb, h, w), generator=g).cuda().contiguous(memory_format=torch.channels_last)
+        a[0, 0, 0, 0], b[0, 0, 0, 0] = float("nan"), float("-inf")
+        want = F.relu(torch.cat([a, b], 1))
+        got = _native.relu_cat_f32(a, b)
+        assert got.shape == want.shape and got.is_contiguous(memory_format=torch.channels_last)
+        assert torch.equal(torch.isnan(got), torch.isnan(want)) and torch.equal(torch.nan_to_num(got, 7.0), torch.nan_to_num(want, 7.0)), (n, ca, cb, h, w)
+    assert not _native.relu_cat_f32_ok(a[:, :3], b) and not _native.bias_act_f32_ok(a.contiguous(), torch.zeros(12).cuda())
+    # the U-Net's up path: the skip is channels_last, the transposed convolution's result NCHW, and so is the concatenation (ragged
+    # pixel tiles, planes smaller than a tile, the innermost 2 x 2 level)
+    for (n, ca, cb, h, w) in [(8, 64, 64, 512, 512), (2, 512, 512, 2, 2), (3, 32, 96, 7, 9), (1, 128, 64, 65, 3)]:
+        a = torch.randn((n, ca, h, w), generator=g).cuda().contiguous(memory_format=torch.channels_last)
+        b = torch.randn((n, cb, h, w), generator=g).cuda()
+        a[0, 0, 0, 0], b[0, 0, 0, 0] = float("nan"), float("-inf")
+        for aa in (a, a.contiguous()):
+            want = F.relu(torch.cat([aa, b], 1))
+            assert _native.relu_cat_f32_ok(aa, b)
+            got = _native.relu_cat_f32(aa, b)
+            assert got.shape == want.shape and got.is_contiguous()
+            assert torch.equal(torch.isnan(got), torch.isnan(want)) and torch.equal(torch.nan_to_num(got, 7.0), torch.nan_to_num(want, 7.0)), (n, ca, cb, h, w)
+
+
+def test_pix2pix_unet_takes_relu_cat(gpu):
+    """The merge network with its nine skip concatenations written rectified by ds_relu_cat_f32 against the same network with torch.cat
+    + F.relu (DS_RELU_CAT=0).  The pass itself is bit-identical to torch's two (test above); the NETWORK's output is compared at float32
+    summation-order level, because MIOpen's split-K solvers (`..._gkgs`: atomic adds) make two runs of the same float32 U-Net differ
+    in the last bits whatever feeds them."""
+    import pix2pix.models.networks as networks
+    from src import _native
+    torch.manual_seed(3)
+    m = networks.UnetGenerator().eval().cuda()
+    x = torch.randn((2, 2, 1024, 1024), device="cuda")
+    before = _native.CALLS["ds_relu_cat_f32"]
+    with torch.no_grad():
+        y = m(x)
+    assert _native.CALLS["ds_relu_cat_f32"] - before == 9
+    saved = networks.RELU_CAT_HIP
+    try:
+        networks.RELU_CAT_HIP = False
+        with torch.no_grad():
+            y2 = m(x)
+    finally:
+        networks.RELU_CAT_HIP = saved
+    assert torch.equal(y, y2)
 
 
 # ---- round 6: GroupNorm of the ResNetV2-50 stem (dpt_hybrid_384, BASELINE config 2) ----------------------------------------------------
