@@ -552,8 +552,14 @@ _pool = None
 _copy_streams = {}
 # wall-clock seconds the host spent per stage of the last FINISHED funnel call (bench.py's funnel leg reports them): 'launch' =
 # decoding + staging + enqueueing the groups, 'wait' = blocked on a group's results.  Every call accumulates into a dict of its
-# own and publishes it here when its generator finishes, so interleaved generators cannot mix their numbers.
+# own and publishes it here when its generator finishes, so interleaved generators cannot mix their numbers.  FUNNEL_STATS is the call
+# that ENDED last ('call' = its serial number, 'finished' = whether its generator ran to completion); a call that starts does not
+# touch it, so a generator that interleaves with another one cannot wipe the other's published numbers; the last few calls stay
+# readable by serial number in FUNNEL_STATS_BY_CALL.
 FUNNEL_STATS = {}
+FUNNEL_STATS_BY_CALL = {}
+_funnel_calls = [0]
+_funnel_calls_lock = _threading.Lock()
 
 
 def _copy_stream(device, index=0):
@@ -759,8 +765,9 @@ def core_generation_funnel(outpath, inputimages, inputdepthmaps, inputnames, inp
     torch = _native.require_gpu()        # the hot path has no CPU implementation, whatever COMPUTE_DEVICE says
     device = torch.device('cuda', torch.cuda.current_device())
     pil_blocks_held = _tune_pil_allocator()
-    stats = {"finished": False}
-    FUNNEL_STATS.clear()                   # a reader never sees the PREVIOUS call's numbers while (or after) this one runs
+    with _funnel_calls_lock:
+        _funnel_calls[0] += 1
+        stats = {"finished": False, "call": _funnel_calls[0]}
     _t_start = _time.perf_counter()
     pending = launched = None
     if _TRACE:
@@ -815,8 +822,12 @@ def core_generation_funnel(outpath, inputimages, inputdepthmaps, inputnames, inp
                 except Exception:            # noqa: BLE001
                     pass
         stats["total"] = _time.perf_counter() - _t_start
-        FUNNEL_STATS.clear()
-        FUNNEL_STATS.update(stats)
+        with _funnel_calls_lock:
+            FUNNEL_STATS.clear()
+            FUNNEL_STATS.update(stats)
+            FUNNEL_STATS_BY_CALL[stats["call"]] = dict(stats)
+            for old in sorted(FUNNEL_STATS_BY_CALL)[:-8]:
+                del FUNNEL_STATS_BY_CALL[old]
         _restore_pil_allocator(pil_blocks_held)
         if ops.get('keepmodels', True):
             model_holder.offload()
