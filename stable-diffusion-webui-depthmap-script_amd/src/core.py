@@ -289,19 +289,42 @@ class _HostStaging:
 _staging = _HostStaging()
 
 
+def _split_run(n, limit):
+    """Group sizes for a run of n same-size images with a device batch of at most `limit`.  DS_FUNNEL_PLAN="24,8" (measurements):
+    the listed sizes first (each capped by 64), `limit` for what is left."""
+    plan = [int(x) for x in _os.environ.get("DS_FUNNEL_PLAN", "").split(",") if x.strip().isdigit() and int(x) > 0]
+    sizes = []
+    for p in plan:
+        if n <= 0:
+            break
+        sizes.append(min(p, n, 64))
+        n -= sizes[-1]
+    while n > 0:
+        sizes.append(min(limit, n))
+        n -= sizes[-1]
+    return sizes
+
+
 def _plan_groups(inputimages, inputdepthmaps, batchable):
-    """Consecutive images of one size and mode (and one kind of depth source) form a device batch."""
-    groups, cur, key = [], [], None
+    """Consecutive images of one size and mode (and one kind of depth source) form a run; a run is cut into device batches."""
+    runs, cur, key = [], [], None
     for i, im in enumerate(inputimages):
         k = (im.size, im.mode, inputdepthmaps[i] is not None)
-        limit = max(1, min(64, FUNNEL_BATCH_PIXELS // max(1, im.size[0] * im.size[1]))) if batchable else 1
-        if cur and (k != key or len(cur) >= limit):
-            groups.append(cur)
+        if cur and k != key:
+            runs.append(cur)
             cur = []
         key = k
         cur.append(i)
     if cur:
-        groups.append(cur)
+        runs.append(cur)
+    groups = []
+    for run in runs:
+        im = inputimages[run[0]]
+        limit = max(1, min(64, FUNNEL_BATCH_PIXELS // max(1, im.size[0] * im.size[1]))) if batchable else 1
+        at = 0
+        for sz in _split_run(len(run), limit):
+            groups.append(run[at:at + sz])
+            at += sz
     return groups
 
 
