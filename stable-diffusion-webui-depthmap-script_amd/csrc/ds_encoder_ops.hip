@@ -166,18 +166,19 @@ DS_API int ds_row_stats(ds_ctx *ctx, const void *x, void *stats, int64_t rows, i
 // DPT decoders (dmidas/blocks.py:429-431, ddepth_anything_v2/.../util/blocks.py:141-145, the heads' Interpolate).  The
 // op is pure HBM streaming (the output is 4x the input); one lane produces 8 channels (16 bytes) of one output pixel from
 // four 16-byte reads that hit L1/L2, consecutive lanes walk the channel axis, so every store instruction writes whole lines.
+// Grid: x = 256-lane pieces of one output row (ow * C8 lanes), y = output row, z = image -- the row and the image are uniform
+// (their interpolation weights and source rows live in scalar registers) and a lane's column is ONE 32-bit division; rounds 1-5
+// derived (image, row, column, channel group) from a flat 64-bit index with three 64-bit divisions per lane, which cost more
+// vector instructions than the interpolation itself and held the pass at ~3 TB/s.  Same arithmetic per element: same bits.
 template <int BF16>
 __global__ __launch_bounds__(256) void k_upsample_bilinear_nhwc(const void *in_, void *out_, int C8, int ih, int iw, int oh, int ow,
-                                                                 float sy, float sx, int align_corners, long long total)
+                                                                 float sy, float sx, int align_corners)
 {
     typedef typename eo_traits<BF16>::T T;
-    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (idx >= total) return;
-    const int c8 = (int)(idx % C8);
-    long long r = idx / C8;
-    const int ox = (int)(r % ow); r /= ow;
-    const int oy = (int)(r % oh);
-    const int b = (int)(r / oh);
+    const unsigned i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= (unsigned)ow * (unsigned)C8) return;
+    const int ox = (int)(i / (unsigned)C8), c8 = (int)(i - (unsigned)ox * (unsigned)C8);
+    const int oy = blockIdx.y, b = blockIdx.z;
     float fy, fx;
     if (align_corners) { fy = sy * oy; fx = sx * ox; }
     else { fy = fmaxf(sy * (oy + 0.5f) - 0.5f, 0.f); fx = fmaxf(sx * (ox + 0.5f) - 0.5f, 0.f); }
@@ -194,7 +195,7 @@ __global__ __launch_bounds__(256) void k_upsample_bilinear_nhwc(const void *in_,
 #pragma unroll
     for (int k = 0; k < 8; k++)
         o[k] = (T)(w00 * (float)a[k] + w01 * (float)bq[k] + w10 * (float)c[k] + w11 * (float)d[k]);
-    __builtin_memcpy((T *)out_ + (size_t)idx * 8, o, 16);
+    __builtin_memcpy((T *)out_ + ((((size_t)b * oh + oy) * ow) * C8 + i) * 8, o, 16);
 }
 
 DS_API int ds_upsample_bilinear_nhwc(ds_ctx *ctx, const void *in, void *out, int batch, int channels, int in_h, int in_w,
@@ -215,13 +216,12 @@ DS_API int ds_upsample_bilinear_nhwc(ds_ctx *ctx, const void *in, void *out, int
         sx = (float)in_w / (float)out_w;
     }
     const int C8 = channels / 8;
-    const long long total = (long long)batch * out_h * out_w * C8;
-    DS_REQUIRE((total + 255) / 256 < (1ll << 31), DS_EUNSUPPORTED, "ds_upsample_bilinear_nhwc: tensor too large");
-    dim3 grid((unsigned)((total + 255) / 256));
+    DS_REQUIRE((long long)out_w * C8 < (1ll << 31) && out_h <= 65535 && batch <= 65535, DS_EUNSUPPORTED, "ds_upsample_bilinear_nhwc: tensor too large");
+    dim3 grid((unsigned)(((long long)out_w * C8 + 255) / 256), (unsigned)out_h, (unsigned)batch);
     if (dtype == DS_DTYPE_F16)
-        hipLaunchKernelGGL((k_upsample_bilinear_nhwc<0>), grid, dim3(256), 0, (hipStream_t)stream, in, out, C8, in_h, in_w, out_h, out_w, sy, sx, align_corners, total);
+        hipLaunchKernelGGL((k_upsample_bilinear_nhwc<0>), grid, dim3(256), 0, (hipStream_t)stream, in, out, C8, in_h, in_w, out_h, out_w, sy, sx, align_corners);
     else
-        hipLaunchKernelGGL((k_upsample_bilinear_nhwc<1>), grid, dim3(256), 0, (hipStream_t)stream, in, out, C8, in_h, in_w, out_h, out_w, sy, sx, align_corners, total);
+        hipLaunchKernelGGL((k_upsample_bilinear_nhwc<1>), grid, dim3(256), 0, (hipStream_t)stream, in, out, C8, in_h, in_w, out_h, out_w, sy, sx, align_corners);
     DS_HIP_CHECK(hipGetLastError());
     return DS_OK;
 }
