@@ -178,24 +178,50 @@ __global__ __launch_bounds__(256) void k_upsample_bilinear_nhwc(const void *in_,
     const unsigned i = blockIdx.x * 256u + threadIdx.x;
     if (i >= (unsigned)ow * (unsigned)C8) return;
     const int ox = (int)(i / (unsigned)C8), c8 = (int)(i - (unsigned)ox * (unsigned)C8);
-    const int oy = blockIdx.y, b = blockIdx.z;
-    float fy, fx;
-    if (align_corners) { fy = sy * oy; fx = sx * ox; }
-    else { fy = fmaxf(sy * (oy + 0.5f) - 0.5f, 0.f); fx = fmaxf(sx * (ox + 0.5f) - 0.5f, 0.f); }
-    const int y0 = min((int)fy, ih - 1), x0 = min((int)fx, iw - 1);
-    const int y1 = min(y0 + 1, ih - 1), x1 = min(x0 + 1, iw - 1);
-    const float ty = fy - y0, tx = fx - x0;
+    const int b = blockIdx.z;
+    float fx;
+    if (align_corners) fx = sx * ox;
+    else fx = fmaxf(sx * (ox + 0.5f) - 0.5f, 0.f);
+    const int x0 = min((int)fx, iw - 1), x1 = min(x0 + 1, iw - 1);
+    const float tx = fx - x0;
     const T *in = (const T *)in_ + (size_t)b * ih * iw * C8 * 8 + (size_t)c8 * 8;
+    // a workgroup renders TWO output rows (2 * blockIdx.y and the next one): when upsampling they mostly interpolate between the same
+    // two source rows, whose four pieces are then loaded once -- the pass is bound by the vector cache's request rate (four 16-byte
+    // requests per 16 bytes written), not by HBM.  Which rows are shared is uniform (scalar branches).
+    int py0 = -1, py1 = -1;
     T a[8], bq[8], c[8], d[8], o[8];
-    __builtin_memcpy(a, in + ((size_t)y0 * iw + x0) * C8 * 8, 16);
-    __builtin_memcpy(bq, in + ((size_t)y0 * iw + x1) * C8 * 8, 16);
-    __builtin_memcpy(c, in + ((size_t)y1 * iw + x0) * C8 * 8, 16);
-    __builtin_memcpy(d, in + ((size_t)y1 * iw + x1) * C8 * 8, 16);
-    const float w00 = (1.f - ty) * (1.f - tx), w01 = (1.f - ty) * tx, w10 = ty * (1.f - tx), w11 = ty * tx;
 #pragma unroll
-    for (int k = 0; k < 8; k++)
-        o[k] = (T)(w00 * (float)a[k] + w01 * (float)bq[k] + w10 * (float)c[k] + w11 * (float)d[k]);
-    __builtin_memcpy((T *)out_ + ((((size_t)b * oh + oy) * ow) * C8 + i) * 8, o, 16);
+    for (int r = 0; r < 2; r++) {
+        const int oy = 2 * (int)blockIdx.y + r;
+        if (oy >= oh) break;
+        float fy;
+        if (align_corners) fy = sy * oy;
+        else fy = fmaxf(sy * (oy + 0.5f) - 0.5f, 0.f);
+        const int y0 = min((int)fy, ih - 1), y1 = min(y0 + 1, ih - 1);
+        const float ty = fy - y0;
+        if (y0 == py1 && y0 != py0) {                         // the previous bottom row is this top row
+#pragma unroll
+            for (int k = 0; k < 8; k++) { a[k] = c[k]; bq[k] = d[k]; }
+        } else if (y0 != py0) {
+            __builtin_memcpy(a, in + ((size_t)y0 * iw + x0) * C8 * 8, 16);
+            __builtin_memcpy(bq, in + ((size_t)y0 * iw + x1) * C8 * 8, 16);
+        }
+        if (y1 != py1 || r == 0) {
+            if (y1 == y0) {
+#pragma unroll
+                for (int k = 0; k < 8; k++) { c[k] = a[k]; d[k] = bq[k]; }
+            } else {
+                __builtin_memcpy(c, in + ((size_t)y1 * iw + x0) * C8 * 8, 16);
+                __builtin_memcpy(d, in + ((size_t)y1 * iw + x1) * C8 * 8, 16);
+            }
+        }
+        py0 = y0; py1 = y1;
+        const float w00 = (1.f - ty) * (1.f - tx), w01 = (1.f - ty) * tx, w10 = ty * (1.f - tx), w11 = ty * tx;
+#pragma unroll
+        for (int k = 0; k < 8; k++)
+            o[k] = (T)(w00 * (float)a[k] + w01 * (float)bq[k] + w10 * (float)c[k] + w11 * (float)d[k]);
+        __builtin_memcpy((T *)out_ + ((((size_t)b * oh + oy) * ow) * C8 + i) * 8, o, 16);
+    }
 }
 
 DS_API int ds_upsample_bilinear_nhwc(ds_ctx *ctx, const void *in, void *out, int batch, int channels, int in_h, int in_w,
@@ -217,7 +243,7 @@ DS_API int ds_upsample_bilinear_nhwc(ds_ctx *ctx, const void *in, void *out, int
     }
     const int C8 = channels / 8;
     DS_REQUIRE((long long)out_w * C8 < (1ll << 31) && out_h <= 65535 && batch <= 65535, DS_EUNSUPPORTED, "ds_upsample_bilinear_nhwc: tensor too large");
-    dim3 grid((unsigned)(((long long)out_w * C8 + 255) / 256), (unsigned)out_h, (unsigned)batch);
+    dim3 grid((unsigned)(((long long)out_w * C8 + 255) / 256), (unsigned)((out_h + 1) / 2), (unsigned)batch);
     if (dtype == DS_DTYPE_F16)
         hipLaunchKernelGGL((k_upsample_bilinear_nhwc<0>), grid, dim3(256), 0, (hipStream_t)stream, in, out, C8, in_h, in_w, out_h, out_w, sy, sx, align_corners);
     else
