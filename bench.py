@@ -60,7 +60,7 @@ import numpy as np  # noqa: E402
 from benchlib import workload as wl  # noqa: E402
 from benchlib.launch import compare_gathered, dist_setup, launch_command, max_over_ranks, self_launch, selftest_launch  # noqa: E402,F401
 from benchlib.legs import funnel_leg, other_configs_leg, route_check_leg  # noqa: E402
-from benchlib.profiles import traffic_from_profile  # noqa: E402
+from benchlib.profiles import traffic_from_profile, valu_from_profile  # noqa: E402
 from benchlib.rooflines import (HBM_COPY_GBPS, HBM_PEAK_GBPS, IN_STEP, MICRO, encoder_rooflines, mfma_roofline,  # noqa: E402,F401
                                 microbench_conv)
 from benchlib.workload import (algo_bytes_normalmap, algo_bytes_stereo, build_model, cpu_baseline, default_net_size, net_grid,  # noqa: E402,F401
@@ -439,7 +439,9 @@ def run_pipeline(args):
                        "exact_fallback_rows": exact_rows, "general_pixels": general_px,
                        # what actually bounds it: float64 VALU issue (bit-exactness forces binary64 in the reference's order)
                        "fp64_valu": {"peak_tflops": 78.6, "note": "see DESIGN.md 3.1: instruction count per 64 pixel-eyes from "
-                                                                  "the committed PMC profile"}}
+                                                                  "the committed PMC profile",
+                                     "main_kernel": valu_from_profile("k_polylines<", batch) if (H, W) == (1024, 1024) else None,
+                                     "general_pass": valu_from_profile("k_polylines_general", batch) if (H, W) == (1024, 1024) else None}}
         wl_text = (f"{minfo['name']} forward (fp16, random-init weights seed {minfo['init_seed']}, net {minfo['net']}, "
               f"{minfo['tokens']} tokens) + " if model is not None else "")
         out = {

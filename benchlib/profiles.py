@@ -29,6 +29,31 @@ def traffic_from_profile(kernel, batch):
     return None
 
 
+def valu_from_profile(kernel, batch):
+    """Vector-ALU issue occupancy of the kernel whose name contains `kernel`, from the committed PMC summary: SQ_ACTIVE_INST_VALU (in
+    units of 4 cycles, summed over all SIMDs) x 4 / 1024 SIMDs = cycles a SIMD's vector pipe was issuing, against GRBM_GUI_ACTIVE / 8
+    XCDs = cycles of one launch.  The roofline of a kernel whose arithmetic is fixed by bit-exactness (binary64 in the reference's
+    order: nothing to trade) is its instruction issue, not HBM."""
+    try:
+        with open(os.path.join(ROOT, PMC_SUMMARY)) as f:
+            j = json.load(f)
+        if int(j.get("batch", -1)) != int(batch):
+            return None
+        for name, row in j.items():
+            if isinstance(row, dict) and kernel in name and "SQ_ACTIVE_INST_VALU" in row and "GRBM_GUI_ACTIVE" in row:
+                active = float(row["SQ_ACTIVE_INST_VALU"]) * 4.0 / 1024.0
+                launch = float(row["GRBM_GUI_ACTIVE"]) / 8.0
+                return {"valu_issue_cycles_per_simd": active, "launch_cycles": launch, "frac_of_issue_bound": active / launch,
+                        "valu_instructions_per_launch": float(row.get("SQ_INSTS_VALU", 0.0)),
+                        "lds_bank_conflict_share_of_lds_active": (float(row["SQ_LDS_BANK_CONFLICT"]) / float(row["SQ_LDS_IDX_ACTIVE"])
+                                                                  if row.get("SQ_LDS_IDX_ACTIVE") else None),
+                        "lds_active_share_of_launch": (float(row["SQ_LDS_IDX_ACTIVE"]) * 4.0 / 1024.0 / launch if row.get("SQ_LDS_IDX_ACTIVE") else None),
+                        "kernel": name, "source": PMC_SUMMARY}
+    except Exception:
+        pass
+    return None
+
+
 def clock_from_profile(kernel, flops, batch):
     """Effective shader clock and MFMA cycle fraction of the kernel whose name contains `kernel` inside the step, from the committed
     profiles: GRBM_GUI_ACTIVE (busy cycles, summed over the 8 XCDs by rocprofv3) of the PMC summary / 8 = cycles of one launch;
