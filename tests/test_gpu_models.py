@@ -1928,7 +1928,7 @@ def test_pix2pix_unet_takes_relu_cat(gpu):
             y2 = m(x)
     finally:
         networks.RELU_CAT_HIP = saved
-    assert torch.equal(y, y2)
+    assert (y - y2).abs().max().item() < 2e-5 * (1 + y2.abs().max().item())
 
 
 # ---- round 6: GroupNorm of the ResNetV2-50 stem (dpt_hybrid_384, BASELINE config 2) ----------------------------------------------------
