@@ -1,3 +1,6 @@
+#!/usr/bin/env python3
+"""ds_upsample_bilinear_nhwc at the four shapes of the bench step's decoder (batch 32, 256 channels, x 2, align_corners): time per
+launch and the sum of a forward.     python tools/upsample_ab.py   (DS_NATIVE_LIB=<other build> for the A side)"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "stable-diffusion-webui-depthmap-script_amd")):
@@ -17,7 +20,7 @@ for hw in (16, 32, 64, 128):
     x = torch.randn((32, 256, hw, hw), device="cuda").half().contiguous(memory_format=torch.channels_last)
     t = timeit(lambda: nat.upsample_bilinear(x, scale_factor=2, align_corners=True))
     gb = x.numel() * 2 * 5 / 1e9
-    print(f"upsample 32 x 256 x {hw}^2 -> {2*hw}^2: {t*1e3:7.1f} us  {gb / t:7.1f} GB/s... = {gb/t/1e3*1e3:.0f}")
+    print(f"upsample 32 x 256 x {hw}^2 -> {2 * hw}^2: {t * 1e3:7.1f} us  {gb / t / 1e3 * 1e3:7.2f} TB/s of input + output")
     tot += t
 y = nat.upsample_bilinear(x, scale_factor=2, align_corners=True)
 import hashlib
