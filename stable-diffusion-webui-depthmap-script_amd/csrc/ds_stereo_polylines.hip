@@ -515,7 +515,7 @@ __host__ __device__ inline PlLds pl_lds_layout(int S, int nwmax, int c, int np)
 }
 
 template <int C, int SHARP, int NE>
-__global__ __launch_bounds__(PL_THREADS, 4) void k_polylines(PolyParams P)
+__global__ __launch_bounds__(PL_THREADS, 5) void k_polylines(PolyParams P)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int NP = SHARP ? 2 : 1;
