@@ -27,13 +27,19 @@
 __device__ __forceinline__ float gc_relu(float v) { return v < 0.f ? 0.f : v; }
 
 // x [batch, H, W, C] float32 NHWC; wt [C / CPG groups][9 taps][CPG in][CPG out]; bias [C] or null; y [batch, H, W, C]
+// GC_NT threads: two sets of 256 share one staged tile -- set `part` renders every other (group, half) unit of the 32-channel block for
+// the same 256 pixels.  The tile's 49 KB of LDS allow three workgroups per CU; with 256 threads that was 3 waves per SIMD for a kernel
+// whose inner loop waits on scalar weight loads and LDS reads, with 512 it is 6 (26-33 VGPRs: registers are no limit).
+#define GC_NT 512
 template <int CPG>
-__global__ __launch_bounds__(256) void k_gconv3x3_nhwc_f32(const float *__restrict__ x, const float *__restrict__ wt, const float *__restrict__ bias,
-                                                           float *__restrict__ y, int H, int W, int C, int tiles_x, int tiles_y, int relu)
+__global__ __launch_bounds__(GC_NT) void k_gconv3x3_nhwc_f32(const float *__restrict__ x, const float *__restrict__ wt, const float *__restrict__ bias,
+                                                             float *__restrict__ y, int H, int W, int C, int tiles_x, int tiles_y, int relu)
 {
     __shared__ __attribute__((aligned(16))) float tile[GC_IH * GC_IW * GC_PS];
     constexpr int COT = CPG < 16 ? CPG : 16;                 // output channels per pass (the accumulators of one thread)
-    const int tid = threadIdx.x;
+    constexpr int HALVES = CPG / COT, UNITS = (GC_CB / CPG) * HALVES;      // 4 / 2 / 2 units for 8 / 16 / 32 channels per group
+    const int tid = threadIdx.x & 255;
+    const int part = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 8));      // uniform per wave: the weights stay scalar loads
     int t = blockIdx.x;
     const int bx = t % tiles_x; t /= tiles_x;
     const int by = t % tiles_y;
@@ -43,7 +49,7 @@ __global__ __launch_bounds__(256) void k_gconv3x3_nhwc_f32(const float *__restri
     const float *xb = x + (size_t)b * H * W * C + c0;
 
     // ---- stage the input tile: (pixel, 16-byte piece) pairs, 8 pieces per pixel; out-of-image pixels are the zero padding ----
-    for (int i = tid; i < GC_IH * GC_IW * (GC_CB / 4); i += 256) {
+    for (int i = threadIdx.x; i < GC_IH * GC_IW * (GC_CB / 4); i += GC_NT) {
         const int piece = i & (GC_CB / 4 - 1), pix = i / (GC_CB / 4);
         const int iy = pix / GC_IW, ix = pix - iy * GC_IW;
         const int gy = oy0 - 1 + iy, gx = ox0 - 1 + ix;
@@ -58,11 +64,11 @@ __global__ __launch_bounds__(256) void k_gconv3x3_nhwc_f32(const float *__restri
     const bool live = oy < H && ox < W;
     float *yp = y + (((size_t)b * H + oy) * W + ox) * C + c0;
 #pragma unroll 1
-    for (int g = 0; g < GC_CB / CPG; ++g) {
+    for (int unit = part; unit < UNITS; unit += GC_NT / 256) {
+        const int g = unit / HALVES, half = unit - g * HALVES;
         const int grp = (c0 + g * CPG) / CPG;                // uniform: the weights below are scalar loads
         const float *wg = wt + (size_t)grp * 9 * CPG * CPG;
-#pragma unroll 1
-        for (int half = 0; half < CPG / COT; ++half) {
+        {
             float acc[COT];
 #pragma unroll
             for (int co = 0; co < COT; ++co) acc[co] = bias ? bias[c0 + g * CPG + half * COT + co] : 0.f;
@@ -110,7 +116,7 @@ DS_API int ds_gconv3x3_nhwc_f32(ds_ctx *ctx, const float *x, const float *w_gtio
     const int tiles_x = (width + GC_TW - 1) / GC_TW, tiles_y = (height + GC_TH - 1) / GC_TH;
     DS_REQUIRE((long long)tiles_x * tiles_y * batch < (1ll << 31) && channels / GC_CB <= 65535, DS_EUNSUPPORTED, "ds_gconv3x3_nhwc_f32: grid too large");
     DS_HIP_CHECK(hipSetDevice(ctx->device));
-    dim3 grid((unsigned)(tiles_x * tiles_y * batch), (unsigned)(channels / GC_CB)), block(256);
+    dim3 grid((unsigned)(tiles_x * tiles_y * batch), (unsigned)(channels / GC_CB)), block(GC_NT);
     hipStream_t st = (hipStream_t)stream;
     switch (channels_per_group) {
     case 8: hipLaunchKernelGGL(k_gconv3x3_nhwc_f32<8>, grid, block, 0, st, x, w_gtio, bias, y, height, width, channels, tiles_x, tiles_y, relu ? 1 : 0); break;
